@@ -1,0 +1,180 @@
+"""Generate the committed golden fixtures by running the UNMODIFIED reference.
+
+Run only in the authoring container (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+Writes tests/golden/*.npz (+ a copy of the reference's own test asset test-mwm.wav, which is
+data, not source).  The fixtures hold inputs and the reference's outputs only; no reference
+source text is stored.  Randomness is pinned by seeding `random` and `numpy.random` immediately
+before each stochastic reference call; the seeds are recorded in the fixture.
+"""
+import os
+import random
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "python-world_amd"))
+
+from oracle import refshim  # noqa: E402
+
+R = refshim.load()  # reference modules (world.* from /root/reference)
+
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("_synthetic", os.path.join(ROOT, "python-world_amd", "world", "_synthetic.py"))
+_syn = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_syn)
+
+SEED = 20260927
+
+
+def stage_fixture(x, fs, tag, with_harvest=True):
+    """Per-stage outputs of the reference for one short utterance."""
+    out = {"x": x, "fs": fs}
+    d = R.dio.dio(x.copy(), fs)
+    out["dio_f0"] = d["f0"].copy()
+    out["dio_vuv"] = d["vuv"].copy()
+    out["dio_raw"] = d["raw_f0_candidates"].copy()
+    out["dio_cands"] = d["f0_candidates"].copy()
+    out["tp"] = d["temporal_positions"].copy()
+    # delay indices the reference picked for each DIO band (argmax of an even Nuttall window, Q5)
+    bands = np.arange(int(np.ceil(np.log2(800 / 71) * 2))) + 1
+    bands = 71 * (2.0 ** (bands / 2))
+    out["dio_index_bias"] = np.array([int(R.dio.nuttall(int(4000 / b / 2 + 0.5) * 4).argmax()) for b in bands])
+    sm = R.stonemask.stonemask(x, fs, d["temporal_positions"], d["f0"])
+    out["stonemask_f0"] = sm.copy()
+
+    src = {"f0": sm.copy(), "vuv": d["vuv"].copy(), "temporal_positions": d["temporal_positions"].copy()}
+    ct = R.cheaptrick.cheaptrick(x, fs, src)
+    out["ct_spectrogram"] = ct["spectrogram"].copy()
+    out["ct_f0_after"] = src["f0"].copy()  # 500 Hz substitutions written back (Q6)
+    cols = np.unique(np.linspace(0, ct["spectrogram"].shape[1] - 1, 6).astype(int))
+    out["ct_ps_cols"] = cols
+    out["ct_ps"] = ct["ps spectrogram"][:, cols].copy()
+
+    src2 = {k: v.copy() for k, v in src.items()}
+    a = R.d4c.d4c(x, fs, src2)
+    out["d4c_aperiodicity"] = a["aperiodicity"].copy()
+    out["d4c_coarse"] = a["coarse_ap"].copy()
+    out["d4c_f0_after"] = a["f0"].copy()
+
+    src3 = {k: v.copy() for k, v in src.items()}
+    rq = R.d4cRequiem.d4cRequiem(x, fs, src3)
+    out["req_band_ap"] = rq["aperiodicity"].copy()
+
+    # pulse-wise synthesis, seeded
+    dat = {"f0": a["f0"].copy(), "vuv": d["vuv"].copy(), "temporal_positions": d["temporal_positions"].copy(),
+           "spectrogram": ct["spectrogram"].copy(), "aperiodicity": a["aperiodicity"].copy(), "fs": fs}
+    np.random.seed(SEED)
+    out["syn_y"] = R.synthesis.synthesis(dat, dat)
+    out["seed"] = SEED
+
+    # modifiers then decode (A-2)
+    W = R.main.World()
+    dat2 = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in dat.items()}
+    dat2["is_requiem"] = False
+    dat2 = W.scale_pitch(dat2, 1.5)
+    dat2 = W.scale_duration(dat2, 2.0)
+    np.random.seed(SEED + 1)
+    y2 = R.synthesis.synthesis(dat2, dat2)
+    out["mod_len"] = len(y2)
+    out["mod_head"] = y2[:2048].copy()
+    out["mod_tail"] = y2[-2048:].copy()
+    out["mod_blocksum"] = np.add.reduceat(y2, np.arange(0, len(y2), 256))
+
+    # Requiem synthesis, seeded seeds + fresh cursor
+    random.seed(SEED)
+    np.random.seed(SEED)
+    seeds = R.get_seeds_signals.get_seeds_signals(fs)
+    out["seeds_pulse"] = seeds["pulse"].copy()
+    out["seeds_noise"] = seeds["noise"].copy()
+    datr = {"f0": rq["f0"].copy(), "vuv": d["vuv"].copy(), "temporal_positions": d["temporal_positions"].copy(),
+            "spectrogram": ct["spectrogram"].copy(), "aperiodicity": rq["aperiodicity"].copy(), "fs": fs}
+    R.synthesisRequiem.generate_noise.current_index = None
+    out["req_y"] = R.synthesisRequiem.synthesisRequiem(datr, datr, seeds)
+    out["req_cursor"] = np.array(R.synthesisRequiem.generate_noise.current_index, dtype=np.float64)
+
+    if with_harvest:
+        h = R.harvest.harvest(x.copy(), fs)
+        out["harvest_f0"] = h["f0"].copy()
+        out["harvest_vuv"] = h["vuv"].copy()
+    np.savez_compressed(os.path.join(HERE, "golden_%s.npz" % tag), **out)
+    print(tag, "written;", {k: getattr(v, "shape", v) for k, v in out.items() if k in ("x", "ct_spectrogram", "syn_y", "req_y")})
+
+
+def summarise(m, cols):
+    return {"colsum": m.sum(axis=0), "rowsum": m.sum(axis=1), "cols": m[:, cols].copy()}
+
+
+def mwm_fixture():
+    """BASELINE config 1: test-mwm.wav through World.encode(harvest)/decode, both synthesis paths."""
+    from scipy.io import wavfile
+
+    src_wav = os.path.join(refshim.REFERENCE_ROOT, "test", "test-mwm.wav")
+    shutil.copyfile(src_wav, os.path.join(HERE, "test-mwm.wav"))
+    fs, xi = wavfile.read(src_wav)
+    x = xi / (2 ** 15 - 1)
+    W = R.main.World()
+    out = {"fs": fs, "n": len(x)}
+    for req in (False, True):
+        tag = "req" if req else "std"
+        dat = W.encode(fs, x, f0_method="harvest", is_requiem=req)
+        if not req:
+            out["f0"] = dat["f0"].copy()
+            out["vuv"] = dat["vuv"].copy()
+            out["tp"] = dat["temporal_positions"].copy()
+            cols = np.unique(np.linspace(0, len(dat["f0"]) - 1, 12).astype(int))
+            out["cols"] = cols
+            for k, v in summarise(dat["spectrogram"], cols).items():
+                out["spec_" + k] = v
+            for k, v in summarise(dat["aperiodicity"], cols).items():
+                out["ap_" + k] = v
+        else:
+            out["req_band_ap"] = dat["aperiodicity"].copy()
+        random.seed(SEED)
+        np.random.seed(SEED)
+        R.synthesisRequiem.generate_noise.current_index = None
+        dat = W.decode(dat)
+        y = dat["out"]
+        out["out_len_" + tag] = len(y)
+        out["out_head_" + tag] = y[:4096].copy()
+        out["out_tail_" + tag] = y[-4096:].copy()
+        out["out_blocksum_" + tag] = np.add.reduceat(y, np.arange(0, len(y), 256))
+    # DIO path F0 on the same file (encode with f0_method='dio')
+    dd = W.encode(fs, x, f0_method="dio")
+    out["dio_f0"] = dd["f0"].copy()
+    out["dio_vuv"] = dd["vuv"].copy()
+    out["seed"] = SEED
+    np.savez_compressed(os.path.join(HERE, "golden_mwm.npz"), **out)
+    print("mwm written; voiced", int(out["vuv"].sum()), "of", len(out["vuv"]))
+
+
+def tables_fixture():
+    """Scalar tables for fs in {16000, 22050, 48000}: frame counts, output lengths, FFT sizes (§8 table)."""
+    out = {}
+    for fs, secs in ((16000, 10.0), (22050, 102400 / 22050), (48000, 10.0)):
+        n = int(round(fs * secs))
+        x = np.zeros(n)
+        nf = int(1000 * len(x) / fs / 5 + 1)
+        tp = np.arange(0, nf) * 5 / 1000
+        out["F_%d" % fs] = nf
+        out["Ny_%d" % fs] = len(np.arange(tp[0], tp[-1] + 1 / fs, 1 / fs))
+        out["Ny2_%d" % fs] = len(np.arange(tp[0] * 2.0, tp[-1] * 2.0 + 1 / fs, 1 / fs))
+        out["ct_fft_%d" % fs] = int(2 ** np.ceil(np.log2(3 * fs / 71 + 1)))
+        out["d4c_fft_%d" % fs] = int(2 ** np.ceil(np.log2(4 * fs / 47 + 1)))
+        out["req_fft_%d" % fs] = int(2 ** np.ceil(np.log2(3 * fs / 47 + 1)))
+    np.savez_compressed(os.path.join(HERE, "golden_tables.npz"), **out)
+    print("tables written", {k: int(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    stage_fixture(_syn.synth_utterance(0, 16000, 1.2), 16000, "syn16k")
+    stage_fixture(_syn.synth_utterance(5, 48000, 0.5), 48000, "syn48k")
+    tables_fixture()
+    mwm_fixture()

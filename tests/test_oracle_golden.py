@@ -1,0 +1,134 @@
+"""Pin the NumPy oracle (oracle/) against the fixtures generated from the real reference
+(tests/golden/make_golden.py).  CPU only."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import rel_rms
+from oracle import aperiodicity, api, envelope, pitch_dio, pitch_harvest, resynth
+
+TAGS = ["syn16k", "syn48k"]
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_dio_stonemask(golden, tag):
+    g = golden(tag)
+    fs = int(g["fs"])
+    d = pitch_dio.dio_np(g["x"], fs)
+    assert [t[1] for t in pitch_dio.dio_band_tables(71 * 2.0 ** ((np.arange(len(g["dio_index_bias"])) + 1) / 2), 4000)] \
+        == list(g["dio_index_bias"]), "host libm/BLAS picks a different Nuttall argmax than the fixture (SURVEY Q5)"
+    assert np.array_equal(d["vuv"], g["dio_vuv"])
+    assert np.allclose(d["raw_f0_candidates"], g["dio_raw"], rtol=0, atol=1e-8)
+    assert np.allclose(d["f0_candidates"], g["dio_cands"], rtol=0, atol=1e-8)
+    assert np.allclose(d["f0"], g["dio_f0"], rtol=0, atol=1e-8)
+    sm = pitch_dio.stonemask_np(g["x"], fs, g["tp"], g["dio_f0"])
+    assert np.allclose(sm, g["stonemask_f0"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_cheaptrick(golden, tag):
+    g = golden(tag)
+    fs = int(g["fs"])
+    sp, ps, f0u = envelope.cheaptrick_np(g["x"], fs, g["stonemask_f0"], g["dio_vuv"], g["tp"])
+    assert sp.shape == g["ct_spectrogram"].shape
+    assert np.array_equal(f0u, g["ct_f0_after"])
+    assert rel_rms(sp, g["ct_spectrogram"]) < 1e-10
+    # eps dither of the reference (Q10) only matters on ~1e-16-level bins
+    assert np.max(np.abs(sp - g["ct_spectrogram"]) / g["ct_spectrogram"]) < 1e-6
+    assert np.allclose(ps[:, g["ct_ps_cols"]], g["ct_ps"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_d4c_and_requiem(golden, tag):
+    g = golden(tag)
+    fs = int(g["fs"])
+    ap, coarse, f0o = aperiodicity.d4c_np(g["x"], fs, g["ct_f0_after"], g["dio_vuv"], g["tp"])
+    assert np.array_equal(f0o, g["d4c_f0_after"])
+    assert np.allclose(coarse, g["d4c_coarse"], rtol=0, atol=1e-8)
+    assert np.allclose(ap, g["d4c_aperiodicity"], rtol=0, atol=1e-9)
+    band, _ = aperiodicity.d4c_requiem_np(g["x"], fs, g["ct_f0_after"], g["dio_vuv"], g["tp"])
+    assert band.shape == g["req_band_ap"].shape
+    assert np.allclose(band, g["req_band_ap"], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_synthesis(golden, tag):
+    g = golden(tag)
+    fs = int(g["fs"])
+    np.random.seed(int(g["seed"]))
+    y = resynth.synthesis_np(g["d4c_f0_after"], g["dio_vuv"], g["tp"], g["ct_spectrogram"], g["d4c_aperiodicity"], fs)
+    assert len(y) == len(g["syn_y"])
+    assert np.allclose(y, g["syn_y"], rtol=0, atol=1e-12)
+    # modifiers: scale_pitch(1.5) + scale_duration(2.0) (world/main.py:154-178)
+    np.random.seed(int(g["seed"]) + 1)
+    y2 = resynth.synthesis_np(g["d4c_f0_after"] * 1.5, g["dio_vuv"], g["tp"] * 2.0, g["ct_spectrogram"],
+                              g["d4c_aperiodicity"], fs)
+    assert len(y2) == int(g["mod_len"])
+    assert np.allclose(y2[:2048], g["mod_head"], rtol=0, atol=1e-12)
+    assert np.allclose(y2[-2048:], g["mod_tail"], rtol=0, atol=1e-12)
+    assert np.allclose(np.add.reduceat(y2, np.arange(0, len(y2), 256)), g["mod_blocksum"], rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_requiem_synthesis_and_seeds(golden, tag):
+    g = golden(tag)
+    fs = int(g["fs"])
+    random.seed(int(g["seed"]))
+    np.random.seed(int(g["seed"]))
+    seeds = resynth.seeds_np(fs)
+    assert np.allclose(seeds["pulse"], g["seeds_pulse"], rtol=0, atol=1e-15)
+    assert np.allclose(seeds["noise"], g["seeds_noise"], rtol=0, atol=1e-13)
+    f0r = np.where(g["dio_vuv"] == 0, 0.0, g["ct_f0_after"])
+    y, cur = resynth.synthesis_requiem_np(f0r, g["dio_vuv"], g["tp"], g["ct_spectrogram"], g["req_band_ap"], fs,
+                                          {"pulse": g["seeds_pulse"], "noise": g["seeds_noise"]})
+    assert np.allclose(y, g["req_y"], rtol=0, atol=1e-12)
+    assert np.array_equal(cur, g["req_cursor"])
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_harvest(golden, tag):
+    g = golden(tag)
+    h = pitch_harvest.harvest_np(g["x"], int(g["fs"]))
+    assert np.array_equal(h["vuv"], g["harvest_vuv"])
+    assert np.allclose(h["f0"], g["harvest_f0"], rtol=1e-10, atol=0)
+
+
+def test_tables(golden):
+    from oracle import common
+
+    g = golden("tables")
+    for fs, n in ((16000, 160000), (22050, 102400), (48000, 480000)):
+        nf = common.frame_count(n, fs, 5)
+        assert nf == int(g["F_%d" % fs])
+        tp = common.frame_times(nf, 5)
+        assert resynth.output_length(tp, fs) == int(g["Ny_%d" % fs])
+        assert resynth.output_length(tp * 2.0, fs) == int(g["Ny2_%d" % fs])
+        assert envelope.default_fft_size(fs) == int(g["ct_fft_%d" % fs])
+
+
+def test_config1_mwm_end_to_end(golden):
+    """BASELINE config 1 through the oracle facade: encode(harvest) + decode on test-mwm.wav."""
+    import os
+
+    from scipy.io import wavfile
+
+    g = golden("mwm")
+    fs, xi = wavfile.read(os.path.join(os.path.dirname(__file__), "golden", "test-mwm.wav"))
+    x = xi / (2 ** 15 - 1)
+    dat = api.encode_np(fs, x, f0_method="harvest")
+    assert np.array_equal(dat["vuv"], g["vuv"])
+    assert np.allclose(dat["f0"], g["f0"], rtol=1e-9, atol=0)
+    assert np.allclose(dat["spectrogram"].sum(axis=0), g["spec_colsum"], rtol=1e-8)
+    # the reference's eps dither (Q10) is visible on ~1e-11-level bins: bound per-bin loosely, RMS tightly
+    assert np.allclose(dat["spectrogram"][:, g["cols"]], g["spec_cols"], rtol=1e-4, atol=1e-300)
+    assert rel_rms(dat["spectrogram"][:, g["cols"]], g["spec_cols"]) < 1e-10
+    assert np.allclose(dat["aperiodicity"].sum(axis=1), g["ap_rowsum"], rtol=1e-8)
+    assert np.allclose(dat["aperiodicity"][:, g["cols"]], g["ap_cols"], rtol=0, atol=1e-8)
+    np.random.seed(int(g["seed"]))
+    dat = api.decode_np(dat)
+    y = dat["out"]
+    assert len(y) == int(g["out_len_std"])
+    assert np.allclose(y[:4096], g["out_head_std"], rtol=0, atol=1e-9)
+    assert np.allclose(y[-4096:], g["out_tail_std"], rtol=0, atol=1e-9)
+    assert np.allclose(np.add.reduceat(y, np.arange(0, len(y), 256)), g["out_blocksum_std"], rtol=0, atol=1e-8)

@@ -1,0 +1,69 @@
+/* world_hip.h — C ABI of libworld_hip.so: the WORLD vocoder analysis/synthesis hot path as
+ * hand-written HIP kernels for AMD MI355X (gfx950).
+ *
+ * The reference (tuanad121/Python-WORLD) has no FFI: its seam is the set of module-level stage
+ * functions imported by world/main.py:14-23.  Each entry point below is the batched, device-side
+ * replacement of ONE of those functions (cited per function); the Python mirror in
+ * python-world_amd/world/ binds them with ctypes and keeps the reference's names, arguments and
+ * result-dict keys.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure; wh_last_error() gives the text
+ *    of the last failure on the calling thread.  No C++ exception crosses the boundary.
+ *  - pointers named h_* are HOST pointers; all other data pointers are DEVICE pointers
+ *    (hipMalloc / torch.cuda memory).  `stream` is a hipStream_t passed as void* (NULL = default).
+ *    Calls are asynchronous with respect to the host unless stated.
+ *  - dtype is IEEE float64 everywhere (the reference is float64 end to end).
+ *  - a *batch* is a set of utterances concatenated sample-wise (x, offsets h_x_off[n_utt+1]) and
+ *    frame-wise (per-frame arrays, offsets h_frame_off[n_utt+1]).  Utterances are independent.
+ *  - dense per-frame outputs are FRAME-MAJOR on the device: spectrogram[frame][bin] (the
+ *    reference's NumPy arrays are (bins, frames); the Python mirror transposes at the boundary).
+ *  - nothing is retained past return except inside wh_ctx / wh_batch objects.
+ */
+#ifndef WORLD_HIP_H
+#define WORLD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wh_ctx wh_ctx;     /* one per device per host thread: twiddle tables + scratch */
+typedef struct wh_batch wh_batch; /* utterance/frame offsets of one batch, resident on the device */
+
+int wh_version(void);
+const char* wh_last_error(void);
+
+/* ---- device / memory helpers (so a host without torch can drive the library) ------------- */
+int wh_device_count(int* count);
+int wh_ctx_create(int device, wh_ctx** out);
+int wh_ctx_destroy(wh_ctx* ctx);
+int wh_malloc(void** dptr, size_t bytes);
+int wh_free(void* dptr);
+int wh_memcpy_h2d(void* dst, const void* h_src, size_t bytes, void* stream);
+int wh_memcpy_d2h(void* h_dst, const void* src, size_t bytes, void* stream);
+int wh_memset(void* dst, int value, size_t bytes, void* stream);
+int wh_stream_sync(void* stream);
+
+/* ---- batch descriptor --------------------------------------------------------------------- */
+/* h_x_off[n_utt+1]: sample offsets into the concatenated waveform; h_frame_off[n_utt+1]: frame
+ * offsets into the concatenated per-frame arrays.  Synchronous (small H2D copies). */
+int wh_batch_create(wh_ctx* ctx, int n_utt, const int64_t* h_x_off, const int64_t* h_frame_off, wh_batch** out);
+int wh_batch_destroy(wh_batch* b);
+/* Frame count of one utterance: int(1000*n/fs/frame_period + 1) — world/dio.py:28, world/harvest.py:46. */
+int64_t wh_num_frames(int64_t n_samples, double fs, double frame_period_ms);
+
+/* ---- CheapTrick: replaces cheaptrick()  (world/cheaptrick.py:9-39) ------------------------ */
+/* x[total_samples]; tp/vuv[total_frames]; f0[total_frames] is IN/OUT: unvoiced frames and frames
+ * below 3*fs/(fft_size-3) are overwritten with 500 Hz exactly as the reference mutates
+ * source_object['f0'] (cheaptrick.py:26-27,32-33).  spectrogram[total_frames][fft_size/2+1];
+ * ps_spectrogram (optional, may be NULL) [total_frames][fft_size] interleaved (re,im) =
+ * the reference's 'ps spectrogram'.  fft_size must be a power of two in [256, 4096]. */
+int wh_cheaptrick(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, double* f0,
+                  const double* vuv, double fs, int fft_size, double q1, double* spectrogram, double* ps_spectrogram);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WORLD_HIP_H */

@@ -1,0 +1,79 @@
+"""Build libworld_hip.so (gfx950) in-tree: hipcc per translation unit, then one shared link.
+
+    python python-world_amd/build.py [--force]
+
+No cmake/ninja: the library is a handful of .hip files.  Output: python-world_amd/lib/libworld_hip.so
+(git-ignored, travels to the GPU box with the source snapshot).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(HERE, "build")
+LIB = os.path.join(OUT_DIR, "libworld_hip.so")
+ARCH = "gfx950"
+# -ffp-contract=off: the reference is NumPy float64 without FMA contraction; keeping mul/add
+# separate keeps the discrete F0 decisions on the same side of their thresholds.
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    units = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "world_hip.h"))
+    jobs = []
+    objs = []
+    for u in units:
+        src = os.path.join(CSRC, u)
+        obj = os.path.join(OBJ_DIR, u[:-4] + ".o")
+        objs.append(obj)
+        if force or _newer([src] + headers, obj):
+            jobs.append((u, [hipcc] + FLAGS + ["-c", src, "-o", obj]))
+
+    def run(job):
+        name, cmd = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return name, r.returncode, r.stdout + r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for name, rc, log in ex.map(run, jobs):
+                if verbose and log.strip():
+                    print(log)
+                if rc != 0:
+                    raise RuntimeError("hipcc failed on %s\n%s" % (name, log))
+                if verbose:
+                    print("compiled", name)
+    if force or jobs or _newer(objs, LIB):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed\n" + r.stdout + r.stderr)
+        if verbose:
+            print("linked", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

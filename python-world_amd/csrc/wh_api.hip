@@ -1,0 +1,174 @@
+// Context, batch descriptor, memory helpers and error reporting of libworld_hip.so.
+#include <math.h>
+#include <string.h>
+
+#include "wh_host.h"
+
+namespace {
+thread_local std::string g_last_error;
+
+__global__ void frame_utt_kernel(const int64_t* __restrict__ frame_off, int n_utt, int64_t total, int32_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    int lo = 0, hi = n_utt;  // largest u with frame_off[u] <= i
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (frame_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    out[i] = lo;
+  }
+}
+}  // namespace
+
+namespace wh {
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(const char* where, hipError_t e) {
+  g_last_error = std::string(where) + ": " + hipGetErrorString(e);
+  return (int)e == 0 ? -1 : (int)e;
+}
+int fail_msg(const char* where, const char* msg) {
+  g_last_error = std::string(where) + ": " + msg;
+  return -1;
+}
+int ws_reserve(wh_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return 0;
+  if (ctx->ws) {
+    WH_CHECK(hipDeviceSynchronize());
+    WH_CHECK(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  size_t want = bytes + bytes / 4;
+  WH_CHECK(hipMalloc(&ctx->ws, want));
+  ctx->ws_bytes = want;
+  return 0;
+}
+}  // namespace wh
+
+extern "C" {
+
+int wh_version(void) { return 100; }
+const char* wh_last_error(void) { return g_last_error.c_str(); }
+
+int wh_device_count(int* count) {
+  WH_CHECK(hipGetDeviceCount(count));
+  return 0;
+}
+
+int wh_ctx_create(int device, wh_ctx** out) {
+  if (!out) return wh::fail_msg("wh_ctx_create", "null out pointer");
+  WH_CHECK(hipSetDevice(device));
+  wh_ctx* c = new wh_ctx();
+  c->device = device;
+  // twiddle tables: for N = 2,4,..,WH_MAX_FFT the table exp(-2*pi*i*k/N), k<N, lives at [N, 2N)
+  std::vector<double2> tw(2 * WH_MAX_FFT);
+  tw[0] = tw[1] = make_double2(1.0, 0.0);
+  for (int n = 2; n <= WH_MAX_FFT; n <<= 1) {
+    for (int k = 0; k < n; ++k) {
+      long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+      tw[n + k] = make_double2((double)cosl(a), (double)sinl(a));
+    }
+    // exact values on the axes
+    tw[n] = make_double2(1.0, 0.0);
+    if (n >= 2) tw[n + n / 2] = make_double2(-1.0, 0.0);
+    if (n >= 4) {
+      tw[n + n / 4] = make_double2(0.0, -1.0);
+      tw[n + 3 * n / 4] = make_double2(0.0, 1.0);
+    }
+  }
+  hipError_t e = hipMalloc((void**)&c->d_twiddle, tw.size() * sizeof(double2));
+  if (e == hipSuccess) e = hipMemcpy(c->d_twiddle, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    delete c;
+    return wh::fail("wh_ctx_create", e);
+  }
+  *out = c;
+  return 0;
+}
+
+int wh_ctx_destroy(wh_ctx* ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  delete ctx;
+  return 0;
+}
+
+int wh_malloc(void** dptr, size_t bytes) {
+  WH_CHECK(hipMalloc(dptr, bytes ? bytes : 8));
+  return 0;
+}
+int wh_free(void* dptr) {
+  if (dptr) WH_CHECK(hipFree(dptr));
+  return 0;
+}
+int wh_memcpy_h2d(void* dst, const void* h_src, size_t bytes, void* stream) {
+  WH_CHECK(hipMemcpyAsync(dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return 0;
+}
+int wh_memcpy_d2h(void* h_dst, const void* src, size_t bytes, void* stream) {
+  WH_CHECK(hipMemcpyAsync(h_dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  WH_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+int wh_memset(void* dst, int value, size_t bytes, void* stream) {
+  WH_CHECK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+  return 0;
+}
+int wh_stream_sync(void* stream) {
+  WH_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int64_t wh_num_frames(int64_t n_samples, double fs, double frame_period_ms) {
+  return (int64_t)(1000.0 * (double)n_samples / fs / frame_period_ms + 1.0);
+}
+
+int wh_batch_create(wh_ctx* ctx, int n_utt, const int64_t* h_x_off, const int64_t* h_frame_off, wh_batch** out) {
+  if (!ctx || !out || !h_x_off || !h_frame_off) return wh::fail_msg("wh_batch_create", "null argument");
+  if (n_utt < 1) return wh::fail_msg("wh_batch_create", "n_utt must be >= 1");
+  for (int u = 0; u < n_utt; ++u) {
+    if (h_x_off[u + 1] < h_x_off[u] || h_frame_off[u + 1] < h_frame_off[u])
+      return wh::fail_msg("wh_batch_create", "offsets must be non-decreasing");
+  }
+  WH_CHECK(hipSetDevice(ctx->device));
+  wh_batch* b = new wh_batch();
+  b->ctx = ctx;
+  b->n_utt = n_utt;
+  b->h_x_off.assign(h_x_off, h_x_off + n_utt + 1);
+  b->h_frame_off.assign(h_frame_off, h_frame_off + n_utt + 1);
+  b->total_samples = h_x_off[n_utt] - h_x_off[0];
+  b->total_frames = h_frame_off[n_utt] - h_frame_off[0];
+  size_t ob = (size_t)(n_utt + 1) * sizeof(int64_t);
+  hipError_t e = hipMalloc((void**)&b->d_x_off, ob);
+  if (e == hipSuccess) e = hipMalloc((void**)&b->d_frame_off, ob);
+  if (e == hipSuccess) e = hipMalloc((void**)&b->d_frame_utt, (size_t)(b->total_frames > 0 ? b->total_frames : 1) * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpy(b->d_x_off, h_x_off, ob, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(b->d_frame_off, h_frame_off, ob, hipMemcpyHostToDevice);
+  if (e == hipSuccess && b->total_frames > 0) {
+    int blocks = (int)((b->total_frames + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    frame_utt_kernel<<<blocks, 256>>>(b->d_frame_off, n_utt, b->total_frames, b->d_frame_utt);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (e != hipSuccess) {
+    wh_batch_destroy(b);
+    return wh::fail("wh_batch_create", e);
+  }
+  *out = b;
+  return 0;
+}
+
+int wh_batch_destroy(wh_batch* b) {
+  if (!b) return 0;
+  if (b->d_x_off) (void)hipFree(b->d_x_off);
+  if (b->d_frame_off) (void)hipFree(b->d_frame_off);
+  if (b->d_frame_utt) (void)hipFree(b->d_frame_utt);
+  delete b;
+  return 0;
+}
+
+}  // extern "C"

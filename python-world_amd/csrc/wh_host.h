@@ -1,0 +1,50 @@
+// Host-side plumbing shared by the C-ABI translation units: context, batch descriptor,
+// error reporting, workspace.  Not part of the public ABI (see include/world_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/world_hip.h"
+
+struct wh_ctx {
+  int device = 0;
+  double2* d_twiddle = nullptr;  // tables for N = 2 .. WH_MAX_FFT, table of size N at offset N
+  void* ws = nullptr;            // growable scratch
+  size_t ws_bytes = 0;
+};
+
+struct wh_batch {
+  wh_ctx* ctx = nullptr;
+  int n_utt = 0;
+  int64_t total_samples = 0;
+  int64_t total_frames = 0;
+  std::vector<int64_t> h_x_off, h_frame_off;
+  int64_t* d_x_off = nullptr;      // [n_utt+1]
+  int64_t* d_frame_off = nullptr;  // [n_utt+1]
+  int32_t* d_frame_utt = nullptr;  // [total_frames]
+};
+
+#define WH_MAX_FFT 8192
+
+namespace wh {
+void set_error(const std::string& msg);
+int fail(const char* where, hipError_t e);
+int fail_msg(const char* where, const char* msg);
+int ws_reserve(wh_ctx* ctx, size_t bytes);  // grows ctx->ws (hipFree + hipMalloc => implicit sync)
+inline const double2* twiddle(const wh_ctx* ctx, int n) { return ctx->d_twiddle + n; }
+}  // namespace wh
+
+#define WH_CHECK(expr)                                   \
+  do {                                                   \
+    hipError_t _e = (expr);                              \
+    if (_e != hipSuccess) return wh::fail(#expr, _e);    \
+  } while (0)
+
+#define WH_LAUNCH_CHECK(name)                            \
+  do {                                                   \
+    hipError_t _e = hipGetLastError();                   \
+    if (_e != hipSuccess) return wh::fail(name, _e);     \
+  } while (0)

@@ -1,0 +1,98 @@
+// Device routines shared by the CheapTrick and D4C kernels: pitch-synchronous sample gather,
+// the "mirror the bins below f0" correction and the cumsum-based rectangular smoothing.
+// Formulas follow world/cheaptrick.py:64-131 and world/d4c.py:92-110,178-233 (reference);
+// the data movement (LDS staging, block scans) is this build's own.
+#pragma once
+#include "wh_device.h"
+
+namespace wh {
+
+// 1-based centre sample int(pos*fs + 0.501) + 1 (Python int() truncates toward zero).
+__device__ __forceinline__ long long frame_centre(double pos, double fs) { return (long long)(pos * fs + 0.501) + 1; }
+
+// Sample of utterance (x, n) at 1-based index clamped to [1, n]  (cheaptrick.py:89, d4c.py:98).
+__device__ __forceinline__ double sample_clamped(const double* __restrict__ x, long long n, long long idx1) {
+  idx1 = idx1 < 1 ? 1 : (idx1 > n ? n : idx1);
+  return x[idx1 - 1];
+}
+
+// Mirror-add the bins below f0 around f0 (cheaptrick.py:67-73 with reach=f0+fs/N; d4c.py:213-220
+// with reach=1.2*f0).  p[] holds bins 0..N/2 (at least every bin below `reach`) in LDS; tmp[] is
+// LDS scratch of at least as many doubles as there are bins below `reach`.
+// Nodes f0 - f_j (j < nlow, f_j < reach) are sorted ascending like interp1d does, queried at f_k
+// with SciPy's linear kernel slope*(x-x_lo)+y_lo and end-segment extrapolation; the result is
+// added to bins with f_k < f0.  Two barriers; p must be visible on entry, is visible on exit.
+__device__ __forceinline__ void low_band_replica(double* p, double* tmp, int N, double fs, double f0, double reach) {
+  int nlow = (int)(reach / fs * N) + 2;  // count of bins with k/N*fs < reach (monotone in k)
+  if (nlow > N) nlow = N;
+  while (nlow > 0 && !(((double)(nlow - 1) / N * fs) < reach)) --nlow;
+  if (nlow >= 2) {
+    for (int kk = threadIdx.x; kk < nlow; kk += WH_BLOCK) {
+      const double fk = (double)kk / N * fs;
+      if (fk < f0) {
+        // ascending nodes a_m = f0 - f_{nlow-1-m}; hi = clamp(#nodes < fk, 1, nlow-1)
+        int cnt = 0;
+        for (int m = 0; m < nlow; ++m) cnt += ((f0 - ((double)(nlow - 1 - m) / N * fs)) < fk) ? 1 : 0;
+        const int hi = cnt < 1 ? 1 : (cnt > nlow - 1 ? nlow - 1 : cnt);
+        const int lo = hi - 1;
+        const double a_lo = f0 - ((double)(nlow - 1 - lo) / N * fs);
+        const double a_hi = f0 - ((double)(nlow - 1 - hi) / N * fs);
+        const double y_lo = p[nlow - 1 - lo];
+        const double y_hi = p[nlow - 1 - hi];
+        const double slope = (y_hi - y_lo) / (a_hi - a_lo);
+        tmp[kk] = slope * (fk - a_lo) + y_lo;
+      }
+    }
+  }
+  __syncthreads();
+  if (nlow >= 2) {
+    for (int kk = threadIdx.x; kk < nlow; kk += WH_BLOCK) {
+      const double fk = (double)kk / N * fs;
+      if (fk < f0) p[kk] = tmp[kk] + p[kk];
+    }
+  }
+  __syncthreads();
+}
+
+// Doubled-spectrum cumulative lookup (cheaptrick.py:103-131 / d4c.py:178-233).
+// cum[i], i<N: inclusive prefix sum of the Hermitian-symmetric spectrum times fs/N.
+struct BandLookup {
+  const double* cum;
+  int N;
+  double x0, dx, xlast, total;
+  __device__ __forceinline__ void init(const double* c, int n, double fs) {
+    cum = c;
+    N = n;
+    const double half = fs / n / 2;
+    x0 = (0.0 / n * fs - fs) + half;
+    const double x1 = (1.0 / n * fs - fs) + half;
+    dx = x1 - x0;
+    xlast = ((double)(2 * n - 1) / n * fs - fs) + half;
+    total = c[n - 1];
+  }
+  __device__ __forceinline__ double seg(int i) const { return i < N ? cum[i] : total + cum[i - N]; }
+  __device__ __forceinline__ double at(double xi) const {
+    xi = fmax(x0, fmin(xlast, xi));
+    const double q = (xi - x0) / dx;
+    const double b = floor(q);
+    const double fr = q - b;
+    const int bi = (int)b;
+    const double y0 = seg(bi);
+    const double dy = (bi < 2 * N - 1) ? seg(bi + 1) - y0 : 0.0;
+    return y0 + dy * fr;
+  }
+};
+
+// p_half[0..N/2] (LDS) → cum[0..N) (LDS) = inclusive scan of the mirrored full spectrum × fs/N.
+// Contains barriers; p_half must be visible on entry; cum visible on exit.
+__device__ __forceinline__ void scan_mirrored(const double* p_half, double* cum, int N, double fs, double* scratch) {
+  const double df = fs / N;
+  for (int i = threadIdx.x; i < N; i += WH_BLOCK) {
+    const int k = i <= N / 2 ? i : N - i;
+    cum[i] = p_half[k] * df;
+  }
+  __syncthreads();
+  block_scan_lds(cum, N, scratch);
+}
+
+}  // namespace wh

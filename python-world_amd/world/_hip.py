@@ -1,0 +1,155 @@
+"""ctypes binding of libworld_hip.so (the C-ABI declared in include/world_hip.h) plus the small
+amount of device plumbing the stage shims need.  PyTorch is used only for device memory and
+streams (torch.cuda tensors are handed to the library as raw device pointers).
+
+There is deliberately NO CPU fallback: if the library or a GPU is missing every stage raises.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libworld_hip.so")
+
+_c_i64p = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+_dbl = ctypes.c_double
+_int = ctypes.c_int
+
+# name -> (restype, argtypes); every symbol include/world_hip.h declares
+SIGNATURES = {
+    "wh_version": (_int, []),
+    "wh_last_error": (ctypes.c_char_p, []),
+    "wh_device_count": (_int, [ctypes.POINTER(_int)]),
+    "wh_ctx_create": (_int, [_int, ctypes.POINTER(_vp)]),
+    "wh_ctx_destroy": (_int, [_vp]),
+    "wh_malloc": (_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
+    "wh_free": (_int, [_vp]),
+    "wh_memcpy_h2d": (_int, [_vp, _vp, ctypes.c_size_t, _vp]),
+    "wh_memcpy_d2h": (_int, [_vp, _vp, ctypes.c_size_t, _vp]),
+    "wh_memset": (_int, [_vp, _int, ctypes.c_size_t, _vp]),
+    "wh_stream_sync": (_int, [_vp]),
+    "wh_batch_create": (_int, [_vp, _int, _c_i64p, _c_i64p, ctypes.POINTER(_vp)]),
+    "wh_batch_destroy": (_int, [_vp]),
+    "wh_num_frames": (ctypes.c_int64, [ctypes.c_int64, _dbl, _dbl]),
+    "wh_cheaptrick": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _dbl, _vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class WorldHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libworld_hip.so and attach the prototypes.  Raises if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise WorldHipError("libworld_hip.so is missing (%s): build it with `python python-world_amd/build.py`; "
+                                "there is no CPU fallback" % LIB_PATH)
+        try:
+            import torch  # noqa: F401  -- make sure torch's HIP runtime is the one already mapped
+        except Exception:
+            pass
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise WorldHipError(load_library().wh_last_error().decode("utf-8", "replace"))
+
+
+class Runtime:
+    """One wh_ctx per device; device buffers are torch tensors."""
+
+    _instances = {}
+
+    def __init__(self, device_index):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise WorldHipError("no AMD GPU visible to PyTorch: the WORLD HIP path has no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        self.index = device_index
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        torch.zeros(1, device=self.device)  # force primary-context creation before our first hip call
+        h = _vp()
+        check(self.lib.wh_ctx_create(device_index, ctypes.byref(h)))
+        self.ctx = h
+
+    @classmethod
+    def get(cls, device_index=None):
+        import torch
+
+        if device_index is None:
+            device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        rt = cls._instances.get(device_index)
+        if rt is None:
+            rt = cls(device_index)
+            cls._instances[device_index] = rt
+        return rt
+
+    # ---- memory ---------------------------------------------------------------------------
+    def stream(self):
+        return _vp(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def to_device(self, a, dtype=np.float64):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        return self.torch.from_numpy(a).to(self.device)
+
+    def empty(self, shape, dtype=None):
+        return self.torch.empty(shape, dtype=dtype or self.torch.float64, device=self.device)
+
+    def zeros(self, shape, dtype=None):
+        return self.torch.zeros(shape, dtype=dtype or self.torch.float64, device=self.device)
+
+    @staticmethod
+    def ptr(t):
+        return _vp(t.data_ptr()) if t is not None else _vp(None)
+
+    # ---- batch descriptor -----------------------------------------------------------------
+    def make_batch(self, x_off, frame_off):
+        return Batch(self, x_off, frame_off)
+
+
+class Batch:
+    def __init__(self, rt, x_off, frame_off):
+        self.rt = rt
+        self.x_off = np.ascontiguousarray(x_off, dtype=np.int64)
+        self.frame_off = np.ascontiguousarray(frame_off, dtype=np.int64)
+        self.n_utt = len(self.x_off) - 1
+        h = _vp()
+        check(rt.lib.wh_batch_create(rt.ctx, self.n_utt, self.x_off.ctypes.data_as(_c_i64p),
+                                     self.frame_off.ctypes.data_as(_c_i64p), ctypes.byref(h)))
+        self.handle = h
+
+    @property
+    def total_frames(self):
+        return int(self.frame_off[-1])
+
+    @property
+    def total_samples(self):
+        return int(self.x_off[-1])
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.rt.lib.wh_batch_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

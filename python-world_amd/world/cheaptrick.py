@@ -1,0 +1,45 @@
+"""CheapTrick spectral envelope — drop-in for world/cheaptrick.py:9 of the reference, executed by
+the HIP kernel behind wh_cheaptrick (include/world_hip.h)."""
+import numpy as np
+
+from . import _hip
+
+
+def default_fft_size(fs, f0_low_limit=71):
+    return int(2 ** np.ceil(np.log2(3 * fs / f0_low_limit + 1)))
+
+
+def cheaptrick_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, fft_size, q1=-0.15, want_ps=False):
+    """Device-resident core: returns (spectrogram [F][K], ps [F][fft] complex or None); f0_d is updated in place."""
+    nf = batch.total_frames
+    k = fft_size // 2 + 1
+    spec = rt.empty((nf, k))
+    ps = rt.empty((nf, fft_size), dtype=rt.torch.complex128) if want_ps else None
+    _hip.check(rt.lib.wh_cheaptrick(rt.ctx, rt.stream(), batch.handle, rt.ptr(x_d), rt.ptr(tp_d), rt.ptr(f0_d),
+                                    rt.ptr(vuv_d), float(fs), int(fft_size), float(q1), rt.ptr(spec), rt.ptr(ps)))
+    return spec, ps
+
+
+def cheaptrick(x, fs, source_object, q1=-0.15, fft_size=None):
+    """Same contract as the reference: returns {'temporal_positions','spectrogram' (K,F),'fs',
+    'ps spectrogram' (fft,F) complex} and overwrites source_object['f0'] in place with the 500 Hz
+    substitutions (world/cheaptrick.py:26-27,32-33)."""
+    if fft_size is None:
+        fft_size = default_fft_size(fs)
+    fft_size = int(fft_size)
+    rt = _hip.Runtime.get()
+    x = np.asarray(x, dtype=np.float64)
+    tp = source_object['temporal_positions']
+    f0 = source_object['f0']
+    nf = len(f0)
+    batch = rt.make_batch([0, len(x)], [0, nf])
+    x_d = rt.to_device(x)
+    tp_d = rt.to_device(tp)
+    f0_d = rt.to_device(f0)
+    vuv_d = rt.to_device(source_object['vuv'])
+    spec, ps = cheaptrick_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, fft_size, q1, want_ps=True)
+    f0[...] = f0_d.cpu().numpy()  # the reference mutates the caller's array
+    return {'temporal_positions': tp,
+            'spectrogram': np.ascontiguousarray(spec.cpu().numpy().T),
+            'fs': fs,
+            'ps spectrogram': np.ascontiguousarray(ps.cpu().numpy().T)}

@@ -63,6 +63,24 @@ int64_t wh_num_frames(int64_t n_samples, double fs, double frame_period_ms);
 int wh_cheaptrick(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, double* f0,
                   const double* vuv, double fs, int fft_size, double q1, double* spectrogram, double* ps_spectrogram);
 
+/* ---- D4C: replaces d4c()  (world/d4c.py:10-64) ------------------------------------------------ */
+/* f0 is IN/OUT: frames with vuv==0 are zeroed like the reference does (d4c.py:32).  The D4C FFT
+ * size 2^ceil(log2(4fs/47+1)), the love-train FFT size and the band layout follow the reference.
+ * aperiodicity[total_frames][fft_size_for_spectrum/2+1] (amplitude, 1-1e-12 on unvoiced frames);
+ * coarse_ap (optional, may be NULL) [total_frames][wh_d4c_bands(fs,0)] = the reference's
+ * 'coarse_ap' debug rows (negative dB). */
+int wh_d4c(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, double* f0,
+           const double* vuv, double fs, double threshold, int fft_size_for_spectrum, double* aperiodicity,
+           double* coarse_ap);
+/* Number of aperiodicity bands: floor(min(15000, fs/2-interval)/interval) (d4c.py:34, d4cRequiem.py:19). */
+int wh_d4c_bands(double fs, int requiem);
+
+/* ---- D4C-Requiem: replaces d4cRequiem()  (world/d4cRequiem.py:9-44) ------------------------- */
+/* fft_size <= 0 selects the reference default 2^ceil(log2(3fs/47+1)).
+ * band_aperiodicity[total_frames][wh_d4c_bands(fs,1)+2] in dB (row 0 = -60, last = -1e-12). */
+int wh_d4c_requiem(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, double* f0,
+                   const double* vuv, double fs, double threshold, int fft_size, double* band_aperiodicity);
+
 #ifdef __cplusplus
 }
 #endif

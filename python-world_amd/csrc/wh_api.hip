@@ -44,6 +44,19 @@ int ws_reserve(wh_ctx* ctx, size_t bytes) {
   ctx->ws_bytes = want;
   return 0;
 }
+int const_table(wh_ctx* ctx, const std::string& key, const std::vector<double>& host, const double** out) {
+  auto it = ctx->tables.find(key);
+  if (it != ctx->tables.end()) {
+    *out = it->second;
+    return 0;
+  }
+  double* d = nullptr;
+  WH_CHECK(hipMalloc((void**)&d, (host.size() ? host.size() : 1) * sizeof(double)));
+  WH_CHECK(hipMemcpy(d, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+  ctx->tables[key] = d;
+  *out = d;
+  return 0;
+}
 }  // namespace wh
 
 extern "C" {
@@ -92,6 +105,7 @@ int wh_ctx_destroy(wh_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  for (auto& kv : ctx->tables) (void)hipFree(kv.second);
   delete ctx;
   return 0;
 }

@@ -1,0 +1,377 @@
+// D4C / D4C-Requiem band aperiodicity.
+//   love_train_kernel : VUV gate, one workgroup per frame, one FFT          (world/d4c.py:68-88)
+//   d4c_kernel        : per gated frame, everything in LDS: two Blackman frames packed as
+//                       x + j*n*x into ONE complex FFT each (spectrum and time-weighted spectrum
+//                       are separated by Hermitian symmetry), Hann frame FFT, three block-scan
+//                       smoothings, then per 3 kHz band: Nuttall-windowed group delay → FFT →
+//                       bitonic sort in LDS → prefix sum → energy ratio      (world/d4c.py:114-209)
+// Replaces d4c() (world/d4c.py:10-64) and d4cRequiem() (world/d4cRequiem.py:9-44).
+#include <map>
+
+#include "wh_host.h"
+#include "wh_spectral.h"
+
+namespace {
+
+// Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110) written to buf[j].x, j<N
+// (zero beyond the window; rows longer than N are cropped like np.fft.fft(x, n), Q7).
+// Returns sum(wave^2) over the FULL window.  BLACKMAN selects window type 2, else Hann.
+template <bool BLACKMAN>
+__device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long long xn, double fs, double cf,
+                                             double pos, double half_length, double2* buf, int N, double* scratch) {
+  const int hwl = (int)(half_length * fs / cf + 0.5);
+  const int L = 2 * hwl + 1;
+  const long long centre = wh::frame_centre(pos, fs);
+  const double phase = (pos * fs - (double)(long long)(pos * fs + 0.5)) / fs;
+  double s_sw = 0.0, s_w = 0.0;
+  for (int j = threadIdx.x; j < L; j += WH_BLOCK) {
+    const int rel = j - hwl;
+    const double seg = wh::sample_clamped(xu, xn, centre + rel);
+    const double t = (double)rel / fs / half_length + phase;
+    const double a = M_PI * t * cf;
+    const double w = BLACKMAN ? (0.08 * cos(a * 2) + 0.5 * cos(a) + 0.42) : (0.5 * cos(a) + 0.5);
+    const double sw = seg * w;
+    s_sw += sw;
+    s_w += w;
+    if (j < N) buf[j] = make_double2(sw, w);
+  }
+  wh::block_sum2(s_sw, s_w, scratch);
+  const double mean_sw = s_sw / (double)L;
+  const double mean_w = s_w / (double)L;
+  double e = 0.0;
+  for (int j = threadIdx.x; j < (L > N ? L : N); j += WH_BLOCK) {
+    double v = 0.0;
+    if (j < L) {
+      double sw, w;
+      if (j < N) {
+        sw = buf[j].x;
+        w = buf[j].y;
+      } else {
+        const int rel = j - hwl;
+        const double seg = wh::sample_clamped(xu, xn, centre + rel);
+        const double a = M_PI * ((double)rel / fs / half_length + phase) * cf;
+        w = BLACKMAN ? (0.08 * cos(a * 2) + 0.5 * cos(a) + 0.42) : (0.5 * cos(a) + 0.5);
+        sw = seg * w;
+      }
+      v = sw - w * mean_sw / mean_w;
+      e += v * v;
+    }
+    if (j < N) buf[j] = make_double2(v, 0.0);
+  }
+  return wh::block_sum(e, scratch);  // barriers inside make buf visible
+}
+
+template <int NLT>
+__global__ __launch_bounds__(WH_BLOCK) void love_train_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
+    const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv, double fs,
+    double threshold, const double2* __restrict__ tw, int32_t* __restrict__ gate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double2* buf = reinterpret_cast<double2*>(smem);
+  double* scratch = reinterpret_cast<double*>(smem + sizeof(double2) * NLT);
+  const int64_t f = blockIdx.x;
+  double f0 = f0_io[f];
+  if (vuv[f] == 0.0) f0 = 0.0;  // d4c.py:32 — written back (Q6)
+  if (threadIdx.x == 0) f0_io[f] = f0;
+  if (f0 == 0.0) {
+    if (threadIdx.x == 0) gate[f] = 0;
+    return;
+  }
+  const int u = frame_utt[f];
+  const double* xu = x + x_off[u];
+  const long long xn = x_off[u + 1] - x_off[u];
+  const double cf = fmax(f0, 40.0);
+  d4c_window<true>(xu, xn, fs, cf, tp[f], 1.5, buf, NLT, scratch);
+  wh::fft_lds<NLT, false>(buf, tw);
+  const int b0 = (int)(ceil(100.0 / (fs / NLT)) + 1);
+  const int b1 = (int)(ceil(4000.0 / (fs / NLT)) + 1);
+  const int b2 = (int)(ceil(7900.0 / (fs / NLT)) + 1);
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = b0 + threadIdx.x; k < b2 && k < NLT; k += WH_BLOCK) {
+    const double2 z = buf[k];
+    const double p = z.x * z.x + z.y * z.y;
+    s2 += p;
+    if (k < b1) s1 += p;
+  }
+  wh::block_sum2(s1, s2, scratch);
+  if (threadIdx.x == 0) gate[f] = (s1 / s2 > threshold) ? 1 : 0;
+}
+
+__device__ __forceinline__ void bitonic_sort_lds(double* s, int n) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n; i += WH_BLOCK) {
+        const int p = i ^ j;
+        if (p > i) {
+          const double a = s[i], b = s[p];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            s[i] = b;
+            s[p] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Accumulate the group-delay centroid of one Blackman frame into cent[0..N/2] (d4c.py:146-153).
+template <int N>
+__device__ __forceinline__ void add_centroid(const double* xu, long long xn, double fs, double cf, double pos,
+                                             double2* buf, double* cent, bool first, const double2* tw,
+                                             double* scratch) {
+  const double energy = d4c_window<true>(xu, xn, fs, cf, pos, 2.0, buf, N, scratch);
+  const double nrm = sqrt(energy);
+  for (int j = threadIdx.x; j < N; j += WH_BLOCK) {
+    const double v = buf[j].x / nrm;
+    buf[j] = make_double2(v, v * (double)(j + 1));  // z = x + i*(n*x), n 1-based
+  }
+  __syncthreads();
+  wh::fft_lds<N, false>(buf, tw);
+  for (int k = threadIdx.x; k <= N / 2; k += WH_BLOCK) {
+    const double2 a = buf[k];
+    const double2 b = buf[(N - k) & (N - 1)];
+    // S = (Z[k]+conj(Z[N-k]))/2 ; T = (Z[k]-conj(Z[N-k]))/(2i)
+    const double sr = 0.5 * (a.x + b.x), si = 0.5 * (a.y - b.y);
+    const double tr = 0.5 * (a.y + b.y), ti = -0.5 * (a.x - b.x);
+    const double c = tr * sr + si * ti;  // -Im(W)Re(S)+Im(S)Re(W) with W = -i*T
+    cent[k] = first ? c : cent[k] + c;
+  }
+  __syncthreads();
+}
+
+template <int N>
+__global__ __launch_bounds__(WH_BLOCK) void d4c_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
+    const double* __restrict__ tp, const double* __restrict__ f0_in, const int32_t* __restrict__ gate, double fs,
+    int nap, int interval, const double* __restrict__ window, int wlen, const double2* __restrict__ tw,
+    int k_spec,                       // >0: dense amplitude output [F][k_spec]; 0: Requiem band output [F][nap+2]
+    double* __restrict__ out, double* __restrict__ coarse_dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int K = N / 2 + 1;
+  double2* buf = reinterpret_cast<double2*>(smem);
+  double* cum = reinterpret_cast<double*>(smem + sizeof(double2) * N);  // N
+  double* cent = cum + N;                                               // K (padded to N/2+8)
+  double* pw = cent + (N / 2 + 8);                                      // K
+  double* scratch = pw + (N / 2 + 8);                                   // 16
+  double* band = scratch + 16;                                          // nap (<= 8)
+
+  const int64_t f = blockIdx.x;
+  if (gate[f] == 0) {
+    if (k_spec > 0) {
+      double* o = out + f * (int64_t)k_spec;
+      for (int k = threadIdx.x; k < k_spec; k += WH_BLOCK) o[k] = 1 - 0.000000000001;
+      if (coarse_dbg) for (int b = threadIdx.x; b < nap; b += WH_BLOCK) coarse_dbg[f * nap + b] = 0.0;
+    } else {
+      double* o = out + f * (int64_t)(nap + 2);
+      for (int b = threadIdx.x; b < nap + 2; b += WH_BLOCK) o[b] = -0.000000000001;
+    }
+    return;
+  }
+  const int u = frame_utt[f];
+  const double* xu = x + x_off[u];
+  const long long xn = x_off[u + 1] - x_off[u];
+  const double pos = tp[f];
+  const double cf = fmax(47.0, f0_in[f]);
+
+  // ---- static centroid from two frames at +-T0/4 (d4c.py:132-142) + DC correction ----------
+  add_centroid<N>(xu, xn, fs, cf, pos + 1 / cf / 4, buf, cent, true, tw, scratch);
+  add_centroid<N>(xu, xn, fs, cf, pos - 1 / cf / 4, buf, cent, false, tw, scratch);
+  wh::low_band_replica(cent, cum, N, fs, cf, 1.2 * cf);
+
+  // ---- smoothed power spectrum (d4c.py:157-161) ----------------------------------------------
+  d4c_window<false>(xu, xn, fs, cf, pos, 2.0, buf, N, scratch);
+  wh::fft_lds<N, false>(buf, tw);
+  for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+    const double2 z = buf[k];
+    pw[k] = z.x * z.x + z.y * z.y;
+  }
+  __syncthreads();
+  wh::low_band_replica(pw, cum, N, fs, cf, 1.2 * cf);
+  wh::scan_mirrored(pw, cum, N, fs, scratch);
+  wh::BandLookup lk;
+  lk.init(cum, N, fs);
+  for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+    const double c = (double)k / N * fs;
+    const double sm = (lk.at(c + cf / 2) - lk.at(c - cf / 2)) / cf;
+    cent[k] = cent[k] / sm;  // T_g = centroid / smoothed power (d4c.py:169; no zero guard, Q14)
+  }
+  __syncthreads();
+  // ---- group-delay shaping (d4c.py:165-174) --------------------------------------------------
+  wh::scan_mirrored(cent, cum, N, fs, scratch);
+  lk.init(cum, N, fs);
+  {
+    const double w2 = cf / 2;
+    for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+      const double c = (double)k / N * fs;
+      pw[k] = (lk.at(c + w2 / 2) - lk.at(c - w2 / 2)) / w2;  // T_gs
+    }
+  }
+  __syncthreads();
+  wh::scan_mirrored(pw, cum, N, fs, scratch);
+  lk.init(cum, N, fs);
+  for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+    const double c = (double)k / N * fs;
+    cent[k] = pw[k] - (lk.at(c + cf / 2) - lk.at(c - cf / 2)) / cf;  // T_D = T_gs - T_gb
+  }
+  __syncthreads();
+
+  // ---- band-wise aperiodicity (d4c.py:192-209) -----------------------------------------------
+  const int boundary = (int)((double)N / wlen * 8 + 0.5);
+  const int half = wlen / 2;
+  for (int b = 0; b < nap; ++b) {
+    const int centre = (int)floor((double)interval * (b + 1) / (fs / N));
+    for (int j = threadIdx.x; j < N; j += WH_BLOCK) {
+      double v = 0.0;
+      if (j < wlen) {
+        int idx = centre - half + j;          // index into the mirrored full group delay
+        idx = idx < 0 ? -idx : idx;
+        idx = idx > N / 2 ? N - idx : idx;
+        v = cent[idx] * window[j];
+      }
+      buf[j] = make_double2(v, 0.0);
+    }
+    __syncthreads();
+    wh::fft_lds<N, false>(buf, tw);
+    for (int k = threadIdx.x; k < N; k += WH_BLOCK) {
+      double p = INFINITY;
+      if (k < K) {
+        const double2 z = buf[k];
+        p = z.x * z.x + z.y * z.y;
+      }
+      cum[k] = p;
+    }
+    __syncthreads();
+    bitonic_sort_lds(cum, N);
+    for (int k = K + threadIdx.x; k < N; k += WH_BLOCK) cum[k] = 0.0;
+    __syncthreads();
+    wh::block_scan_lds(cum, N, scratch);
+    if (threadIdx.x == 0) band[b] = -10 * log10(cum[N / 2 - boundary - 1] / cum[K - 1]);
+    __syncthreads();
+  }
+
+  // ---- outputs (d4c.py:56-59 / d4cRequiem.py:40) ---------------------------------------------
+  const double tilt = (cf - 100) * 2 / 100;
+  if (k_spec > 0) {
+    if (coarse_dbg) for (int b = threadIdx.x; b < nap; b += WH_BLOCK) coarse_dbg[f * nap + b] = -fmax(0.0, band[b] - tilt);
+    double* o = out + f * (int64_t)k_spec;
+    const int nn = nap + 2;  // nodes: 0, interval, ..., interval*nap, fs/2
+    for (int k = threadIdx.x; k < k_spec; k += WH_BLOCK) {
+      const double q = (double)k * fs / (double)(2 * (k_spec - 1));
+      int cnt = 0;  // searchsorted-left over the coarse axis
+      for (int m = 0; m < nn; ++m) {
+        const double am = m <= nap ? (double)(m * interval) : fs / 2;
+        cnt += (am < q) ? 1 : 0;
+      }
+      const int hi = cnt < 1 ? 1 : (cnt > nn - 1 ? nn - 1 : cnt);
+      const int lo = hi - 1;
+      const double a_lo = lo <= nap ? (double)(lo * interval) : fs / 2;
+      const double a_hi = hi <= nap ? (double)(hi * interval) : fs / 2;
+      const double y_lo = lo == 0 ? -60.0 : -fmax(0.0, band[lo - 1] - tilt);
+      const double y_hi = hi == nn - 1 ? -0.000000000001 : -fmax(0.0, band[hi - 1] - tilt);
+      const double slope = (y_hi - y_lo) / (a_hi - a_lo);
+      const double db = slope * (q - a_lo) + y_lo;
+      o[k] = pow(10.0, db / 20);
+    }
+  } else {
+    double* o = out + f * (int64_t)(nap + 2);
+    for (int b = threadIdx.x; b < nap + 2; b += WH_BLOCK)
+      o[b] = b == 0 ? -60.0 : (b == nap + 1 ? -0.000000000001 : -fmax(0.0, band[b - 1] - tilt));
+  }
+}
+
+int pow2_at_least(double v) { return (int)llround(pow(2.0, ceil(log2(v)))); }
+
+// Nuttall window of (possibly float-valued) length n, world/d4c.py:237-245.
+std::vector<double> nuttall(int n) {
+  std::vector<double> w(n);
+  for (int i = 0; i < n; ++i) {
+    const double t = (double)i * 2 * M_PI / (double)(n - 1);
+    w[i] = 0.355768 * cos(0 * t) + -0.487396 * cos(t) + 0.144232 * cos(2 * t) + -0.012604 * cos(3 * t);
+  }
+  return w;
+}
+
+template <int NLT>
+int launch_lt(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
+              const double* vuv, double fs, double thr, int32_t* gate) {
+  const size_t lds = sizeof(double2) * NLT + sizeof(double) * 16;
+  if (int rc = wh::allow_lds(&love_train_kernel<NLT>, lds)) return rc;
+  hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)b->total_frames), dim3(WH_BLOCK), lds, st, x, b->d_x_off,
+                     b->d_frame_utt, tp, f0, vuv, fs, thr, wh::twiddle(ctx, NLT), gate);
+  WH_LAUNCH_CHECK("love_train_kernel");
+  return 0;
+}
+
+template <int N>
+int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, const double* f0,
+                const int32_t* gate, double fs, int nap, int interval, const double* win, int wlen, int k_spec,
+                double* out, double* coarse) {
+  const size_t lds = sizeof(double2) * N + sizeof(double) * (N + 2 * (N / 2 + 8) + 16 + 8);
+  if (int rc = wh::allow_lds(&d4c_kernel<N>, lds)) return rc;
+  hipLaunchKernelGGL(d4c_kernel<N>, dim3((unsigned)b->total_frames), dim3(WH_BLOCK), lds, st, x, b->d_x_off,
+                     b->d_frame_utt, tp, f0, gate, fs, nap, interval, win, wlen, wh::twiddle(ctx, N), k_spec, out,
+                     coarse);
+  WH_LAUNCH_CHECK("d4c_kernel");
+  return 0;
+}
+
+int d4c_common(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, double* f0,
+               const double* vuv, double fs, double threshold, int nfft, int interval, int k_spec, double* out,
+               double* coarse) {
+  hipStream_t st = (hipStream_t)stream;
+  if (b->total_frames == 0) return 0;
+  const int nap = (int)floor(fmin(15000.0, fs / 2 - interval) / interval);
+  if (nap <= 0) return wh::fail_msg("wh_d4c", "sampling rate too low: no aperiodicity band (reference asserts, d4c.py:35)");
+  if (nap > 8) return wh::fail_msg("wh_d4c", "more than 8 aperiodicity bands unsupported");
+  const int nlt = pow2_at_least(3 * fs / 40.0 + 1);
+  const int wlen = (int)(floor(interval / (fs / nfft)) * 2 + 1);
+  // workspace: gate[F]; the band window is a cached constant table
+  if (int rc = wh::ws_reserve(ctx, (size_t)b->total_frames * sizeof(int32_t))) return rc;
+  int32_t* gate = reinterpret_cast<int32_t*>(ctx->ws);
+  const double* d_win = nullptr;
+  if (int rc = wh::const_table(ctx, "nuttall:" + std::to_string(wlen), nuttall(wlen), &d_win)) return rc;
+  int rc;
+  switch (nlt) {
+    case 512: rc = launch_lt<512>(ctx, st, b, x, tp, f0, vuv, fs, threshold, gate); break;
+    case 1024: rc = launch_lt<1024>(ctx, st, b, x, tp, f0, vuv, fs, threshold, gate); break;
+    case 2048: rc = launch_lt<2048>(ctx, st, b, x, tp, f0, vuv, fs, threshold, gate); break;
+    case 4096: rc = launch_lt<4096>(ctx, st, b, x, tp, f0, vuv, fs, threshold, gate); break;
+    default: return wh::fail_msg("wh_d4c", "love-train FFT size outside [512, 4096] (fs must be <= ~54 kHz)");
+  }
+  if (rc) return rc;
+  switch (nfft) {
+    case 512: return launch_main<512>(ctx, st, b, x, tp, f0, gate, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+    case 1024: return launch_main<1024>(ctx, st, b, x, tp, f0, gate, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+    case 2048: return launch_main<2048>(ctx, st, b, x, tp, f0, gate, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+    case 4096: return launch_main<4096>(ctx, st, b, x, tp, f0, gate, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+    default: return wh::fail_msg("wh_d4c", "D4C FFT size outside [512, 4096]");
+  }
+}
+
+}  // namespace
+
+extern "C" int wh_d4c_bands(double fs, int requiem) {
+  const int interval = (!requiem && fs < 16000) ? 2000 : 3000;
+  return (int)floor(fmin(15000.0, fs / 2 - interval) / interval);
+}
+
+extern "C" int wh_d4c(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, double* f0,
+                      const double* vuv, double fs, double threshold, int fft_size_for_spectrum, double* aperiodicity,
+                      double* coarse_ap) {
+  if (!ctx || !b || !x || !tp || !f0 || !vuv || !aperiodicity) return wh::fail_msg("wh_d4c", "null argument");
+  if (fft_size_for_spectrum < 2) return wh::fail_msg("wh_d4c", "fft_size_for_spectrum must be >= 2");
+  const int nfft = pow2_at_least(4 * fs / 47.0 + 1);
+  const int interval = fs < 16000 ? 2000 : 3000;
+  return d4c_common(ctx, stream, b, x, tp, f0, vuv, fs, threshold, nfft, interval, fft_size_for_spectrum / 2 + 1,
+                    aperiodicity, coarse_ap);
+}
+
+extern "C" int wh_d4c_requiem(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp,
+                              double* f0, const double* vuv, double fs, double threshold, int fft_size,
+                              double* band_aperiodicity) {
+  if (!ctx || !b || !x || !tp || !f0 || !vuv || !band_aperiodicity) return wh::fail_msg("wh_d4c_requiem", "null argument");
+  const int nfft = fft_size > 0 ? fft_size : pow2_at_least(3 * fs / 47.0 + 1);
+  return d4c_common(ctx, stream, b, x, tp, f0, vuv, fs, threshold, nfft, 3000, 0, band_aperiodicity, nullptr);
+}

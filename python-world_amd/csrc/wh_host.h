@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -14,6 +15,7 @@ struct wh_ctx {
   double2* d_twiddle = nullptr;  // tables for N = 2 .. WH_MAX_FFT, table of size N at offset N
   void* ws = nullptr;            // growable scratch
   size_t ws_bytes = 0;
+  std::map<std::string, double*> tables;  // small constant tables resident on the device (windows, taps)
 };
 
 struct wh_batch {
@@ -35,6 +37,15 @@ int fail(const char* where, hipError_t e);
 int fail_msg(const char* where, const char* msg);
 int ws_reserve(wh_ctx* ctx, size_t bytes);  // grows ctx->ws (hipFree + hipMalloc => implicit sync)
 inline const double2* twiddle(const wh_ctx* ctx, int n) { return ctx->d_twiddle + n; }
+// Upload-once constant table keyed by name (synchronous on first use, cached afterwards).
+int const_table(wh_ctx* ctx, const std::string& key, const std::vector<double>& host, const double** out);
+// Opt a kernel into more than 64 KiB of dynamic LDS (gfx950: up to 160 KiB per workgroup).
+template <typename K>
+inline int allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 65536) return 0;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return e == hipSuccess ? 0 : fail("hipFuncSetAttribute", e);
+}
 }  // namespace wh
 
 #define WH_CHECK(expr)                                   \

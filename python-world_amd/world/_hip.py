@@ -35,6 +35,9 @@ SIGNATURES = {
     "wh_batch_destroy": (_int, [_vp]),
     "wh_num_frames": (ctypes.c_int64, [ctypes.c_int64, _dbl, _dbl]),
     "wh_cheaptrick": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _dbl, _vp, _vp]),
+    "wh_d4c": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int, _vp, _vp]),
+    "wh_d4c_bands": (_int, [_dbl, _int]),
+    "wh_d4c_requiem": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int, _vp]),
 }
 
 _lib = None

@@ -46,6 +46,15 @@ int wh_memcpy_d2h(void* h_dst, const void* src, size_t bytes, void* stream);
 int wh_memset(void* dst, int value, size_t bytes, void* stream);
 int wh_stream_sync(void* stream);
 
+/* Sticky device-side condition flags raised by kernels instead of failing silently; reading them
+ * synchronises the stream and clears them.  h_flags16[WH_FLAG_*] != 0 means the condition occurred. */
+#define WH_FLAG_STONEMASK_WINDOW 0 /* a frame's f0 needed a longer window than kmax: left unrefined */
+#define WH_FLAG_EVENT_OVERFLOW 1   /* a zero-crossing list exceeded its capacity (cannot happen for cap = len/2+2) */
+#define WH_FLAG_NOISE_SHORT 2      /* synthesis ran out of host-supplied noise samples */
+#define WH_FLAG_NO_PULSE 3         /* an utterance produced no pulse (reference asserts, synthesis.py:131) */
+#define WH_FLAG_PULSE_OVERFLOW 4   /* more pulses than the pulse capacity */
+int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16);
+
 /* ---- batch descriptor --------------------------------------------------------------------- */
 /* h_x_off[n_utt+1]: sample offsets into the concatenated waveform; h_frame_off[n_utt+1]: frame
  * offsets into the concatenated per-frame arrays.  Synchronous (small H2D copies). */
@@ -80,6 +89,30 @@ int wh_d4c_bands(double fs, int requiem);
  * band_aperiodicity[total_frames][wh_d4c_bands(fs,1)+2] in dB (row 0 = -60, last = -1e-12). */
 int wh_d4c_requiem(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, double* f0,
                    const double* vuv, double fs, double threshold, int fft_size, double* band_aperiodicity);
+
+/* ---- DIO: replaces dio()  (world/dio.py:10-55) -------------------------------------------------- */
+/* tp[total_frames]: frame times (s) = arange(nf)*frame_period/1000, nf = wh_num_frames(n, fs, frame_period).
+ * The band filters are DATA supplied by the host (so that the even-length Nuttall argmax tie that fixes
+ * each band's delay, dio.py:130-131, is decided by the host's NumPy exactly like the reference):
+ *   h_band_f0[n_bands]   boundary f0 of each band: f0_floor*2^((i+1)/channels_in_octave)   (dio.py:32-34)
+ *   h_band_len[n_bands]  tap count 4*int(target_fs/f/2+0.5);  h_band_taps: the Nuttall windows, concatenated
+ *   h_band_bias[n_bands] argmax of each window (the reference's index_bias)
+ *   h_lowcut[2*lowcut_half+1]  the zero-phase low-cut FIR of dio.py:80-83, lowcut_half = int(target_fs/50+0.5)
+ * Outputs: f0_out, vuv_out [total_frames]; optional cand_out / raw_out: for utterance u a row-major
+ * [n_bands][nf_u] block at offset frame_off[u]*n_bands (the reference's 'f0_candidates' / 'raw_f0_candidates').
+ * Decimation ratio is int(fs/target_fs) and the decimated rate is taken as target_fs, like the reference. */
+int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, double fs, double f0_floor,
+           double f0_ceil, double target_fs, double frame_period_ms, double allowed_range, int n_bands,
+           const double* h_band_f0, const int32_t* h_band_bias, const int32_t* h_band_len, const double* h_band_taps,
+           const double* h_lowcut, int lowcut_half, double* f0_out, double* vuv_out, double* cand_out, double* raw_out);
+
+/* ---- StoneMask: replaces stonemask()  (world/stonemask.py:8-27) -------------------------------- */
+/* f0[total_frames] in, refined_f0[total_frames] out (a different buffer: the reference returns a new
+ * array).  h_qtime[2*kmax+1] (HOST): h_qtime[k+kmax] = float("%.4f" % (k/fs)) — the reference
+ * quantises its window time base through string formatting (stonemask.py:38); the table is built by
+ * the host language so that the decimal rounding is exactly Python's.  kmax >= ceil(1.5*fs/min f0). */
+int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, const double* f0,
+                 double fs, const double* h_qtime, int kmax, double* refined_f0);
 
 #ifdef __cplusplus
 }

@@ -92,6 +92,8 @@ int wh_ctx_create(int device, wh_ctx** out) {
   }
   hipError_t e = hipMalloc((void**)&c->d_twiddle, tw.size() * sizeof(double2));
   if (e == hipSuccess) e = hipMemcpy(c->d_twiddle, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, 16 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemset(c->d_flags, 0, 16 * sizeof(int32_t));
   if (e != hipSuccess) {
     delete c;
     return wh::fail("wh_ctx_create", e);
@@ -105,8 +107,18 @@ int wh_ctx_destroy(wh_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   for (auto& kv : ctx->tables) (void)hipFree(kv.second);
   delete ctx;
+  return 0;
+}
+
+int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16) {
+  if (!ctx || !h_flags16) return wh::fail_msg("wh_take_flags", "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  WH_CHECK(hipMemcpyAsync(h_flags16, ctx->d_flags, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  WH_CHECK(hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int32_t), st));
+  WH_CHECK(hipStreamSynchronize(st));
   return 0;
 }
 

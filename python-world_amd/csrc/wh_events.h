@@ -1,0 +1,139 @@
+// Zero-crossing event extraction and event→frame interpolation shared by DIO and Harvest.
+// Reference semantics: ZeroCrossingEngine (world/dio.py:190-204 = world/harvest.py:283-297) and
+// get_f0_candidates / GetF0Candidates (world/dio.py:156-185, world/harvest.py:499-529).
+// The reference builds four ragged NumPy arrays per band and four interp1d objects; here the
+// crossings of a tile are flagged in registers, compacted in order with ONE packed 4x16-bit block
+// scan, and appended to per-(band, train) edge lists; frames later binary-search those lists.
+#pragma once
+#include "wh_device.h"
+
+namespace wh {
+
+__device__ __forceinline__ unsigned long long wave_scan_incl_u64(unsigned long long v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long u = (unsigned long long)__shfl_up((long long)v, o, 64);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+
+// Append the four crossing trains of one signal tile to their edge lists, preserving order.
+//   sig[i] = s[t0+i] for i in [0, tile+2) (LDS; values beyond M are ignored)
+//   train 0: negative-going crossings of s, 1: positive-going, 2: negative-going of diff(s), 3: positive-going
+//   edge value = (1-based sample position) - v[i]/(v[i+1]-v[i])   (dio.py:201)
+// edges: [4][cap]; base_cnt[4]: running counts (block-uniform registers, updated).
+// 256 threads, tile == 1024 (4 positions per thread).  Contains barriers.
+__device__ __forceinline__ void emit_crossings(const double* sig, int64_t t0, int64_t M, int tile, double* edges,
+                                               int64_t cap, int* base_cnt, unsigned long long* scratch,
+                                               int32_t* overflow_flag) {
+  const int tid = threadIdx.x;
+  double fine[4][4];
+  unsigned mask[4] = {0, 0, 0, 0};
+  unsigned long long packed = 0;
+  const int per = tile / WH_BLOCK;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q >= per) break;
+    const int i = tid * per + q;
+    const int64_t g = t0 + i;
+    const double a = sig[i], b = sig[i + 1], c = sig[i + 2];
+    if (g + 1 < M && a * b < 0) {  // crossing of s between g and g+1
+      const double fe = (double)(g + 1) - a / (b - a);
+      if (b < a) {
+        mask[0] |= 1u << q;
+        fine[0][q] = fe;
+      } else if (b > a) {
+        mask[1] |= 1u << q;
+        fine[1][q] = fe;
+      }
+    }
+    if (g + 2 < M) {
+      const double d0 = b - a, d1 = c - b;
+      if (d0 * d1 < 0) {
+        const double fe = (double)(g + 1) - d0 / (d1 - d0);
+        if (d1 < d0) {
+          mask[2] |= 1u << q;
+          fine[2][q] = fe;
+        } else if (d1 > d0) {
+          mask[3] |= 1u << q;
+          fine[3][q] = fe;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) packed |= (unsigned long long)__popc(mask[t]) << (16 * t);
+  const unsigned long long incl = wave_scan_incl_u64(packed);
+  const int w = tid >> 6;
+  __syncthreads();
+  if ((tid & 63) == 63) scratch[w] = incl;
+  __syncthreads();
+  unsigned long long excl = incl - packed;
+  unsigned long long total = 0;
+#pragma unroll
+  for (int i = 0; i < WH_BLOCK / 64; ++i) {
+    if (i < w) excl += scratch[i];
+    total += scratch[i];
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int pos = base_cnt[t] + (int)((excl >> (16 * t)) & 0xFFFF);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (mask[t] & (1u << q)) {
+        if (pos < cap) edges[(int64_t)t * cap + pos] = fine[t][q];
+        else atomicOr(overflow_flag, 1);
+        ++pos;
+      }
+    }
+    base_cnt[t] += (int)((total >> (16 * t)) & 0xFFFF);
+  }
+}
+
+// Interpolate the four interval-F0 trains at time t (linear, end-segment extrapolation — SciPy's
+// interp1d(..., fill_value='extrapolate') arithmetic) and reduce: mean and, optionally, ddof=1 std.
+// Fewer than 3 intervals in any train → (0, 1000) (dio.py:159-162,182-184).
+__device__ __forceinline__ void interp_four_trains(const double* __restrict__ edges, int64_t cap,
+                                                   const int32_t* __restrict__ cnt, double fs, double t, bool want_dev,
+                                                   double* cand, double* dev) {
+  bool usable = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) usable = usable && (cnt[k] - 1 >= 3);
+  if (!usable) {
+    *cand = 0.0;
+    *dev = 1000.0;
+    return;
+  }
+  double v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double* e = edges + (int64_t)k * cap;
+    const int ni = cnt[k] - 1;  // intervals; location i = (e[i]+e[i+1])/2/fs
+    int lo = 0, hi = ni;        // lower_bound: count of locations < t
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const double loc = (e[mid] + e[mid + 1]) / 2 / fs;
+      if (loc < t) lo = mid + 1; else hi = mid;
+    }
+    int ih = lo < 1 ? 1 : (lo > ni - 1 ? ni - 1 : lo);
+    const int il = ih - 1;
+    const double x_lo = (e[il] + e[il + 1]) / 2 / fs;
+    const double x_hi = (e[ih] + e[ih + 1]) / 2 / fs;
+    const double y_lo = fs / (e[il + 1] - e[il]);
+    const double y_hi = fs / (e[ih + 1] - e[ih]);
+    const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+    v[k] = slope * (t - x_lo) + y_lo;
+  }
+  const double mean = (((v[0] + v[1]) + v[2]) + v[3]) / 4;
+  *cand = mean;
+  if (want_dev) {
+    const double d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+    *dev = sqrt((((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3) / 3);
+  } else {
+    *dev = 0.0;
+  }
+}
+
+}  // namespace wh

@@ -16,6 +16,7 @@ struct wh_ctx {
   void* ws = nullptr;            // growable scratch
   size_t ws_bytes = 0;
   std::map<std::string, double*> tables;  // small constant tables resident on the device (windows, taps)
+  int32_t* d_flags = nullptr;             // [16] sticky device-side condition flags (see wh_take_flags)
 };
 
 struct wh_batch {

@@ -35,6 +35,10 @@ SIGNATURES = {
     "wh_batch_destroy": (_int, [_vp]),
     "wh_num_frames": (ctypes.c_int64, [ctypes.c_int64, _dbl, _dbl]),
     "wh_cheaptrick": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _dbl, _vp, _vp]),
+    "wh_take_flags": (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
+    "wh_dio": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _int,
+                      _vp, _vp, _vp, _vp]),
+    "wh_stonemask": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _int, _vp]),
     "wh_d4c": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int, _vp, _vp]),
     "wh_d4c_bands": (_int, [_dbl, _int]),
     "wh_d4c_requiem": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int, _vp]),
@@ -124,6 +128,12 @@ class Runtime:
     @staticmethod
     def ptr(t):
         return _vp(t.data_ptr()) if t is not None else _vp(None)
+
+    def take_flags(self):
+        """Read-and-clear the sticky device condition flags (synchronises the current stream)."""
+        buf = (ctypes.c_int32 * 16)()
+        check(self.lib.wh_take_flags(self.ctx, self.stream(), buf))
+        return list(buf)
 
     # ---- batch descriptor -----------------------------------------------------------------
     def make_batch(self, x_off, frame_off):

@@ -1,0 +1,66 @@
+"""Host-built constant tables handed to the HIP library as data.
+
+These are the places where the reference's result depends on Python/NumPy *host* semantics
+(string-formatted rounding, an argmax tie decided by the last bit of np.cos), so they are
+evaluated here with the same NumPy expressions and uploaded.
+"""
+import math
+
+import numpy as np
+from scipy.signal.windows import hann
+
+
+def nuttall(n):
+    """4-term Nuttall window through the (1x4)@(4xN) product the reference uses (world/dio.py:208-212),
+    so that the two mathematically equal maxima of an even-length window compare the same way."""
+    t = np.asmatrix(np.arange(n) * 2 * math.pi / (n - 1))
+    coefs = np.array([0.355768, -0.487396, 0.144232, -0.012604])
+    w = coefs @ np.cos(np.matrix([0, 1, 2, 3]).T @ t)
+    return np.squeeze(np.asarray(w))
+
+
+def dio_tables(f0_floor, f0_ceil, channels_in_octave, target_fs):
+    """Band list, Nuttall low-pass taps, delay indices and the low-cut FIR of DIO
+    (world/dio.py:32-34,80-83,129-131)."""
+    bands = np.arange(math.ceil(np.log2(f0_ceil / f0_floor) * channels_in_octave)) + 1
+    bands = f0_floor * (2.0 ** (bands / channels_in_octave))
+    taps, lens, bias = [], [], []
+    for bf in bands:
+        half = int(target_fs / bf / 2 + 0.5)
+        w = nuttall(half * 4)
+        taps.append(w)
+        lens.append(len(w))
+        bias.append(int(w.argmax()))
+    cut = int(target_fs / 50 + 0.5)
+    h = hann(2 * cut + 3)[1:-1]
+    h = -h / np.sum(h)
+    h[cut] += 1
+    return {
+        "band_f0": np.ascontiguousarray(bands, dtype=np.float64),
+        "band_len": np.asarray(lens, dtype=np.int32),
+        "band_bias": np.asarray(bias, dtype=np.int32),
+        "band_taps": np.ascontiguousarray(np.concatenate(taps), dtype=np.float64),
+        "lowcut": np.ascontiguousarray(h, dtype=np.float64),
+        "lowcut_half": cut,
+    }
+
+
+_QT_CACHE = {}
+
+
+def quantised_times(fs, kmax):
+    """table[k+kmax] = float('%.4f' % (k/fs)) for k in [-kmax, kmax] (world/stonemask.py:38)."""
+    key = (float(fs), int(kmax))
+    t = _QT_CACHE.get(key)
+    if t is None:
+        t = np.array([float("{0:.4f}".format(e)) for e in (np.arange(-kmax, kmax + 1) / fs)], dtype=np.float64)
+        _QT_CACHE[key] = t
+    return t
+
+
+def frame_count(n_samples, fs, frame_period):
+    return int(1000 * n_samples / fs / frame_period + 1)
+
+
+def frame_times(n_frames, frame_period):
+    return np.arange(0, n_frames) * frame_period / 1000

@@ -114,6 +114,31 @@ int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const 
 int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, const double* f0,
                  double fs, const double* h_qtime, int kmax, double* refined_f0);
 
+/* ---- Synthesis: replaces synthesis()  (world/synthesis.py:21-82) ------------------------------- */
+/* Inputs per frame (batch frame layout): tp, f0, vuv [total_frames]; spectrogram and aperiodicity
+ * [total_frames][fft_size/2+1] frame-major (aperiodicity = amplitude as produced by wh_d4c).
+ * Output y: concatenated waveforms, offsets h_y_off[n_utt+1] (HOST).  The length of utterance u must be
+ * len(np.arange(tp[0], tp[-1]+1/fs, 1/fs)) and its time axis is t_i = h_t0[u] + i*h_dt[u] with
+ * h_dt = (t0 + 1/fs) - t0: NumPy's float arange semantics are evaluated by the host (synthesis.py:39; the
+ * 48 kHz case yields 480002 samples, not 480001).
+ * pulse_cap: pulse slots per utterance (>= number of pulses; ny/8+64 suffices for mean f0 < fs/8);
+ *   overflow raises WH_FLAG_PULSE_OVERFLOW.
+ * noise: optional DEVICE array of standard-normal samples, utterance u reads noise[h_noise_off[u] ..
+ *   h_noise_off[u+1]); pulse i consumes max(3, noise_size_i) consecutive samples in pulse order — exactly
+ *   the reference's np.random.randn call sequence (synthesis.py:93), so feeding np.random.randn(total)
+ *   reproduces the reference bit-for-bit in the noise it uses.  noise == NULL: a counter-based Philox
+ *   generator seeded by `seed` is used on the device instead (statistically equivalent, not the same samples).
+ * pulse_count_out: optional DEVICE int32[n_utt]. */
+int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0, const double* vuv,
+                 const double* spectrogram, const double* aperiodicity, double fs, int fft_size, const int64_t* h_y_off,
+                 const double* h_t0, const double* h_dt, int64_t pulse_cap, const double* noise,
+                 const int64_t* h_noise_off, uint64_t seed, double* y, int32_t* pulse_count_out);
+/* Pulse bookkeeping only (synchronous): per-utterance pulse count and the exact number of normal
+ * samples the reference would draw, sum_i max(3, noise_size_i).  HOST outputs. */
+int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,
+                      const double* vuv, double fs, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
+                      int64_t pulse_cap, int32_t* h_pulse_count, int64_t* h_noise_total);
+
 #ifdef __cplusplus
 }
 #endif

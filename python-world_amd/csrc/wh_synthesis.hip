@@ -1,0 +1,613 @@
+// Pulse-by-pulse overlap-add synthesis, batched.  Replaces synthesis() (world/synthesis.py:21-82).
+//
+//   prep_kernel     : per output sample: f0/vuv linear interpolation at t_i, phase increment
+//                     2*pi*f0/fs (synthesis.py:121-128).  Embarrassingly parallel.
+//   phase_kernel    : one wave per utterance: the cumulative phase is a SEQUENTIAL float64 sum in the
+//                     reference (np.cumsum); each lane rebuilds exactly that left-to-right sum for its
+//                     element from wave-broadcast values, so loads/stores are coalesced and the pulse
+//                     positions derived from the phase are bit-identical to NumPy's.
+//   pulse_kernel    : per utterance: wrap phase, detect pulses (|d wrap| > pi), ordered compaction,
+//                     1-based sample index and fractional shift per pulse, noise-stream offsets
+//                     (synthesis.py:129-138, 65).
+//   response_kernel : one workgroup per pulse: interpolate the two neighbouring frames, build the
+//                     minimum-phase periodic and aperiodic responses with six LDS FFTs
+//                     (synthesis.py:86-116,144-180), excite the aperiodic one with zero-mean noise
+//                     (direct convolution == the reference's truncated fftfilt), and scatter-add into
+//                     y with the reference's clipped-index semantics.
+#include "wh_host.h"
+#include "wh_device.h"
+
+namespace {
+
+struct SynUtt {
+  int64_t f_off, nf;      // frames
+  int64_t y_off, ny;      // output samples
+  int64_t p_off, pcap;    // pulse slots
+  int64_t noise_off, noise_len;  // host-supplied noise stream (if any)
+  double t0, dt;          // time axis t_i = t0 + i*dt  (NumPy arange semantics, host-computed)
+  uint64_t seed;          // device RNG stream id when no noise is supplied
+};
+
+__device__ __forceinline__ double lerp_tp(const double* __restrict__ tp, const double* __restrict__ v, int64_t nf, double t) {
+  // searchsorted-left, hi clipped to [1, nf-1]; slope*(t-x_lo)+y_lo  (SciPy interp1d linear + extrapolate)
+  int64_t lo = 0, hi = nf;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (tp[mid] < t) lo = mid + 1; else hi = mid;
+  }
+  int64_t ih = lo < 1 ? 1 : (lo > nf - 1 ? nf - 1 : lo);
+  const int64_t il = ih - 1;
+  const double slope = (v[ih] - v[il]) / (tp[ih] - tp[il]);
+  return slope * (t - tp[il]) + v[il];
+}
+
+__global__ __launch_bounds__(256) void prep_kernel(const SynUtt* __restrict__ meta, const double* __restrict__ tp,
+                                                   const double* __restrict__ f0, const double* __restrict__ vuv,
+                                                   double fs, double* __restrict__ phase, uint8_t* __restrict__ vuv_s) {
+  const SynUtt m = meta[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m.ny) return;
+  const double t = m.t0 + (double)i * m.dt;
+  const double* tpu = tp + m.f_off;
+  const double f_raw = lerp_tp(tpu, f0 + m.f_off, m.nf, t);
+  const bool v = lerp_tp(tpu, vuv + m.f_off, m.nf, t) > 0.5;
+  double fi = f_raw * (v ? 1.0 : 0.0);
+  if (fi == 0.0) fi = fi + 500.0;  // default_f0, synthesis.py:126
+  phase[m.y_off + i] = 2 * M_PI * fi / fs;
+  vuv_s[m.y_off + i] = v ? 1 : 0;
+}
+
+// In-place sequential cumulative sum, one 64-lane wave per utterance.
+__global__ __launch_bounds__(64) void phase_kernel(const SynUtt* __restrict__ meta, double* __restrict__ phase) {
+  const SynUtt m = meta[blockIdx.x];
+  double* p = phase + m.y_off;
+  const int lane = threadIdx.x;
+  double carry = 0.0;
+  for (int64_t base = 0; base < m.ny; base += 64) {
+    const int64_t i = base + lane;
+    const double v = i < m.ny ? p[i] : 0.0;
+    double run = carry;
+    double mine = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+      run += __shfl(v, j, 64);  // every lane adds in the same left-to-right order
+      if (j == lane) mine = run;
+    }
+    if (i < m.ny) p[i] = mine;
+    carry = run;  // includes zeros past the end only on the last tile
+  }
+}
+
+constexpr int kPTile = 1024;
+
+__global__ __launch_bounds__(256) void pulse_kernel(const SynUtt* __restrict__ meta, const double* __restrict__ phase,
+                                                    double fs, double* __restrict__ p_time, int64_t* __restrict__ p_idx,
+                                                    double* __restrict__ p_shift, int64_t* __restrict__ p_noff,
+                                                    int32_t* __restrict__ p_count, int32_t* __restrict__ flags) {
+  __shared__ double wr[kPTile + 1];
+  __shared__ int wsum[8];
+  __shared__ long long wsum64[8];
+  const SynUtt m = meta[blockIdx.x];
+  const double* ph = phase + m.y_off;
+  double* pt = p_time + m.p_off;
+  int64_t* pi = p_idx + m.p_off;
+  double* psh = p_shift + m.p_off;
+  int64_t* pn = p_noff + m.p_off;
+  const double two_pi = 2 * M_PI;
+  int count = 0;
+  for (int64_t t0 = 0; t0 < m.ny - 1; t0 += kPTile) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kPTile + 1; i += 256) {
+      const int64_t g = t0 + i;
+      wr[i] = g < m.ny ? fmod(ph[g], two_pi) : 0.0;  // np.remainder of a non-negative value
+    }
+    __syncthreads();
+    // 4 consecutive samples per thread
+    unsigned mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = threadIdx.x * 4 + q;
+      const int64_t g = t0 + i;
+      if (g < m.ny - 1 && fabs(wr[i + 1] - wr[i]) > M_PI) mask |= 1u << q;
+    }
+    int c = __popc(mask);
+    int incl = c;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int uu = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += uu;
+    }
+    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int excl = incl - c, total = 0;
+    for (int w = 0; w < 4; ++w) {
+      if (w < (int)(threadIdx.x >> 6)) excl += wsum[w];
+      total += wsum[w];
+    }
+    int pos = count + excl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (mask & (1u << q)) {
+        const int64_t g = t0 + threadIdx.x * 4 + q;
+        if (pos < m.pcap) {
+          const double tt = m.t0 + (double)g * m.dt;
+          pt[pos] = tt;
+          pi[pos] = (int64_t)floor(tt * fs + 0.5) + 1;  // Decimal ROUND_HALF_UP then +1 (synthesis.py:132)
+        } else {
+          atomicOr(flags + WH_FLAG_PULSE_OVERFLOW, 1);
+        }
+        ++pos;
+      }
+    }
+    count += total;
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (count > m.pcap) count = (int)m.pcap;
+  if (threadIdx.x == 0) {
+    p_count[blockIdx.x] = count;
+    if (count == 0) atomicOr(flags + WH_FLAG_NO_PULSE, 1);
+  }
+  // fractional shift and noise-stream offsets (exclusive prefix sum of max(3, noise_size))
+  long long run = 0;
+  for (int base = 0; base < count; base += 256) {
+    const int i = base + threadIdx.x;
+    long long d = 0;
+    if (i < count) {
+      int64_t id = pi[i];
+      int64_t a = id - 1, b = id;  // wrap_phase[idx-1], wrap_phase[idx]
+      a = a < 0 ? 0 : (a > m.ny - 1 ? m.ny - 1 : a);
+      b = b < 0 ? 0 : (b > m.ny - 1 ? m.ny - 1 : b);
+      const double y1 = fmod(ph[a], two_pi) - 2.0 * M_PI;
+      const double y2 = fmod(ph[b], two_pi);
+      psh[i] = (-y1 / (y2 - y1)) / fs;
+      const int64_t nxt = pi[i + 1 < count ? i + 1 : count - 1];
+      const int64_t ns = nxt - id;
+      d = ns > 3 ? ns : 3;
+    }
+    long long incl = d;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long uu = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += uu;
+    }
+    __syncthreads();
+    if (lane == 63) wsum64[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    long long excl = incl - d, total = 0;
+    for (int w = 0; w < 4; ++w) {
+      if (w < (int)(threadIdx.x >> 6)) excl += wsum64[w];
+      total += wsum64[w];
+    }
+    if (i < count) pn[i] = run + excl;
+    run += total;
+  }
+  if (threadIdx.x == 0 && m.noise_len >= 0 && run > m.noise_len) atomicOr(flags + WH_FLAG_NOISE_SHORT, 1);
+}
+
+// Exclusive prefix of the per-utterance pulse counts → flat pulse numbering for the response grid.
+__global__ void pulse_base_kernel(const int32_t* __restrict__ p_count, int n_utt, int64_t* __restrict__ base) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int u = 0; u < n_utt; ++u) {
+      base[u] = run;
+      run += p_count[u];
+    }
+    base[n_utt] = run;
+  }
+}
+
+// ---- counter-based normal generator (Philox-4x32-10 + Box-Muller) for the no-host-noise mode ----
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+  c1 = (uint32_t)p1;
+  c3 = (uint32_t)p0;
+  c0 = n0;
+  c2 = n2;
+}
+__device__ __forceinline__ double normal_at(uint64_t seed, uint64_t q) {
+  uint32_t c0 = (uint32_t)(q >> 1), c1 = (uint32_t)((q >> 1) >> 32), c2 = 0x9E3779B9u, c3 = 0x243F6A88u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const double u1 = ((double)c0 * 4294967296.0 + (double)c1 + 0.5) * (1.0 / 18446744073709551616.0);
+  const double u2 = ((double)c2 * 4294967296.0 + (double)c3 + 0.5) * (1.0 / 18446744073709551616.0);
+  const double rr = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincos(2 * M_PI * u2, &s, &c);
+  return (q & 1) ? rr * s : rr * c;
+}
+
+// log|.|/2 of a K-bin amplitude-like spectrum (mirrored to N), FFT, fold the cepstrum onto its upper half
+// (x2, bin 0 kept), IFFT, complex exp  → minimum-phase spectrum in buf[0..N)  (synthesis.py:103-111).
+template <int N>
+__device__ __forceinline__ void min_phase(const double* amp_half, double2* buf, const double2* tw) {
+  for (int n = threadIdx.x; n < N; n += WH_BLOCK) {
+    const int k = n <= N / 2 ? n : N - n;
+    buf[n] = make_double2(log(fabs(amp_half[k])) / 2, 0.0);
+  }
+  __syncthreads();
+  wh::fft_lds<N, false>(buf, tw);
+  for (int n = threadIdx.x; n < N; n += WH_BLOCK) {
+    const double c = buf[n].x;
+    const double v = n == 0 ? c : (n >= N / 2 ? c * 2 : 0.0);
+    buf[n] = make_double2(v, 0.0);
+  }
+  __syncthreads();
+  wh::fft_lds<N, true>(buf, tw);
+  for (int n = threadIdx.x; n < N; n += WH_BLOCK) {
+    const double2 z = buf[n];
+    const double e = exp(z.x / N);
+    double s, c;
+    sincos(z.y / N, &s, &c);
+    buf[n] = make_double2(e * c, e * s);
+  }
+  __syncthreads();
+}
+
+template <int N>
+__global__ __launch_bounds__(WH_BLOCK) void response_kernel(
+    const SynUtt* __restrict__ meta, const double* __restrict__ tp, const double* __restrict__ spectrogram,
+    const double* __restrict__ aperiodicity, double fs, const double* __restrict__ p_time,
+    const int64_t* __restrict__ p_idx, const double* __restrict__ p_shift, const int64_t* __restrict__ p_noff,
+    const int32_t* __restrict__ p_count, const int64_t* __restrict__ p_base, int n_utt,
+    const uint8_t* __restrict__ vuv_s, const double* __restrict__ noise, const double* __restrict__ dc_base,
+    const double2* __restrict__ tw, double* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int K = N / 2 + 1;
+  constexpr int NZ = 256;
+  double2* buf = reinterpret_cast<double2*>(smem);                      // N
+  double* resp = reinterpret_cast<double*>(smem + sizeof(double2) * N);  // N   periodic response (or zeros)
+  double* ra = resp + N;                                                 // N   aperiodic response
+  double* spec = ra + N;                                                 // K+7
+  double* asp = spec + (K + 7);                                          // K+7
+  double* nz = asp + (K + 7);                                            // NZ
+  double* scratch = nz + NZ;                                             // 16
+
+  const int64_t total_pulses = p_base[n_utt];
+  for (int64_t gp = blockIdx.x; gp < total_pulses; gp += gridDim.x) {
+  __syncthreads();
+  int u;
+  {
+    int lo = 0, hi = n_utt;  // largest u with p_base[u] <= gp
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (p_base[mid] <= gp) lo = mid; else hi = mid;
+    }
+    u = lo;
+  }
+  const SynUtt m = meta[u];
+  const int i = (int)(gp - p_base[u]);
+  const int count = p_count[u];
+  const double ptime = p_time[m.p_off + i];
+  const int64_t pidx = p_idx[m.p_off + i];
+  const double shift = p_shift[m.p_off + i];
+  const int64_t pidx_next = p_idx[m.p_off + (i + 1 < count ? i + 1 : count - 1)];
+  const int64_t noise_size = pidx_next - pidx;
+  const double* tpu = tp + m.f_off;
+
+  // ---- spectral parameters of this pulse (synthesis.py:49-51,144-180) -------------------------
+  int64_t flo, fhi;
+  double a, b;
+  bool same;
+  {
+    // temporal_position_index = interp(tp -> 1..F)(time), clipped to [1, F]
+    int64_t lo = 0, hi = m.nf;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (tpu[mid] < ptime) lo = mid + 1; else hi = mid;
+    }
+    int64_t ih = lo < 1 ? 1 : (lo > m.nf - 1 ? m.nf - 1 : lo);
+    const int64_t il = ih - 1;
+    const double slope = ((double)(ih + 1) - (double)(il + 1)) / (tpu[ih] - tpu[il]);
+    double pos = slope * (ptime - tpu[il]) + (double)(il + 1);
+    pos = fmax(1.0, fmin((double)m.nf, pos));
+    flo = (int64_t)floor(pos) - 1;
+    fhi = (int64_t)ceil(pos) - 1;
+    const double t1 = tpu[flo], t2 = tpu[fhi];
+    const double xq = fmax(t1, fmin(t2, ptime));
+    same = (t1 == t2);
+    b = same ? 0.0 : (xq - t1) / (t2 - t1);
+    a = 1 - b;
+  }
+  const double* s_lo = spectrogram + (m.f_off + flo) * K;
+  const double* s_hi = spectrogram + (m.f_off + fhi) * K;
+  const double* a_lo = aperiodicity + (m.f_off + flo) * K;
+  const double* a_hi = aperiodicity + (m.f_off + fhi) * K;
+  // aperiodic_slice[0] decides voicing (synthesis.py:69)
+  double aper0;
+  {
+    const double al = a_lo[0] * a_lo[0], ah = a_hi[0] * a_hi[0];
+    aper0 = same ? al : a * al + b * ah;
+  }
+  int64_t vi = pidx - 1;
+  vi = vi < 0 ? 0 : (vi > m.ny - 1 ? m.ny - 1 : vi);
+  const bool voiced = (vuv_s[m.y_off + vi] != 0) && (aper0 <= 0.999);
+
+  for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+    const double sl = s_lo[k], sh = s_hi[k];
+    const double al = a_lo[k] * a_lo[k], ah = a_hi[k] * a_hi[k];
+    const double pl = fmax(0.001, 1 - al), ph = fmax(0.001, 1 - ah);
+    const double sp = same ? sl : a * sl + b * sh;
+    const double pe = same ? pl : a * pl + b * ph;
+    const double ap = same ? al : a * al + b * ah;
+    double v = sp * pe;  // periodic spectrum
+    if (v == 0.0) v = 2.220446049250313e-16;
+    spec[k] = v;
+    double w = voiced ? sp * ap : sp;  // aperiodic spectrum
+    if (w == 0.0) w = 2.220446049250313e-16;
+    asp[k] = w;
+  }
+  __syncthreads();
+
+  // ---- periodic response (synthesis.py:100-116) -------------------------------------------------
+  if (voiced) {
+    min_phase<N>(spec, buf, tw);
+    const double coef = 2.0 * M_PI * fs / N;
+    // keep bins 0..N/2, apply the fractional delay, Hermitian-extend
+    for (int k = threadIdx.x; k <= N / 2; k += WH_BLOCK) {
+      const double th = coef * shift * (double)k;
+      double s, c;
+      sincos(th, &s, &c);
+      const double2 z = buf[k];
+      const double2 r = make_double2(z.x * c + z.y * s, z.y * c - z.x * s);  // z * exp(-i th)
+      spec[k] = r.x;       // stash (spec/asp periodic copy no longer needed: spec reused as re, nz.. careful)
+      resp[k] = r.y;       // imag parts parked in resp[0..N/2]
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += WH_BLOCK) {
+      const int k = n <= N / 2 ? n : N - n;
+      const double re = spec[k], im = resp[k];
+      buf[n] = make_double2(re, n <= N / 2 ? im : -im);
+    }
+    __syncthreads();
+    wh::fft_lds<N, true>(buf, tw);
+    double part = 0.0;
+    for (int mm = threadIdx.x; mm < N; mm += WH_BLOCK) {
+      const double v = buf[(mm + N / 2) & (N - 1)].x / N;  // fftshift(real(ifft))
+      resp[mm] = v;
+      part += v;
+    }
+    const double total = wh::block_sum(part, scratch);
+    const double gain = sqrt((double)(noise_size > 1 ? noise_size : 1));
+    for (int mm = threadIdx.x; mm < N; mm += WH_BLOCK) resp[mm] = (resp[mm] + dc_base[mm] * -total) * gain;
+  } else {
+    for (int mm = threadIdx.x; mm < N; mm += WH_BLOCK) resp[mm] = 0.0;
+  }
+  __syncthreads();
+
+  // ---- aperiodic response (synthesis.py:86-96) --------------------------------------------------
+  min_phase<N>(asp, buf, tw);
+  wh::fft_lds<N, true>(buf, tw);
+  for (int mm = threadIdx.x; mm < N; mm += WH_BLOCK) ra[mm] = buf[(mm + N / 2) & (N - 1)].x / N;
+  __syncthreads();
+
+  // noise excitation: zero-mean, max(3, noise_size) samples, y[m] = sum_j nz[j] * ra[m-j], m < N
+  const int64_t nd = noise_size > 3 ? noise_size : 3;
+  const int64_t noff = p_noff[m.p_off + i];
+  auto noise_at = [&](int64_t j) -> double {
+    if (noise) {
+      const int64_t q = noff + j;
+      return q < m.noise_len ? noise[m.noise_off + q] : 0.0;
+    }
+    return normal_at(m.seed, (uint64_t)(noff + j));
+  };
+  double part = 0.0;
+  for (int64_t j = threadIdx.x; j < nd; j += WH_BLOCK) part += noise_at(j);
+  const double mean = wh::block_sum(part, scratch) / (double)nd;
+  double acc[N / WH_BLOCK];
+#pragma unroll
+  for (int q = 0; q < N / WH_BLOCK; ++q) acc[q] = 0.0;
+  for (int64_t j0 = 0; j0 < nd; j0 += NZ) {
+    const int cnt = (int)(nd - j0 < NZ ? nd - j0 : NZ);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cnt; j += WH_BLOCK) nz[j] = noise_at(j0 + j) - mean;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N / WH_BLOCK; ++q) {
+      const int mm = threadIdx.x + q * WH_BLOCK;
+      double s = 0.0;
+      const int jmax = (int)((int64_t)mm - j0 < cnt - 1 ? (int64_t)mm - j0 : cnt - 1);
+      for (int j = 0; j <= jmax; ++j) s += nz[j] * ra[mm - (int)j0 - j];
+      acc[q] += s;
+    }
+  }
+
+  // ---- overlap-add with the reference's clipped fancy-index semantics (Q8) -----------------------
+  double* yu = y + m.y_off;
+#pragma unroll
+  for (int q = 0; q < N / WH_BLOCK; ++q) {
+    const int mm = threadIdx.x + q * WH_BLOCK;
+    const int64_t tgt = pidx - N / 2 + 1 + mm;  // 1-based
+    const double v = resp[mm] + acc[q];
+    if (tgt < 1) continue;                    // clipped to 1 and overwritten by the in-range tap
+    if (tgt < m.ny) atomicAdd(&yu[tgt - 1], v);
+    else if (mm == N - 1) atomicAdd(&yu[m.ny - 1], v);  // last duplicate wins on the high side
+  }
+  }  // pulse loop
+}
+
+template <int N>
+int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynUtt* d_meta, const double* tp,
+                const double* spec, const double* ap, double fs, const double* p_time, const int64_t* p_idx,
+                const double* p_shift, const int64_t* p_noff, const int32_t* p_count, const int64_t* p_base,
+                const uint8_t* vuv_s, const double* noise, double* y) {
+  std::vector<double> dc(N);
+  double sum = 0.0;
+  for (int n = 0; n < N; ++n) {  // hanning(N+2)[1:-1] normalised (synthesis.py:57-58)
+    dc[n] = 0.5 - 0.5 * cos(2.0 * M_PI * (double)(n + 1) / (double)(N + 1));
+    sum += dc[n];
+  }
+  for (int n = 0; n < N; ++n) dc[n] /= sum;
+  const double* d_dc = nullptr;
+  if (int rc = wh::const_table(ctx, "dc_base:" + std::to_string(N), dc, &d_dc)) return rc;
+  const size_t lds = sizeof(double2) * N + sizeof(double) * (2 * N + 2 * (N / 2 + 8) + 256 + 16);
+  if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
+  int64_t grid = pcap_max * B;
+  if (grid > 256 * 16) grid = 256 * 16;  // persistent-style: workgroups stride over the flat pulse list
+  hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(WH_BLOCK), lds, st, d_meta, tp, spec, ap, fs,
+                     p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, d_dc, wh::twiddle(ctx, N), y);
+  WH_LAUNCH_CHECK("response_kernel");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,
+                            const double* vuv, const double* spectrogram, const double* aperiodicity, double fs,
+                            int fft_size, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
+                            int64_t pulse_cap, const double* noise, const int64_t* h_noise_off, uint64_t seed, double* y,
+                            int32_t* pulse_count_out) {
+  if (!ctx || !b || !tp || !f0 || !vuv || !spectrogram || !aperiodicity || !h_y_off || !h_t0 || !h_dt || !y)
+    return wh::fail_msg("wh_synthesis", "null argument");
+  if (noise && !h_noise_off) return wh::fail_msg("wh_synthesis", "noise given without h_noise_off");
+  if (pulse_cap < 1) return wh::fail_msg("wh_synthesis", "pulse_cap must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = b->n_utt;
+  std::vector<SynUtt> meta(B);
+  int64_t max_ny = 0;
+  for (int u = 0; u < B; ++u) {
+    SynUtt& m = meta[u];
+    m.f_off = b->h_frame_off[u];
+    m.nf = b->h_frame_off[u + 1] - b->h_frame_off[u];
+    if (m.nf < 2) return wh::fail_msg("wh_synthesis", "an utterance has fewer than 2 frames");
+    m.y_off = h_y_off[u];
+    m.ny = h_y_off[u + 1] - h_y_off[u];
+    m.p_off = (int64_t)u * pulse_cap;
+    m.pcap = pulse_cap;
+    m.noise_off = noise ? h_noise_off[u] : 0;
+    m.noise_len = noise ? h_noise_off[u + 1] - h_noise_off[u] : -1;
+    m.t0 = h_t0[u];
+    m.dt = h_dt[u];
+    m.seed = seed * 0x9E3779B97F4A7C15ull + (uint64_t)u * 0xD1B54A32D192ED03ull + 1;
+    max_ny = std::max(max_ny, m.ny);
+  }
+  const int64_t ny_tot = h_y_off[B];
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  const size_t o_meta = off; off += al(sizeof(SynUtt) * B);
+  const size_t o_phase = off; off += al(sizeof(double) * ny_tot);
+  const size_t o_vuv = off; off += al((size_t)ny_tot);
+  const size_t o_pt = off; off += al(sizeof(double) * B * pulse_cap);
+  const size_t o_pi = off; off += al(sizeof(int64_t) * B * pulse_cap);
+  const size_t o_ps = off; off += al(sizeof(double) * B * pulse_cap);
+  const size_t o_pn = off; off += al(sizeof(int64_t) * B * pulse_cap);
+  const size_t o_pc = off; off += al(sizeof(int32_t) * B);
+  const size_t o_pb = off; off += al(sizeof(int64_t) * (B + 1));
+  if (int rc = wh::ws_reserve(ctx, off)) return rc;
+  char* ws = reinterpret_cast<char*>(ctx->ws);
+  SynUtt* d_meta = reinterpret_cast<SynUtt*>(ws + o_meta);
+  double* d_phase = reinterpret_cast<double*>(ws + o_phase);
+  uint8_t* d_vuv = reinterpret_cast<uint8_t*>(ws + o_vuv);
+  int64_t* d_pb = reinterpret_cast<int64_t*>(ws + o_pb);
+  double* d_pt = reinterpret_cast<double*>(ws + o_pt);
+  int64_t* d_pi = reinterpret_cast<int64_t*>(ws + o_pi);
+  double* d_ps = reinterpret_cast<double*>(ws + o_ps);
+  int64_t* d_pn = reinterpret_cast<int64_t*>(ws + o_pn);
+  int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
+  WH_CHECK(hipMemcpyAsync(d_meta, meta.data(), sizeof(SynUtt) * B, hipMemcpyHostToDevice, st));
+  WH_CHECK(hipStreamSynchronize(st));
+  WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
+  hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
+                     d_phase, d_vuv);
+  WH_LAUNCH_CHECK("prep_kernel");
+  hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(64), 0, st, d_meta, d_phase);
+  WH_LAUNCH_CHECK("phase_kernel");
+  hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc,
+                     ctx->d_flags);
+  WH_LAUNCH_CHECK("pulse_kernel");
+  hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb);
+  WH_LAUNCH_CHECK("pulse_base_kernel");
+  int rc;
+  switch (fft_size) {
+    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, y); break;
+    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, y); break;
+    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, y); break;
+    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, y); break;
+    default: return wh::fail_msg("wh_synthesis", "fft_size must be a power of two in [512, 4096]");
+  }
+  if (rc) return rc;
+  if (pulse_count_out) WH_CHECK(hipMemcpyAsync(pulse_count_out, d_pc, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// Pulse bookkeeping only (no responses): per-utterance pulse count and total noise draws
+// sum(max(3, noise_size)) — lets a host draw EXACTLY the reference's number of randn samples.
+extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,
+                                 const double* vuv, double fs, const int64_t* h_y_off, const double* h_t0,
+                                 const double* h_dt, int64_t pulse_cap, int32_t* h_pulse_count,
+                                 int64_t* h_noise_total) {
+  if (!ctx || !b || !tp || !f0 || !vuv || !h_y_off || !h_t0 || !h_dt || !h_pulse_count || !h_noise_total)
+    return wh::fail_msg("wh_synthesis_plan", "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = b->n_utt;
+  std::vector<SynUtt> meta(B);
+  int64_t max_ny = 0;
+  for (int u = 0; u < B; ++u) {
+    SynUtt& m = meta[u];
+    m.f_off = b->h_frame_off[u];
+    m.nf = b->h_frame_off[u + 1] - b->h_frame_off[u];
+    if (m.nf < 2) return wh::fail_msg("wh_synthesis_plan", "an utterance has fewer than 2 frames");
+    m.y_off = h_y_off[u];
+    m.ny = h_y_off[u + 1] - h_y_off[u];
+    m.p_off = (int64_t)u * pulse_cap;
+    m.pcap = pulse_cap;
+    m.noise_off = 0;
+    m.noise_len = -1;
+    m.t0 = h_t0[u];
+    m.dt = h_dt[u];
+    m.seed = 0;
+    max_ny = std::max(max_ny, m.ny);
+  }
+  const int64_t ny_tot = h_y_off[B];
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  const size_t o_meta = off; off += al(sizeof(SynUtt) * B);
+  const size_t o_phase = off; off += al(sizeof(double) * ny_tot);
+  const size_t o_vuv = off; off += al((size_t)ny_tot);
+  const size_t o_pt = off; off += al(sizeof(double) * B * pulse_cap);
+  const size_t o_pi = off; off += al(sizeof(int64_t) * B * pulse_cap);
+  const size_t o_ps = off; off += al(sizeof(double) * B * pulse_cap);
+  const size_t o_pn = off; off += al(sizeof(int64_t) * B * pulse_cap);
+  const size_t o_pc = off; off += al(sizeof(int32_t) * B);
+  if (int rc = wh::ws_reserve(ctx, off)) return rc;
+  char* ws = reinterpret_cast<char*>(ctx->ws);
+  SynUtt* d_meta = reinterpret_cast<SynUtt*>(ws + o_meta);
+  double* d_phase = reinterpret_cast<double*>(ws + o_phase);
+  uint8_t* d_vuv = reinterpret_cast<uint8_t*>(ws + o_vuv);
+  int64_t* d_pi = reinterpret_cast<int64_t*>(ws + o_pi);
+  int64_t* d_pn = reinterpret_cast<int64_t*>(ws + o_pn);
+  int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
+  WH_CHECK(hipMemcpyAsync(d_meta, meta.data(), sizeof(SynUtt) * B, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
+                     d_phase, d_vuv);
+  WH_LAUNCH_CHECK("prep_kernel");
+  hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(64), 0, st, d_meta, d_phase);
+  WH_LAUNCH_CHECK("phase_kernel");
+  hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, reinterpret_cast<double*>(ws + o_pt),
+                     d_pi, reinterpret_cast<double*>(ws + o_ps), d_pn, d_pc, ctx->d_flags);
+  WH_LAUNCH_CHECK("pulse_kernel");
+  WH_CHECK(hipMemcpyAsync(h_pulse_count, d_pc, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
+  WH_CHECK(hipStreamSynchronize(st));
+  // total draws = noff[last] + max(3, 0)
+  for (int u = 0; u < B; ++u) {
+    int64_t total = 0;
+    if (h_pulse_count[u] > 0) {
+      int64_t last_off = 0;
+      WH_CHECK(hipMemcpy(&last_off, d_pn + (int64_t)u * pulse_cap + h_pulse_count[u] - 1, sizeof(int64_t),
+                         hipMemcpyDeviceToHost));
+      total = last_off + 3;
+    }
+    h_noise_total[u] = total;
+  }
+  return 0;
+}

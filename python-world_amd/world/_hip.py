@@ -39,6 +39,9 @@ SIGNATURES = {
     "wh_dio": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _int,
                       _vp, _vp, _vp, _vp]),
     "wh_stonemask": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _int, _vp]),
+    "wh_synthesis": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp,
+                            ctypes.c_uint64, _vp, _vp]),
+    "wh_synthesis_plan": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
     "wh_d4c": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int, _vp, _vp]),
     "wh_d4c_bands": (_int, [_dbl, _int]),
     "wh_d4c_requiem": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int, _vp]),

@@ -1,0 +1,80 @@
+"""Pulse-by-pulse overlap-add synthesis — drop-in for world/synthesis.py:21 of the reference, executed
+by the HIP kernels behind wh_synthesis (include/world_hip.h)."""
+import ctypes
+
+import numpy as np
+
+from . import _hip
+
+
+def time_axis_params(temporal_positions, fs):
+    """(ny, t0, dt) of np.arange(tp[0], tp[-1] + 1/fs, 1/fs) — evaluated with NumPy itself so that the
+    float-arange length quirk is reproduced; dt is the step NumPy actually uses."""
+    tp0 = float(temporal_positions[0])
+    step = 1 / fs
+    ny = len(np.arange(tp0, float(temporal_positions[-1]) + step, step))
+    dt = (tp0 + step) - tp0
+    return ny, tp0, dt
+
+
+def synthesis_device(rt, batch, tp_d, f0_d, vuv_d, spec_d, ap_d, fs, fft_size, ny_list, t0_list, dt_list,
+                     noise_d=None, noise_off=None, seed=0, pulse_cap=None):
+    """Device-resident core.  spec_d/ap_d are frame-major [F][K].  Returns the concatenated waveform tensor."""
+    y_off = np.concatenate([[0], np.cumsum(ny_list)]).astype(np.int64)
+    t0 = np.ascontiguousarray(t0_list, dtype=np.float64)
+    dt = np.ascontiguousarray(dt_list, dtype=np.float64)
+    if pulse_cap is None:
+        pulse_cap = int(max(ny_list)) // 8 + 64
+    y = rt.empty((int(y_off[-1]),))
+    vp = ctypes.c_void_p
+    noff = None
+    if noise_d is not None:
+        noff = np.ascontiguousarray(noise_off, dtype=np.int64)
+    _hip.check(rt.lib.wh_synthesis(rt.ctx, rt.stream(), batch.handle, rt.ptr(tp_d), rt.ptr(f0_d), rt.ptr(vuv_d),
+                                   rt.ptr(spec_d), rt.ptr(ap_d), float(fs), int(fft_size), y_off.ctypes.data_as(vp),
+                                   t0.ctypes.data_as(vp), dt.ctypes.data_as(vp), int(pulse_cap), rt.ptr(noise_d),
+                                   noff.ctypes.data_as(vp) if noff is not None else vp(None), int(seed), rt.ptr(y),
+                                   vp(None)))
+    return y, y_off
+
+
+def synthesis_plan(rt, batch, tp_d, f0_d, vuv_d, fs, ny_list, t0_list, dt_list, pulse_cap):
+    """(pulse counts, exact reference randn draw counts) per utterance."""
+    y_off = np.concatenate([[0], np.cumsum(ny_list)]).astype(np.int64)
+    t0 = np.ascontiguousarray(t0_list, dtype=np.float64)
+    dt = np.ascontiguousarray(dt_list, dtype=np.float64)
+    counts = np.zeros(batch.n_utt, dtype=np.int32)
+    draws = np.zeros(batch.n_utt, dtype=np.int64)
+    vp = ctypes.c_void_p
+    _hip.check(rt.lib.wh_synthesis_plan(rt.ctx, rt.stream(), batch.handle, rt.ptr(tp_d), rt.ptr(f0_d), rt.ptr(vuv_d),
+                                        float(fs), y_off.ctypes.data_as(vp), t0.ctypes.data_as(vp),
+                                        dt.ctypes.data_as(vp), int(pulse_cap), counts.ctypes.data_as(vp),
+                                        draws.ctypes.data_as(vp)))
+    return counts, draws
+
+
+def synthesis(source_object, filter_object):
+    """Same contract as the reference.  Randomness: exactly as many np.random.randn samples are drawn
+    from NumPy's global stream as the reference draws (one randn(max(3, noise_size)) per pulse), so a
+    seeded call reproduces the reference's noise and leaves the generator in the same state."""
+    rt = _hip.Runtime.get()
+    vuv = np.asarray(source_object['vuv'], dtype=np.float64)
+    f0 = np.asarray(source_object['f0'], dtype=np.float64)
+    fs = filter_object['fs']
+    spectrogram = np.asarray(filter_object['spectrogram'], dtype=np.float64)
+    aperiodicity = np.asarray(source_object['aperiodicity'], dtype=np.float64)
+    tp = np.asarray(source_object['temporal_positions'], dtype=np.float64)
+    nf = len(tp)
+    fft_size = (spectrogram.shape[0] - 1) * 2
+    ny, t0, dt = time_axis_params(tp, fs)
+    batch = rt.make_batch([0, 0], [0, nf])
+    tp_d, f0_d, vuv_d = rt.to_device(tp), rt.to_device(f0), rt.to_device(vuv)
+    spec_d = rt.to_device(np.ascontiguousarray(spectrogram.T))
+    ap_d = rt.to_device(np.ascontiguousarray(aperiodicity.T))
+    cap = ny // 2 + 16
+    counts, draws = synthesis_plan(rt, batch, tp_d, f0_d, vuv_d, fs, [ny], [t0], [dt], cap)
+    assert counts[0] > 0  # world/synthesis.py:131
+    noise = np.random.randn(int(draws[0]))
+    y, _ = synthesis_device(rt, batch, tp_d, f0_d, vuv_d, spec_d, ap_d, fs, fft_size, [ny], [t0], [dt],
+                            noise_d=rt.to_device(noise), noise_off=[0, len(noise)], pulse_cap=cap)
+    return y.cpu().numpy()

@@ -55,6 +55,12 @@ int wh_stream_sync(void* stream);
 #define WH_FLAG_PULSE_OVERFLOW 4   /* more pulses than the pulse capacity */
 int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16);
 
+/* Per-kernel timing: while enabled every kernel launch of this ctx is bracketed by a HIP event pair on
+ * its launch stream.  wh_profile_collect synchronises the device and returns one record per launch in
+ * launch order: names = '\n'-joined kernel names, ms[i] = elapsed milliseconds. Clears the record list. */
+int wh_profile_enable(wh_ctx* ctx, int on);
+int wh_profile_collect(wh_ctx* ctx, char* names, size_t names_bytes, float* ms, int max_records, int* n_records);
+
 /* ---- batch descriptor --------------------------------------------------------------------- */
 /* h_x_off[n_utt+1]: sample offsets into the concatenated waveform; h_frame_off[n_utt+1]: frame
  * offsets into the concatenated per-frame arrays.  Synchronous (small H2D copies). */

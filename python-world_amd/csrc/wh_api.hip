@@ -109,6 +109,7 @@ int wh_ctx_destroy(wh_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   for (auto& kv : ctx->tables) (void)hipFree(kv.second);
+  for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
   delete ctx;
   return 0;
 }
@@ -119,6 +120,33 @@ int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16) {
   WH_CHECK(hipMemcpyAsync(h_flags16, ctx->d_flags, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   WH_CHECK(hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int32_t), st));
   WH_CHECK(hipStreamSynchronize(st));
+  return 0;
+}
+
+int wh_profile_enable(wh_ctx* ctx, int on) {
+  if (!ctx) return wh::fail_msg("wh_profile_enable", "null ctx");
+  ctx->prof = on != 0;
+  ctx->prof_names.clear();
+  return 0;
+}
+
+int wh_profile_collect(wh_ctx* ctx, char* names, size_t names_bytes, float* ms, int max_records, int* n_records) {
+  if (!ctx || !names || !ms || !n_records) return wh::fail_msg("wh_profile_collect", "null argument");
+  WH_CHECK(hipDeviceSynchronize());
+  const int n = (int)ctx->prof_names.size();
+  std::string joined;
+  int out = 0;
+  for (int i = 0; i < n && out < max_records; ++i) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]) != hipSuccess) t = -1.f;
+    ms[out++] = t;
+    joined += ctx->prof_names[i];
+    joined += '\n';
+  }
+  if (joined.size() + 1 > names_bytes) return wh::fail_msg("wh_profile_collect", "names buffer too small");
+  memcpy(names, joined.c_str(), joined.size() + 1);
+  *n_records = out;
+  ctx->prof_names.clear();
   return 0;
 }
 

@@ -134,9 +134,9 @@ int launch(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, cons
   const size_t lds = sizeof(double2) * N + sizeof(double) * (N + 16);
   const double low = fs * 3.0 / (N - 3.0);
   if (int rc = wh::allow_lds(&cheaptrick_kernel<N>, lds)) return rc;
-  hipLaunchKernelGGL(cheaptrick_kernel<N>, dim3((unsigned)b->total_frames), dim3(WH_BLOCK), lds, st, x, b->d_x_off,
+  { wh::KernelTimer _kt(ctx, st, "cheaptrick_kernel"); hipLaunchKernelGGL(cheaptrick_kernel<N>, dim3((unsigned)b->total_frames), dim3(WH_BLOCK), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, fs, q1, low, wh::twiddle(ctx, N), spec,
-                     reinterpret_cast<double2*>(ps));
+                     reinterpret_cast<double2*>(ps)); }
   WH_LAUNCH_CHECK("cheaptrick_kernel");
   return 0;
 }

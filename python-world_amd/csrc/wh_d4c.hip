@@ -298,8 +298,8 @@ int launch_lt(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, c
               const double* vuv, double fs, double thr, int32_t* gate) {
   const size_t lds = sizeof(double2) * NLT + sizeof(double) * 16;
   if (int rc = wh::allow_lds(&love_train_kernel<NLT>, lds)) return rc;
-  hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)b->total_frames), dim3(WH_BLOCK), lds, st, x, b->d_x_off,
-                     b->d_frame_utt, tp, f0, vuv, fs, thr, wh::twiddle(ctx, NLT), gate);
+  { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)b->total_frames), dim3(WH_BLOCK), lds, st, x, b->d_x_off,
+                     b->d_frame_utt, tp, f0, vuv, fs, thr, wh::twiddle(ctx, NLT), gate); }
   WH_LAUNCH_CHECK("love_train_kernel");
   return 0;
 }
@@ -310,9 +310,9 @@ int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x,
                 double* out, double* coarse) {
   const size_t lds = sizeof(double2) * N + sizeof(double) * (N + 2 * (N / 2 + 8) + 16 + 8);
   if (int rc = wh::allow_lds(&d4c_kernel<N>, lds)) return rc;
-  hipLaunchKernelGGL(d4c_kernel<N>, dim3((unsigned)b->total_frames), dim3(WH_BLOCK), lds, st, x, b->d_x_off,
+  { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL(d4c_kernel<N>, dim3((unsigned)b->total_frames), dim3(WH_BLOCK), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, gate, fs, nap, interval, win, wlen, wh::twiddle(ctx, N), k_spec, out,
-                     coarse);
+                     coarse); }
   WH_LAUNCH_CHECK("d4c_kernel");
   return 0;
 }

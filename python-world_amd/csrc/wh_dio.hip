@@ -495,27 +495,27 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   if (!(rad < 0.9999)) warm = 1 << 30;  // unstable / unknown: fall back to a fully serial pass per lane
   const int chunks = (int)((max_len + kChunk - 1) / kChunk);
   dim3 gi((chunks + 63) / 64, B);
-  hipLaunchKernelGGL(iir_fwd_kernel, gi, dim3(64), 0, st, x, d_meta, coef, warm, d_tmp);
+  { wh::KernelTimer _kt(ctx, st, "iir_fwd_kernel"); hipLaunchKernelGGL(iir_fwd_kernel, gi, dim3(64), 0, st, x, d_meta, coef, warm, d_tmp); }
   WH_LAUNCH_CHECK("iir_fwd_kernel");
-  hipLaunchKernelGGL(iir_bwd_kernel, gi, dim3(64), 0, st, d_meta, coef, warm, r, d_tmp, d_y);
+  { wh::KernelTimer _kt(ctx, st, "iir_bwd_kernel"); hipLaunchKernelGGL(iir_bwd_kernel, gi, dim3(64), 0, st, d_meta, coef, warm, r, d_tmp, d_y); }
   WH_LAUNCH_CHECK("iir_bwd_kernel");
   // ---- low-cut + band events ----------------------------------------------------------------------
-  hipLaunchKernelGGL(lowcut_kernel, dim3((unsigned)((max_ylen + 2 * pad + 255) / 256), B), dim3(256), 0, st, d_meta, d_y,
-                     d_lc, lowcut_half, pad, d_z);
+  { wh::KernelTimer _kt(ctx, st, "lowcut_kernel"); hipLaunchKernelGGL(lowcut_kernel, dim3((unsigned)((max_ylen + 2 * pad + 255) / 256), B), dim3(256), 0, st, d_meta, d_y,
+                     d_lc, lowcut_half, pad, d_z); }
   WH_LAUNCH_CHECK("lowcut_kernel");
   const size_t lds = sizeof(double) * (((max_lb + 1) & ~1) + ((kTile + 2 + max_lb + 1) & ~1) + kTile + 2) + 64;
-  hipLaunchKernelGGL(band_kernel, dim3(n_bands, B), dim3(256), lds, st, d_meta, d_z, pad, d_taps, d_ti, d_ti + n_bands,
-                     d_ti + 2 * n_bands, n_bands, d_e, d_cnt, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW);
+  { wh::KernelTimer _kt(ctx, st, "band_kernel"); hipLaunchKernelGGL(band_kernel, dim3(n_bands, B), dim3(256), lds, st, d_meta, d_z, pad, d_taps, d_ti, d_ti + n_bands,
+                     d_ti + 2 * n_bands, n_bands, d_e, d_cnt, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW); }
   WH_LAUNCH_CHECK("band_kernel");
   // ---- candidates, sort, contour ------------------------------------------------------------------
-  hipLaunchKernelGGL(cand_kernel, dim3((unsigned)((max_nf + 255) / 256), n_bands, B), dim3(256), 0, st, d_meta, tp, d_e,
-                     d_cnt, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw, d_stab);
+  { wh::KernelTimer _kt(ctx, st, "cand_kernel"); hipLaunchKernelGGL(cand_kernel, dim3((unsigned)((max_nf + 255) / 256), n_bands, B), dim3(256), 0, st, d_meta, tp, d_e,
+                     d_cnt, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw, d_stab); }
   WH_LAUNCH_CHECK("cand_kernel");
-  hipLaunchKernelGGL(sort_kernel, dim3((unsigned)((max_nf + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw,
-                     d_stab, d_sorted, cand_out);
+  { wh::KernelTimer _kt(ctx, st, "sort_kernel"); hipLaunchKernelGGL(sort_kernel, dim3((unsigned)((max_nf + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw,
+                     d_stab, d_sorted, cand_out); }
   WH_LAUNCH_CHECK("sort_kernel");
-  hipLaunchKernelGGL(contour_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_meta, B, n_bands, frame_period_ms, f0_floor,
-                     allowed_range, d_sorted, d_work, f0_out, vuv_out);
+  { wh::KernelTimer _kt(ctx, st, "contour_kernel"); hipLaunchKernelGGL(contour_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_meta, B, n_bands, frame_period_ms, f0_floor,
+                     allowed_range, d_sorted, d_work, f0_out, vuv_out); }
   WH_LAUNCH_CHECK("contour_kernel");
   return 0;
 }

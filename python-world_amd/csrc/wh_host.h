@@ -17,6 +17,10 @@ struct wh_ctx {
   size_t ws_bytes = 0;
   std::map<std::string, double*> tables;  // small constant tables resident on the device (windows, taps)
   int32_t* d_flags = nullptr;             // [16] sticky device-side condition flags (see wh_take_flags)
+  // optional per-kernel timing (HIP events on the launch stream), see wh_profile_*
+  bool prof = false;
+  std::vector<hipEvent_t> prof_events;    // pool, two per record
+  std::vector<const char*> prof_names;    // one per record
 };
 
 struct wh_batch {
@@ -47,6 +51,28 @@ inline int allow_lds(K kernel, size_t bytes) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   return e == hipSuccess ? 0 : fail("hipFuncSetAttribute", e);
 }
+// RAII bracket around one kernel launch: records a start/stop event pair on the launch stream when
+// profiling is enabled (zero cost otherwise).
+struct KernelTimer {
+  wh_ctx* c;
+  hipStream_t st;
+  int slot = -1;
+  KernelTimer(wh_ctx* ctx, hipStream_t s, const char* name) : c(ctx), st(s) {
+    if (!c->prof) return;
+    const size_t rec = c->prof_names.size();
+    while (c->prof_events.size() < 2 * (rec + 1)) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      c->prof_events.push_back(e);
+    }
+    c->prof_names.push_back(name);
+    slot = (int)rec;
+    (void)hipEventRecord(c->prof_events[2 * slot], st);
+  }
+  ~KernelTimer() {
+    if (slot >= 0) (void)hipEventRecord(c->prof_events[2 * slot + 1], st);
+  }
+};
 }  // namespace wh
 
 #define WH_CHECK(expr)                                   \

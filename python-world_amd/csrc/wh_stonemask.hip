@@ -173,8 +173,8 @@ extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   if (int rc = wh::const_table(ctx, key, qt, &d_qt)) return rc;
   int32_t* err = ctx->d_flags + WH_FLAG_STONEMASK_WINDOW;
   if (int rc = wh::allow_lds(&stonemask_kernel, lds)) return rc;
-  hipLaunchKernelGGL(stonemask_kernel, dim3((unsigned)b->total_frames), dim3(64), lds, st, x, b->d_x_off,
-                     b->d_frame_utt, tp, f0, refined_f0, fs, d_qt, kmax, ctx->d_twiddle, err);
+  { wh::KernelTimer _kt(ctx, st, "stonemask_kernel"); hipLaunchKernelGGL(stonemask_kernel, dim3((unsigned)b->total_frames), dim3(64), lds, st, x, b->d_x_off,
+                     b->d_frame_utt, tp, f0, refined_f0, fs, d_qt, kmax, ctx->d_twiddle, err); }
   WH_LAUNCH_CHECK("stonemask_kernel");
   return 0;
 }

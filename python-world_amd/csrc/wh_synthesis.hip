@@ -454,8 +454,8 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
   int64_t grid = pcap_max * B;
   if (grid > 256 * 16) grid = 256 * 16;  // persistent-style: workgroups stride over the flat pulse list
-  hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(WH_BLOCK), lds, st, d_meta, tp, spec, ap, fs,
-                     p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, d_dc, wh::twiddle(ctx, N), y);
+  { wh::KernelTimer _kt(ctx, st, "response_kernel"); hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(WH_BLOCK), lds, st, d_meta, tp, spec, ap, fs,
+                     p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, d_dc, wh::twiddle(ctx, N), y); }
   WH_LAUNCH_CHECK("response_kernel");
   return 0;
 }
@@ -517,15 +517,15 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   WH_CHECK(hipMemcpyAsync(d_meta, meta.data(), sizeof(SynUtt) * B, hipMemcpyHostToDevice, st));
   WH_CHECK(hipStreamSynchronize(st));
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
-  hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
-                     d_phase, d_vuv);
+  { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
+                     d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
-  hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(64), 0, st, d_meta, d_phase);
+  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(64), 0, st, d_meta, d_phase); }
   WH_LAUNCH_CHECK("phase_kernel");
-  hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc,
-                     ctx->d_flags);
+  { wh::KernelTimer _kt(ctx, st, "pulse_kernel"); hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc,
+                     ctx->d_flags); }
   WH_LAUNCH_CHECK("pulse_kernel");
-  hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb);
+  { wh::KernelTimer _kt(ctx, st, "pulse_base_kernel"); hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb); }
   WH_LAUNCH_CHECK("pulse_base_kernel");
   int rc;
   switch (fft_size) {
@@ -588,13 +588,13 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
   int64_t* d_pn = reinterpret_cast<int64_t*>(ws + o_pn);
   int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
   WH_CHECK(hipMemcpyAsync(d_meta, meta.data(), sizeof(SynUtt) * B, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
-                     d_phase, d_vuv);
+  { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
+                     d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
-  hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(64), 0, st, d_meta, d_phase);
+  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(64), 0, st, d_meta, d_phase); }
   WH_LAUNCH_CHECK("phase_kernel");
-  hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, reinterpret_cast<double*>(ws + o_pt),
-                     d_pi, reinterpret_cast<double*>(ws + o_ps), d_pn, d_pc, ctx->d_flags);
+  { wh::KernelTimer _kt(ctx, st, "pulse_kernel"); hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, reinterpret_cast<double*>(ws + o_pt),
+                     d_pi, reinterpret_cast<double*>(ws + o_ps), d_pn, d_pc, ctx->d_flags); }
   WH_LAUNCH_CHECK("pulse_kernel");
   WH_CHECK(hipMemcpyAsync(h_pulse_count, d_pc, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
   WH_CHECK(hipStreamSynchronize(st));

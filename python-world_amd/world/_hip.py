@@ -35,6 +35,9 @@ SIGNATURES = {
     "wh_batch_destroy": (_int, [_vp]),
     "wh_num_frames": (ctypes.c_int64, [ctypes.c_int64, _dbl, _dbl]),
     "wh_cheaptrick": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _dbl, _vp, _vp]),
+    "wh_profile_enable": (_int, [_vp, _int]),
+    "wh_profile_collect": (_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_float), _int,
+                                  ctypes.POINTER(_int)]),
     "wh_take_flags": (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
     "wh_dio": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _int,
                       _vp, _vp, _vp, _vp]),
@@ -131,6 +134,18 @@ class Runtime:
     @staticmethod
     def ptr(t):
         return _vp(t.data_ptr()) if t is not None else _vp(None)
+
+    def profile(self, on=True):
+        check(self.lib.wh_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_collect(self, max_records=4096):
+        """[(kernel name, ms), ...] in launch order since the last collect; synchronises the device."""
+        names = ctypes.create_string_buffer(64 * max_records)
+        ms = (ctypes.c_float * max_records)()
+        n = _int(0)
+        check(self.lib.wh_profile_collect(self.ctx, names, len(names), ms, max_records, ctypes.byref(n)))
+        nm = names.value.decode().split("\n")[:n.value]
+        return list(zip(nm, [float(ms[i]) for i in range(n.value)]))
 
     def take_flags(self):
         """Read-and-clear the sticky device condition flags (synchronises the current stream)."""

@@ -1,0 +1,135 @@
+"""Batched, device-resident WORLD pipeline (not in the reference API: it is the harness the benchmark
+configs need — SURVEY.md §8(b) "World.encode_batch/decode_batch").
+
+Utterances are concatenated into one waveform tensor; every stage runs ONE launch per kernel over all
+frames x utterances.  Results stay in HBM as torch tensors (frame-major spectrogram / aperiodicity);
+`BatchEncoding.to_dicts()` materialises reference-layout NumPy dicts on demand.
+"""
+import numpy as np
+
+from . import _hip, _tables
+from .cheaptrick import cheaptrick_device, default_fft_size
+from .d4c import d4c_device
+from .d4cRequiem import d4c_requiem_device
+from .dio import dio_device
+from .stonemask import stonemask_device
+from .synthesis import synthesis_device, time_axis_params
+
+
+class BatchEncoding:
+    def __init__(self, rt, batch, fs, tp, f0, vuv, spectrogram, aperiodicity, fft_size, is_requiem, frame_period):
+        self.rt, self.batch, self.fs = rt, batch, fs
+        self.temporal_positions, self.f0, self.vuv = tp, f0, vuv
+        self.spectrogram, self.aperiodicity = spectrogram, aperiodicity
+        self.fft_size, self.is_requiem, self.frame_period = fft_size, is_requiem, frame_period
+
+    @property
+    def n_utt(self):
+        return self.batch.n_utt
+
+    def scale_pitch(self, factor):
+        """world/main.py:154-162, on the device."""
+        self.f0 *= factor
+        return self
+
+    def scale_duration(self, factor):
+        """world/main.py:170-178, on the device."""
+        self.temporal_positions *= factor
+        return self
+
+    def to_dicts(self):
+        """List of per-utterance dicts with the reference's keys and (bins, frames) layouts."""
+        fo = self.batch.frame_off
+        tp, f0, vuv = (t.cpu().numpy() for t in (self.temporal_positions, self.f0, self.vuv))
+        sp = self.spectrogram.cpu().numpy()
+        ap = self.aperiodicity.cpu().numpy()
+        out = []
+        for u in range(self.n_utt):
+            s = slice(int(fo[u]), int(fo[u + 1]))
+            out.append({'temporal_positions': tp[s].copy(), 'vuv': vuv[s].copy(), 'fs': self.fs, 'f0': f0[s].copy(),
+                        'aperiodicity': np.ascontiguousarray(ap[s].T), 'spectrogram': np.ascontiguousarray(sp[s].T),
+                        'is_requiem': self.is_requiem})
+        return out
+
+
+class WorldBatch:
+    def __init__(self, device_index=None):
+        self.rt = _hip.Runtime.get(device_index)
+
+    def upload(self, xs, fs, frame_period=5):
+        """Concatenate and upload a list of 1-D waveforms (or a 2-D array).  Returns (batch, x_d, tp_d)."""
+        rt = self.rt
+        xs = [np.asarray(x, dtype=np.float64) for x in xs]
+        lens = [len(x) for x in xs]
+        nfs = [_tables.frame_count(n, fs, frame_period) for n in lens]
+        batch = rt.make_batch(np.concatenate([[0], np.cumsum(lens)]), np.concatenate([[0], np.cumsum(nfs)]))
+        x_d = rt.to_device(np.concatenate(xs))
+        tp_d = rt.to_device(np.concatenate([_tables.frame_times(n, frame_period) for n in nfs]))
+        return batch, x_d, tp_d
+
+    def encode_device(self, batch, x_d, tp_d, fs, f0_method='dio', f0_floor=71, f0_ceil=800, channels_in_octave=2,
+                      target_fs=4000, frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False):
+        """world/main.py:106-152 for a resident batch.  tp_d is not modified (a copy is kept in the result)."""
+        rt = self.rt
+        if fft_size is not None:
+            f0_floor = 3.0 * fs / fft_size
+        if f0_method == 'dio':
+            f0_d, vuv_d, _, _ = dio_device(rt, batch, x_d, tp_d, fs, f0_floor, f0_ceil, channels_in_octave, target_fs,
+                                           frame_period, allowed_range)
+            f0_d = stonemask_device(rt, batch, x_d, tp_d, f0_d, fs, f0_floor)
+        elif f0_method == 'harvest':
+            from .harvest import harvest_device
+            f0_d, vuv_d = harvest_device(rt, batch, x_d, tp_d, fs, f0_floor, f0_ceil, frame_period)
+        else:
+            raise Exception
+        ct_fft = int(fft_size) if fft_size is not None else default_fft_size(fs)
+        spec_d, _ = cheaptrick_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, ct_fft)
+        if is_requiem:
+            ap_d = d4c_requiem_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, fft_size)
+        else:
+            ap_d, _ = d4c_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, ct_fft)
+        return BatchEncoding(rt, batch, fs, tp_d.clone(), f0_d, vuv_d, spec_d, ap_d, ct_fft, is_requiem, frame_period)
+
+    def encode(self, xs, fs, **kw):
+        batch, x_d, tp_d = self.upload(xs, fs, kw.get('frame_period', 5))
+        return self.encode_device(batch, x_d, tp_d, fs, **kw)
+
+    def decode_device(self, enc, noise=None, seed=0, pulse_cap=None):
+        """world/main.py:198-214 for a resident encoding.  Returns (y tensor, y_off) — concatenated
+        waveforms, peak-normalised per utterance where max|y| > 1.  ``noise``: optional list of per-utterance
+        standard-normal arrays (reference-parity mode); default = on-device Philox stream ``seed``."""
+        rt = self.rt
+        fo = enc.batch.frame_off
+        tp_h = enc.temporal_positions.cpu().numpy()
+        geo = [time_axis_params(tp_h[int(fo[u]):int(fo[u + 1])], enc.fs) for u in range(enc.n_utt)]
+        ny = [g[0] for g in geo]
+        if enc.is_requiem:
+            from .synthesisRequiem import synthesis_requiem_device
+            y, y_off = synthesis_requiem_device(rt, enc, ny, geo)
+        else:
+            noise_d = noise_off = None
+            if noise is not None:
+                noise_off = np.concatenate([[0], np.cumsum([len(n) for n in noise])])
+                noise_d = rt.to_device(np.concatenate(noise))
+            y, y_off = synthesis_device(rt, enc.batch, enc.temporal_positions, enc.f0, enc.vuv, enc.spectrogram,
+                                        enc.aperiodicity, enc.fs, enc.fft_size, ny, [g[1] for g in geo],
+                                        [g[2] for g in geo], noise_d=noise_d, noise_off=noise_off, seed=seed,
+                                        pulse_cap=pulse_cap)
+        self._peak_normalise(y, y_off)
+        return y, y_off
+
+    def _peak_normalise(self, y, y_off):
+        """y /= max|y| where it exceeds 1 (world/main.py:209-212), per utterance, on the device."""
+        torch = self.rt.torch
+        n = len(y_off) - 1
+        lens = np.diff(y_off)
+        if n > 0 and np.all(lens == lens[0]):
+            v = y.view(n, int(lens[0]))
+            m = v.abs().amax(dim=1, keepdim=True)
+            v /= torch.where(m > 1.0, m, torch.ones_like(m))
+        else:
+            for u in range(n):
+                seg = y[int(y_off[u]):int(y_off[u + 1])]
+                m = seg.abs().max()
+                if float(m) > 1.0:
+                    seg /= m

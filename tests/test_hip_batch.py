@@ -1,0 +1,52 @@
+"""GPU: the batched device-resident pipeline equals the per-utterance drop-in API, and matches the oracle
+end to end (BASELINE config 2 shape at reduced size)."""
+import numpy as np
+import pytest
+
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_equals_single_and_oracle():
+    from oracle import api as oapi
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+    from world.cheaptrick import cheaptrick
+    from world.d4c import d4c
+    from world.dio import dio
+    from world.stonemask import stonemask
+
+    fs = 16000
+    xs = [synth_utterance(20 + i, fs, 0.8 + 0.2 * i) for i in range(3)]  # ragged
+    wb = WorldBatch()
+    enc = wb.encode(xs, fs, f0_method='dio')
+    dicts = enc.to_dicts()
+    for u, x in enumerate(xs):
+        src = dio(x, fs)
+        src['f0'] = stonemask(x, fs, src['temporal_positions'], src['f0'])
+        filt = cheaptrick(x, fs, src)
+        src = d4c(x, fs, src)
+        d = dicts[u]
+        assert np.array_equal(d['f0'], src['f0'])
+        assert np.array_equal(d['vuv'], src['vuv'])
+        assert np.array_equal(d['spectrogram'], filt['spectrogram'])
+        assert np.array_equal(d['aperiodicity'], src['aperiodicity'])
+        # against the oracle (tolerance: north_star 1e-4 relative RMS per tensor; exact vuv / frame count)
+        o = oapi.encode_np(fs, x, f0_method='dio')
+        assert np.array_equal(d['vuv'], o['vuv'])
+        assert rel_rms(d['f0'], o['f0']) < 1e-8
+        assert rel_rms(d['spectrogram'], o['spectrogram']) < 1e-8
+        assert rel_rms(d['aperiodicity'], o['aperiodicity']) < 1e-8
+    # decode with host-supplied noise == oracle decode with the same noise
+    rng = np.random.RandomState(5)
+    noise = [rng.randn(2 * len(x)) for x in xs]
+    y, y_off = wb.decode_device(enc, noise=noise)
+    y = y.cpu().numpy()
+    for u in range(len(xs)):
+        o = dict(dicts[u])
+        yo = oapi.decode_np(o, noise=noise[u])['out']
+        seg = y[y_off[u]:y_off[u + 1]]
+        assert len(seg) == len(yo)
+        assert rel_rms(seg, yo) < 1e-8
+    assert wb.rt.take_flags() == [0] * 16

@@ -112,6 +112,23 @@ int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const 
            const double* h_band_f0, const int32_t* h_band_bias, const int32_t* h_band_len, const double* h_band_taps,
            const double* h_lowcut, int lowcut_half, double* f0_out, double* vuv_out, double* cand_out, double* raw_out);
 
+/* ---- Harvest: replaces harvest()  (world/harvest.py:17-54) ---------------------------------------- */
+/* tp[total_frames]: output frame times (s).  Host-supplied filter DATA (the reference obtains them from
+ * SciPy / NumPy at run time, so the host language evaluates the same expressions):
+ *   decimation_ratio r = int(fs/8000 + 0.5); if r > 1: h_ba[8] = (b0..b3, a0..a3) of
+ *   scipy.signal.cheby1(3, 0.05, 0.8/r) and h_zi[3] = scipy.signal.lfilter_zi(b, a)   (harvest.py:599-603);
+ *   h_band_f0[n_bands]: channel centre frequencies (harvest.py:22-29, 152 for the default range);
+ *   h_band_half[n_bands]: h = round-half-up(2*fs_d/f) (harvest.py:253);
+ *   h_band_taps: concatenated band-pass FIRs nuttall(2h+1)*cos(2*pi*f*k/fs_d), k=-h..h (harvest.py:254-256).
+ * Outputs f0_out / vuv_out [total_frames].  Optional debug outputs (DEVICE, may be NULL): dbg_y — the
+ * decimated, mean-removed signals concatenated; dbg_raw — per utterance [n_bands][nf1] raw channel candidates
+ * on the 1 ms grid; dbg_f0_1ms — the 1 ms contour before smoothing. */
+int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, double fs,
+               double f0_floor, double f0_ceil, double frame_period_ms, int decimation_ratio, const double* h_ba,
+               const double* h_zi, int n_bands, const double* h_band_f0, const int32_t* h_band_half,
+               const double* h_band_taps, double* f0_out, double* vuv_out, double* dbg_y, double* dbg_raw,
+               double* dbg_f0_1ms);
+
 /* ---- StoneMask: replaces stonemask()  (world/stonemask.py:8-27) -------------------------------- */
 /* f0[total_frames] in, refined_f0[total_frames] out (a different buffer: the reference returns a new
  * array).  h_qtime[2*kmax+1] (HOST): h_qtime[k+kmax] = float("%.4f" % (k/fs)) — the reference

@@ -19,6 +19,7 @@
 #include "wh_host.h"
 #include "wh_device.h"
 #include "wh_events.h"
+#include "wh_bands.h"
 
 namespace {
 
@@ -135,50 +136,6 @@ __global__ __launch_bounds__(256) void lowcut_kernel(const DioUtt* __restrict__ 
     acc += h[k + half] * v;
   }
   z[m.z_off + j] = acc;
-}
-
-constexpr int kTile = 1024;
-
-__global__ __launch_bounds__(256) void band_kernel(const DioUtt* __restrict__ meta, const double* __restrict__ z,
-                                                   int pad, const double* __restrict__ taps_all,
-                                                   const int32_t* __restrict__ tap_off, const int32_t* __restrict__ tap_len,
-                                                   const int32_t* __restrict__ bias, int nb, double* __restrict__ edges,
-                                                   int32_t* __restrict__ counts, int32_t* __restrict__ flags) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.x;
-  const DioUtt m = meta[blockIdx.y];
-  const int lb = tap_len[b];
-  double* taps = reinterpret_cast<double*>(smem);  // lb
-  double* zt = taps + ((lb + 1) & ~1);             // kTile + 2 + lb
-  double* sig = zt + ((kTile + 2 + lb + 1) & ~1);  // kTile + 2
-  unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(sig + kTile + 2);  // 8
-  for (int k = threadIdx.x; k < lb; k += 256) taps[k] = taps_all[tap_off[b] + k];
-  const double* zu = z + m.z_off;
-  double* eb = edges + m.e_off + (int64_t)b * 4 * m.cap;
-  int base_cnt[4] = {0, 0, 0, 0};
-  const int64_t M = m.ylen;
-  // signal sample s[g] = filtered[bias + 1 + g] = sum_k taps[k] * z[(bias+1+g) - k]
-  for (int64_t t0 = 0; t0 < M; t0 += kTile) {
-    __syncthreads();
-    // stage z over m in [t0+bias+1-(lb-1), t0+bias+1+kTile+2)
-    const int64_t zlo = t0 + bias[b] + 1 - (lb - 1);
-    for (int i = threadIdx.x; i < kTile + 2 + lb - 1; i += 256) {
-      const int64_t mm = zlo + i;
-      const int64_t j = mm + pad;
-      zt[i] = (j >= 0 && j < M + 2 * pad) ? zu[j] : 0.0;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kTile + 2; i += 256) {
-      double acc = 0.0;
-      if (t0 + i < M) {
-        for (int k = 0; k < lb; ++k) acc += taps[k] * zt[i + (lb - 1) - k];
-      }
-      sig[i] = acc;
-    }
-    __syncthreads();
-    wh::emit_crossings(sig, t0, M, kTile, eb, m.cap, base_cnt, scan_scratch, flags);
-  }
-  if (threadIdx.x < 4) counts[((int64_t)blockIdx.y * nb + b) * 4 + threadIdx.x] = base_cnt[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void cand_kernel(const DioUtt* __restrict__ meta, const double* __restrict__ tp,
@@ -457,6 +414,7 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   const size_t o_lc = off; off += al(sizeof(double) * (2 * lowcut_half + 1));
   const size_t o_bf = off; off += al(sizeof(double) * n_bands);
   const size_t o_ti = off; off += al(sizeof(int32_t) * n_bands * 3);
+  const size_t o_jobs = off; off += al(sizeof(wh::BandJob) * (size_t)B * n_bands);
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
   DioUtt* d_meta = reinterpret_cast<DioUtt*>(ws + o_meta);
@@ -473,6 +431,7 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   double* d_lc = reinterpret_cast<double*>(ws + o_lc);
   double* d_bf = reinterpret_cast<double*>(ws + o_bf);
   int32_t* d_ti = reinterpret_cast<int32_t*>(ws + o_ti);
+  wh::BandJob* d_jobs = reinterpret_cast<wh::BandJob*>(ws + o_jobs);
   std::vector<int32_t> ti(n_bands * 3);
   for (int i = 0; i < n_bands; ++i) {
     ti[i] = tap_off[i];
@@ -503,10 +462,23 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   { wh::KernelTimer _kt(ctx, st, "lowcut_kernel"); hipLaunchKernelGGL(lowcut_kernel, dim3((unsigned)((max_ylen + 2 * pad + 255) / 256), B), dim3(256), 0, st, d_meta, d_y,
                      d_lc, lowcut_half, pad, d_z); }
   WH_LAUNCH_CHECK("lowcut_kernel");
-  const size_t lds = sizeof(double) * (((max_lb + 1) & ~1) + ((kTile + 2 + max_lb + 1) & ~1) + kTile + 2) + 64;
-  { wh::KernelTimer _kt(ctx, st, "band_kernel"); hipLaunchKernelGGL(band_kernel, dim3(n_bands, B), dim3(256), lds, st, d_meta, d_z, pad, d_taps, d_ti, d_ti + n_bands,
-                     d_ti + 2 * n_bands, n_bands, d_e, d_cnt, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW); }
-  WH_LAUNCH_CHECK("band_kernel");
+  {
+    std::vector<wh::BandJob> jobs((size_t)B * n_bands);
+    for (int u = 0; u < B; ++u)
+      for (int i = 0; i < n_bands; ++i) {
+        wh::BandJob& j = jobs[(size_t)u * n_bands + i];
+        j.z = d_z + meta[u].z_off;
+        j.M = meta[u].ylen;
+        j.edges = d_e + meta[u].e_off + (int64_t)i * 4 * meta[u].cap;
+        j.cap = meta[u].cap;
+        j.counts = d_cnt + ((int64_t)u * n_bands + i) * 4;
+      }
+    WH_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(wh::BandJob) * jobs.size(), hipMemcpyHostToDevice, st));
+    WH_CHECK(hipStreamSynchronize(st));
+  }
+  if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands, d_ti + 2 * n_bands,
+                                      max_lb, false, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW))
+    return rc;
   // ---- candidates, sort, contour ------------------------------------------------------------------
   { wh::KernelTimer _kt(ctx, st, "cand_kernel"); hipLaunchKernelGGL(cand_kernel, dim3((unsigned)((max_nf + 255) / 256), n_bands, B), dim3(256), 0, st, d_meta, tp, d_e,
                      d_cnt, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw, d_stab); }

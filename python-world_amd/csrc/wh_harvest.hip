@@ -1,0 +1,611 @@
+// Harvest F0 estimator, batched.  Replaces harvest() of the reference (world/harvest.py:17-54).
+//
+// Front end (this file):
+//   hv_iir_fwd/bwd   : zero-phase Chebyshev-I decimation to ~8 kHz, SciPy filtfilt semantics (odd
+//                      extension by 9, steady-state initial conditions), chunk-parallel with state warm-up
+//                      (harvest.py:58-71,584-609)
+//   band_events      : 152 band-pass channels as direct FIR from LDS + zero-crossing compaction (wh_bands.h)
+//   hv_raw_kernel    : per (1 ms frame, channel) interpolation of the four interval-F0 trains (harvest.py:252-278)
+//   hv_detect_kernel : per frame: runs of >= 10 live channels -> candidate = mean (harvest.py:88-110)
+//   hv_refine_kernel : per frame: every overlapped candidate (+-3 frames, harvest.py:114-125) refined by
+//                      instantaneous frequency at <= 6 harmonics.  The reference farms ~178 k two-FFT calls per
+//                      10 s utterance to a process pool (harvest.py:131-211); here a wave stages the two
+//                      windowed sequences in LDS and evaluates only the harmonic bins as direct DFT sums.
+//   hv_prune_kernel  : neighbour-frame consistency test (harvest.py:215-248)
+// Back end (wh_harvest_contour.h): contour tracking, smoothing, 5 ms pick.
+#include <math.h>
+
+#include "wh_bands.h"
+#include "wh_device.h"
+#include "wh_host.h"
+
+namespace {
+
+constexpr int kMaxC = 15;          // int(152/10 + 0.5): candidate rows per frame before overlapping
+constexpr int kRows = 7 * kMaxC;   // overlapped candidate rows (shift-major, candidate-minor)
+constexpr int kFPad = 9;           // filtfilt padlen
+constexpr int kHChunk = 1024;
+
+struct HvUtt {
+  int64_t x_off, n;
+  int64_t nd, offset;     // constant-padded length, pad amount
+  int64_t t_off;          // pass-1 output (nd + 18)
+  int64_t y_off, ylen;    // decimated + trimmed signal
+  int64_t z_off;          // zero-padded, mean-removed copy: ylen + 2*pad
+  int64_t pick0;          // index into the filtfilt output of y[0]
+  int64_t f1_off, nf1;    // 1 ms frames
+  int64_t f_off, nf;      // output frames
+};
+
+struct Tdf2 {
+  double b0, b1, b2, b3, a1, a2, a3, zi0, zi1, zi2;
+};
+
+#include "wh_harvest_contour.h"
+
+__device__ __forceinline__ double hv_xp(const double* __restrict__ x, const HvUtt& m, int64_t i) {
+  int64_t k = i - m.offset;  // constant edge padding (harvest.py:66)
+  k = k < 0 ? 0 : (k > m.n - 1 ? m.n - 1 : k);
+  return x[k];
+}
+// odd extension by 9 samples of the constant-padded signal (scipy.signal.filtfilt, padtype='odd')
+__device__ __forceinline__ double hv_ext(const double* __restrict__ x, const HvUtt& m, int64_t e) {
+  if (e < kFPad) return 2 * hv_xp(x, m, 0) - hv_xp(x, m, kFPad - e);
+  if (e < kFPad + m.nd) return hv_xp(x, m, e - kFPad);
+  return 2 * hv_xp(x, m, m.nd - 1) - hv_xp(x, m, m.nd - 2 - (e - (kFPad + m.nd)));
+}
+
+#define TDF2_STEP(IN)                     \
+  {                                       \
+    const double xin = (IN);              \
+    yv = z0 + c.b0 * xin;                 \
+    z0 = z1 + xin * c.b1 - yv * c.a1;     \
+    z1 = z2 + xin * c.b2 - yv * c.a2;     \
+    z2 = xin * c.b3 - yv * c.a3;          \
+  }
+
+__global__ __launch_bounds__(64) void hv_iir_fwd_kernel(const double* __restrict__ x, const HvUtt* __restrict__ meta,
+                                                        Tdf2 c, int warm, double* __restrict__ tmp) {
+  const HvUtt m = meta[blockIdx.y];
+  const int64_t len = m.nd + 2 * kFPad;
+  const int64_t s = ((int64_t)blockIdx.x * 64 + threadIdx.x) * kHChunk;
+  if (s >= len) return;
+  const int64_t e = s + kHChunk < len ? s + kHChunk : len;
+  const double* xu = x + m.x_off;
+  double* out = tmp + m.t_off;
+  double z0 = 0, z1 = 0, z2 = 0, yv = 0;
+  int64_t i = s - warm;
+  if (i <= 0) {  // the true start: steady-state initial conditions scaled by the first sample
+    i = 0;
+    const double x0 = hv_ext(xu, m, 0);
+    z0 = c.zi0 * x0;
+    z1 = c.zi1 * x0;
+    z2 = c.zi2 * x0;
+  }
+  for (; i < s; ++i) TDF2_STEP(hv_ext(xu, m, i));
+  for (i = s; i < e; ++i) {
+    TDF2_STEP(hv_ext(xu, m, i));
+    out[i] = yv;
+  }
+}
+
+__global__ __launch_bounds__(64) void hv_iir_bwd_kernel(const HvUtt* __restrict__ meta, Tdf2 c, int warm, int r,
+                                                        const double* __restrict__ tmp, double* __restrict__ y) {
+  const HvUtt m = meta[blockIdx.y];
+  const int64_t len = m.nd + 2 * kFPad;
+  const int64_t s = ((int64_t)blockIdx.x * 64 + threadIdx.x) * kHChunk;
+  if (s >= len) return;
+  const int64_t e = s + kHChunk < len ? s + kHChunk : len;
+  const double* in = tmp + m.t_off;
+  double* yo = y + m.y_off;
+  double z0 = 0, z1 = 0, z2 = 0, yv = 0;
+  int64_t i = s - warm;
+  if (i <= 0) {
+    i = 0;
+    const double y0 = in[len - 1];
+    z0 = c.zi0 * y0;
+    z1 = c.zi1 * y0;
+    z2 = c.zi2 * y0;
+  }
+  for (; i < s; ++i) TDF2_STEP(in[len - 1 - i]);
+  for (i = s; i < e; ++i) {
+    TDF2_STEP(in[len - 1 - i]);
+    const int64_t p = (len - 1 - i) - kFPad;  // index into the filtfilt result
+    const int64_t d = p - m.pick0;
+    if (d >= 0 && d % r == 0 && d / r < m.ylen) yo[d / r] = yv;
+  }
+}
+
+__global__ __launch_bounds__(256) void hv_copy_kernel(const double* __restrict__ x, const HvUtt* __restrict__ meta,
+                                                      double* __restrict__ y) {
+  const HvUtt m = meta[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < m.ylen) y[m.y_off + i] = x[m.x_off + i];
+}
+
+__global__ __launch_bounds__(256) void hv_mean_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
+                                                      double* __restrict__ mean) {
+  __shared__ double scratch[16];
+  const HvUtt m = meta[blockIdx.x];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < m.ylen; i += 256) s += y[m.y_off + i];
+  s = wh::block_sum(s, scratch);
+  if (threadIdx.x == 0) mean[blockIdx.x] = s / (double)m.ylen;
+}
+
+// z = [zeros(pad), y - mean, zeros(pad)]; also rewrites y itself mean-removed (the refinement reads it)
+__global__ __launch_bounds__(256) void hv_pad_kernel(const HvUtt* __restrict__ meta, double* __restrict__ y,
+                                                     const double* __restrict__ mean, int pad, double* __restrict__ z) {
+  const HvUtt m = meta[blockIdx.y];
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= m.ylen + 2 * pad) return;
+  const int64_t i = j - pad;
+  double v = 0.0;
+  if (i >= 0 && i < m.ylen) {
+    v = y[m.y_off + i] - mean[blockIdx.y];
+    y[m.y_off + i] = v;
+  }
+  z[m.z_off + j] = v;
+}
+
+__global__ __launch_bounds__(256) void hv_raw_kernel(const HvUtt* __restrict__ meta, const wh::BandJob* __restrict__ jobs,
+                                                     const double* __restrict__ band_f0, int nb, double fs_d,
+                                                     double f0_floor, double f0_ceil, double* __restrict__ raw) {
+  const HvUtt m = meta[blockIdx.z];
+  const int b = blockIdx.y;
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= m.nf1) return;
+  const double t = (double)f * 1 / 1000;  // basic_temporal_positions (harvest.py:21)
+  const wh::BandJob job = jobs[(int64_t)blockIdx.z * nb + b];
+  double cand, dev;
+  wh::interp_four_trains(job.edges, job.cap, job.counts, fs_d, t, false, &cand, &dev);
+  const double bf = band_f0[b];
+  if (cand > bf * 1.1 || cand < bf * 0.9 || cand > f0_ceil || cand < f0_floor) cand = 0.0;  // harvest.py:273-276
+  raw[m.f1_off * nb + (int64_t)b * m.nf1 + f] = cand;
+}
+
+// NumPy's pairwise summation for n <= 128 (what np.mean does on the run of channel values)
+__device__ __forceinline__ double np_sum_strided(const double* __restrict__ a, int64_t stride, int n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r += a[i * stride];
+    return r;
+  }
+  double r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a[j * stride];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += a[(i + j) * stride];
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += a[i * stride];
+  return res;
+}
+
+__global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict__ meta, int nb,
+                                                        const double* __restrict__ raw, double* __restrict__ dc,
+                                                        int32_t* __restrict__ dcount) {
+  const HvUtt m = meta[blockIdx.y];
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= m.nf1) return;
+  const double* col = raw + m.f1_off * nb + f;  // element b at col[b * nf1]
+  double* out = dc + (m.f1_off + f) * kMaxC;
+  for (int c = 0; c < kMaxC; ++c) out[c] = 0.0;
+  int count = 0;
+  int run_start = -1;  // 'st': index of the last dead channel before a live run
+  bool prev = false;   // channel 0 is forced dead
+  for (int b = 1; b < nb; ++b) {
+    const bool live = (b < nb - 1) && (col[(int64_t)b * m.nf1] > 0);  // last channel forced dead
+    if (live && !prev) run_start = b - 1;
+    if (!live && prev) {
+      const int ed = b - 1;
+      if (ed - run_start >= 10 && count < kMaxC) {
+        const int n = ed - run_start;
+        out[count++] = np_sum_strided(col + (int64_t)(run_start + 1) * m.nf1, m.nf1, n) / (double)n;
+      }
+    }
+    prev = live;
+  }
+  dcount[m.f1_off + f] = count;
+}
+
+// ---- candidate refinement ------------------------------------------------------------------------
+// One wave refines one (frame, candidate): GetRefinedF0, harvest.py:169-211.
+__device__ __forceinline__ void hv_refine_one(const double* __restrict__ yl, int64_t ybase, int64_t ylen, double fs,
+                                              double t0, double f0c, double f0_floor, double f0_ceil,
+                                              double* __restrict__ sm, double* __restrict__ sd,
+                                              const double2* __restrict__ tw_base, double* out_f0, double* out_sc) {
+  const int lane = threadIdx.x & 63;
+  const double hwl_d = ceil(3 * fs / f0c / 2);
+  const int hwl = (int)hwl_d;
+  const int L = 2 * hwl + 1;
+  const double wlit = (2 * hwl_d + 1) / fs;
+  int nfft;
+  {
+    int e = 0;
+    while ((1 << e) < L) ++e;
+    nfft = 1 << (e + 1);
+  }
+  auto idx_raw_at = [&](int j) -> double {
+    const double bt = (double)(j - hwl) / fs;
+    const double v = (t0 + bt) * fs + 0.001;  // "first-aid treatment", harvest.py:178
+    return v > 0 ? v + 0.5 : v - 0.5;         // round_matlab does not truncate (Q1)
+  };
+  auto main_at = [&](int j) -> double {
+    if (j < 0 || j >= L) return 0.0;
+    const double common = M_PI * ((idx_raw_at(j) - 1) / fs - t0) / wlit;
+    return 0.42 + 0.5 * cos(2 * common) + 0.08 * cos(4 * common);
+  };
+  double prev_last = 0.0;
+  double cur = main_at(lane);
+  for (int base = 0; base < L; base += 64) {
+    const int j = base + lane;
+    const double nxt = main_at(j + 64);
+    double left = __shfl_up(cur, 1, 64);
+    if (lane == 0) left = prev_last;
+    double right = __shfl_down(cur, 1, 64);
+    const double nxt0 = __shfl(nxt, 0, 64);
+    if (lane == 63) right = nxt0;
+    if (j < L) {
+      double dw;
+      if (j == 0) dw = -right / 2;
+      else if (j == L - 1) dw = left / 2;
+      else dw = -((right - cur) + (cur - left)) / 2;
+      double ir = idx_raw_at(j);
+      ir = fmax(1.0, fmin((double)ylen, ir)) - 1;
+      const int64_t gi = (int64_t)ir;  // 0-based sample
+      const double s = yl[gi - ybase];
+      sm[j] = s * cur;
+      sd[j] = s * dw;
+    }
+    prev_last = __shfl(cur, 63, 64);
+    cur = nxt;
+  }
+  // wave-private LDS: no block barrier, just make the writes visible to the other lanes of this wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const int nh = (int)fmin(floor(fs / 2 / f0c), 6.0);
+  const double2* tw = tw_base + nfft;
+  double2 X[6], D[6];
+  int bins[6];
+  for (int h = 0; h < 6; ++h) {
+    X[h] = make_double2(0.0, 0.0);
+    D[h] = make_double2(0.0, 0.0);
+    const double b = f0c * nfft / fs * (double)(h + 1);
+    bins[h] = (int)(b + 0.5);
+  }
+  for (int j = lane; j < L; j += 64) {
+    const double a = sm[j], d = sd[j];
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      if (h < nh) {
+        const double2 w = tw[(int)(((long long)bins[h] * j) & (nfft - 1))];
+        X[h].x += a * w.x;
+        X[h].y += a * w.y;
+        D[h].x += d * w.x;
+        D[h].y += d * w.y;
+      }
+    }
+  }
+  double num = 0.0, den = 0.0, var = 0.0;
+#pragma unroll
+  for (int h = 0; h < 6; ++h) {
+    if (h < nh) {
+      const double xr = wh::wave_sum(X[h].x), xi = wh::wave_sum(X[h].y);
+      const double dr = wh::wave_sum(D[h].x), di = wh::wave_sum(D[h].y);
+      const double p = xr * xr + xi * xi;
+      const double nm = xr * di - xi * dr;
+      const double inst = ((double)bins[h] / nfft + nm / p / 2 / M_PI) * fs;
+      const double amp = sqrt(p);
+      num += amp * inst;
+      den += amp * (double)(h + 1);
+      var += fabs((inst / (double)(h + 1) - f0c) / f0c);
+    }
+  }
+  double rf = num / den;
+  double sc = 1 / (0.000000000001 + var / (double)nh);
+  if (rf < f0_floor || rf > f0_ceil || sc < 2.5) {
+    rf = 0.0;
+    sc = 0.0;
+  }
+  *out_f0 = rf;
+  *out_sc = sc;
+}
+
+__global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
+                                                        const double* __restrict__ dc, const int32_t* __restrict__ dcount,
+                                                        double fs, double f0_floor, double f0_ceil, int hmax,
+                                                        const double2* __restrict__ tw_base, double* __restrict__ rf0,
+                                                        double* __restrict__ rsc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const HvUtt m = meta[blockIdx.y];
+  const int64_t f = blockIdx.x;
+  if (f >= m.nf1) return;
+  const int seglen = 2 * hmax + 8;
+  double* yl = reinterpret_cast<double*>(smem);  // staged signal around the frame centre
+  double* wbuf = yl + seglen;                     // 4 waves x 2 x (2*hmax+1)
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double t0 = (double)f * 1 / 1000;
+  const int64_t centre = (int64_t)floor(t0 * fs + 0.5);
+  int64_t ybase = centre - hmax - 3;
+  if (ybase < 0) ybase = 0;
+  const double* yu = y + m.y_off;
+  for (int i = threadIdx.x; i < seglen; i += 256) {
+    const int64_t g = ybase + i;
+    yl[i] = g < m.ylen ? yu[g] : 0.0;
+  }
+  double* of0 = rf0 + (m.f1_off + f) * kRows;
+  double* osc = rsc + (m.f1_off + f) * kRows;
+  for (int e = threadIdx.x; e < kRows; e += 256) {
+    of0[e] = 0.0;
+    osc[e] = 0.0;
+  }
+  __syncthreads();
+  double* sm = wbuf + (size_t)w * 2 * (2 * hmax + 1);
+  double* sd = sm + (2 * hmax + 1);
+  for (int e = w; e < kRows; e += 4) {  // wave-uniform loop over overlapped rows (shift-major)
+    const int s = e / kMaxC - 3, c = e % kMaxC;
+    const int64_t src = f + s;
+    double cand = 0.0;
+    if (src >= 0 && src < m.nf1 && c < dcount[m.f1_off + src]) cand = dc[(m.f1_off + src) * kMaxC + c];
+    if (e == 0 && f < 3) cand = dc[(m.f1_off + f) * kMaxC + 6];  // stray seeding of row 0 (harvest.py:119)
+    if (cand == 0.0) continue;
+    const double hw = ceil(3 * fs / cand / 2);
+    if (!(hw <= (double)hmax)) continue;  // cannot happen for candidates >= f0_floor
+    double r0, r1;
+    hv_refine_one(yl, ybase, m.ylen, fs, t0, cand, f0_floor, f0_ceil, sm, sd, tw_base, &r0, &r1);
+    if (lane == 0) {
+      of0[e] = r0;
+      osc[e] = r1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// RemoveUnreliableCandidates (harvest.py:215-234): a candidate survives if some candidate of frame j-1
+// or j+1 lies within 5 %.
+__global__ __launch_bounds__(128) void hv_prune_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ rf0,
+                                                       const double* __restrict__ rsc, double* __restrict__ pf0,
+                                                       double* __restrict__ psc) {
+  __shared__ double nb_prev[kRows], nb_next[kRows];
+  const HvUtt m = meta[blockIdx.y];
+  const int64_t f = blockIdx.x;
+  if (f >= m.nf1) return;
+  const int e = threadIdx.x;
+  const int64_t o = (m.f1_off + f) * kRows;
+  const bool inner = f >= 1 && f <= m.nf1 - 2;
+  if (e < kRows && inner) {
+    nb_prev[e] = rf0[o - kRows + e];
+    nb_next[e] = rf0[o + kRows + e];
+  }
+  __syncthreads();
+  if (e >= kRows) return;
+  double v = rf0[o + e], s = rsc[o + e];
+  if (inner && v != 0.0) {
+    double e1 = 1.0, e2 = 1.0;  // SelectBestF0 with allowed_range = 1
+    for (int k = 0; k < kRows; ++k) {
+      const double a = fabs(v - nb_next[k]) / v;
+      if (!(a > e1)) e1 = a;
+      const double b = fabs(v - nb_prev[k]) / v;
+      if (!(b > e2)) e2 = b;
+    }
+    if (fmin(e1, e2) > 0.05) {
+      v = 0.0;
+      s = 0.0;
+    }
+  }
+  pf0[o + e] = v;
+  psc[o + e] = s;
+}
+
+double tdf2_pole_radius(double a1, double a2, double a3) {
+  // max |root| of z^3 + a1 z^2 + a2 z + a3 (Durand-Kerner)
+  double re[3] = {0.4, -0.2, 0.3}, im[3] = {0.9, 0.5, -0.7};
+  for (int it = 0; it < 300; ++it)
+    for (int i = 0; i < 3; ++i) {
+      const double zr = re[i], zi = im[i];
+      double pr = zr + a1, pi = zi;
+      double tr = pr * zr - pi * zi + a2, ti = pr * zi + pi * zr;
+      pr = tr * zr - ti * zi + a3;
+      pi = tr * zi + ti * zr;
+      double dr = 1, di = 0;
+      for (int j = 0; j < 3; ++j)
+        if (j != i) {
+          const double ar = zr - re[j], ai = zi - im[j];
+          const double nr = dr * ar - di * ai, ni = dr * ai + di * ar;
+          dr = nr;
+          di = ni;
+        }
+      const double den = dr * dr + di * di;
+      if (den == 0) continue;
+      re[i] -= (pr * dr + pi * di) / den;
+      im[i] -= (pi * dr - pr * di) / den;
+    }
+  double r = 0;
+  for (int i = 0; i < 3; ++i) r = fmax(r, hypot(re[i], im[i]));
+  return r;
+}
+
+}  // namespace
+
+extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp, double fs,
+                          double f0_floor, double f0_ceil, double frame_period_ms, int decimation_ratio,
+                          const double* h_ba, const double* h_zi, int n_bands, const double* h_band_f0,
+                          const int32_t* h_band_half, const double* h_band_taps, double* f0_out, double* vuv_out,
+                          double* dbg_y, double* dbg_raw, double* dbg_f0_1ms) {
+  if (!ctx || !b || !x || !tp || !h_band_f0 || !h_band_half || !h_band_taps || !f0_out || !vuv_out)
+    return wh::fail_msg("wh_harvest", "null argument");
+  if (decimation_ratio > 1 && (!h_ba || !h_zi)) return wh::fail_msg("wh_harvest", "decimation filter missing");
+  if (n_bands < 3 || n_bands > 1024) return wh::fail_msg("wh_harvest", "n_bands out of range");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = b->n_utt;
+  const int r = decimation_ratio < 1 ? 1 : decimation_ratio;
+  const double fs_d = fs / r;
+  int max_lb = 0, taps_total = 0;
+  std::vector<int32_t> ti(n_bands * 3);
+  for (int i = 0; i < n_bands; ++i) {
+    const int lb = 2 * h_band_half[i] + 1;
+    ti[i] = taps_total;
+    ti[n_bands + i] = lb;
+    ti[2 * n_bands + i] = h_band_half[i];  // filtered[(h+1) + g] == filtered[bias + 1 + g] with bias = h
+    taps_total += lb;
+    if (lb > max_lb) max_lb = lb;
+  }
+  const int pad = max_lb + 2;
+  const int hmax = (int)ceil(3 * fs_d / f0_floor / 2) + 1;
+  if (2 * hmax + 1 > WH_MAX_FFT / 2) return wh::fail_msg("wh_harvest", "f0_floor too low for the twiddle tables");
+  std::vector<HvUtt> meta(B);
+  std::vector<int64_t> e_off((size_t)B * n_bands), e_cap((size_t)B * n_bands);
+  int64_t t_tot = 0, y_tot = 0, z_tot = 0, e_tot = 0, f1_tot = 0, max_len = 0, max_ylen = 0, max_nf1 = 0, max_nf = 0;
+  for (int u = 0; u < B; ++u) {
+    HvUtt& m = meta[u];
+    m.x_off = b->h_x_off[u];
+    m.n = b->h_x_off[u + 1] - b->h_x_off[u];
+    if (m.n < 32) return wh::fail_msg("wh_harvest", "utterance shorter than 32 samples");
+    if (r > 1) {
+      m.offset = (int64_t)ceil(140.0 / r) * r;
+      m.nd = m.n + 2 * m.offset;
+      const double n_out = ceil((double)m.nd / r);
+      const int64_t n_beg = (int64_t)(r - (r * n_out - m.nd));
+      const int64_t picks = (m.nd - (n_beg - 1) + r - 1) / r;
+      m.ylen = picks - 2 * (m.offset / r);
+      m.pick0 = (n_beg - 1) + (m.offset / r) * r;
+    } else {
+      m.offset = 0;
+      m.nd = m.n;
+      m.ylen = m.n;
+      m.pick0 = 0;
+    }
+    m.t_off = t_tot;
+    t_tot += m.nd + 2 * kFPad;
+    m.y_off = y_tot;
+    y_tot += m.ylen;
+    m.z_off = z_tot;
+    z_tot += m.ylen + 2 * pad;
+    m.nf1 = (int64_t)(1000.0 * (double)m.n / fs / 1 + 1);
+    m.f1_off = f1_tot;
+    f1_tot += m.nf1;
+    m.f_off = b->h_frame_off[u];
+    m.nf = b->h_frame_off[u + 1] - b->h_frame_off[u];
+    for (int i = 0; i < n_bands; ++i) {
+      // a band-limited channel centred on f crosses zero ~f times per second; 3x head-room + slack
+      const int64_t cap = (int64_t)ceil((double)m.ylen / fs_d * h_band_f0[i] * 3.0) + 64;
+      e_off[(size_t)u * n_bands + i] = e_tot;
+      e_cap[(size_t)u * n_bands + i] = cap;
+      e_tot += 4 * cap;
+    }
+    max_len = std::max(max_len, m.nd + 2 * kFPad);
+    max_ylen = std::max(max_ylen, m.ylen);
+    max_nf1 = std::max(max_nf1, m.nf1);
+    max_nf = std::max(max_nf, m.nf);
+  }
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  const size_t o_meta = off; off += al(sizeof(HvUtt) * B);
+  const size_t o_tmp = off; off += al(sizeof(double) * t_tot);
+  const size_t o_y = off; off += al(sizeof(double) * y_tot);
+  const size_t o_z = off; off += al(sizeof(double) * z_tot);
+  const size_t o_mean = off; off += al(sizeof(double) * B);
+  const size_t o_e = off; off += al(sizeof(double) * e_tot);
+  const size_t o_cnt = off; off += al(sizeof(int32_t) * (size_t)B * n_bands * 4);
+  const size_t o_jobs = off; off += al(sizeof(wh::BandJob) * (size_t)B * n_bands);
+  const size_t o_raw = off; off += al(sizeof(double) * f1_tot * n_bands);
+  const size_t o_dc = off; off += al(sizeof(double) * f1_tot * kMaxC);
+  const size_t o_dn = off; off += al(sizeof(int32_t) * f1_tot);
+  const size_t o_rf0 = off; off += al(sizeof(double) * f1_tot * kRows);
+  const size_t o_rsc = off; off += al(sizeof(double) * f1_tot * kRows);
+  const size_t o_pf0 = off; off += al(sizeof(double) * f1_tot * kRows);
+  const size_t o_psc = off; off += al(sizeof(double) * f1_tot * kRows);
+  const size_t o_taps = off; off += al(sizeof(double) * taps_total);
+  const size_t o_bf = off; off += al(sizeof(double) * n_bands);
+  const size_t o_ti = off; off += al(sizeof(int32_t) * n_bands * 3);
+  const size_t o_ct = off; off += al(contour_workspace_bytes(f1_tot, B));
+  if (int rc = wh::ws_reserve(ctx, off)) return rc;
+  char* ws = reinterpret_cast<char*>(ctx->ws);
+  HvUtt* d_meta = reinterpret_cast<HvUtt*>(ws + o_meta);
+  double* d_tmp = reinterpret_cast<double*>(ws + o_tmp);
+  double* d_y = reinterpret_cast<double*>(ws + o_y);
+  double* d_z = reinterpret_cast<double*>(ws + o_z);
+  double* d_mean = reinterpret_cast<double*>(ws + o_mean);
+  double* d_e = reinterpret_cast<double*>(ws + o_e);
+  int32_t* d_cnt = reinterpret_cast<int32_t*>(ws + o_cnt);
+  wh::BandJob* d_jobs = reinterpret_cast<wh::BandJob*>(ws + o_jobs);
+  double* d_raw = reinterpret_cast<double*>(ws + o_raw);
+  double* d_dc = reinterpret_cast<double*>(ws + o_dc);
+  int32_t* d_dn = reinterpret_cast<int32_t*>(ws + o_dn);
+  double* d_rf0 = reinterpret_cast<double*>(ws + o_rf0);
+  double* d_rsc = reinterpret_cast<double*>(ws + o_rsc);
+  double* d_pf0 = reinterpret_cast<double*>(ws + o_pf0);
+  double* d_psc = reinterpret_cast<double*>(ws + o_psc);
+  double* d_taps = reinterpret_cast<double*>(ws + o_taps);
+  double* d_bf = reinterpret_cast<double*>(ws + o_bf);
+  int32_t* d_ti = reinterpret_cast<int32_t*>(ws + o_ti);
+  char* d_ct = ws + o_ct;
+  std::vector<wh::BandJob> jobs((size_t)B * n_bands);
+  for (int u = 0; u < B; ++u)
+    for (int i = 0; i < n_bands; ++i) {
+      wh::BandJob& j = jobs[(size_t)u * n_bands + i];
+      j.z = d_z + meta[u].z_off;
+      j.M = meta[u].ylen;
+      j.edges = d_e + e_off[(size_t)u * n_bands + i];
+      j.cap = e_cap[(size_t)u * n_bands + i];
+      j.counts = d_cnt + ((int64_t)u * n_bands + i) * 4;
+    }
+  WH_CHECK(hipMemcpyAsync(d_meta, meta.data(), sizeof(HvUtt) * B, hipMemcpyHostToDevice, st));
+  WH_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(wh::BandJob) * jobs.size(), hipMemcpyHostToDevice, st));
+  WH_CHECK(hipMemcpyAsync(d_taps, h_band_taps, sizeof(double) * taps_total, hipMemcpyHostToDevice, st));
+  WH_CHECK(hipMemcpyAsync(d_bf, h_band_f0, sizeof(double) * n_bands, hipMemcpyHostToDevice, st));
+  WH_CHECK(hipMemcpyAsync(d_ti, ti.data(), sizeof(int32_t) * n_bands * 3, hipMemcpyHostToDevice, st));
+  WH_CHECK(hipStreamSynchronize(st));
+
+  // ---- decimation -----------------------------------------------------------------------------------
+  if (r > 1) {
+    Tdf2 c;
+    c.b0 = h_ba[0]; c.b1 = h_ba[1]; c.b2 = h_ba[2]; c.b3 = h_ba[3];
+    c.a1 = h_ba[5] / h_ba[4]; c.a2 = h_ba[6] / h_ba[4]; c.a3 = h_ba[7] / h_ba[4];
+    if (h_ba[4] != 1.0) { c.b0 /= h_ba[4]; c.b1 /= h_ba[4]; c.b2 /= h_ba[4]; c.b3 /= h_ba[4]; }
+    c.zi0 = h_zi[0]; c.zi1 = h_zi[1]; c.zi2 = h_zi[2];
+    const double rad = tdf2_pole_radius(c.a1, c.a2, c.a3);
+    int warm = 64;
+    if (rad > 0 && rad < 1) warm = (int)ceil(-46.0 / log(rad));
+    warm = ((warm + 63) / 64) * 64;
+    if (!(rad < 0.9999)) warm = 1 << 30;
+    const int chunks = (int)((max_len + kHChunk - 1) / kHChunk);
+    dim3 gi((chunks + 63) / 64, B);
+    { wh::KernelTimer _kt(ctx, st, "hv_iir_fwd_kernel"); hipLaunchKernelGGL(hv_iir_fwd_kernel, gi, dim3(64), 0, st, x, d_meta, c, warm, d_tmp); }
+    WH_LAUNCH_CHECK("hv_iir_fwd_kernel");
+    { wh::KernelTimer _kt(ctx, st, "hv_iir_bwd_kernel"); hipLaunchKernelGGL(hv_iir_bwd_kernel, gi, dim3(64), 0, st, d_meta, c, warm, r, d_tmp, d_y); }
+    WH_LAUNCH_CHECK("hv_iir_bwd_kernel");
+  } else {
+    { wh::KernelTimer _kt(ctx, st, "hv_copy_kernel"); hipLaunchKernelGGL(hv_copy_kernel, dim3((unsigned)((max_ylen + 255) / 256), B), dim3(256), 0, st, x, d_meta, d_y); }
+    WH_LAUNCH_CHECK("hv_copy_kernel");
+  }
+  { wh::KernelTimer _kt(ctx, st, "hv_mean_kernel"); hipLaunchKernelGGL(hv_mean_kernel, dim3(B), dim3(256), 0, st, d_meta, d_y, d_mean); }
+  WH_LAUNCH_CHECK("hv_mean_kernel");
+  { wh::KernelTimer _kt(ctx, st, "hv_pad_kernel"); hipLaunchKernelGGL(hv_pad_kernel, dim3((unsigned)((max_ylen + 2 * pad + 255) / 256), B), dim3(256), 0, st, d_meta, d_y, d_mean, pad, d_z); }
+  WH_LAUNCH_CHECK("hv_pad_kernel");
+  if (dbg_y) WH_CHECK(hipMemcpyAsync(dbg_y, d_y, sizeof(double) * y_tot, hipMemcpyDeviceToDevice, st));
+
+  // ---- 152 channels: FIR + crossings, then per-frame raw candidates ------------------------------------
+  if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands, d_ti + 2 * n_bands,
+                                      max_lb, true, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW))
+    return rc;
+  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3((unsigned)((max_nf1 + 255) / 256), n_bands, B), dim3(256), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw); }
+  WH_LAUNCH_CHECK("hv_raw_kernel");
+  if (dbg_raw) WH_CHECK(hipMemcpyAsync(dbg_raw, d_raw, sizeof(double) * f1_tot * n_bands, hipMemcpyDeviceToDevice, st));
+  { wh::KernelTimer _kt(ctx, st, "hv_detect_kernel"); hipLaunchKernelGGL(hv_detect_kernel, dim3((unsigned)((max_nf1 + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw, d_dc, d_dn); }
+  WH_LAUNCH_CHECK("hv_detect_kernel");
+  // ---- refinement + pruning ------------------------------------------------------------------------------
+  {
+    const size_t lds = sizeof(double) * ((size_t)(2 * hmax + 8) + 4 * 2 * (size_t)(2 * hmax + 1));
+    if (int rc = wh::allow_lds(&hv_refine_kernel, lds)) return rc;
+    { wh::KernelTimer _kt(ctx, st, "hv_refine_kernel"); hipLaunchKernelGGL(hv_refine_kernel, dim3((unsigned)max_nf1, B), dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, ctx->d_twiddle, d_rf0, d_rsc); }
+    WH_LAUNCH_CHECK("hv_refine_kernel");
+  }
+  { wh::KernelTimer _kt(ctx, st, "hv_prune_kernel"); hipLaunchKernelGGL(hv_prune_kernel, dim3((unsigned)max_nf1, B), dim3(128), 0, st, d_meta, d_rf0, d_rsc, d_pf0, d_psc); }
+  WH_LAUNCH_CHECK("hv_prune_kernel");
+  // ---- contour, smoothing, 5 ms pick -------------------------------------------------------------------------
+  return harvest_contour(ctx, st, B, d_meta, meta, f1_tot, max_nf1, max_nf, d_pf0, d_psc, d_ct, tp, f0_out, vuv_out,
+                         dbg_f0_1ms);
+}

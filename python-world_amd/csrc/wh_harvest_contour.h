@@ -1,0 +1,519 @@
+// Harvest back end: contour tracking (FixF0Contour), smoothing (SmoothF0) and the pick onto the output
+// frame grid.  Included by wh_harvest.hip inside its anonymous namespace (needs HvUtt, kRows).
+// Reference: world/harvest.py:301-559.  The reference walks one utterance at a time in Python; here
+// everything that is independent runs in parallel (frames, voiced sections, merge scoring) and only the
+// genuinely sequential bookkeeping (ordering/merging of a few dozen sections) is done by one lane.
+#pragma once
+
+struct HcUtt {  // per-utterance slices of the contour workspace (element offsets)
+  int64_t f_base;    // 6 rows of nf1 doubles: base, s1, s2, s3, s4, smoothed
+  int64_t run_base;  // run lists: 2 x rcap int32 (starts, ends)
+  int64_t rcap;
+  int64_t sec_base;  // section records (HcSec), rcap of them
+  int64_t ch_base;   // channel windows, 32*nf1 + 1024 doubles
+  int64_t ch_cap;
+};
+
+struct HcSec {
+  int32_t st, ed;    // voiced run in s2
+  int32_t w0, wlen;  // channel window covers frames [w0, w0+wlen)
+  int64_t ch_off;    // offset of the window inside the utterance's channel area
+  int32_t r0, r1;    // extended range
+  int32_t kept;
+  int32_t pad_;
+};
+
+inline size_t contour_workspace_bytes(int64_t f1_tot, int n_utt) {
+  // rows + runs + sections + channels, generously aligned
+  return (size_t)f1_tot * 6 * 8 + (size_t)(f1_tot + 16 * n_utt) * 2 * 4 + (size_t)(f1_tot / 2 + 16 * n_utt) * sizeof(HcSec) +
+         (size_t)(f1_tot * 32 + 1024 * n_utt) * 8 + sizeof(HcUtt) * n_utt + 4096;
+}
+
+__global__ __launch_bounds__(256) void hc_base_kernel(const HvUtt* __restrict__ meta, const HcUtt* __restrict__ hc,
+                                                      const double* __restrict__ pf0, const double* __restrict__ psc,
+                                                      double* __restrict__ rows) {
+  const HvUtt m = meta[blockIdx.y];
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= m.nf1) return;
+  const double* f = pf0 + (m.f1_off + j) * kRows;
+  const double* s = psc + (m.f1_off + j) * kRows;
+  int best = 0;
+  double bs = s[0];
+  for (int e = 1; e < kRows; ++e)
+    if (s[e] > bs) {  // np.argmax: first maximum
+      bs = s[e];
+      best = e;
+    }
+  rows[hc[blockIdx.y].f_base + j] = f[best];
+}
+
+__global__ __launch_bounds__(256) void hc_step1_kernel(const HvUtt* __restrict__ meta, const HcUtt* __restrict__ hc,
+                                                       double* __restrict__ rows) {
+  const HvUtt m = meta[blockIdx.y];
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= m.nf1) return;
+  const double* base = rows + hc[blockIdx.y].f_base;
+  double* s1 = rows + hc[blockIdx.y].f_base + m.nf1;
+  const double EPS = 2.220446049250313e-16;
+  double v = base[j];
+  if (j < 2) v = 0.0;
+  else if (v != 0.0) {
+    const double ref = base[j - 1] * 2 - base[j - 2];
+    if (fabs((v - ref) / (ref + EPS)) > 0.008 && fabs((v - base[j - 1]) / (base[j - 1] + EPS)) > 0.008) v = 0.0;
+  }
+  s1[j] = v;
+}
+
+// Ordered list of voiced runs of a[0..n): starts[k]..ends[k] inclusive.  With force_ends the first and
+// last frame count as unvoiced (GetBoundaryList, harvest.py:572-580).  Block-wide; returns the run count
+// (clamped to cap) to every thread.  Contains barriers.
+__device__ __forceinline__ int find_runs(const double* __restrict__ a, int64_t n, bool force_ends,
+                                         int32_t* __restrict__ starts, int32_t* __restrict__ ends, int cap,
+                                         int* sh /* >= 16 ints of LDS */) {
+  int base_s = 0, base_e = 0;
+  auto voiced = [&](int64_t j) -> bool {
+    if (j < 0 || j >= n) return false;
+    if (force_ends && (j == 0 || j == n - 1)) return false;
+    return a[j] != 0.0;
+  };
+  for (int64_t t0 = 0; t0 < n; t0 += 256) {
+    const int64_t j = t0 + threadIdx.x;
+    const bool v = voiced(j);
+    const bool is_s = v && !voiced(j - 1);
+    const bool is_e = v && !voiced(j + 1);
+    const unsigned long long ms = __ballot(is_s), me = __ballot(is_e);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) {
+      sh[w] = __popcll(ms);
+      sh[4 + w] = __popcll(me);
+    }
+    __syncthreads();
+    int off_s = base_s, off_e = base_e, tot_s = 0, tot_e = 0;
+    for (int i = 0; i < 4; ++i) {
+      if (i < w) {
+        off_s += sh[i];
+        off_e += sh[4 + i];
+      }
+      tot_s += sh[i];
+      tot_e += sh[4 + i];
+    }
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (is_s) {
+      const int p = off_s + __popcll(ms & below);
+      if (p < cap) starts[p] = (int32_t)j;
+    }
+    if (is_e) {
+      const int p = off_e + __popcll(me & below);
+      if (p < cap) ends[p] = (int32_t)j;
+    }
+    base_s += tot_s;
+    base_e += tot_e;
+  }
+  __threadfence_block();
+  __syncthreads();
+  return base_s < cap ? base_s : cap;
+}
+
+// step 2 (drop runs shorter than 6 frames) and the section table for step 3
+__global__ __launch_bounds__(256) void hc_sections_kernel(const HvUtt* __restrict__ meta, const HcUtt* __restrict__ hc,
+                                                          double* __restrict__ rows, int32_t* __restrict__ runs,
+                                                          HcSec* __restrict__ secs, int32_t* __restrict__ nsec_out) {
+  __shared__ int sh[16];
+  const HvUtt m = meta[blockIdx.x];
+  const HcUtt h = hc[blockIdx.x];
+  const int64_t n = m.nf1;
+  const double* s1 = rows + h.f_base + n;
+  double* s2 = rows + h.f_base + 2 * n;
+  int32_t* starts = runs + h.run_base;
+  int32_t* ends = starts + h.rcap;
+  for (int64_t j = threadIdx.x; j < n; j += 256) s2[j] = s1[j];
+  __threadfence_block();
+  __syncthreads();
+  int nr = find_runs(s1, n, true, starts, ends, (int)h.rcap, sh);
+  for (int k = threadIdx.x; k < nr; k += 256) {
+    if (ends[k] - starts[k] < 6)
+      for (int j = starts[k]; j <= ends[k]; ++j) s2[j] = 0.0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  nr = find_runs(s2, n, true, starts, ends, (int)h.rcap, sh);
+  HcSec* sc = secs + h.sec_base;
+  if (threadIdx.x == 0) {
+    int64_t off = 0;
+    int kept_n = 0;
+    for (int k = 0; k < nr; ++k) {
+      HcSec s;
+      s.st = starts[k];
+      s.ed = ends[k];
+      int w0 = s.st - 101;
+      if (w0 < 0) w0 = 0;
+      int w1 = s.ed + 101;
+      if (w1 > n - 1) w1 = (int)n - 1;
+      s.w0 = w0;
+      s.wlen = w1 - w0 + 1;
+      s.ch_off = off;
+      s.r0 = s.st;
+      s.r1 = s.ed;
+      s.kept = 0;
+      s.pad_ = 0;
+      if (off + s.wlen > h.ch_cap) break;  // cannot happen with runs >= 6 frames (32x head-room)
+      off += s.wlen;
+      sc[k] = s;
+      ++kept_n;
+    }
+    nsec_out[blockIdx.x] = kept_n;
+  }
+}
+
+// SelectBestF0 (harvest.py:238-248) over one frame's kRows candidates, wave-parallel.
+__device__ __forceinline__ double select_best_wave(double ref, const double* __restrict__ col, double allowed) {
+  const int lane = threadIdx.x & 63;
+  double best_err = INFINITY, best_val = 0.0;
+  int best_idx = -1;
+  for (int e = lane; e < kRows; e += 64) {
+    const double c = col[e];
+    const double err = fabs(ref - c) / ref;
+    if (!(err > allowed) && !(err > best_err)) {  // later entries win ties
+      best_err = err;
+      best_val = c;
+      best_idx = e;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double oe = __shfl_xor(best_err, o, 64);
+    const double ov = __shfl_xor(best_val, o, 64);
+    const int oi = __shfl_xor(best_idx, o, 64);
+    const bool take = (oi >= 0) && (best_idx < 0 || oe < best_err || (oe == best_err && oi > best_idx));
+    if (take) {
+      best_err = oe;
+      best_val = ov;
+      best_idx = oi;
+    }
+  }
+  return best_idx >= 0 ? best_val : 0.0;
+}
+
+// FixStep3, first half: extend every section forward then backward through the candidate map
+// (ExtendF0, harvest.py:408-429) — one wave per section.
+__global__ __launch_bounds__(64) void hc_extend_kernel(const HvUtt* __restrict__ meta, const HcUtt* __restrict__ hc,
+                                                       const double* __restrict__ rows, const double* __restrict__ pf0,
+                                                       HcSec* __restrict__ secs, const int32_t* __restrict__ nsec,
+                                                       double* __restrict__ chan) {
+  const int u = blockIdx.y;
+  if ((int)blockIdx.x >= nsec[u]) return;
+  const HvUtt m = meta[u];
+  const HcUtt h = hc[u];
+  const int64_t n = m.nf1;
+  HcSec* sp = secs + h.sec_base + blockIdx.x;
+  HcSec s = *sp;
+  const double* s2 = rows + h.f_base + 2 * n;
+  double* ch = chan + h.ch_base + s.ch_off;  // ch[j - w0]
+  const int lane = threadIdx.x;
+  for (int i = lane; i < s.wlen; i += 64) {
+    const int j = s.w0 + i;
+    ch[i] = (j >= s.st && j <= s.ed) ? s2[j] : 0.0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const double* cands = pf0 + m.f1_off * kRows;
+  // forward
+  int r1 = s.ed;
+  {
+    double cur = ch[s.ed - s.w0];
+    int miss = 0;
+    int last = (int)(n - 2 < (int64_t)s.ed + 100 ? n - 2 : (int64_t)s.ed + 100) + 1;
+    for (int i = s.ed; i < last; ++i) {
+      const double b = select_best_wave(cur, cands + (int64_t)(i + 1) * kRows, 0.18);
+      if (lane == 0) ch[i + 1 - s.w0] = b;
+      if (b != 0.0) {
+        cur = b;
+        miss = 0;
+        r1 = i + 1;
+      } else if (++miss == 4) break;
+    }
+  }
+  // backward
+  int r0 = s.st;
+  {
+    double cur = ch[s.st - s.w0];
+    int miss = 0;
+    int last = (s.st - 100 > 1 ? s.st - 100 : 1) - 1;
+    for (int i = s.st; i > last; --i) {
+      const double b = select_best_wave(cur, cands + (int64_t)(i - 1) * kRows, 0.18);
+      if (lane == 0) ch[i - 1 - s.w0] = b;
+      if (b != 0.0) {
+        cur = b;
+        miss = 0;
+        r0 = i - 1;
+      } else if (++miss == 4) break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double sum = 0.0;
+  for (int j = r0 + lane; j <= r1; j += 64) sum += ch[j - s.w0];
+  sum = wh::wave_sum(sum);
+  const double mean = sum / (double)(r1 - r0 + 1);
+  if (lane == 0) {
+    s.r0 = r0;
+    s.r1 = r1;
+    s.kept = (2200.0 / mean < (double)(r1 - r0)) ? 1 : 0;
+    *sp = s;
+  }
+}
+
+__device__ __forceinline__ double chan_at(const double* __restrict__ chan_u, const HcSec& s, int64_t j) {
+  return (j >= s.w0 && j < (int64_t)s.w0 + s.wlen) ? chan_u[s.ch_off + (j - s.w0)] : 0.0;
+}
+
+// SerachScore (harvest.py:490-495)
+__device__ __forceinline__ double search_score(double f0, const double* __restrict__ cf, const double* __restrict__ cs) {
+  double sc = 0.0;
+  for (int e = 0; e < kRows; ++e)
+    if (f0 == cf[e] && sc < cs[e]) sc = cs[e];
+  return sc;
+}
+
+// FixStep3 second half (MergeF0, harvest.py:442-486), FixStep4 (harvest.py:388-404), vuv.
+__global__ __launch_bounds__(256) void hc_merge_kernel(const HvUtt* __restrict__ meta, const HcUtt* __restrict__ hc,
+                                                       double* __restrict__ rows, const double* __restrict__ pf0,
+                                                       const double* __restrict__ psc, const HcSec* __restrict__ secs,
+                                                       const int32_t* __restrict__ nsec, const double* __restrict__ chan,
+                                                       int32_t* __restrict__ runs) {
+  __shared__ int sh[16];
+  __shared__ double red[16];
+  __shared__ int order_n;
+  const HvUtt m = meta[blockIdx.x];
+  const HcUtt h = hc[blockIdx.x];
+  const int64_t n = m.nf1;
+  const double* s2 = rows + h.f_base + 2 * n;
+  double* s3 = rows + h.f_base + 3 * n;
+  double* s4 = rows + h.f_base + 4 * n;
+  const HcSec* sc = secs + h.sec_base;
+  const double* chan_u = chan + h.ch_base;
+  int32_t* order = runs + h.run_base;  // reuse the run list area for the kept-section order
+  const int ns = nsec[blockIdx.x];
+  if (threadIdx.x == 0) {
+    int k = 0;
+    for (int i = 0; i < ns; ++i)
+      if (sc[i].kept) {  // stable insertion by extended start (np.argsort of the range starts)
+        int p = k++;
+        while (p > 0 && sc[order[p - 1]].r0 > sc[i].r0) {
+          order[p] = order[p - 1];
+          --p;
+        }
+        order[p] = i;
+      }
+    order_n = k;
+  }
+  __syncthreads();
+  const int nk = order_n;
+  if (nk == 0) {
+    for (int64_t j = threadIdx.x; j < n; j += 256) s3[j] = s2[j];
+  } else {
+    const HcSec first = sc[order[0]];
+    for (int64_t j = threadIdx.x; j < n; j += 256) s3[j] = chan_at(chan_u, first, j);
+    int R0 = first.r0, R1 = first.r1;
+    for (int q = 1; q < nk; ++q) {
+      __threadfence_block();
+      __syncthreads();
+      const HcSec s = sc[order[q]];
+      if (s.r0 - R1 > 0) {
+        for (int64_t j = s.r0 + threadIdx.x; j <= s.r1; j += 256) s3[j] = chan_at(chan_u, s, j);
+        R0 = s.r0;
+        R1 = s.r1;
+      } else if (R0 <= s.r0 && R1 >= s.r1) {
+        // completely covered: nothing changes
+      } else {
+        double a = 0.0, b = 0.0;
+        for (int64_t j = s.r0 + threadIdx.x; j <= R1; j += 256) {
+          const double* cf = pf0 + (m.f1_off + j) * kRows;
+          const double* cs = psc + (m.f1_off + j) * kRows;
+          a += search_score(s3[j], cf, cs);
+          b += search_score(chan_at(chan_u, s, j), cf, cs);
+        }
+        wh::block_sum2(a, b, red);
+        const int64_t from = (a > b) ? R1 : s.r0;
+        for (int64_t j = from + threadIdx.x; j <= s.r1; j += 256) s3[j] = chan_at(chan_u, s, j);
+        R1 = s.r1;
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- step 4: bridge unvoiced gaps shorter than 9 frames ------------------------------------------------
+  for (int64_t j = threadIdx.x; j < n; j += 256) s4[j] = s3[j];
+  int32_t* starts = runs + h.run_base;
+  int32_t* ends = starts + h.rcap;
+  const int nr = find_runs(s3, n, true, starts, ends, (int)h.rcap, sh);
+  for (int k = 1 + threadIdx.x; k < nr; k += 256) {
+    const int e0 = ends[k - 1], s1 = starts[k];
+    const int dist = s1 - e0 - 1;
+    if (dist >= 9) continue;
+    const double t0 = s3[e0] + 1;
+    const double t1 = s3[s1] - 1;
+    const double c = (t1 - t0) / (double)(dist + 1);
+    int cnt = 1;
+    for (int j = e0 + 1; j < s1; ++j, ++cnt) s4[j] = t0 + c * (double)cnt;
+  }
+}
+
+// SmoothF0 (harvest.py:533-559): per voiced run, edge-held signal through a 2nd-order Butterworth
+// forward and backward.  The reference filters the whole zero-padded contour per run; the state of a
+// stable IIR forgets its start within the 300-sample hold (|pole|^300 < 1e-17), so each run is filtered
+// from 300 samples before to 300 samples after it.
+__global__ __launch_bounds__(256) void hc_smooth_kernel(const HvUtt* __restrict__ meta, const HcUtt* __restrict__ hc,
+                                                        double* __restrict__ rows, int32_t* __restrict__ runs,
+                                                        double* __restrict__ chan) {
+  __shared__ int sh[16];
+  __shared__ long long offs[2];
+  const HvUtt m = meta[blockIdx.x];
+  const HcUtt h = hc[blockIdx.x];
+  const int64_t n = m.nf1;
+  const double* s4 = rows + h.f_base + 4 * n;
+  double* sm = rows + h.f_base + 5 * n;
+  int32_t* starts = runs + h.run_base;
+  int32_t* ends = starts + h.rcap;
+  for (int64_t j = threadIdx.x; j < n; j += 256) sm[j] = s4[j];
+  const int nr = find_runs(s4, n, false, starts, ends, (int)h.rcap, sh);  // padded contour: ends are not forced
+  const double b0 = 0.0078202080334971724, b1 = 0.015640416066994345, b2 = 0.0078202080334971724;
+  const double a1 = -1.7347257688092754, a2 = 0.76600660094326412;
+  double* scratch = chan + h.ch_base;
+  // runs are processed 256 at a time; each thread owns a scratch slice of (len + 300) doubles
+  for (int k0 = 0; k0 < nr; k0 += 256) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      offs[0] = 0;
+    }
+    __syncthreads();
+    const int k = k0 + threadIdx.x;
+    long long my_off = 0;
+    int st = 0, ed = -1;
+    if (k < nr) {
+      st = starts[k];
+      ed = ends[k];
+    }
+    // exclusive prefix of slice lengths, serial per block tile (few runs in practice)
+    __shared__ long long lens[256];
+    lens[threadIdx.x] = k < nr ? (long long)(ed - st + 1 + 300) : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long run = 0;
+      for (int i = 0; i < 256; ++i) {
+        const long long l = lens[i];
+        lens[i] = run;
+        run += l;
+      }
+    }
+    __syncthreads();
+    my_off = lens[threadIdx.x];
+    if (k < nr && my_off + (ed - st + 1 + 300) <= h.ch_cap) {
+      double* fw = scratch + my_off;  // forward outputs for frames st .. ed+300
+      const double c0 = s4[st], c1 = s4[ed];
+      double z0 = 0.0, z1 = 0.0, yv = 0.0;
+#define BW_STEP(X)                \
+  {                               \
+    const double xin = (X);       \
+    yv = z0 + b0 * xin;           \
+    z0 = z1 + xin * b1 - yv * a1; \
+    z1 = xin * b2 - yv * a2;      \
+  }
+      for (int i = 0; i < 300; ++i) BW_STEP(c0);
+      for (int j = st; j <= ed; ++j) {
+        BW_STEP(s4[j]);
+        fw[j - st] = yv;
+      }
+      for (int i = 0; i < 300; ++i) {
+        BW_STEP(c1);
+        fw[ed - st + 1 + i] = yv;
+      }
+      z0 = 0.0;
+      z1 = 0.0;
+      for (int i = 299; i >= 0; --i) BW_STEP(fw[ed - st + 1 + i]);
+      for (int j = ed; j >= st; --j) {
+        BW_STEP(fw[j - st]);
+        sm[j] = yv;
+      }
+#undef BW_STEP
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void hc_pick_kernel(const HvUtt* __restrict__ meta, const HcUtt* __restrict__ hc,
+                                                      const double* __restrict__ rows, const double* __restrict__ tp,
+                                                      double* __restrict__ f0_out, double* __restrict__ vuv_out) {
+  const HvUtt m = meta[blockIdx.y];
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= m.nf) return;
+  const int64_t n = m.nf1;
+  const double* s4 = rows + hc[blockIdx.y].f_base + 4 * n;
+  const double* sm = rows + hc[blockIdx.y].f_base + 5 * n;
+  const double v = tp[m.f_off + f] * 1000;
+  double r = v > 0 ? v + 0.5 : v - 0.5;  // round_matlab, truncated by the int cast (harvest.py:48-49)
+  r = fmin((double)(n - 1), r);
+  const int64_t idx = (int64_t)r;
+  f0_out[m.f_off + f] = sm[idx];
+  vuv_out[m.f_off + f] = s4[idx] != 0.0 ? 1.0 : 0.0;
+}
+
+inline int harvest_contour(wh_ctx* ctx, hipStream_t st, int B, const HvUtt* d_meta, const std::vector<HvUtt>& meta,
+                           int64_t f1_tot, int64_t max_nf1, int64_t max_nf, const double* d_pf0, const double* d_psc,
+                           char* d_ws, const double* tp, double* f0_out, double* vuv_out, double* dbg_f0_1ms) {
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  std::vector<HcUtt> hc(B);
+  int64_t run_tot = 0, sec_tot = 0, ch_tot = 0, max_secs = 0;
+  for (int u = 0; u < B; ++u) {
+    HcUtt& h = hc[u];
+    h.f_base = meta[u].f1_off * 6;
+    h.rcap = meta[u].nf1 / 2 + 8;
+    h.run_base = run_tot;
+    run_tot += 2 * h.rcap;
+    h.sec_base = sec_tot;
+    sec_tot += h.rcap;
+    h.ch_base = ch_tot;
+    h.ch_cap = meta[u].nf1 * 32 + 1024;
+    ch_tot += h.ch_cap;
+    max_secs = std::max(max_secs, meta[u].nf1 / 7 + 2);
+  }
+  size_t off = 0;
+  const size_t o_hc = off; off += al(sizeof(HcUtt) * B);
+  const size_t o_rows = off; off += al(sizeof(double) * f1_tot * 6);
+  const size_t o_runs = off; off += al(sizeof(int32_t) * run_tot);
+  const size_t o_secs = off; off += al(sizeof(HcSec) * sec_tot);
+  const size_t o_ns = off; off += al(sizeof(int32_t) * B);
+  const size_t o_ch = off; off += al(sizeof(double) * ch_tot);
+  (void)off;
+  HcUtt* d_hc = reinterpret_cast<HcUtt*>(d_ws + o_hc);
+  double* d_rows = reinterpret_cast<double*>(d_ws + o_rows);
+  int32_t* d_runs = reinterpret_cast<int32_t*>(d_ws + o_runs);
+  HcSec* d_secs = reinterpret_cast<HcSec*>(d_ws + o_secs);
+  int32_t* d_ns = reinterpret_cast<int32_t*>(d_ws + o_ns);
+  double* d_ch = reinterpret_cast<double*>(d_ws + o_ch);
+  WH_CHECK(hipMemcpyAsync(d_hc, hc.data(), sizeof(HcUtt) * B, hipMemcpyHostToDevice, st));
+  WH_CHECK(hipStreamSynchronize(st));
+  const dim3 gf((unsigned)((max_nf1 + 255) / 256), B);
+  { wh::KernelTimer _kt(ctx, st, "hc_base_kernel"); hipLaunchKernelGGL(hc_base_kernel, gf, dim3(256), 0, st, d_meta, d_hc, d_pf0, d_psc, d_rows); }
+  WH_LAUNCH_CHECK("hc_base_kernel");
+  { wh::KernelTimer _kt(ctx, st, "hc_step1_kernel"); hipLaunchKernelGGL(hc_step1_kernel, gf, dim3(256), 0, st, d_meta, d_hc, d_rows); }
+  WH_LAUNCH_CHECK("hc_step1_kernel");
+  { wh::KernelTimer _kt(ctx, st, "hc_sections_kernel"); hipLaunchKernelGGL(hc_sections_kernel, dim3(B), dim3(256), 0, st, d_meta, d_hc, d_rows, d_runs, d_secs, d_ns); }
+  WH_LAUNCH_CHECK("hc_sections_kernel");
+  { wh::KernelTimer _kt(ctx, st, "hc_extend_kernel"); hipLaunchKernelGGL(hc_extend_kernel, dim3((unsigned)max_secs, B), dim3(64), 0, st, d_meta, d_hc, d_rows, d_pf0, d_secs, d_ns, d_ch); }
+  WH_LAUNCH_CHECK("hc_extend_kernel");
+  { wh::KernelTimer _kt(ctx, st, "hc_merge_kernel"); hipLaunchKernelGGL(hc_merge_kernel, dim3(B), dim3(256), 0, st, d_meta, d_hc, d_rows, d_pf0, d_psc, d_secs, d_ns, d_ch, d_runs); }
+  WH_LAUNCH_CHECK("hc_merge_kernel");
+  { wh::KernelTimer _kt(ctx, st, "hc_smooth_kernel"); hipLaunchKernelGGL(hc_smooth_kernel, dim3(B), dim3(256), 0, st, d_meta, d_hc, d_rows, d_runs, d_ch); }
+  WH_LAUNCH_CHECK("hc_smooth_kernel");
+  { wh::KernelTimer _kt(ctx, st, "hc_pick_kernel"); hipLaunchKernelGGL(hc_pick_kernel, dim3((unsigned)((max_nf + 255) / 256), B), dim3(256), 0, st, d_meta, d_hc, d_rows, tp, f0_out, vuv_out); }
+  WH_LAUNCH_CHECK("hc_pick_kernel");
+  if (dbg_f0_1ms) {
+    for (int u = 0; u < B; ++u)
+      WH_CHECK(hipMemcpyAsync(dbg_f0_1ms + meta[u].f1_off, d_rows + hc[u].f_base + 4 * meta[u].nf1,
+                              sizeof(double) * meta[u].nf1, hipMemcpyDeviceToDevice, st));
+  }
+  return 0;
+}

@@ -41,6 +41,8 @@ SIGNATURES = {
     "wh_take_flags": (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
     "wh_dio": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _int,
                       _vp, _vp, _vp, _vp]),
+    "wh_harvest": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp,
+                          _vp, _vp, _vp]),
     "wh_stonemask": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _int, _vp]),
     "wh_synthesis": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp,
                             ctypes.c_uint64, _vp, _vp]),

@@ -64,3 +64,44 @@ def frame_count(n_samples, fs, frame_period):
 
 def frame_times(n_frames, frame_period):
     return np.arange(0, n_frames) * frame_period / 1000
+
+
+_HV_CACHE = {}
+
+
+def harvest_tables(fs, f0_floor, f0_ceil):
+    """Decimation filter, channel list and band-pass FIRs of Harvest (world/harvest.py:19-29,59,253-256,599)."""
+    from decimal import ROUND_HALF_UP, Decimal
+
+    from scipy import signal
+
+    key = (float(fs), float(f0_floor), float(f0_ceil))
+    t = _HV_CACHE.get(key)
+    if t is not None:
+        return t
+    target_fs = 8000
+    r = int(fs / target_fs + 0.5)
+    if fs <= target_fs:
+        r = 1
+    fs_d = fs / r if r > 1 else fs
+    if r > 1:
+        b, a = signal.cheby1(3, 0.05, 0.8 / r)
+        ba = np.concatenate([b, a]).astype(np.float64)
+        zi = np.asarray(signal.lfilter_zi(b, a), dtype=np.float64)
+    else:
+        ba = np.zeros(8)
+        zi = np.zeros(3)
+    lo = f0_floor * 0.9
+    hi = f0_ceil * 1.1
+    bands = np.arange(np.ceil(np.log2(hi / lo) * 40)) + 1
+    bands = (2.0 ** (bands / 40)) * lo
+    halves, taps = [], []
+    for bf in bands:
+        h = int(Decimal(fs_d / bf * 2).quantize(0, ROUND_HALF_UP))
+        halves.append(h)
+        taps.append(nuttall(h * 2 + 1) * np.cos(2 * math.pi * bf * np.arange(-h, h + 1) / fs_d))
+    t = {"r": r, "fs_d": fs_d, "ba": np.ascontiguousarray(ba), "zi": np.ascontiguousarray(zi),
+         "band_f0": np.ascontiguousarray(bands, dtype=np.float64), "band_half": np.asarray(halves, dtype=np.int32),
+         "band_taps": np.ascontiguousarray(np.concatenate(taps), dtype=np.float64)}
+    _HV_CACHE[key] = t
+    return t

@@ -162,6 +162,21 @@ int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, const double
                       const double* vuv, double fs, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
                       int64_t pulse_cap, int32_t* h_pulse_count, int64_t* h_noise_total);
 
+/* ---- Requiem synthesis: replaces synthesisRequiem()  (world/synthesisRequiem.py:12-25) ------------ */
+/* band_aperiodicity[total_frames][n_bands] in dB as produced by wh_d4c_requiem (n_bands = bands+2 <= 8).
+ * Seed tables (DEVICE, row-major like the reference's NumPy arrays): pulse_seed[pulse_fft][n_bands],
+ * noise_seed[noise_len][n_bands] — built by the host (get_seeds_signals, world/get_seeds_signals.py:8).
+ * h_hop[u] = int((tp[1]-tp[0])*fs) of utterance u (synthesisRequiem.py:78, truncating).
+ * h_cursor[n_utt][n_bands]: read position in the circular noise seed at which utterance u starts — the
+ * reference keeps this in a function attribute that persists across calls (synthesisRequiem.py:131-141);
+ * after an utterance of ny samples the position is (cursor + ny - 1) mod noise_len.
+ * y / h_y_off / h_t0 / h_dt / pulse_cap as for wh_synthesis. */
+int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,
+                         const double* vuv, const double* spectrogram, const double* band_aperiodicity, double fs,
+                         int fft_size, const int64_t* h_y_off, const double* h_t0, const double* h_dt, const int64_t* h_hop,
+                         int64_t pulse_cap, const double* pulse_seed, int pulse_fft, const double* noise_seed,
+                         int64_t noise_len, int n_bands, const int64_t* h_cursor, double* y);
+
 #ifdef __cplusplus
 }
 #endif

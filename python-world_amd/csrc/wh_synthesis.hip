@@ -460,6 +460,163 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   return 0;
 }
 
+
+// ================================================================================================
+// Requiem synthesis (world/synthesisRequiem.py:12-141): excitation = band-weighted seed noise +
+// band-mixed seed pulses, then frame-wise minimum-phase filtering with overlap-add.
+// ================================================================================================
+struct ReqUtt {
+  int64_t hop;        // int((tp[1]-tp[0])*fs), host-evaluated
+  int64_t cursor[8];  // per-band start position in the circular noise seed
+};
+
+__global__ __launch_bounds__(256) void req_linap_kernel(const double* __restrict__ band_db, int64_t count,
+                                                        double* __restrict__ lin) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) lin[i] = pow(10.0, band_db[i] / 10);  // synthesisRequiem.py:125
+}
+
+// bracketing frames of time t (SciPy interp1d linear + extrapolate)
+__device__ __forceinline__ void bracket(const double* __restrict__ tp, int64_t nf, double t, int64_t* il, int64_t* ih) {
+  int64_t lo = 0, hi = nf;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (tp[mid] < t) lo = mid + 1; else hi = mid;
+  }
+  *ih = lo < 1 ? 1 : (lo > nf - 1 ? nf - 1 : lo);
+  *il = *ih - 1;
+}
+
+__global__ __launch_bounds__(256) void req_noise_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
+                                                        const double* __restrict__ tp, const double* __restrict__ lin,
+                                                        int nb, const double* __restrict__ noise_seed, int64_t nlen,
+                                                        double* __restrict__ exc) {
+  const SynUtt m = meta[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m.ny) return;
+  const double t = m.t0 + (double)i * m.dt;
+  const double* tpu = tp + m.f_off;
+  int64_t il, ih;
+  bracket(tpu, m.nf, t, &il, &ih);
+  const double dx = tpu[ih] - tpu[il];
+  double acc = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    const double y_lo = lin[(m.f_off + il) * nb + b], y_hi = lin[(m.f_off + ih) * nb + b];
+    const double ap = (y_hi - y_lo) / dx * (t - tpu[il]) + y_lo;
+    const int64_t pos = (rq[blockIdx.y].cursor[b] + i) % nlen;
+    acc += noise_seed[pos * nb + b] * ap;
+  }
+  exc[m.y_off + i] = acc;
+}
+
+__global__ __launch_bounds__(256) void req_pulse_kernel(const SynUtt* __restrict__ meta, const double* __restrict__ tp,
+                                                        const double* __restrict__ lin, int nb,
+                                                        const double* __restrict__ pulse_seed, int pfft,
+                                                        const int64_t* __restrict__ p_idx, const int32_t* __restrict__ p_count,
+                                                        const int64_t* __restrict__ p_base, int n_utt,
+                                                        const uint8_t* __restrict__ vuv_s, double* __restrict__ exc) {
+  const int64_t total = p_base[n_utt];
+  for (int64_t gp = blockIdx.x; gp < total; gp += gridDim.x) {
+    int u;
+    {
+      int lo = 0, hi = n_utt;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (p_base[mid] <= gp) lo = mid; else hi = mid;
+      }
+      u = lo;
+    }
+    const SynUtt m = meta[u];
+    const int i = (int)(gp - p_base[u]);
+    const int count = p_count[u];
+    const int64_t pidx = p_idx[m.p_off + i];
+    int64_t p = pidx - 1;
+    p = p < 0 ? 0 : (p > m.ny - 1 ? m.ny - 1 : p);
+    if (vuv_s[m.y_off + p] == 0) continue;
+    const double t = m.t0 + (double)p * m.dt;
+    const double* tpu = tp + m.f_off;
+    int64_t il, ih;
+    bracket(tpu, m.nf, t, &il, &ih);
+    const double dx = tpu[ih] - tpu[il];
+    double w[8];
+    for (int b = 0; b < nb; ++b) {
+      const double y_lo = lin[(m.f_off + il) * nb + b], y_hi = lin[(m.f_off + ih) * nb + b];
+      w[b] = (y_hi - y_lo) / dx * (t - tpu[il]) + y_lo;
+    }
+    if (w[0] > 0.999) continue;  // synthesisRequiem.py:55
+    const int64_t nxt = p_idx[m.p_off + (i + 1 < count ? i + 1 : count - 1)];
+    const int64_t ns = nxt - pidx;
+    const double gain = sqrt((double)(ns > 1 ? ns : 1));
+    double* eu = exc + m.y_off;
+    for (int mm = threadIdx.x; mm < pfft; mm += 256) {
+      double r = 0.0;
+      for (int b = 0; b < nb; ++b) r += pulse_seed[(int64_t)mm * nb + b] * (1 - w[b]);
+      r *= gain;
+      const int64_t tgt = pidx - pfft / 2 + 1 + mm;  // 1-based
+      if (tgt < 1) continue;
+      if (tgt < m.ny) atomicAdd(&eu[tgt - 1], r);
+      else if (mm == pfft - 1) atomicAdd(&eu[m.ny - 1], r);
+    }
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(WH_BLOCK) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
+                                                              const double* __restrict__ spectrogram,
+                                                              const double* __restrict__ exc,
+                                                              const double2* __restrict__ tw, double* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int K = N / 2 + 1;
+  double2* buf = reinterpret_cast<double2*>(smem);
+  double2* seg = buf + N;
+  double* amp = reinterpret_cast<double*>(seg + N);  // K
+  const SynUtt m = meta[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x + 2;  // frames 2 .. F-2  (synthesisRequiem.py:83)
+  if (i > m.nf - 2) return;
+  const int64_t hop = rq[blockIdx.y].hop;
+  const int64_t wlen = 2 * hop - 1;
+  const int64_t origin = (i - 1) * hop - (hop - 1);  // 1-based
+  const double* eu = exc + m.y_off;
+  for (int j = threadIdx.x; j < N; j += WH_BLOCK) {
+    double v = 0.0;
+    if (j < wlen) {
+      int64_t g = origin + j;
+      g = g > m.ny ? m.ny : g;
+      g = g < 1 ? 1 : g;
+      const double wv = 0.5 - 0.5 * cos(2.0 * M_PI * (double)(j + 1) / (double)(wlen + 1));  // hanning(wlen+2)[1:-1]
+      v = eu[g - 1] * wv;
+    }
+    seg[j] = make_double2(v, 0.0);
+  }
+  const double* sp = spectrogram + (m.f_off + (i - 1)) * K;
+  for (int k = threadIdx.x; k < K; k += WH_BLOCK) amp[k] = sp[k];
+  __syncthreads();
+  wh::fft_lds<N, false>(seg, tw);
+  min_phase<N>(amp, buf, tw);
+  for (int n = threadIdx.x; n < N; n += WH_BLOCK) buf[n] = wh::cmul(buf[n], seg[n]);
+  __syncthreads();
+  wh::fft_lds<N, true>(buf, tw);
+  double* yu = y + m.y_off;
+  for (int mm = threadIdx.x; mm < N; mm += WH_BLOCK) {
+    const int64_t tgt = origin + mm;
+    const double v = buf[mm].x / N;
+    if (tgt < 1) continue;
+    if (tgt < m.ny) atomicAdd(&yu[tgt - 1], v);
+    else if (mm == N - 1) atomicAdd(&yu[m.ny - 1], v);
+  }
+}
+
+template <int N>
+int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, const SynUtt* d_meta, const ReqUtt* d_rq,
+                      const double* spec, const double* exc, double* y) {
+  const size_t lds = sizeof(double2) * 2 * N + sizeof(double) * (N / 2 + 8);
+  if (int rc = wh::allow_lds(&req_filter_kernel<N>, lds)) return rc;
+  if (max_nf < 4) return 0;
+  { wh::KernelTimer _kt(ctx, st, "req_filter_kernel"); hipLaunchKernelGGL(req_filter_kernel<N>, dim3((unsigned)(max_nf - 3), B), dim3(WH_BLOCK), lds, st, d_meta, d_rq, spec, exc, wh::twiddle(ctx, N), y); }
+  WH_LAUNCH_CHECK("req_filter_kernel");
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,
@@ -610,4 +767,102 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
     h_noise_total[u] = total;
   }
   return 0;
+}
+
+
+extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,
+                                    const double* vuv, const double* spectrogram, const double* band_aperiodicity,
+                                    double fs, int fft_size, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
+                                    const int64_t* h_hop, int64_t pulse_cap, const double* pulse_seed, int pulse_fft,
+                                    const double* noise_seed, int64_t noise_len, int n_bands, const int64_t* h_cursor,
+                                    double* y) {
+  if (!ctx || !b || !tp || !f0 || !vuv || !spectrogram || !band_aperiodicity || !h_y_off || !h_t0 || !h_dt || !h_hop ||
+      !pulse_seed || !noise_seed || !h_cursor || !y)
+    return wh::fail_msg("wh_synthesis_requiem", "null argument");
+  if (n_bands < 1 || n_bands > 8) return wh::fail_msg("wh_synthesis_requiem", "n_bands must be in [1, 8]");
+  if (pulse_cap < 1 || noise_len < 1) return wh::fail_msg("wh_synthesis_requiem", "bad pulse_cap / noise_len");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = b->n_utt;
+  std::vector<SynUtt> meta(B);
+  std::vector<ReqUtt> rq(B);
+  int64_t max_ny = 0, max_nf = 0;
+  for (int u = 0; u < B; ++u) {
+    SynUtt& m = meta[u];
+    m.f_off = b->h_frame_off[u];
+    m.nf = b->h_frame_off[u + 1] - b->h_frame_off[u];
+    if (m.nf < 2) return wh::fail_msg("wh_synthesis_requiem", "an utterance has fewer than 2 frames");
+    m.y_off = h_y_off[u];
+    m.ny = h_y_off[u + 1] - h_y_off[u];
+    m.p_off = (int64_t)u * pulse_cap;
+    m.pcap = pulse_cap;
+    m.noise_off = 0;
+    m.noise_len = -1;
+    m.t0 = h_t0[u];
+    m.dt = h_dt[u];
+    m.seed = 0;
+    rq[u].hop = h_hop[u];
+    if (rq[u].hop < 1) return wh::fail_msg("wh_synthesis_requiem", "frame hop below one sample");
+    for (int k = 0; k < 8; ++k) rq[u].cursor[k] = k < n_bands ? ((h_cursor[(int64_t)u * n_bands + k] % noise_len) + noise_len) % noise_len : 0;
+    max_ny = std::max(max_ny, m.ny);
+    max_nf = std::max(max_nf, m.nf);
+  }
+  const int64_t ny_tot = h_y_off[B];
+  const int64_t F = b->total_frames;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  const size_t o_meta = off; off += al(sizeof(SynUtt) * B);
+  const size_t o_rq = off; off += al(sizeof(ReqUtt) * B);
+  const size_t o_phase = off; off += al(sizeof(double) * ny_tot);
+  const size_t o_vuv = off; off += al((size_t)ny_tot);
+  const size_t o_pt = off; off += al(sizeof(double) * B * pulse_cap);
+  const size_t o_pi = off; off += al(sizeof(int64_t) * B * pulse_cap);
+  const size_t o_ps = off; off += al(sizeof(double) * B * pulse_cap);
+  const size_t o_pn = off; off += al(sizeof(int64_t) * B * pulse_cap);
+  const size_t o_pc = off; off += al(sizeof(int32_t) * B);
+  const size_t o_pb = off; off += al(sizeof(int64_t) * (B + 1));
+  const size_t o_lin = off; off += al(sizeof(double) * F * n_bands);
+  const size_t o_exc = off; off += al(sizeof(double) * ny_tot);
+  if (int rc = wh::ws_reserve(ctx, off)) return rc;
+  char* ws = reinterpret_cast<char*>(ctx->ws);
+  SynUtt* d_meta = reinterpret_cast<SynUtt*>(ws + o_meta);
+  ReqUtt* d_rq = reinterpret_cast<ReqUtt*>(ws + o_rq);
+  double* d_phase = reinterpret_cast<double*>(ws + o_phase);
+  uint8_t* d_vuv = reinterpret_cast<uint8_t*>(ws + o_vuv);
+  double* d_pt = reinterpret_cast<double*>(ws + o_pt);
+  int64_t* d_pi = reinterpret_cast<int64_t*>(ws + o_pi);
+  double* d_ps = reinterpret_cast<double*>(ws + o_ps);
+  int64_t* d_pn = reinterpret_cast<int64_t*>(ws + o_pn);
+  int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
+  int64_t* d_pb = reinterpret_cast<int64_t*>(ws + o_pb);
+  double* d_lin = reinterpret_cast<double*>(ws + o_lin);
+  double* d_exc = reinterpret_cast<double*>(ws + o_exc);
+  WH_CHECK(hipMemcpyAsync(d_meta, meta.data(), sizeof(SynUtt) * B, hipMemcpyHostToDevice, st));
+  WH_CHECK(hipMemcpyAsync(d_rq, rq.data(), sizeof(ReqUtt) * B, hipMemcpyHostToDevice, st));
+  WH_CHECK(hipStreamSynchronize(st));
+  WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
+  { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs, d_phase, d_vuv); }
+  WH_LAUNCH_CHECK("prep_kernel");
+  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(64), 0, st, d_meta, d_phase); }
+  WH_LAUNCH_CHECK("phase_kernel");
+  { wh::KernelTimer _kt(ctx, st, "pulse_kernel"); hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ctx->d_flags); }
+  WH_LAUNCH_CHECK("pulse_kernel");
+  { wh::KernelTimer _kt(ctx, st, "pulse_base_kernel"); hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb); }
+  WH_LAUNCH_CHECK("pulse_base_kernel");
+  { wh::KernelTimer _kt(ctx, st, "req_linap_kernel"); hipLaunchKernelGGL(req_linap_kernel, dim3((unsigned)((F * n_bands + 255) / 256)), dim3(256), 0, st, band_aperiodicity, F * n_bands, d_lin); }
+  WH_LAUNCH_CHECK("req_linap_kernel");
+  { wh::KernelTimer _kt(ctx, st, "req_noise_kernel"); hipLaunchKernelGGL(req_noise_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, d_rq, tp, d_lin, n_bands, noise_seed, noise_len, d_exc); }
+  WH_LAUNCH_CHECK("req_noise_kernel");
+  {
+    int64_t grid = pulse_cap * B;
+    if (grid > 256 * 16) grid = 256 * 16;
+    { wh::KernelTimer _kt(ctx, st, "req_pulse_kernel"); hipLaunchKernelGGL(req_pulse_kernel, dim3((unsigned)grid), dim3(256), 0, st, d_meta, tp, d_lin, n_bands, pulse_seed, pulse_fft, d_pi, d_pc, d_pb, B, d_vuv, d_exc); }
+    WH_LAUNCH_CHECK("req_pulse_kernel");
+  }
+  switch (fft_size) {
+    case 512: return launch_req_filter<512>(ctx, st, B, max_nf, d_meta, d_rq, spectrogram, d_exc, y);
+    case 1024: return launch_req_filter<1024>(ctx, st, B, max_nf, d_meta, d_rq, spectrogram, d_exc, y);
+    case 2048: return launch_req_filter<2048>(ctx, st, B, max_nf, d_meta, d_rq, spectrogram, d_exc, y);
+    case 4096: return launch_req_filter<4096>(ctx, st, B, max_nf, d_meta, d_rq, spectrogram, d_exc, y);
+    default: return wh::fail_msg("wh_synthesis_requiem", "fft_size must be a power of two in [512, 4096]");
+  }
 }

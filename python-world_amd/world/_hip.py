@@ -47,6 +47,8 @@ SIGNATURES = {
     "wh_synthesis": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp,
                             ctypes.c_uint64, _vp, _vp]),
     "wh_synthesis_plan": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    "wh_synthesis_requiem": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp, _vp, ctypes.c_int64,
+                                    _vp, _int, _vp, ctypes.c_int64, _int, _vp, _vp]),
     "wh_d4c": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int, _vp, _vp]),
     "wh_d4c_bands": (_int, [_dbl, _int]),
     "wh_d4c_requiem": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int, _vp]),

@@ -1,0 +1,103 @@
+"""Requiem synthesis — drop-in for world/synthesisRequiem.py:12 of the reference, executed by the HIP
+kernels behind wh_synthesis_requiem (include/world_hip.h)."""
+import ctypes
+
+import numpy as np
+
+from . import _hip
+from .synthesis import time_axis_params
+
+
+def generate_noise(N, noise_seed, frequency_band):
+    """Host mirror of the reference helper (world/synthesisRequiem.py:131-141).  The device path does not
+    call it; it exists because the reference keeps the circular-read cursor in this function's
+    ``current_index`` attribute, and callers reset it there (`generate_noise.current_index = None`)."""
+    if np.all(generate_noise.current_index == None):  # noqa: E711
+        generate_noise.current_index = np.zeros(noise_seed.shape[1])
+    n_len = noise_seed.shape[0]
+    start = generate_noise.current_index[frequency_band]
+    index = np.remainder(np.arange(start, start + N), n_len).astype(int)
+    generate_noise.current_index[frequency_band] = index[-1]
+    return noise_seed[index, frequency_band]
+
+
+generate_noise.current_index = None
+
+
+def _advance(cursor, ny, noise_len):
+    """Cursor after reading ny samples: the reference stores index[-1], not index[-1]+1."""
+    return np.remainder(cursor + ny - 1, noise_len)
+
+
+def synthesis_requiem_core(rt, batch, tp_d, f0_d, vuv_d, spec_d, band_d, fs, fft_size, geo, hops, seeds, cursors,
+                           pulse_cap=None):
+    """Device-resident core.  geo: [(ny, t0, dt)] per utterance; cursors: (n_utt, nb) start positions."""
+    ny = [g[0] for g in geo]
+    y_off = np.concatenate([[0], np.cumsum(ny)]).astype(np.int64)
+    t0 = np.ascontiguousarray([g[1] for g in geo], dtype=np.float64)
+    dt = np.ascontiguousarray([g[2] for g in geo], dtype=np.float64)
+    hop = np.ascontiguousarray(hops, dtype=np.int64)
+    cur = np.ascontiguousarray(cursors, dtype=np.int64)
+    pulse = np.ascontiguousarray(seeds['pulse'], dtype=np.float64)
+    noise = np.ascontiguousarray(seeds['noise'], dtype=np.float64)
+    nb = pulse.shape[1]
+    if pulse_cap is None:
+        pulse_cap = int(max(ny)) // 8 + 64
+    y = rt.empty((int(y_off[-1]),))
+    vp = ctypes.c_void_p
+    pulse_d, noise_d = rt.to_device(pulse), rt.to_device(noise)
+    _hip.check(rt.lib.wh_synthesis_requiem(
+        rt.ctx, rt.stream(), batch.handle, rt.ptr(tp_d), rt.ptr(f0_d), rt.ptr(vuv_d), rt.ptr(spec_d), rt.ptr(band_d),
+        float(fs), int(fft_size), y_off.ctypes.data_as(vp), t0.ctypes.data_as(vp), dt.ctypes.data_as(vp),
+        hop.ctypes.data_as(vp), int(pulse_cap), rt.ptr(pulse_d), int(pulse.shape[0]), rt.ptr(noise_d),
+        int(noise.shape[0]), int(nb), cur.ctypes.data_as(vp), rt.ptr(y)))
+    return y, y_off
+
+
+def synthesis_requiem_device(rt, enc, ny, geo, seeds=None, cursor=None):
+    """Batch decode of a BatchEncoding (is_requiem=True).  Utterances consume the noise seed one after the
+    other exactly like consecutive reference calls sharing the persistent cursor."""
+    from .get_seeds_signals import get_seeds_signals
+
+    if seeds is None:
+        seeds = get_seeds_signals(enc.fs)
+    nb = seeds['pulse'].shape[1]
+    nlen = seeds['noise'].shape[0]
+    cur = np.zeros(nb) if cursor is None else np.array(cursor, dtype=np.float64)
+    fo = enc.batch.frame_off
+    tp_h = enc.temporal_positions.cpu().numpy()
+    hops, cursors = [], []
+    for u in range(enc.n_utt):
+        t = tp_h[int(fo[u]):int(fo[u + 1])]
+        hops.append(int((t[1] - t[0]) * enc.fs))
+        cursors.append(cur.copy())
+        cur = _advance(cur, ny[u], nlen)
+    y, y_off = synthesis_requiem_core(rt, enc.batch, enc.temporal_positions, enc.f0, enc.vuv, enc.spectrogram,
+                                      enc.aperiodicity, enc.fs, enc.fft_size, geo, hops, seeds, np.array(cursors))
+    return y, y_off
+
+
+def synthesisRequiem(source_object, filter_object, seeds_signals):
+    """Same contract as the reference, including the cursor that persists across calls in
+    ``generate_noise.current_index``."""
+    rt = _hip.Runtime.get()
+    fs = filter_object['fs']
+    tp = np.asarray(source_object['temporal_positions'], dtype=np.float64)
+    f0 = np.asarray(source_object['f0'], dtype=np.float64)
+    vuv = np.asarray(source_object['vuv'], dtype=np.float64)
+    spectrogram = np.asarray(filter_object['spectrogram'], dtype=np.float64)
+    band = np.asarray(source_object['aperiodicity'], dtype=np.float64)
+    fft_size = (spectrogram.shape[0] - 1) * 2
+    nb = seeds_signals['pulse'].shape[1]
+    nlen = seeds_signals['noise'].shape[0]
+    if np.all(generate_noise.current_index == None):  # noqa: E711
+        generate_noise.current_index = np.zeros(nb)
+    geo = [time_axis_params(tp, fs)]
+    batch = rt.make_batch([0, 0], [0, len(tp)])
+    y, _ = synthesis_requiem_core(rt, batch, rt.to_device(tp), rt.to_device(f0), rt.to_device(vuv),
+                                  rt.to_device(np.ascontiguousarray(spectrogram.T)),
+                                  rt.to_device(np.ascontiguousarray(band.T)), fs, fft_size, geo,
+                                  [int((tp[1] - tp[0]) * fs)], seeds_signals,
+                                  np.array([generate_noise.current_index]), pulse_cap=geo[0][0] // 2 + 16)
+    generate_noise.current_index = _advance(np.asarray(generate_noise.current_index, dtype=np.float64), geo[0][0], nlen)
+    return y.cpu().numpy()

@@ -4,7 +4,7 @@
 //                       x + j*n*x into ONE complex FFT each (spectrum and time-weighted spectrum
 //                       are separated by Hermitian symmetry), Hann frame FFT, three block-scan
 //                       smoothings, then per 3 kHz band: Nuttall-windowed group delay → FFT →
-//                       bitonic sort in LDS → prefix sum → energy ratio      (world/d4c.py:114-209)
+//                       rank-select of the smallest-energy bins → energy ratio      (world/d4c.py:114-209)
 // Replaces d4c() (world/d4c.py:10-64) and d4cRequiem() (world/d4cRequiem.py:9-44).
 #include <map>
 
@@ -97,23 +97,100 @@ __global__ __launch_bounds__(WH_BLOCK) void love_train_kernel(
   if (threadIdx.x == 0) gate[f] = (s1 / s2 > threshold) ? 1 : 0;
 }
 
-__device__ __forceinline__ void bitonic_sort_lds(double* s, int n) {
-  for (int k = 2; k <= n; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < n; i += WH_BLOCK) {
-        const int p = i ^ j;
-        if (p > i) {
-          const double a = s[i], b = s[p];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            s[i] = b;
-            s[p] = a;
-          }
-        }
+// Sum of the m smallest of p[0..K) (all >= 0) and the total, without sorting.
+// The reference sorts the K powers and prefix-sums them (world/d4c.py:206-208); only membership in the
+// "m smallest" set matters, so: (1) histogram the IEEE exponents in LDS, (2) scan the 2048 bins to find the
+// bin holding the m-th smallest, (3) everything in lower bins is in, the few elements of that one bin are
+// ranked against each other (ties by index).  ~9 barrier phases instead of a 66-phase bitonic sort.
+// work: >= 2056 ints + K doubles + K ints of free LDS.  p must be visible on entry.
+template <int K>
+__device__ __forceinline__ void sum_smallest(const double* __restrict__ p, int m, void* work, double* scratch,
+                                             double* s_small, double* s_total) {
+  constexpr int PER = (K + WH_BLOCK - 1) / WH_BLOCK;
+  constexpr int BINS = 2048;
+  int* hist = reinterpret_cast<int*>(work);
+  double* list = reinterpret_cast<double*>(hist + BINS + 8);
+  int* ctl = hist + BINS;  // [0] target bin, [1] count below it, [2] list length
+  for (int i = threadIdx.x; i < BINS + 8; i += WH_BLOCK) hist[i] = 0;
+  double x[PER];
+  int key[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int i = threadIdx.x + q * WH_BLOCK;
+    x[q] = i < K ? p[i] : 0.0;
+    key[q] = (int)((__double_as_longlong(x[q]) >> 52) & 0x7FF);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PER; ++q)
+    if (threadIdx.x + q * WH_BLOCK < K) atomicAdd(&hist[key[q]], 1);
+  __syncthreads();
+  // exclusive scan over the bins (8 per thread) → which bin holds the m-th smallest (0-based rank m-1)
+  {
+    constexpr int BP = BINS / WH_BLOCK;
+    int c[BP], run = 0;
+#pragma unroll
+    for (int q = 0; q < BP; ++q) {
+      c[q] = hist[threadIdx.x * BP + q];
+      run += c[q];
+    }
+    int incl = run;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    int* wsum = reinterpret_cast<int*>(scratch);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int excl = incl - run;
+    for (int i = 0; i < w; ++i) excl += wsum[i];
+#pragma unroll
+    for (int q = 0; q < BP; ++q) {
+      if (excl < m && excl + c[q] >= m) {
+        ctl[0] = threadIdx.x * BP + q;
+        ctl[1] = excl;
       }
-      __syncthreads();
+      excl += c[q];
     }
   }
+  __syncthreads();
+  const int tbin = ctl[0], below = ctl[1];
+  int* list_idx = reinterpret_cast<int*>(list + K);
+  double a = 0.0, t = 0.0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int i = threadIdx.x + q * WH_BLOCK;
+    if (i < K) {
+      t += x[q];
+      if (key[q] < tbin) a += x[q];
+      else if (key[q] == tbin) {
+        const int pos = atomicAdd(&ctl[2], 1);  // list order is arbitrary; ranks below do not depend on it
+        list[pos] = x[q];
+        list_idx[pos] = i;
+      }
+    }
+  }
+  __syncthreads();
+  const int cnt = ctl[2];
+  const int need = m - below;  // how many of the target bin's elements belong to the m smallest
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int i = threadIdx.x + q * WH_BLOCK;
+    if (i < K && key[q] == tbin) {
+      const double v = x[q];
+      int rank = 0;
+      for (int j = 0; j < cnt; ++j) {
+        const double o = list[j];
+        rank += (o < v || (o == v && list_idx[j] < i)) ? 1 : 0;
+      }
+      if (rank < need) a += v;  // each thread adds its own elements in a fixed order → deterministic sums
+    }
+  }
+  wh::block_sum2(a, t, scratch);
+  *s_small = a;
+  *s_total = t;
 }
 
 // Accumulate the group-delay centroid of one Blackman frame into cent[0..N/2] (d4c.py:146-153).
@@ -234,20 +311,14 @@ __global__ __launch_bounds__(WH_BLOCK) void d4c_kernel(
     }
     __syncthreads();
     wh::fft_lds<N, false>(buf, tw);
-    for (int k = threadIdx.x; k < N; k += WH_BLOCK) {
-      double p = INFINITY;
-      if (k < K) {
-        const double2 z = buf[k];
-        p = z.x * z.x + z.y * z.y;
-      }
-      cum[k] = p;
+    for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+      const double2 z = buf[k];
+      cum[k] = z.x * z.x + z.y * z.y;
     }
     __syncthreads();
-    bitonic_sort_lds(cum, N);
-    for (int k = K + threadIdx.x; k < N; k += WH_BLOCK) cum[k] = 0.0;
-    __syncthreads();
-    wh::block_scan_lds(cum, N, scratch);
-    if (threadIdx.x == 0) band[b] = -10 * log10(cum[N / 2 - boundary - 1] / cum[K - 1]);
+    double s_small, s_total;
+    sum_smallest<K>(cum, N / 2 - boundary, buf, scratch, &s_small, &s_total);  // FFT buffer is free: scratch for the selection
+    if (threadIdx.x == 0) band[b] = -10 * log10(s_small / s_total);
     __syncthreads();
   }
 

@@ -222,95 +222,126 @@ __device__ __forceinline__ double select_best(double cur, double past, const dou
   return best;
 }
 
-// One thread per utterance: dio.py:216-326.  s1..s4 are F-sized scratch rows.
-__global__ void contour_kernel(const DioUtt* __restrict__ meta, int n_utt, int nb, double frame_period, double f0_floor,
-                               double allowed, double* __restrict__ cands_all, double* __restrict__ work,
-                               double* __restrict__ f0_out, double* __restrict__ vuv_out) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n_utt) return;
+// One workgroup per utterance: dio.py:216-326.  Element-wise steps (end zeroing, 6-decimal jump test,
+// erosion, copies) run on all 256 threads, the change-point list is built by ordered ballot compaction,
+// and only the data-dependent forward/backward extensions (a few frames per voiced section) are walked
+// by one lane.
+__global__ __launch_bounds__(256) void contour_kernel(const DioUtt* __restrict__ meta, int n_utt, int nb,
+                                                      double frame_period, double f0_floor, double allowed,
+                                                      double* __restrict__ cands_all, double* __restrict__ work,
+                                                      double* __restrict__ f0_out, double* __restrict__ vuv_out) {
+  __shared__ int sh[8];
+  __shared__ int sh_first;
+  const int u = blockIdx.x;
   const DioUtt m = meta[u];
   const int64_t n = m.nf;
+  const int tid = threadIdx.x;
   double* cands = cands_all + m.f_off * nb;  // [nb][n]
-  double* s1 = work + m.f_off * 5 + 8 * u;  // 3 rows + a 2n+8 row for the boundary list
+  double* s1 = work + m.f_off * 5 + 8 * u;   // 3 rows + a 2n+8 row for the boundary list
   double* s2 = s1 + n;
   double* s3 = s2 + n;
-  double* s4 = s3 + n;
+  double* bl = s3 + n;                       // boundary list (as doubles)
   double* f0 = f0_out + m.f_off;
   double* vuv = vuv_out + m.f_off;
   const int64_t vrm = (int64_t)(1 / (frame_period / 1000) / f0_floor + 0.5) * 2 + 1;
   if (n < 2 * vrm + 2) {  // too short for the reference's slicing to leave anything voiced
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = tid; i < n; i += 256) {
       f0[i] = 0.0;
       vuv[i] = 0.0;
     }
     return;
   }
   double* base = cands;  // row 0, mutated like the reference's view (Q6)
-  for (int64_t i = 0; i < vrm; ++i) base[i] = 0.0;
-  for (int64_t i = n - vrm; i < n; ++i) base[i] = 0.0;
-  // step 1
-  for (int64_t i = 0; i < n; ++i) s1[i] = base[i];
-  {
-    double prev = round6(base[vrm - 2]);
-    for (int64_t i = vrm - 1; i < n; ++i) {
-      const double cur = round6(base[i]);
-      if (fabs((cur - prev) / (0.000001 + cur)) > allowed) s1[i] = 0.0;
-      prev = cur;
-    }
+  for (int64_t i = tid; i < vrm; i += 256) {
+    base[i] = 0.0;
+    base[n - vrm + i] = 0.0;
   }
+  __threadfence_block();
+  __syncthreads();
+  // step 1: jumps between 6-decimal rounded neighbours
+  for (int64_t i = tid; i < n; i += 256) {
+    double v = base[i];
+    if (i >= vrm - 1) {
+      const double cur = round6(v), prev = round6(base[i - 1]);
+      if (fabs((cur - prev) / (0.000001 + cur)) > allowed) v = 0.0;
+    }
+    s1[i] = v;
+  }
+  __threadfence_block();
+  __syncthreads();
   // step 2: erode by hw frames on both sides
   const int64_t hw = (vrm - 1) / 2;
-  for (int64_t i = 0; i < n; ++i) s2[i] = s1[i];
-  for (int64_t i = hw; i < n - hw; ++i) {
-    for (int64_t j = -hw; j <= hw; ++j) {
-      if (s1[i + j] == 0.0) {
-        s2[i] = 0.0;
-        break;
+  for (int64_t i = tid; i < n; i += 256) {
+    double v = s1[i];
+    if (i >= hw && i < n - hw) {
+      for (int64_t j = -hw; j <= hw; ++j)
+        if (s1[i + j] == 0.0) {
+          v = 0.0;
+          break;
+        }
+    }
+    s2[i] = v;
+    s3[i] = v;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // boundary list of s2: 0, every i with vuv[i] != vuv[i+1], n-2  (dio.py:318)
+  int nbl = 1;
+  if (tid == 0) bl[0] = 0.0;
+  for (int64_t t0 = 0; t0 < n - 1; t0 += 256) {
+    const int64_t i = t0 + tid;
+    const bool chg = i < n - 1 && ((s2[i] != 0.0) != (s2[i + 1] != 0.0));
+    const unsigned long long mk = __ballot(chg);
+    const int w = tid >> 6, lane = tid & 63;
+    __syncthreads();
+    if (lane == 0) sh[w] = __popcll(mk);
+    __syncthreads();
+    int off = nbl, tot = 0;
+    for (int k = 0; k < 4; ++k) {
+      if (k < w) off += sh[k];
+      tot += sh[k];
+    }
+    if (chg) bl[off + __popcll(mk & (lane == 0 ? 0ull : (~0ull >> (64 - lane))))] = (double)i;
+    nbl += tot;
+  }
+  if (tid == 0) {
+    bl[nbl] = (double)(n - 2);
+    const int64_t bl1 = (int64_t)bl[1];
+    const int d1 = (int)(s2[bl1 + 1] != 0.0) - (int)(s2[bl1] != 0.0);
+    sh_first = (int)ceil(-0.5 * d1);  // first_section
+  }
+  ++nbl;
+  __threadfence_block();
+  __syncthreads();
+  const int first = sh_first;
+  const int64_t nsec = (int64_t)floor((double)(nbl - (1 - first)) / 2);
+  auto sec_start = [&](int64_t i) { return 1 + (int64_t)bl[(i - 1) * 2 + 1 + (1 - first) + 1]; };
+  auto sec_end = [&](int64_t i) { return (int64_t)bl[i * 2 + (1 - first) + 1]; };
+  if (tid == 0) {
+    // step 3 forward extension
+    for (int64_t i = 0; i < nsec; ++i) {
+      const int64_t limit = (i == nsec - 1) ? n - 1 : sec_start(i + 1) + 1;
+      for (int64_t j = sec_end(i); j < limit; ++j) {
+        s3[j + 1] = select_best(s3[j], s3[j - 1], cands + (j + 1), nb, n, allowed);
+        if (s3[j + 1] == 0.0) break;
+      }
+    }
+    // step 4 backward extension, in place (the reference copies step 3 first; nothing else reads it)
+    for (int64_t i = nsec - 1; i >= 0; --i) {
+      const int64_t limit = (i == 0) ? 1 : sec_end(i - 1);
+      for (int64_t j = sec_start(i); j >= limit; --j) {
+        s3[j - 1] = select_best(s3[j], s3[j + 1], cands + (j - 1), nb, n, allowed);
+        if (s3[j - 1] == 0.0) break;
       }
     }
   }
-  for (int64_t i = 0; i < n; ++i) s3[i] = s2[i];
-  // voiced sections of s2 with the reference's boundary conventions (dio.py:314-326), visited in order.
-  // boundary list: 0, every i with vuv[i] != vuv[i+1], n-2.
-  auto is_v = [&](int64_t i) { return s2[i] != 0.0; };
-  // first_section = ceil(-0.5 * diff_vuv[bl[1]])
-  int64_t bl1 = n - 2;
-  for (int64_t i = 0; i < n - 1; ++i) {
-    if (is_v(i) != is_v(i + 1)) {
-      bl1 = i;
-      break;
-    }
+  __threadfence_block();
+  __syncthreads();
+  for (int64_t i = tid; i < n; i += 256) {
+    const double v = s3[i];
+    f0[i] = v;
+    vuv[i] = v != 0.0 ? 1.0 : 0.0;
   }
-  const int d1 = (int)is_v(bl1 + 1) - (int)is_v(bl1);
-  const int first = (int)ceil(-0.5 * d1);
-  // Enumerate boundaries lazily: bl[0]=0, then change points, then n-2.
-  // section i: start = 1 + bl[2i-1+(1-first)+1] ... implemented by materialising the list into s4 (as doubles).
-  int64_t nbl = 0;
-  s4[nbl++] = 0.0;
-  for (int64_t i = 0; i < n - 1; ++i)
-    if (is_v(i) != is_v(i + 1)) s4[nbl++] = (double)i;
-  s4[nbl++] = (double)(n - 2);
-  const int64_t nsec = (int64_t)floor((double)(nbl - (1 - first)) / 2);
-  auto sec_start = [&](int64_t i) { return 1 + (int64_t)s4[(i - 1) * 2 + 1 + (1 - first) + 1]; };
-  auto sec_end = [&](int64_t i) { return (int64_t)s4[i * 2 + (1 - first) + 1]; };
-  // step 3 forward extension
-  for (int64_t i = 0; i < nsec; ++i) {
-    const int64_t limit = (i == nsec - 1) ? n - 1 : sec_start(i + 1) + 1;
-    for (int64_t j = sec_end(i); j < limit; ++j) {
-      s3[j + 1] = select_best(s3[j], s3[j - 1], cands + (j + 1), nb, n, allowed);
-      if (s3[j + 1] == 0.0) break;
-    }
-  }
-  // step 4 backward extension (sections kept in s4's boundary list, result written to f0)
-  for (int64_t i = 0; i < n; ++i) f0[i] = s3[i];
-  for (int64_t i = nsec - 1; i >= 0; --i) {
-    const int64_t limit = (i == 0) ? 1 : sec_end(i - 1);
-    for (int64_t j = sec_start(i); j >= limit; --j) {
-      f0[j - 1] = select_best(f0[j], f0[j + 1], cands + (j - 1), nb, n, allowed);
-      if (f0[j - 1] == 0.0) break;
-    }
-  }
-  for (int64_t i = 0; i < n; ++i) vuv[i] = f0[i] != 0.0 ? 1.0 : 0.0;
 }
 
 double pole_radius(const IirCoef& c) {
@@ -486,7 +517,7 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   { wh::KernelTimer _kt(ctx, st, "sort_kernel"); hipLaunchKernelGGL(sort_kernel, dim3((unsigned)((max_nf + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw,
                      d_stab, d_sorted, cand_out); }
   WH_LAUNCH_CHECK("sort_kernel");
-  { wh::KernelTimer _kt(ctx, st, "contour_kernel"); hipLaunchKernelGGL(contour_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_meta, B, n_bands, frame_period_ms, f0_floor,
+  { wh::KernelTimer _kt(ctx, st, "contour_kernel"); hipLaunchKernelGGL(contour_kernel, dim3(B), dim3(256), 0, st, d_meta, B, n_bands, frame_period_ms, f0_floor,
                      allowed_range, d_sorted, d_work, f0_out, vuv_out); }
   WH_LAUNCH_CHECK("contour_kernel");
   return 0;

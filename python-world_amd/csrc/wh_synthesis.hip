@@ -57,24 +57,43 @@ __global__ __launch_bounds__(256) void prep_kernel(const SynUtt* __restrict__ me
   vuv_s[m.y_off + i] = v ? 1 : 0;
 }
 
-// In-place sequential cumulative sum, one 64-lane wave per utterance.
+// In-place sequential cumulative sum, one 64-lane wave per utterance.  Tiles of 2048 samples are staged
+// through LDS with coalesced loads/stores by all lanes; lane 0 walks the tile with the exact left-to-right
+// float64 additions of np.cumsum (16 values per LDS round trip, so the only serial cost is the add chain).
+constexpr int kScanTile = 2048;
 __global__ __launch_bounds__(64) void phase_kernel(const SynUtt* __restrict__ meta, double* __restrict__ phase) {
+  __shared__ __attribute__((aligned(16))) double tile[kScanTile];
   const SynUtt m = meta[blockIdx.x];
   double* p = phase + m.y_off;
   const int lane = threadIdx.x;
   double carry = 0.0;
-  for (int64_t base = 0; base < m.ny; base += 64) {
-    const int64_t i = base + lane;
-    const double v = i < m.ny ? p[i] : 0.0;
-    double run = carry;
-    double mine = 0.0;
-#pragma unroll 8
-    for (int j = 0; j < 64; ++j) {
-      run += __shfl(v, j, 64);  // every lane adds in the same left-to-right order
-      if (j == lane) mine = run;
+  for (int64_t base = 0; base < m.ny; base += kScanTile) {
+    const int cnt = (int)(m.ny - base < kScanTile ? m.ny - base : kScanTile);
+    for (int i = lane; i < kScanTile; i += 64) tile[i] = i < cnt ? p[base + i] : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) {
+      double run = carry;
+      for (int k = 0; k < kScanTile; k += 16) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = tile[k + q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          run += v[q];
+          v[q] = run;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tile[k + q] = v[q];
+      }
+      carry = run;
     }
-    if (i < m.ny) p[i] = mine;
-    carry = run;  // includes zeros past the end only on the last tile
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int i = lane; i < cnt; i += 64) p[base + i] = tile[i];
+    carry = __shfl(carry, 0, 64);
   }
 }
 

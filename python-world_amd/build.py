@@ -36,6 +36,7 @@ def _newer(src_list, target):
 
 
 def build(force=False, verbose=True):
+    extra = os.environ.get("WH_EXTRA_FLAGS", "").split()  # tuning experiments, e.g. -DWH_FRAME_THREADS=64
     os.makedirs(OUT_DIR, exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
@@ -49,7 +50,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ_DIR, u[:-4] + ".o")
         objs.append(obj)
         if force or _newer([src] + headers, obj):
-            jobs.append((u, [hipcc] + FLAGS + ["-c", src, "-o", obj]))
+            jobs.append((u, [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]))
 
     def run(job):
         name, cmd = job

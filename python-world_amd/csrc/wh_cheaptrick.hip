@@ -1,22 +1,30 @@
 // CheapTrick spectral envelope — one 256-thread workgroup per frame, everything between the
-// waveform gather and the final envelope stays in LDS (24*N bytes): window → FFT → power →
-// low-band replica → block-scan smoothing → log → FFT → lifter → IFFT → exp.
+// waveform gather and the final envelope stays in LDS (12*N bytes): window → real FFT → power →
+// low-band replica → block-scan smoothing → log → real FFT → lifter → inverse real FFT → exp.
+// All three transforms run as N/2-point complex FFTs on sample pairs (wh_device.h: rfft_lds / irfft_lds).
 // Replaces cheaptrick()/estimate_one_slice() of the reference (world/cheaptrick.py:9-157).
 #include "wh_host.h"
 #include "wh_spectral.h"
 
 namespace {
 
+#ifndef WH_FRAME_THREADS
+#define WH_FRAME_THREADS 256
+#endif
+constexpr int FT = WH_FRAME_THREADS;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
+
 template <int N>
-__global__ __launch_bounds__(WH_BLOCK) void cheaptrick_kernel(
+__global__ __launch_bounds__(FT) void cheaptrick_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv, double fs, double q1,
-    double f0_low_limit, const double2* __restrict__ tw, double* __restrict__ spec_out, double2* __restrict__ ps_out) {
+    double f0_low_limit, const double2* __restrict__ tw_base, double* __restrict__ spec_out,
+    double2* __restrict__ ps_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double2* buf = reinterpret_cast<double2*>(smem);                    // N complex
-  double* aux = reinterpret_cast<double*>(smem + sizeof(double2) * N);  // N real
-  double* scratch = aux + N;                                            // 16 doubles
   constexpr int K = N / 2 + 1;
+  double2* zb = reinterpret_cast<double2*>(smem);   // N/2+1 complex = the N-sample real buffer (+1 bin)
+  double* zr = reinterpret_cast<double*>(smem);     // same memory viewed as reals; also the prefix-sum array
+  double* aux = zr + (N + 2);                       // K+1 reals
+  double* scratch = aux + (K + 1);                  // 16 doubles
 
   const int64_t f = blockIdx.x;
   const int u = frame_utt[f];
@@ -34,108 +42,101 @@ __global__ __launch_bounds__(WH_BLOCK) void cheaptrick_kernel(
   const int L = 2 * hwl + 1;
   const long long centre = wh::frame_centre(pos, fs);
   double s_w2 = 0.0;
-  for (int j = threadIdx.x; j < L; j += WH_BLOCK) {
-    const int rel = j - hwl;
-    const double seg = wh::sample_clamped(xu, xn, centre + rel);
-    const double t = (double)rel / fs / 1.5;
-    const double w = 0.5 * cos(M_PI * t * f0) + 0.5;
+  for (int j = threadIdx.x; j < L; j += FT) {
+    const double t = (double)(j - hwl) / fs / 1.5;
+    const double w = 0.5 * cospi(t * f0) + 0.5;  // cos(pi*t*f0)
     s_w2 += w * w;
-    if (j < N) {
-      buf[j].x = seg;
-      aux[j] = w;
-    }
+    if (j < N) zr[j] = w;
   }
-  const double norm = sqrt(wh::block_sum(s_w2, scratch));
+  const double norm = sqrt(wh::block_sum<FT>(s_w2, scratch));
   double s_sw = 0.0, s_w = 0.0;
-  for (int j = threadIdx.x; j < L; j += WH_BLOCK) {
-    double seg, w;
-    if (j < N) {
-      seg = buf[j].x;
-      w = aux[j];
-    } else {  // np.fft crops rows longer than N, the means still see them (Q7)
-      const int rel = j - hwl;
-      seg = wh::sample_clamped(xu, xn, centre + rel);
-      w = 0.5 * cos(M_PI * ((double)rel / fs / 1.5) * f0) + 0.5;
-    }
+  for (int j = threadIdx.x; j < L; j += FT) {
+    const double seg = wh::sample_clamped(xu, xn, centre + (j - hwl));
+    // np.fft crops rows longer than N, the means still see them (Q7)
+    double w = j < N ? zr[j] : 0.5 * cospi(((double)(j - hwl) / fs / 1.5) * f0) + 0.5;
     w = w / norm;
     s_sw += seg * w;
     s_w += w;
-    if (j < N) aux[j] = w;
+    if (j < N) zr[j] = w;
   }
-  wh::block_sum2(s_sw, s_w, scratch);
+  wh::block_sum2<FT>(s_sw, s_w, scratch);
   const double mean_sw = s_sw / (double)L;
   const double mean_w = s_w / (double)L;
-  for (int j = threadIdx.x; j < N; j += WH_BLOCK) {
+  for (int j = threadIdx.x; j < N; j += FT) {
     double v = 0.0;
     if (j < L) {
-      const double w = aux[j];
-      v = buf[j].x * w - w * mean_sw / mean_w;
+      const double w = zr[j];
+      v = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w - w * mean_sw / mean_w;
     }
-    buf[j] = make_double2(v, 0.0);
+    zr[j] = v;
   }
-  __syncthreads();
+  wh::sync<FT>();
 
-  // ---- power spectrum (cheaptrick.py:64-75) -------------------------------------------------
-  wh::fft_lds<N, false>(buf, tw);
+  // ---- power spectrum (cheaptrick.py:64-75): real FFT through an N/2-point complex transform -------
+  wh::rfft_lds<N, FT>(zb, tw_base);
   if (ps_out) {
     double2* o = ps_out + f * (int64_t)N;
-    for (int k = threadIdx.x; k < N; k += WH_BLOCK) o[k] = buf[k];
+    for (int k = threadIdx.x; k < N; k += FT) {
+      const double2 z = zb[k <= N / 2 ? k : N - k];
+      o[k] = k <= N / 2 ? z : make_double2(z.x, -z.y);
+    }
   }
-  for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
-    const double2 z = buf[k];
+  for (int k = threadIdx.x; k < K; k += FT) {
+    const double2 z = zb[k];
     aux[k] = z.x * z.x + z.y * z.y;
   }
-  __syncthreads();
-  double* cum = reinterpret_cast<double*>(buf);  // FFT buffer is free now: N doubles of prefix sums
-  wh::low_band_replica(aux, cum, N, fs, f0, f0 + fs / N);
+  wh::sync<FT>();
+  wh::low_band_replica<FT>(aux, zr, N, fs, f0, f0 + fs / N);
 
   // ---- step 2: rectangular smoothing, width 2*f0/3 (cheaptrick.py:103-131) -------------------
-  wh::scan_mirrored(aux, cum, N, fs, scratch);
+  wh::scan_mirrored<FT>(aux, zr, N, fs, scratch);
   wh::BandLookup lk;
-  lk.init(cum, N, fs);
-  for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+  lk.init(zr, N, fs);
+  for (int k = threadIdx.x; k < K; k += FT) {
     const double c = (double)k / N * fs;
     const double lo = lk.at(c - f0 / 3);
     const double hi = lk.at(c + f0 / 3);
-    aux[k] = (hi - lo) * 1.5 / f0;  // the reference's rand*eps dither is omitted (Q10)
+    aux[k] = log((hi - lo) * 1.5 / f0);  // the reference's rand*eps dither is omitted (Q10)
   }
-  __syncthreads();
+  wh::sync<FT>();
 
   // ---- step 3: liftering in the quefrency domain (cheaptrick.py:136-157) ---------------------
-  for (int n = threadIdx.x; n < N; n += WH_BLOCK) {
-    const int k = n <= N / 2 ? n : N - n;
-    buf[n] = make_double2(log(aux[k]), 0.0);
-  }
-  __syncthreads();
-  wh::fft_lds<N, false>(buf, tw);
-  for (int n = threadIdx.x; n < N; n += WH_BLOCK) {
-    const int m = n <= N / 2 ? n : N - n;  // both lifters are mirrored about N/2
+  // The log-spectrum and both lifters are even about N/2, so the transcendental functions run on the K
+  // distinct bins only and both transforms are real (forward of a real sequence, inverse to a real one).
+  for (int n = threadIdx.x; n < N; n += FT) zr[n] = aux[n <= N / 2 ? n : N - n];
+  wh::sync<FT>();
+  for (int m = threadIdx.x; m < K; m += FT) {
     const double q = (double)m / fs;
-    double sl = 1.0;
+    double sl = 1.0, sn = 0.0;
     if (m > 0) {
-      const double a = M_PI * f0 * q;
-      sl = sin(a) / a;
+      sn = sinpi(f0 * q);  // sin(pi*f0*q)
+      sl = sn / (M_PI * f0 * q);
     }
-    const double cl = (1 - 2 * q1) + 2 * q1 * cos(2 * M_PI * q * f0);
-    double2 z = buf[n];
-    z.x = z.x * sl * cl;
-    z.y = z.y * sl * cl;
-    buf[n] = z;
+    const double cl = (1 - 2 * q1) + 2 * q1 * (1 - 2 * sn * sn);  // cos(2*pi*q*f0) = 1 - 2 sin^2(pi*q*f0)
+    aux[m] = sl * cl;
   }
-  __syncthreads();
-  wh::fft_lds<N, true>(buf, tw);
+  wh::rfft_lds<N, FT>(zb, tw_base);
+  for (int k = threadIdx.x; k < K; k += FT) {
+    const double l = aux[k];
+    double2 z = zb[k];
+    z.x = z.x * l;
+    z.y = z.y * l;
+    zb[k] = z;
+  }
+  wh::sync<FT>();
+  wh::irfft_lds<N, FT>(zb, tw_base);
   double* o = spec_out + f * (int64_t)K;
-  for (int k = threadIdx.x; k < K; k += WH_BLOCK) o[k] = exp(buf[k].x / N);
+  for (int k = threadIdx.x; k < K; k += FT) o[k] = exp(zr[k] / N);
 }
 
 template <int N>
 int launch(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
            const double* vuv, double fs, double q1, double* spec, double* ps) {
-  const size_t lds = sizeof(double2) * N + sizeof(double) * (N + 16);
+  const size_t lds = sizeof(double) * ((N + 2) + (N / 2 + 2) + 16);
   const double low = fs * 3.0 / (N - 3.0);
   if (int rc = wh::allow_lds(&cheaptrick_kernel<N>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "cheaptrick_kernel"); hipLaunchKernelGGL(cheaptrick_kernel<N>, dim3((unsigned)b->total_frames), dim3(WH_BLOCK), lds, st, x, b->d_x_off,
-                     b->d_frame_utt, tp, f0, vuv, fs, q1, low, wh::twiddle(ctx, N), spec,
+  { wh::KernelTimer _kt(ctx, st, "cheaptrick_kernel"); hipLaunchKernelGGL(cheaptrick_kernel<N>, dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
+                     b->d_frame_utt, tp, f0, vuv, fs, q1, low, ctx->d_twiddle, spec,
                      reinterpret_cast<double2*>(ps)); }
   WH_LAUNCH_CHECK("cheaptrick_kernel");
   return 0;

@@ -13,6 +13,11 @@
 
 namespace {
 
+#ifndef WH_FRAME_THREADS
+#define WH_FRAME_THREADS 256
+#endif
+constexpr int FT = WH_FRAME_THREADS;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
+
 // Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110) written to buf[j].x, j<N
 // (zero beyond the window; rows longer than N are cropped like np.fft.fft(x, n), Q7).
 // Returns sum(wave^2) over the FULL window.  BLACKMAN selects window type 2, else Hann.
@@ -24,22 +29,22 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
   const long long centre = wh::frame_centre(pos, fs);
   const double phase = (pos * fs - (double)(long long)(pos * fs + 0.5)) / fs;
   double s_sw = 0.0, s_w = 0.0;
-  for (int j = threadIdx.x; j < L; j += WH_BLOCK) {
+  for (int j = threadIdx.x; j < L; j += FT) {
     const int rel = j - hwl;
     const double seg = wh::sample_clamped(xu, xn, centre + rel);
     const double t = (double)rel / fs / half_length + phase;
-    const double a = M_PI * t * cf;
-    const double w = BLACKMAN ? (0.08 * cos(a * 2) + 0.5 * cos(a) + 0.42) : (0.5 * cos(a) + 0.5);
+    const double c1 = cospi(t * cf);  // cos(pi*t*f0); cos(2a) = 2cos^2(a) - 1 saves the second evaluation
+    const double w = BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);
     const double sw = seg * w;
     s_sw += sw;
     s_w += w;
     if (j < N) buf[j] = make_double2(sw, w);
   }
-  wh::block_sum2(s_sw, s_w, scratch);
+  wh::block_sum2<FT>(s_sw, s_w, scratch);
   const double mean_sw = s_sw / (double)L;
   const double mean_w = s_w / (double)L;
   double e = 0.0;
-  for (int j = threadIdx.x; j < (L > N ? L : N); j += WH_BLOCK) {
+  for (int j = threadIdx.x; j < (L > N ? L : N); j += FT) {
     double v = 0.0;
     if (j < L) {
       double sw, w;
@@ -49,8 +54,8 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
       } else {
         const int rel = j - hwl;
         const double seg = wh::sample_clamped(xu, xn, centre + rel);
-        const double a = M_PI * ((double)rel / fs / half_length + phase) * cf;
-        w = BLACKMAN ? (0.08 * cos(a * 2) + 0.5 * cos(a) + 0.42) : (0.5 * cos(a) + 0.5);
+        const double c1 = cospi(((double)rel / fs / half_length + phase) * cf);
+        w = BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);
         sw = seg * w;
       }
       v = sw - w * mean_sw / mean_w;
@@ -58,11 +63,11 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
     }
     if (j < N) buf[j] = make_double2(v, 0.0);
   }
-  return wh::block_sum(e, scratch);  // barriers inside make buf visible
+  return wh::block_sum<FT>(e, scratch);  // barriers inside make buf visible
 }
 
 template <int NLT>
-__global__ __launch_bounds__(WH_BLOCK) void love_train_kernel(
+__global__ __launch_bounds__(FT) void love_train_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv, double fs,
     double threshold, const double2* __restrict__ tw, int32_t* __restrict__ gate) {
@@ -82,18 +87,18 @@ __global__ __launch_bounds__(WH_BLOCK) void love_train_kernel(
   const long long xn = x_off[u + 1] - x_off[u];
   const double cf = fmax(f0, 40.0);
   d4c_window<true>(xu, xn, fs, cf, tp[f], 1.5, buf, NLT, scratch);
-  wh::fft_lds<NLT, false>(buf, tw);
+  wh::fft_lds<NLT, false, FT>(buf, tw);
   const int b0 = (int)(ceil(100.0 / (fs / NLT)) + 1);
   const int b1 = (int)(ceil(4000.0 / (fs / NLT)) + 1);
   const int b2 = (int)(ceil(7900.0 / (fs / NLT)) + 1);
   double s1 = 0.0, s2 = 0.0;
-  for (int k = b0 + threadIdx.x; k < b2 && k < NLT; k += WH_BLOCK) {
+  for (int k = b0 + threadIdx.x; k < b2 && k < NLT; k += FT) {
     const double2 z = buf[k];
     const double p = z.x * z.x + z.y * z.y;
     s2 += p;
     if (k < b1) s1 += p;
   }
-  wh::block_sum2(s1, s2, scratch);
+  wh::block_sum2<FT>(s1, s2, scratch);
   if (threadIdx.x == 0) gate[f] = (s1 / s2 > threshold) ? 1 : 0;
 }
 
@@ -106,28 +111,28 @@ __global__ __launch_bounds__(WH_BLOCK) void love_train_kernel(
 template <int K>
 __device__ __forceinline__ void sum_smallest(const double* __restrict__ p, int m, void* work, double* scratch,
                                              double* s_small, double* s_total) {
-  constexpr int PER = (K + WH_BLOCK - 1) / WH_BLOCK;
+  constexpr int PER = (K + FT - 1) / FT;
   constexpr int BINS = 2048;
   int* hist = reinterpret_cast<int*>(work);
   double* list = reinterpret_cast<double*>(hist + BINS + 8);
   int* ctl = hist + BINS;  // [0] target bin, [1] count below it, [2] list length
-  for (int i = threadIdx.x; i < BINS + 8; i += WH_BLOCK) hist[i] = 0;
+  for (int i = threadIdx.x; i < BINS + 8; i += FT) hist[i] = 0;
   double x[PER];
   int key[PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
-    const int i = threadIdx.x + q * WH_BLOCK;
+    const int i = threadIdx.x + q * FT;
     x[q] = i < K ? p[i] : 0.0;
     key[q] = (int)((__double_as_longlong(x[q]) >> 52) & 0x7FF);
   }
-  __syncthreads();
+  wh::sync<FT>();
 #pragma unroll
   for (int q = 0; q < PER; ++q)
-    if (threadIdx.x + q * WH_BLOCK < K) atomicAdd(&hist[key[q]], 1);
-  __syncthreads();
+    if (threadIdx.x + q * FT < K) atomicAdd(&hist[key[q]], 1);
+  wh::sync<FT>();
   // exclusive scan over the bins (8 per thread) → which bin holds the m-th smallest (0-based rank m-1)
   {
-    constexpr int BP = BINS / WH_BLOCK;
+    constexpr int BP = BINS / FT;
     int c[BP], run = 0;
 #pragma unroll
     for (int q = 0; q < BP; ++q) {
@@ -143,7 +148,7 @@ __device__ __forceinline__ void sum_smallest(const double* __restrict__ p, int m
     }
     int* wsum = reinterpret_cast<int*>(scratch);
     if (lane == 63) wsum[w] = incl;
-    __syncthreads();
+    wh::sync<FT>();
     int excl = incl - run;
     for (int i = 0; i < w; ++i) excl += wsum[i];
 #pragma unroll
@@ -155,13 +160,13 @@ __device__ __forceinline__ void sum_smallest(const double* __restrict__ p, int m
       excl += c[q];
     }
   }
-  __syncthreads();
+  wh::sync<FT>();
   const int tbin = ctl[0], below = ctl[1];
   int* list_idx = reinterpret_cast<int*>(list + K);
   double a = 0.0, t = 0.0;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
-    const int i = threadIdx.x + q * WH_BLOCK;
+    const int i = threadIdx.x + q * FT;
     if (i < K) {
       t += x[q];
       if (key[q] < tbin) a += x[q];
@@ -172,12 +177,12 @@ __device__ __forceinline__ void sum_smallest(const double* __restrict__ p, int m
       }
     }
   }
-  __syncthreads();
+  wh::sync<FT>();
   const int cnt = ctl[2];
   const int need = m - below;  // how many of the target bin's elements belong to the m smallest
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
-    const int i = threadIdx.x + q * WH_BLOCK;
+    const int i = threadIdx.x + q * FT;
     if (i < K && key[q] == tbin) {
       const double v = x[q];
       int rank = 0;
@@ -188,7 +193,7 @@ __device__ __forceinline__ void sum_smallest(const double* __restrict__ p, int m
       if (rank < need) a += v;  // each thread adds its own elements in a fixed order → deterministic sums
     }
   }
-  wh::block_sum2(a, t, scratch);
+  wh::block_sum2<FT>(a, t, scratch);
   *s_small = a;
   *s_total = t;
 }
@@ -200,13 +205,13 @@ __device__ __forceinline__ void add_centroid(const double* xu, long long xn, dou
                                              double* scratch) {
   const double energy = d4c_window<true>(xu, xn, fs, cf, pos, 2.0, buf, N, scratch);
   const double nrm = sqrt(energy);
-  for (int j = threadIdx.x; j < N; j += WH_BLOCK) {
+  for (int j = threadIdx.x; j < N; j += FT) {
     const double v = buf[j].x / nrm;
     buf[j] = make_double2(v, v * (double)(j + 1));  // z = x + i*(n*x), n 1-based
   }
-  __syncthreads();
-  wh::fft_lds<N, false>(buf, tw);
-  for (int k = threadIdx.x; k <= N / 2; k += WH_BLOCK) {
+  wh::sync<FT>();
+  wh::fft_lds<N, false, FT>(buf, tw);
+  for (int k = threadIdx.x; k <= N / 2; k += FT) {
     const double2 a = buf[k];
     const double2 b = buf[(N - k) & (N - 1)];
     // S = (Z[k]+conj(Z[N-k]))/2 ; T = (Z[k]-conj(Z[N-k]))/(2i)
@@ -215,11 +220,11 @@ __device__ __forceinline__ void add_centroid(const double* xu, long long xn, dou
     const double c = tr * sr + si * ti;  // -Im(W)Re(S)+Im(S)Re(W) with W = -i*T
     cent[k] = first ? c : cent[k] + c;
   }
-  __syncthreads();
+  wh::sync<FT>();
 }
 
 template <int N>
-__global__ __launch_bounds__(WH_BLOCK) void d4c_kernel(
+__global__ __launch_bounds__(FT) void d4c_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, const double* __restrict__ f0_in, const int32_t* __restrict__ gate, double fs,
     int nap, int interval, const double* __restrict__ window, int wlen, const double2* __restrict__ tw,
@@ -238,11 +243,11 @@ __global__ __launch_bounds__(WH_BLOCK) void d4c_kernel(
   if (gate[f] == 0) {
     if (k_spec > 0) {
       double* o = out + f * (int64_t)k_spec;
-      for (int k = threadIdx.x; k < k_spec; k += WH_BLOCK) o[k] = 1 - 0.000000000001;
-      if (coarse_dbg) for (int b = threadIdx.x; b < nap; b += WH_BLOCK) coarse_dbg[f * nap + b] = 0.0;
+      for (int k = threadIdx.x; k < k_spec; k += FT) o[k] = 1 - 0.000000000001;
+      if (coarse_dbg) for (int b = threadIdx.x; b < nap; b += FT) coarse_dbg[f * nap + b] = 0.0;
     } else {
       double* o = out + f * (int64_t)(nap + 2);
-      for (int b = threadIdx.x; b < nap + 2; b += WH_BLOCK) o[b] = -0.000000000001;
+      for (int b = threadIdx.x; b < nap + 2; b += FT) o[b] = -0.000000000001;
     }
     return;
   }
@@ -255,51 +260,51 @@ __global__ __launch_bounds__(WH_BLOCK) void d4c_kernel(
   // ---- static centroid from two frames at +-T0/4 (d4c.py:132-142) + DC correction ----------
   add_centroid<N>(xu, xn, fs, cf, pos + 1 / cf / 4, buf, cent, true, tw, scratch);
   add_centroid<N>(xu, xn, fs, cf, pos - 1 / cf / 4, buf, cent, false, tw, scratch);
-  wh::low_band_replica(cent, cum, N, fs, cf, 1.2 * cf);
+  wh::low_band_replica<FT>(cent, cum, N, fs, cf, 1.2 * cf);
 
   // ---- smoothed power spectrum (d4c.py:157-161) ----------------------------------------------
   d4c_window<false>(xu, xn, fs, cf, pos, 2.0, buf, N, scratch);
-  wh::fft_lds<N, false>(buf, tw);
-  for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+  wh::fft_lds<N, false, FT>(buf, tw);
+  for (int k = threadIdx.x; k < K; k += FT) {
     const double2 z = buf[k];
     pw[k] = z.x * z.x + z.y * z.y;
   }
-  __syncthreads();
-  wh::low_band_replica(pw, cum, N, fs, cf, 1.2 * cf);
-  wh::scan_mirrored(pw, cum, N, fs, scratch);
+  wh::sync<FT>();
+  wh::low_band_replica<FT>(pw, cum, N, fs, cf, 1.2 * cf);
+  wh::scan_mirrored<FT>(pw, cum, N, fs, scratch);
   wh::BandLookup lk;
   lk.init(cum, N, fs);
-  for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+  for (int k = threadIdx.x; k < K; k += FT) {
     const double c = (double)k / N * fs;
     const double sm = (lk.at(c + cf / 2) - lk.at(c - cf / 2)) / cf;
     cent[k] = cent[k] / sm;  // T_g = centroid / smoothed power (d4c.py:169; no zero guard, Q14)
   }
-  __syncthreads();
+  wh::sync<FT>();
   // ---- group-delay shaping (d4c.py:165-174) --------------------------------------------------
-  wh::scan_mirrored(cent, cum, N, fs, scratch);
+  wh::scan_mirrored<FT>(cent, cum, N, fs, scratch);
   lk.init(cum, N, fs);
   {
     const double w2 = cf / 2;
-    for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+    for (int k = threadIdx.x; k < K; k += FT) {
       const double c = (double)k / N * fs;
       pw[k] = (lk.at(c + w2 / 2) - lk.at(c - w2 / 2)) / w2;  // T_gs
     }
   }
-  __syncthreads();
-  wh::scan_mirrored(pw, cum, N, fs, scratch);
+  wh::sync<FT>();
+  wh::scan_mirrored<FT>(pw, cum, N, fs, scratch);
   lk.init(cum, N, fs);
-  for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+  for (int k = threadIdx.x; k < K; k += FT) {
     const double c = (double)k / N * fs;
     cent[k] = pw[k] - (lk.at(c + cf / 2) - lk.at(c - cf / 2)) / cf;  // T_D = T_gs - T_gb
   }
-  __syncthreads();
+  wh::sync<FT>();
 
   // ---- band-wise aperiodicity (d4c.py:192-209) -----------------------------------------------
   const int boundary = (int)((double)N / wlen * 8 + 0.5);
   const int half = wlen / 2;
   for (int b = 0; b < nap; ++b) {
     const int centre = (int)floor((double)interval * (b + 1) / (fs / N));
-    for (int j = threadIdx.x; j < N; j += WH_BLOCK) {
+    for (int j = threadIdx.x; j < N; j += FT) {
       double v = 0.0;
       if (j < wlen) {
         int idx = centre - half + j;          // index into the mirrored full group delay
@@ -309,26 +314,26 @@ __global__ __launch_bounds__(WH_BLOCK) void d4c_kernel(
       }
       buf[j] = make_double2(v, 0.0);
     }
-    __syncthreads();
-    wh::fft_lds<N, false>(buf, tw);
-    for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+    wh::sync<FT>();
+    wh::fft_lds<N, false, FT>(buf, tw);
+    for (int k = threadIdx.x; k < K; k += FT) {
       const double2 z = buf[k];
       cum[k] = z.x * z.x + z.y * z.y;
     }
-    __syncthreads();
+    wh::sync<FT>();
     double s_small, s_total;
     sum_smallest<K>(cum, N / 2 - boundary, buf, scratch, &s_small, &s_total);  // FFT buffer is free: scratch for the selection
     if (threadIdx.x == 0) band[b] = -10 * log10(s_small / s_total);
-    __syncthreads();
+    wh::sync<FT>();
   }
 
   // ---- outputs (d4c.py:56-59 / d4cRequiem.py:40) ---------------------------------------------
   const double tilt = (cf - 100) * 2 / 100;
   if (k_spec > 0) {
-    if (coarse_dbg) for (int b = threadIdx.x; b < nap; b += WH_BLOCK) coarse_dbg[f * nap + b] = -fmax(0.0, band[b] - tilt);
+    if (coarse_dbg) for (int b = threadIdx.x; b < nap; b += FT) coarse_dbg[f * nap + b] = -fmax(0.0, band[b] - tilt);
     double* o = out + f * (int64_t)k_spec;
     const int nn = nap + 2;  // nodes: 0, interval, ..., interval*nap, fs/2
-    for (int k = threadIdx.x; k < k_spec; k += WH_BLOCK) {
+    for (int k = threadIdx.x; k < k_spec; k += FT) {
       const double q = (double)k * fs / (double)(2 * (k_spec - 1));
       int cnt = 0;  // searchsorted-left over the coarse axis
       for (int m = 0; m < nn; ++m) {
@@ -343,11 +348,11 @@ __global__ __launch_bounds__(WH_BLOCK) void d4c_kernel(
       const double y_hi = hi == nn - 1 ? -0.000000000001 : -fmax(0.0, band[hi - 1] - tilt);
       const double slope = (y_hi - y_lo) / (a_hi - a_lo);
       const double db = slope * (q - a_lo) + y_lo;
-      o[k] = pow(10.0, db / 20);
+      o[k] = exp(db * (M_LN10 / 20));  // 10^(db/20)
     }
   } else {
     double* o = out + f * (int64_t)(nap + 2);
-    for (int b = threadIdx.x; b < nap + 2; b += WH_BLOCK)
+    for (int b = threadIdx.x; b < nap + 2; b += FT)
       o[b] = b == 0 ? -60.0 : (b == nap + 1 ? -0.000000000001 : -fmax(0.0, band[b - 1] - tilt));
   }
 }
@@ -369,7 +374,7 @@ int launch_lt(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, c
               const double* vuv, double fs, double thr, int32_t* gate) {
   const size_t lds = sizeof(double2) * NLT + sizeof(double) * 16;
   if (int rc = wh::allow_lds(&love_train_kernel<NLT>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)b->total_frames), dim3(WH_BLOCK), lds, st, x, b->d_x_off,
+  { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, fs, thr, wh::twiddle(ctx, NLT), gate); }
   WH_LAUNCH_CHECK("love_train_kernel");
   return 0;
@@ -381,7 +386,7 @@ int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x,
                 double* out, double* coarse) {
   const size_t lds = sizeof(double2) * N + sizeof(double) * (N + 2 * (N / 2 + 8) + 16 + 8);
   if (int rc = wh::allow_lds(&d4c_kernel<N>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL(d4c_kernel<N>, dim3((unsigned)b->total_frames), dim3(WH_BLOCK), lds, st, x, b->d_x_off,
+  { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL(d4c_kernel<N>, dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, gate, fs, nap, interval, win, wlen, wh::twiddle(ctx, N), k_spec, out,
                      coarse); }
   WH_LAUNCH_CHECK("d4c_kernel");

@@ -18,6 +18,20 @@
 
 namespace wh {
 
+// Workgroup-wide synchronisation for NT cooperating threads.  A single-wave group (NT == 64) needs no
+// hardware barrier: its lanes run in lockstep, so a compiler-level wavefront fence is enough to order the
+// LDS traffic.  This is what lets the per-frame kernels run as one wave per frame with zero s_barrier.
+template <int NT>
+__device__ __forceinline__ void sync() {
+  if constexpr (NT <= WH_WAVE) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = WH_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WH_WAVE);
@@ -26,22 +40,32 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Sum over the whole 256-thread block; result broadcast to every thread.
 // `scratch` must hold >= 8 doubles of LDS.  Contains two barriers.
+template <int NT = WH_BLOCK>
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
   v = wave_sum(v);
+  if constexpr (NT <= WH_WAVE) {
+    sync<NT>();
+    return v;
+  }
   const int w = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) scratch[w] = v;
   __syncthreads();
   double t = 0.0;
 #pragma unroll
-  for (int i = 0; i < WH_BLOCK / WH_WAVE; ++i) t += scratch[i];
+  for (int i = 0; i < NT / WH_WAVE; ++i) t += scratch[i];
   return t;
 }
 
 // Two sums at once (saves barriers).
+template <int NT = WH_BLOCK>
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch) {
   a = wave_sum(a);
   b = wave_sum(b);
+  if constexpr (NT <= WH_WAVE) {
+    sync<NT>();
+    return;
+  }
   const int w = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) {
@@ -51,7 +75,7 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
   __syncthreads();
   double ta = 0.0, tb = 0.0;
 #pragma unroll
-  for (int i = 0; i < WH_BLOCK / WH_WAVE; ++i) {
+  for (int i = 0; i < NT / WH_WAVE; ++i) {
     ta += scratch[i];
     tb += scratch[4 + i];
   }
@@ -59,10 +83,15 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
   b = tb;
 }
 
+template <int NT = WH_BLOCK>
 __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* scratch) {
   a = wave_sum(a);
   b = wave_sum(b);
   c = wave_sum(c);
+  if constexpr (NT <= WH_WAVE) {
+    sync<NT>();
+    return;
+  }
   const int w = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) {
@@ -73,7 +102,7 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
   __syncthreads();
   double ta = 0.0, tb = 0.0, tc = 0.0;
 #pragma unroll
-  for (int i = 0; i < WH_BLOCK / WH_WAVE; ++i) {
+  for (int i = 0; i < NT / WH_WAVE; ++i) {
     ta += scratch[i];
     tb += scratch[4 + i];
     tc += scratch[8 + i];
@@ -93,10 +122,11 @@ __device__ __forceinline__ double wave_scan_incl(double v) {
   return v;
 }
 
-// In-place inclusive prefix sum of n doubles in LDS (n a multiple of WH_BLOCK).  Each thread
+// In-place inclusive prefix sum of n doubles in LDS (n a multiple of NT).  Each thread
 // owns a contiguous run of n/256 elements.  `scratch` >= 8 doubles.  Ends with a barrier.
+template <int NT = WH_BLOCK>
 __device__ __forceinline__ void block_scan_lds(double* a, int n, double* scratch) {
-  const int per = n / WH_BLOCK;
+  const int per = n / NT;
   const int base = threadIdx.x * per;
   double run = 0.0;
   for (int i = 0; i < per; ++i) {
@@ -104,21 +134,24 @@ __device__ __forceinline__ void block_scan_lds(double* a, int n, double* scratch
     a[base + i] = run;
   }
   double incl = wave_scan_incl(run);
-  const int w = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 63) scratch[w] = incl;
-  __syncthreads();
   double off = incl - run;
-  for (int i = 0; i < w; ++i) off += scratch[i];
+  if constexpr (NT > WH_WAVE) {
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) scratch[w] = incl;
+    __syncthreads();
+    for (int i = 0; i < w; ++i) off += scratch[i];
+  }
   for (int i = 0; i < per; ++i) a[base + i] += off;
-  __syncthreads();
+  sync<NT>();
 }
 
 // ------------------------------------------------------------------------------------------
 // FFT
 // ------------------------------------------------------------------------------------------
+// complex multiply with fused multiply-adds (2 mul + 2 fma instead of 4 mul + 2 add)
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
-  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+  return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
 }
 
 // One Stockham pass of radix R over N points with NT threads; NS = product of earlier radices.
@@ -137,7 +170,7 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ s, const double2*
       for (int r = 0; r < R; ++r) v[p][r] = s[j + r * J];
     }
   }
-  __syncthreads();
+  sync<NT>();
 #pragma unroll
   for (int p = 0; p < PER; ++p) {
     const int j = tid + p * NT;
@@ -170,7 +203,7 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ s, const double2*
       }
     }
   }
-  __syncthreads();
+  sync<NT>();
 }
 
 template <int N, int NT, int NS, bool INV>
@@ -189,9 +222,61 @@ __device__ __forceinline__ void fft_passes(double2* s, const double2* tw) {
 // In-place unnormalised DFT of N complex doubles resident in LDS.  Caller guarantees that the
 // buffer is fully written and visible (barrier) on entry; visible on exit.  The inverse does
 // NOT divide by N.
-template <int N, bool INV>
+template <int N, bool INV, int NT = WH_BLOCK>
 __device__ __forceinline__ void fft_lds(double2* s, const double2* tw) {
-  fft_passes<N, WH_BLOCK, 1, INV>(s, tw);
+  fft_passes<N, NT, 1, INV>(s, tw);
+}
+
+// ------------------------------------------------------------------------------------------
+// Real-input / real-output transforms through a half-size complex FFT
+// ------------------------------------------------------------------------------------------
+// Every WORLD transform is of real data or produces real data, so an N-point transform is done as an
+// N/2-point complex FFT on the sample pairs (x[2j], x[2j+1]) plus one O(N) butterfly pass: half the
+// butterflies and half the LDS of a complex N-point FFT.  tw_base is the context's table base: the table of
+// size M (exp(-2*pi*i*k/M), k < M) lives at tw_base + M.
+
+// Forward.  in: z[j] = (x[2j], x[2j+1]), j < N/2 (i.e. the real array itself).  out: z[k] = X[k], k = 0..N/2
+// (N/2 + 1 entries).  Buffer must be visible on entry; visible on exit.
+template <int N, int NT = WH_BLOCK>
+__device__ __forceinline__ void rfft_lds(double2* z, const double2* __restrict__ tw_base) {
+  fft_lds<N / 2, false, NT>(z, tw_base + N / 2);
+  const double2* __restrict__ w = tw_base + N;
+  for (int k = threadIdx.x; k <= N / 4; k += NT) {
+    if (k == 0) {
+      const double2 a = z[0];
+      z[0] = make_double2(a.x + a.y, 0.0);
+      z[N / 2] = make_double2(a.x - a.y, 0.0);
+    } else {
+      const double2 a = z[k], b = z[N / 2 - k];
+      const double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);  // E = (A + conj(B))/2   (even samples)
+      const double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);  // D = (A - conj(B))/2 ; O = -i*D (odd samples)
+      const double2 wk = w[k];
+      const double tr = fma(wk.x, di, wk.y * dr);   // T = W^k * O,  O = (di, -dr)
+      const double ti = fma(wk.y, di, -(wk.x * dr));
+      z[k] = make_double2(er + tr, ei + ti);
+      z[N / 2 - k] = make_double2(er - tr, ti - ei);  // conj(E - T)
+    }
+  }
+  sync<NT>();
+}
+
+// Inverse.  in: z[k] = X[k], k = 0..N/2, the Hermitian half of a spectrum whose inverse DFT is real.
+// out: z[j] = N * (x[2j], x[2j+1]), j < N/2 (unnormalised like fft_lds<.., true>: divide by N).
+template <int N, int NT = WH_BLOCK>
+__device__ __forceinline__ void irfft_lds(double2* z, const double2* __restrict__ tw_base) {
+  const double2* __restrict__ w = tw_base + N;
+  for (int k = threadIdx.x; k <= N / 4; k += NT) {
+    const double2 a = z[k], b = z[N / 2 - k];
+    const double er = a.x + b.x, ei = a.y - b.y;  // 2E = A + conj(B)
+    const double dr = a.x - b.x, di = a.y + b.y;  // 2D = A - conj(B)
+    const double2 wk = w[k];
+    const double orr = fma(dr, wk.x, di * wk.y);     // 2O = 2D * conj(W^k),  conj(wk) = (wk.x, -wk.y)
+    const double oi = fma(di, wk.x, -(dr * wk.y));
+    z[k] = make_double2(er - oi, ei + orr);                      // Z[k]     = 2E + i*2O
+    if (k != 0) z[N / 2 - k] = make_double2(er + oi, orr - ei);  // Z[N/2-k] = conj(2E) + i*conj(2O)
+  }
+  sync<NT>();
+  fft_lds<N / 2, true, NT>(z, tw_base + N / 2);
 }
 
 }  // namespace wh

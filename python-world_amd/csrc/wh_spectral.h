@@ -22,12 +22,13 @@ __device__ __forceinline__ double sample_clamped(const double* __restrict__ x, l
 // Nodes f0 - f_j (j < nlow, f_j < reach) are sorted ascending like interp1d does, queried at f_k
 // with SciPy's linear kernel slope*(x-x_lo)+y_lo and end-segment extrapolation; the result is
 // added to bins with f_k < f0.  Two barriers; p must be visible on entry, is visible on exit.
+template <int NT = WH_BLOCK>
 __device__ __forceinline__ void low_band_replica(double* p, double* tmp, int N, double fs, double f0, double reach) {
   int nlow = (int)(reach / fs * N) + 2;  // count of bins with k/N*fs < reach (monotone in k)
   if (nlow > N) nlow = N;
   while (nlow > 0 && !(((double)(nlow - 1) / N * fs) < reach)) --nlow;
   if (nlow >= 2) {
-    for (int kk = threadIdx.x; kk < nlow; kk += WH_BLOCK) {
+    for (int kk = threadIdx.x; kk < nlow; kk += NT) {
       const double fk = (double)kk / N * fs;
       if (fk < f0) {
         // ascending nodes a_m = f0 - f_{nlow-1-m}; hi = clamp(#nodes < fk, 1, nlow-1)
@@ -44,14 +45,14 @@ __device__ __forceinline__ void low_band_replica(double* p, double* tmp, int N, 
       }
     }
   }
-  __syncthreads();
+  sync<NT>();
   if (nlow >= 2) {
-    for (int kk = threadIdx.x; kk < nlow; kk += WH_BLOCK) {
+    for (int kk = threadIdx.x; kk < nlow; kk += NT) {
       const double fk = (double)kk / N * fs;
       if (fk < f0) p[kk] = tmp[kk] + p[kk];
     }
   }
-  __syncthreads();
+  sync<NT>();
 }
 
 // Doubled-spectrum cumulative lookup (cheaptrick.py:103-131 / d4c.py:178-233).
@@ -59,7 +60,7 @@ __device__ __forceinline__ void low_band_replica(double* p, double* tmp, int N, 
 struct BandLookup {
   const double* cum;
   int N;
-  double x0, dx, xlast, total;
+  double x0, dx, inv_dx, xlast, total;
   __device__ __forceinline__ void init(const double* c, int n, double fs) {
     cum = c;
     N = n;
@@ -67,13 +68,14 @@ struct BandLookup {
     x0 = (0.0 / n * fs - fs) + half;
     const double x1 = (1.0 / n * fs - fs) + half;
     dx = x1 - x0;
+    inv_dx = 1.0 / dx;  // the interpolant is continuous across bins, so a last-bit change of q is harmless
     xlast = ((double)(2 * n - 1) / n * fs - fs) + half;
     total = c[n - 1];
   }
   __device__ __forceinline__ double seg(int i) const { return i < N ? cum[i] : total + cum[i - N]; }
   __device__ __forceinline__ double at(double xi) const {
     xi = fmax(x0, fmin(xlast, xi));
-    const double q = (xi - x0) / dx;
+    const double q = (xi - x0) * inv_dx;
     const double b = floor(q);
     const double fr = q - b;
     const int bi = (int)b;
@@ -85,14 +87,15 @@ struct BandLookup {
 
 // p_half[0..N/2] (LDS) → cum[0..N) (LDS) = inclusive scan of the mirrored full spectrum × fs/N.
 // Contains barriers; p_half must be visible on entry; cum visible on exit.
+template <int NT = WH_BLOCK>
 __device__ __forceinline__ void scan_mirrored(const double* p_half, double* cum, int N, double fs, double* scratch) {
   const double df = fs / N;
-  for (int i = threadIdx.x; i < N; i += WH_BLOCK) {
+  for (int i = threadIdx.x; i < N; i += NT) {
     const int k = i <= N / 2 ? i : N - i;
     cum[i] = p_half[k] * df;
   }
-  __syncthreads();
-  block_scan_lds(cum, N, scratch);
+  sync<NT>();
+  block_scan_lds<NT>(cum, N, scratch);
 }
 
 }  // namespace wh

@@ -19,6 +19,11 @@
 
 namespace {
 
+#ifndef WH_FRAME_THREADS
+#define WH_FRAME_THREADS 256
+#endif
+constexpr int FT = WH_FRAME_THREADS;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
+
 struct SynUtt {
   int64_t f_off, nf;      // frames
   int64_t y_off, ny;      // output samples
@@ -246,35 +251,44 @@ __device__ __forceinline__ double normal_at(uint64_t seed, uint64_t q) {
   return (q & 1) ? rr * s : rr * c;
 }
 
-// log|.|/2 of a K-bin amplitude-like spectrum (mirrored to N), FFT, fold the cepstrum onto its upper half
+// log|.|/2 of a K-bin amplitude-like spectrum (overwritten!) mirrored to N, FFT, fold the cepstrum onto its upper half
 // (x2, bin 0 kept), IFFT, complex exp  → minimum-phase spectrum in buf[0..N)  (synthesis.py:103-111).
 template <int N>
-__device__ __forceinline__ void min_phase(const double* amp_half, double2* buf, const double2* tw) {
-  for (int n = threadIdx.x; n < N; n += WH_BLOCK) {
+__device__ __forceinline__ void min_phase(double* amp_half, double2* buf, const double2* tw) {
+  // log on the K distinct bins only (in place), then mirror into the FFT buffer
+  for (int k = threadIdx.x; k <= N / 2; k += FT) amp_half[k] = log(fabs(amp_half[k])) / 2;
+  wh::sync<FT>();
+  for (int n = threadIdx.x; n < N; n += FT) {
     const int k = n <= N / 2 ? n : N - n;
-    buf[n] = make_double2(log(fabs(amp_half[k])) / 2, 0.0);
+    buf[n] = make_double2(amp_half[k], 0.0);
   }
-  __syncthreads();
-  wh::fft_lds<N, false>(buf, tw);
-  for (int n = threadIdx.x; n < N; n += WH_BLOCK) {
+  wh::sync<FT>();
+  wh::fft_lds<N, false, FT>(buf, tw);
+  for (int n = threadIdx.x; n < N; n += FT) {
     const double c = buf[n].x;
     const double v = n == 0 ? c : (n >= N / 2 ? c * 2 : 0.0);
     buf[n] = make_double2(v, 0.0);
   }
-  __syncthreads();
-  wh::fft_lds<N, true>(buf, tw);
-  for (int n = threadIdx.x; n < N; n += WH_BLOCK) {
-    const double2 z = buf[n];
+  wh::sync<FT>();
+  wh::fft_lds<N, true, FT>(buf, tw);
+  // the folded cepstrum is real, so its (inverse) DFT is Hermitian: exp() of bins 0..N/2, the rest by conjugation
+  for (int k = threadIdx.x; k <= N / 2; k += FT) {
+    const double2 z = buf[k];
     const double e = exp(z.x / N);
     double s, c;
     sincos(z.y / N, &s, &c);
-    buf[n] = make_double2(e * c, e * s);
+    buf[k] = make_double2(e * c, e * s);
   }
-  __syncthreads();
+  wh::sync<FT>();
+  for (int n = N / 2 + 1 + threadIdx.x; n < N; n += FT) {
+    const double2 z = buf[N - n];
+    buf[n] = make_double2(z.x, -z.y);
+  }
+  wh::sync<FT>();
 }
 
 template <int N>
-__global__ __launch_bounds__(WH_BLOCK) void response_kernel(
+__global__ __launch_bounds__(FT) void response_kernel(
     const SynUtt* __restrict__ meta, const double* __restrict__ tp, const double* __restrict__ spectrogram,
     const double* __restrict__ aperiodicity, double fs, const double* __restrict__ p_time,
     const int64_t* __restrict__ p_idx, const double* __restrict__ p_shift, const int64_t* __restrict__ p_noff,
@@ -294,7 +308,7 @@ __global__ __launch_bounds__(WH_BLOCK) void response_kernel(
 
   const int64_t total_pulses = p_base[n_utt];
   for (int64_t gp = blockIdx.x; gp < total_pulses; gp += gridDim.x) {
-  __syncthreads();
+  wh::sync<FT>();
   int u;
   {
     int lo = 0, hi = n_utt;  // largest u with p_base[u] <= gp
@@ -352,7 +366,7 @@ __global__ __launch_bounds__(WH_BLOCK) void response_kernel(
   vi = vi < 0 ? 0 : (vi > m.ny - 1 ? m.ny - 1 : vi);
   const bool voiced = (vuv_s[m.y_off + vi] != 0) && (aper0 <= 0.999);
 
-  for (int k = threadIdx.x; k < K; k += WH_BLOCK) {
+  for (int k = threadIdx.x; k < K; k += FT) {
     const double sl = s_lo[k], sh = s_hi[k];
     const double al = a_lo[k] * a_lo[k], ah = a_hi[k] * a_hi[k];
     const double pl = fmax(0.001, 1 - al), ph = fmax(0.001, 1 - ah);
@@ -366,14 +380,14 @@ __global__ __launch_bounds__(WH_BLOCK) void response_kernel(
     if (w == 0.0) w = 2.220446049250313e-16;
     asp[k] = w;
   }
-  __syncthreads();
+  wh::sync<FT>();
 
   // ---- periodic response (synthesis.py:100-116) -------------------------------------------------
   if (voiced) {
     min_phase<N>(spec, buf, tw);
     const double coef = 2.0 * M_PI * fs / N;
     // keep bins 0..N/2, apply the fractional delay, Hermitian-extend
-    for (int k = threadIdx.x; k <= N / 2; k += WH_BLOCK) {
+    for (int k = threadIdx.x; k <= N / 2; k += FT) {
       const double th = coef * shift * (double)k;
       double s, c;
       sincos(th, &s, &c);
@@ -382,33 +396,33 @@ __global__ __launch_bounds__(WH_BLOCK) void response_kernel(
       spec[k] = r.x;       // stash (spec/asp periodic copy no longer needed: spec reused as re, nz.. careful)
       resp[k] = r.y;       // imag parts parked in resp[0..N/2]
     }
-    __syncthreads();
-    for (int n = threadIdx.x; n < N; n += WH_BLOCK) {
+    wh::sync<FT>();
+    for (int n = threadIdx.x; n < N; n += FT) {
       const int k = n <= N / 2 ? n : N - n;
       const double re = spec[k], im = resp[k];
       buf[n] = make_double2(re, n <= N / 2 ? im : -im);
     }
-    __syncthreads();
-    wh::fft_lds<N, true>(buf, tw);
+    wh::sync<FT>();
+    wh::fft_lds<N, true, FT>(buf, tw);
     double part = 0.0;
-    for (int mm = threadIdx.x; mm < N; mm += WH_BLOCK) {
+    for (int mm = threadIdx.x; mm < N; mm += FT) {
       const double v = buf[(mm + N / 2) & (N - 1)].x / N;  // fftshift(real(ifft))
       resp[mm] = v;
       part += v;
     }
-    const double total = wh::block_sum(part, scratch);
+    const double total = wh::block_sum<FT>(part, scratch);
     const double gain = sqrt((double)(noise_size > 1 ? noise_size : 1));
-    for (int mm = threadIdx.x; mm < N; mm += WH_BLOCK) resp[mm] = (resp[mm] + dc_base[mm] * -total) * gain;
+    for (int mm = threadIdx.x; mm < N; mm += FT) resp[mm] = (resp[mm] + dc_base[mm] * -total) * gain;
   } else {
-    for (int mm = threadIdx.x; mm < N; mm += WH_BLOCK) resp[mm] = 0.0;
+    for (int mm = threadIdx.x; mm < N; mm += FT) resp[mm] = 0.0;
   }
-  __syncthreads();
+  wh::sync<FT>();
 
   // ---- aperiodic response (synthesis.py:86-96) --------------------------------------------------
   min_phase<N>(asp, buf, tw);
-  wh::fft_lds<N, true>(buf, tw);
-  for (int mm = threadIdx.x; mm < N; mm += WH_BLOCK) ra[mm] = buf[(mm + N / 2) & (N - 1)].x / N;
-  __syncthreads();
+  wh::fft_lds<N, true, FT>(buf, tw);
+  for (int mm = threadIdx.x; mm < N; mm += FT) ra[mm] = buf[(mm + N / 2) & (N - 1)].x / N;
+  wh::sync<FT>();
 
   // noise excitation: zero-mean, max(3, noise_size) samples, y[m] = sum_j nz[j] * ra[m-j], m < N
   const int64_t nd = noise_size > 3 ? noise_size : 3;
@@ -421,19 +435,19 @@ __global__ __launch_bounds__(WH_BLOCK) void response_kernel(
     return normal_at(m.seed, (uint64_t)(noff + j));
   };
   double part = 0.0;
-  for (int64_t j = threadIdx.x; j < nd; j += WH_BLOCK) part += noise_at(j);
-  const double mean = wh::block_sum(part, scratch) / (double)nd;
-  double acc[N / WH_BLOCK];
+  for (int64_t j = threadIdx.x; j < nd; j += FT) part += noise_at(j);
+  const double mean = wh::block_sum<FT>(part, scratch) / (double)nd;
+  double acc[N / FT];
 #pragma unroll
-  for (int q = 0; q < N / WH_BLOCK; ++q) acc[q] = 0.0;
+  for (int q = 0; q < N / FT; ++q) acc[q] = 0.0;
   for (int64_t j0 = 0; j0 < nd; j0 += NZ) {
     const int cnt = (int)(nd - j0 < NZ ? nd - j0 : NZ);
-    __syncthreads();
-    for (int j = threadIdx.x; j < cnt; j += WH_BLOCK) nz[j] = noise_at(j0 + j) - mean;
-    __syncthreads();
+    wh::sync<FT>();
+    for (int j = threadIdx.x; j < cnt; j += FT) nz[j] = noise_at(j0 + j) - mean;
+    wh::sync<FT>();
 #pragma unroll
-    for (int q = 0; q < N / WH_BLOCK; ++q) {
-      const int mm = threadIdx.x + q * WH_BLOCK;
+    for (int q = 0; q < N / FT; ++q) {
+      const int mm = threadIdx.x + q * FT;
       double s = 0.0;
       const int jmax = (int)((int64_t)mm - j0 < cnt - 1 ? (int64_t)mm - j0 : cnt - 1);
       for (int j = 0; j <= jmax; ++j) s += nz[j] * ra[mm - (int)j0 - j];
@@ -444,8 +458,8 @@ __global__ __launch_bounds__(WH_BLOCK) void response_kernel(
   // ---- overlap-add with the reference's clipped fancy-index semantics (Q8) -----------------------
   double* yu = y + m.y_off;
 #pragma unroll
-  for (int q = 0; q < N / WH_BLOCK; ++q) {
-    const int mm = threadIdx.x + q * WH_BLOCK;
+  for (int q = 0; q < N / FT; ++q) {
+    const int mm = threadIdx.x + q * FT;
     const int64_t tgt = pidx - N / 2 + 1 + mm;  // 1-based
     const double v = resp[mm] + acc[q];
     if (tgt < 1) continue;                    // clipped to 1 and overwritten by the in-range tap
@@ -473,7 +487,7 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
   int64_t grid = pcap_max * B;
   if (grid > 256 * 16) grid = 256 * 16;  // persistent-style: workgroups stride over the flat pulse list
-  { wh::KernelTimer _kt(ctx, st, "response_kernel"); hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(WH_BLOCK), lds, st, d_meta, tp, spec, ap, fs,
+  { wh::KernelTimer _kt(ctx, st, "response_kernel"); hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(FT), lds, st, d_meta, tp, spec, ap, fs,
                      p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, d_dc, wh::twiddle(ctx, N), y); }
   WH_LAUNCH_CHECK("response_kernel");
   return 0;
@@ -580,7 +594,7 @@ __global__ __launch_bounds__(256) void req_pulse_kernel(const SynUtt* __restrict
 }
 
 template <int N>
-__global__ __launch_bounds__(WH_BLOCK) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
+__global__ __launch_bounds__(FT) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
                                                               const double* __restrict__ spectrogram,
                                                               const double* __restrict__ exc,
                                                               const double2* __restrict__ tw, double* __restrict__ y) {
@@ -596,7 +610,7 @@ __global__ __launch_bounds__(WH_BLOCK) void req_filter_kernel(const SynUtt* __re
   const int64_t wlen = 2 * hop - 1;
   const int64_t origin = (i - 1) * hop - (hop - 1);  // 1-based
   const double* eu = exc + m.y_off;
-  for (int j = threadIdx.x; j < N; j += WH_BLOCK) {
+  for (int j = threadIdx.x; j < N; j += FT) {
     double v = 0.0;
     if (j < wlen) {
       int64_t g = origin + j;
@@ -608,15 +622,15 @@ __global__ __launch_bounds__(WH_BLOCK) void req_filter_kernel(const SynUtt* __re
     seg[j] = make_double2(v, 0.0);
   }
   const double* sp = spectrogram + (m.f_off + (i - 1)) * K;
-  for (int k = threadIdx.x; k < K; k += WH_BLOCK) amp[k] = sp[k];
-  __syncthreads();
-  wh::fft_lds<N, false>(seg, tw);
+  for (int k = threadIdx.x; k < K; k += FT) amp[k] = sp[k];
+  wh::sync<FT>();
+  wh::fft_lds<N, false, FT>(seg, tw);
   min_phase<N>(amp, buf, tw);
-  for (int n = threadIdx.x; n < N; n += WH_BLOCK) buf[n] = wh::cmul(buf[n], seg[n]);
-  __syncthreads();
-  wh::fft_lds<N, true>(buf, tw);
+  for (int n = threadIdx.x; n < N; n += FT) buf[n] = wh::cmul(buf[n], seg[n]);
+  wh::sync<FT>();
+  wh::fft_lds<N, true, FT>(buf, tw);
   double* yu = y + m.y_off;
-  for (int mm = threadIdx.x; mm < N; mm += WH_BLOCK) {
+  for (int mm = threadIdx.x; mm < N; mm += FT) {
     const int64_t tgt = origin + mm;
     const double v = buf[mm].x / N;
     if (tgt < 1) continue;
@@ -631,7 +645,7 @@ int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, const 
   const size_t lds = sizeof(double2) * 2 * N + sizeof(double) * (N / 2 + 8);
   if (int rc = wh::allow_lds(&req_filter_kernel<N>, lds)) return rc;
   if (max_nf < 4) return 0;
-  { wh::KernelTimer _kt(ctx, st, "req_filter_kernel"); hipLaunchKernelGGL(req_filter_kernel<N>, dim3((unsigned)(max_nf - 3), B), dim3(WH_BLOCK), lds, st, d_meta, d_rq, spec, exc, wh::twiddle(ctx, N), y); }
+  { wh::KernelTimer _kt(ctx, st, "req_filter_kernel"); hipLaunchKernelGGL(req_filter_kernel<N>, dim3((unsigned)(max_nf - 3), B), dim3(FT), lds, st, d_meta, d_rq, spec, exc, wh::twiddle(ctx, N), y); }
   WH_LAUNCH_CHECK("req_filter_kernel");
   return 0;
 }

@@ -18,62 +18,64 @@ namespace {
 #endif
 constexpr int FT = WH_FRAME_THREADS;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
 
-// Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110) written to buf[j].x, j<N
-// (zero beyond the window; rows longer than N are cropped like np.fft.fft(x, n), Q7).
-// Returns sum(wave^2) over the FULL window.  BLACKMAN selects window type 2, else Hann.
-template <bool BLACKMAN>
+// Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110).  Values for samples j = tid + q*FT land
+// in the caller's registers v[q] (zero beyond the window; rows longer than N are cropped like
+// np.fft.fft(x, n), Q7).  tmp: 2N doubles of LDS scratch.  Returns sum(wave^2) over the FULL window.
+// BLACKMAN selects window type 2, else Hann.
+template <bool BLACKMAN, int N>
 __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long long xn, double fs, double cf,
-                                             double pos, double half_length, double2* buf, int N, double* scratch) {
+                                             double pos, double half_length, double* tmp, double (&v)[N / FT],
+                                             double* scratch) {
   const int hwl = (int)(half_length * fs / cf + 0.5);
   const int L = 2 * hwl + 1;
   const long long centre = wh::frame_centre(pos, fs);
   const double phase = (pos * fs - (double)(long long)(pos * fs + 0.5)) / fs;
+  auto win = [&](int j) -> double {
+    const double c1 = cospi(((double)(j - hwl) / fs / half_length + phase) * cf);  // cos(pi*t*f0)
+    return BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);  // cos(2a) = 2cos^2(a)-1
+  };
   double s_sw = 0.0, s_w = 0.0;
   for (int j = threadIdx.x; j < L; j += FT) {
-    const int rel = j - hwl;
-    const double seg = wh::sample_clamped(xu, xn, centre + rel);
-    const double t = (double)rel / fs / half_length + phase;
-    const double c1 = cospi(t * cf);  // cos(pi*t*f0); cos(2a) = 2cos^2(a) - 1 saves the second evaluation
-    const double w = BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);
-    const double sw = seg * w;
+    const double w = win(j);
+    const double sw = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w;
     s_sw += sw;
     s_w += w;
-    if (j < N) buf[j] = make_double2(sw, w);
+    if (j < N) {
+      tmp[j] = sw;
+      tmp[N + j] = w;
+    }
   }
   wh::block_sum2<FT>(s_sw, s_w, scratch);
   const double mean_sw = s_sw / (double)L;
   const double mean_w = s_w / (double)L;
   double e = 0.0;
-  for (int j = threadIdx.x; j < (L > N ? L : N); j += FT) {
-    double v = 0.0;
+#pragma unroll
+  for (int q = 0; q < N / FT; ++q) {
+    const int j = threadIdx.x + q * FT;
+    double val = 0.0;
     if (j < L) {
-      double sw, w;
-      if (j < N) {
-        sw = buf[j].x;
-        w = buf[j].y;
-      } else {
-        const int rel = j - hwl;
-        const double seg = wh::sample_clamped(xu, xn, centre + rel);
-        const double c1 = cospi(((double)rel / fs / half_length + phase) * cf);
-        w = BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);
-        sw = seg * w;
-      }
-      v = sw - w * mean_sw / mean_w;
-      e += v * v;
+      val = tmp[j] - tmp[N + j] * mean_sw / mean_w;
+      e += val * val;
     }
-    if (j < N) buf[j] = make_double2(v, 0.0);
+    v[q] = val;
   }
-  return wh::block_sum<FT>(e, scratch);  // barriers inside make buf visible
+  for (int j = N + threadIdx.x; j < L; j += FT) {  // cropped tail still counts in the energy
+    const double w = win(j);
+    const double val = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w - w * mean_sw / mean_w;
+    e += val * val;
+  }
+  return wh::block_sum<FT>(e, scratch);  // barriers inside: every thread is done reading tmp
 }
 
 template <int NLT>
 __global__ __launch_bounds__(FT) void love_train_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv, double fs,
-    double threshold, const double2* __restrict__ tw, int32_t* __restrict__ gate) {
+    double threshold, const double2* __restrict__ tw_base, int32_t* __restrict__ gate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double2* buf = reinterpret_cast<double2*>(smem);
-  double* scratch = reinterpret_cast<double*>(smem + sizeof(double2) * NLT);
+  double2* zb = reinterpret_cast<double2*>(smem);  // NLT/2+1 complex after the real FFT
+  double* zr = reinterpret_cast<double*>(smem);    // 2*NLT doubles while windowing
+  double* scratch = zr + 2 * NLT;
   const int64_t f = blockIdx.x;
   double f0 = f0_io[f];
   if (vuv[f] == 0.0) f0 = 0.0;  // d4c.py:32 — written back (Q6)
@@ -86,14 +88,18 @@ __global__ __launch_bounds__(FT) void love_train_kernel(
   const double* xu = x + x_off[u];
   const long long xn = x_off[u + 1] - x_off[u];
   const double cf = fmax(f0, 40.0);
-  d4c_window<true>(xu, xn, fs, cf, tp[f], 1.5, buf, NLT, scratch);
-  wh::fft_lds<NLT, false, FT>(buf, tw);
+  double v[NLT / FT];
+  d4c_window<true, NLT>(xu, xn, fs, cf, tp[f], 1.5, zr, v, scratch);
+#pragma unroll
+  for (int q = 0; q < NLT / FT; ++q) zr[threadIdx.x + q * FT] = v[q];
+  wh::sync<FT>();
+  wh::rfft_lds<NLT, FT>(zb, tw_base);
   const int b0 = (int)(ceil(100.0 / (fs / NLT)) + 1);
   const int b1 = (int)(ceil(4000.0 / (fs / NLT)) + 1);
   const int b2 = (int)(ceil(7900.0 / (fs / NLT)) + 1);
   double s1 = 0.0, s2 = 0.0;
   for (int k = b0 + threadIdx.x; k < b2 && k < NLT; k += FT) {
-    const double2 z = buf[k];
+    const double2 z = zb[k <= NLT / 2 ? k : NLT - k];  // |X[k]|^2 is even about NLT/2
     const double p = z.x * z.x + z.y * z.y;
     s2 += p;
     if (k < b1) s1 += p;
@@ -199,18 +205,22 @@ __device__ __forceinline__ void sum_smallest(const double* __restrict__ p, int m
 }
 
 // Accumulate the group-delay centroid of one Blackman frame into cent[0..N/2] (d4c.py:146-153).
+// x and n*x (two real sequences) share ONE complex FFT: z = x + i*n*x, separated afterwards by symmetry.
 template <int N>
 __device__ __forceinline__ void add_centroid(const double* xu, long long xn, double fs, double cf, double pos,
-                                             double2* buf, double* cent, bool first, const double2* tw,
+                                             double2* buf, double* cent, bool first, const double2* tw_base,
                                              double* scratch) {
-  const double energy = d4c_window<true>(xu, xn, fs, cf, pos, 2.0, buf, N, scratch);
+  double v[N / FT];
+  const double energy = d4c_window<true, N>(xu, xn, fs, cf, pos, 2.0, reinterpret_cast<double*>(buf), v, scratch);
   const double nrm = sqrt(energy);
-  for (int j = threadIdx.x; j < N; j += FT) {
-    const double v = buf[j].x / nrm;
-    buf[j] = make_double2(v, v * (double)(j + 1));  // z = x + i*(n*x), n 1-based
+#pragma unroll
+  for (int q = 0; q < N / FT; ++q) {
+    const int j = threadIdx.x + q * FT;
+    const double val = v[q] / nrm;
+    buf[j] = make_double2(val, val * (double)(j + 1));  // n is 1-based
   }
   wh::sync<FT>();
-  wh::fft_lds<N, false, FT>(buf, tw);
+  wh::fft_lds<N, false, FT>(buf, tw_base + N);
   for (int k = threadIdx.x; k <= N / 2; k += FT) {
     const double2 a = buf[k];
     const double2 b = buf[(N - k) & (N - 1)];
@@ -227,17 +237,17 @@ template <int N>
 __global__ __launch_bounds__(FT) void d4c_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, const double* __restrict__ f0_in, const int32_t* __restrict__ gate, double fs,
-    int nap, int interval, const double* __restrict__ window, int wlen, const double2* __restrict__ tw,
+    int nap, int interval, const double* __restrict__ window, int wlen, const double2* __restrict__ tw_base,
     int k_spec,                       // >0: dense amplitude output [F][k_spec]; 0: Requiem band output [F][nap+2]
     double* __restrict__ out, double* __restrict__ coarse_dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = N / 2 + 1;
-  double2* buf = reinterpret_cast<double2*>(smem);
-  double* cum = reinterpret_cast<double*>(smem + sizeof(double2) * N);  // N
-  double* cent = cum + N;                                               // K (padded to N/2+8)
-  double* pw = cent + (N / 2 + 8);                                      // K
-  double* scratch = pw + (N / 2 + 8);                                   // 16
-  double* band = scratch + 16;                                          // nap (<= 8)
+  double2* buf = reinterpret_cast<double2*>(smem);   // N complex (centroid FFT) / N/2+1 complex (real FFTs)
+  double* zr = reinterpret_cast<double*>(smem);      // the same 2N doubles: real buffers, prefix sums, scratch
+  double* cent = zr + 2 * N;                         // K (padded to N/2+8)
+  double* pw = cent + (N / 2 + 8);                   // K
+  double* scratch = pw + (N / 2 + 8);                // 16
+  double* band = scratch + 16;                       // nap (<= 8)
 
   const int64_t f = blockIdx.x;
   if (gate[f] == 0) {
@@ -258,18 +268,25 @@ __global__ __launch_bounds__(FT) void d4c_kernel(
   const double cf = fmax(47.0, f0_in[f]);
 
   // ---- static centroid from two frames at +-T0/4 (d4c.py:132-142) + DC correction ----------
-  add_centroid<N>(xu, xn, fs, cf, pos + 1 / cf / 4, buf, cent, true, tw, scratch);
-  add_centroid<N>(xu, xn, fs, cf, pos - 1 / cf / 4, buf, cent, false, tw, scratch);
-  wh::low_band_replica<FT>(cent, cum, N, fs, cf, 1.2 * cf);
+  add_centroid<N>(xu, xn, fs, cf, pos + 1 / cf / 4, buf, cent, true, tw_base, scratch);
+  add_centroid<N>(xu, xn, fs, cf, pos - 1 / cf / 4, buf, cent, false, tw_base, scratch);
+  wh::low_band_replica<FT>(cent, zr, N, fs, cf, 1.2 * cf);
 
   // ---- smoothed power spectrum (d4c.py:157-161) ----------------------------------------------
-  d4c_window<false>(xu, xn, fs, cf, pos, 2.0, buf, N, scratch);
-  wh::fft_lds<N, false, FT>(buf, tw);
+  {
+    double v[N / FT];
+    d4c_window<false, N>(xu, xn, fs, cf, pos, 2.0, zr, v, scratch);
+#pragma unroll
+    for (int q = 0; q < N / FT; ++q) zr[threadIdx.x + q * FT] = v[q];
+    wh::sync<FT>();
+  }
+  wh::rfft_lds<N, FT>(buf, tw_base);
   for (int k = threadIdx.x; k < K; k += FT) {
     const double2 z = buf[k];
     pw[k] = z.x * z.x + z.y * z.y;
   }
   wh::sync<FT>();
+  double* cum = zr;  // the FFT buffer is idle during the smoothing steps
   wh::low_band_replica<FT>(pw, cum, N, fs, cf, 1.2 * cf);
   wh::scan_mirrored<FT>(pw, cum, N, fs, scratch);
   wh::BandLookup lk;
@@ -305,24 +322,24 @@ __global__ __launch_bounds__(FT) void d4c_kernel(
   for (int b = 0; b < nap; ++b) {
     const int centre = (int)floor((double)interval * (b + 1) / (fs / N));
     for (int j = threadIdx.x; j < N; j += FT) {
-      double v = 0.0;
+      double val = 0.0;
       if (j < wlen) {
         int idx = centre - half + j;          // index into the mirrored full group delay
         idx = idx < 0 ? -idx : idx;
         idx = idx > N / 2 ? N - idx : idx;
-        v = cent[idx] * window[j];
+        val = cent[idx] * window[j];
       }
-      buf[j] = make_double2(v, 0.0);
+      zr[j] = val;
     }
     wh::sync<FT>();
-    wh::fft_lds<N, false, FT>(buf, tw);
+    wh::rfft_lds<N, FT>(buf, tw_base);
     for (int k = threadIdx.x; k < K; k += FT) {
       const double2 z = buf[k];
-      cum[k] = z.x * z.x + z.y * z.y;
+      pw[k] = z.x * z.x + z.y * z.y;
     }
     wh::sync<FT>();
     double s_small, s_total;
-    sum_smallest<K>(cum, N / 2 - boundary, buf, scratch, &s_small, &s_total);  // FFT buffer is free: scratch for the selection
+    sum_smallest<K>(pw, N / 2 - boundary, buf, scratch, &s_small, &s_total);  // FFT buffer is free: selection scratch
     if (threadIdx.x == 0) band[b] = -10 * log10(s_small / s_total);
     wh::sync<FT>();
   }
@@ -372,10 +389,10 @@ std::vector<double> nuttall(int n) {
 template <int NLT>
 int launch_lt(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
               const double* vuv, double fs, double thr, int32_t* gate) {
-  const size_t lds = sizeof(double2) * NLT + sizeof(double) * 16;
+  const size_t lds = sizeof(double) * (2 * NLT + 16);
   if (int rc = wh::allow_lds(&love_train_kernel<NLT>, lds)) return rc;
   { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
-                     b->d_frame_utt, tp, f0, vuv, fs, thr, wh::twiddle(ctx, NLT), gate); }
+                     b->d_frame_utt, tp, f0, vuv, fs, thr, ctx->d_twiddle, gate); }
   WH_LAUNCH_CHECK("love_train_kernel");
   return 0;
 }
@@ -384,10 +401,10 @@ template <int N>
 int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, const double* f0,
                 const int32_t* gate, double fs, int nap, int interval, const double* win, int wlen, int k_spec,
                 double* out, double* coarse) {
-  const size_t lds = sizeof(double2) * N + sizeof(double) * (N + 2 * (N / 2 + 8) + 16 + 8);
+  const size_t lds = sizeof(double) * (2 * N + 2 * (N / 2 + 8) + 16 + 8);
   if (int rc = wh::allow_lds(&d4c_kernel<N>, lds)) return rc;
   { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL(d4c_kernel<N>, dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
-                     b->d_frame_utt, tp, f0, gate, fs, nap, interval, win, wlen, wh::twiddle(ctx, N), k_spec, out,
+                     b->d_frame_utt, tp, f0, gate, fs, nap, interval, win, wlen, ctx->d_twiddle, k_spec, out,
                      coarse); }
   WH_LAUNCH_CHECK("d4c_kernel");
   return 0;

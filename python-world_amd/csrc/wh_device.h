@@ -260,13 +260,18 @@ __device__ __forceinline__ void rfft_lds(double2* z, const double2* __restrict__
   sync<NT>();
 }
 
-// Inverse.  in: z[k] = X[k], k = 0..N/2, the Hermitian half of a spectrum whose inverse DFT is real.
+// Inverse.  in: z[k] = X[k], k = 0..N/2: the half spectrum; the result is Re(IDFT) of its Hermitian extension
+// (imaginary parts of the DC / Nyquist bins are ignored, as taking .real of a full complex IFFT would).
 // out: z[j] = N * (x[2j], x[2j+1]), j < N/2 (unnormalised like fft_lds<.., true>: divide by N).
 template <int N, int NT = WH_BLOCK>
 __device__ __forceinline__ void irfft_lds(double2* z, const double2* __restrict__ tw_base) {
   const double2* __restrict__ w = tw_base + N;
   for (int k = threadIdx.x; k <= N / 4; k += NT) {
-    const double2 a = z[k], b = z[N / 2 - k];
+    double2 a = z[k], b = z[N / 2 - k];
+    if (k == 0) {  // DC and Nyquist bins: only their real parts reach a real output (Re of the inverse DFT)
+      a.y = 0.0;
+      b.y = 0.0;
+    }
     const double er = a.x + b.x, ei = a.y - b.y;  // 2E = A + conj(B)
     const double dr = a.x - b.x, di = a.y + b.y;  // 2D = A - conj(B)
     const double2 wk = w[k];

@@ -251,41 +251,36 @@ __device__ __forceinline__ double normal_at(uint64_t seed, uint64_t q) {
   return (q & 1) ? rr * s : rr * c;
 }
 
-// log|.|/2 of a K-bin amplitude-like spectrum (overwritten!) mirrored to N, FFT, fold the cepstrum onto its upper half
-// (x2, bin 0 kept), IFFT, complex exp  → minimum-phase spectrum in buf[0..N)  (synthesis.py:103-111).
+// Minimum-phase half spectrum (synthesis.py:103-111) from K = N/2+1 amplitude-like bins:
+// log|.|/2 (in place, amp is destroyed) → real FFT → fold the cepstrum onto its upper half (x2, bin 0 kept)
+// → inverse transform of that REAL sequence = conj of its real FFT → complex exp.  Both transforms are
+// N/2-point complex FFTs.  Result: zb[k], k = 0..N/2 (the rest of the spectrum is its Hermitian mirror).
 template <int N>
-__device__ __forceinline__ void min_phase(double* amp_half, double2* buf, const double2* tw) {
-  // log on the K distinct bins only (in place), then mirror into the FFT buffer
-  for (int k = threadIdx.x; k <= N / 2; k += FT) amp_half[k] = log(fabs(amp_half[k])) / 2;
+__device__ __forceinline__ void min_phase_half(double* amp, double2* zb, const double2* tw_base) {
+  double* zr = reinterpret_cast<double*>(zb);
+  for (int k = threadIdx.x; k <= N / 2; k += FT) amp[k] = log(fabs(amp[k])) / 2;
   wh::sync<FT>();
-  for (int n = threadIdx.x; n < N; n += FT) {
-    const int k = n <= N / 2 ? n : N - n;
-    buf[n] = make_double2(amp_half[k], 0.0);
-  }
+  for (int n = threadIdx.x; n < N; n += FT) zr[n] = amp[n <= N / 2 ? n : N - n];
   wh::sync<FT>();
-  wh::fft_lds<N, false, FT>(buf, tw);
-  for (int n = threadIdx.x; n < N; n += FT) {
-    const double c = buf[n].x;
-    const double v = n == 0 ? c : (n >= N / 2 ? c * 2 : 0.0);
-    buf[n] = make_double2(v, 0.0);
-  }
+  wh::rfft_lds<N, FT>(zb, tw_base);
+  for (int k = threadIdx.x; k <= N / 2; k += FT) amp[k] = zb[k].x;  // real cepstrum (even)
   wh::sync<FT>();
-  wh::fft_lds<N, true, FT>(buf, tw);
-  // the folded cepstrum is real, so its (inverse) DFT is Hermitian: exp() of bins 0..N/2, the rest by conjugation
+  for (int n = threadIdx.x; n < N; n += FT) zr[n] = n == 0 ? amp[0] : (n >= N / 2 ? 2 * amp[N - n] : 0.0);
+  wh::sync<FT>();
+  wh::rfft_lds<N, FT>(zb, tw_base);
   for (int k = threadIdx.x; k <= N / 2; k += FT) {
-    const double2 z = buf[k];
-    const double e = exp(z.x / N);
-    double s, c;
-    sincos(z.y / N, &s, &c);
-    buf[k] = make_double2(e * c, e * s);
-  }
-  wh::sync<FT>();
-  for (int n = N / 2 + 1 + threadIdx.x; n < N; n += FT) {
-    const double2 z = buf[N - n];
-    buf[n] = make_double2(z.x, -z.y);
+    const double2 r = zb[k];  // sum c[n] e^{+i..} = conj(r)
+    const double e = exp(r.x / N);
+    double sn, cs;
+    sincos(-r.y / N, &sn, &cs);
+    zb[k] = make_double2(e * cs, e * sn);
   }
   wh::sync<FT>();
 }
+
+// padded index of the aperiodic response for the register-tiled convolution: 2 doubles of padding every 32
+// keep the 16-byte pair reads of lanes that are 4..8 samples apart on different LDS banks
+__device__ __forceinline__ int rap_index(int i) { return i + 2 * (i >> 5); }
 
 template <int N>
 __global__ __launch_bounds__(FT) void response_kernel(
@@ -294,17 +289,19 @@ __global__ __launch_bounds__(FT) void response_kernel(
     const int64_t* __restrict__ p_idx, const double* __restrict__ p_shift, const int64_t* __restrict__ p_noff,
     const int32_t* __restrict__ p_count, const int64_t* __restrict__ p_base, int n_utt,
     const uint8_t* __restrict__ vuv_s, const double* __restrict__ noise, const double* __restrict__ dc_base,
-    const double2* __restrict__ tw, double* __restrict__ y) {
+    const double2* __restrict__ tw_base, double* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = N / 2 + 1;
   constexpr int NZ = 256;
-  double2* buf = reinterpret_cast<double2*>(smem);                      // N
-  double* resp = reinterpret_cast<double*>(smem + sizeof(double2) * N);  // N   periodic response (or zeros)
-  double* ra = resp + N;                                                 // N   aperiodic response
-  double* spec = ra + N;                                                 // K+7
-  double* asp = spec + (K + 7);                                          // K+7
-  double* nz = asp + (K + 7);                                            // NZ
-  double* scratch = nz + NZ;                                             // 16
+  constexpr int R = N / FT;  // consecutive output samples per thread
+  static_assert(R % 2 == 0, "pairwise reads need an even number of outputs per thread");
+  double2* zb = reinterpret_cast<double2*>(smem);                  // N/2+1 complex
+  double* zr = reinterpret_cast<double*>(smem);                     // = N+2 reals
+  double* rap = zr + (N + 2);                                       // N + N/16 (+2): aperiodic response, padded
+  double* spec = rap + (N + N / 16 + 2);                            // K+7
+  double* asp = spec + (K + 7);                                     // K+7
+  double* nz = asp + (K + 7);                                       // NZ
+  double* scratch = nz + NZ;                                        // 16
 
   const int64_t total_pulses = p_base[n_utt];
   for (int64_t gp = blockIdx.x; gp < total_pulses; gp += gridDim.x) {
@@ -380,51 +377,7 @@ __global__ __launch_bounds__(FT) void response_kernel(
     if (w == 0.0) w = 2.220446049250313e-16;
     asp[k] = w;
   }
-  wh::sync<FT>();
-
-  // ---- periodic response (synthesis.py:100-116) -------------------------------------------------
-  if (voiced) {
-    min_phase<N>(spec, buf, tw);
-    const double coef = 2.0 * M_PI * fs / N;
-    // keep bins 0..N/2, apply the fractional delay, Hermitian-extend
-    for (int k = threadIdx.x; k <= N / 2; k += FT) {
-      const double th = coef * shift * (double)k;
-      double s, c;
-      sincos(th, &s, &c);
-      const double2 z = buf[k];
-      const double2 r = make_double2(z.x * c + z.y * s, z.y * c - z.x * s);  // z * exp(-i th)
-      spec[k] = r.x;       // stash (spec/asp periodic copy no longer needed: spec reused as re, nz.. careful)
-      resp[k] = r.y;       // imag parts parked in resp[0..N/2]
-    }
-    wh::sync<FT>();
-    for (int n = threadIdx.x; n < N; n += FT) {
-      const int k = n <= N / 2 ? n : N - n;
-      const double re = spec[k], im = resp[k];
-      buf[n] = make_double2(re, n <= N / 2 ? im : -im);
-    }
-    wh::sync<FT>();
-    wh::fft_lds<N, true, FT>(buf, tw);
-    double part = 0.0;
-    for (int mm = threadIdx.x; mm < N; mm += FT) {
-      const double v = buf[(mm + N / 2) & (N - 1)].x / N;  // fftshift(real(ifft))
-      resp[mm] = v;
-      part += v;
-    }
-    const double total = wh::block_sum<FT>(part, scratch);
-    const double gain = sqrt((double)(noise_size > 1 ? noise_size : 1));
-    for (int mm = threadIdx.x; mm < N; mm += FT) resp[mm] = (resp[mm] + dc_base[mm] * -total) * gain;
-  } else {
-    for (int mm = threadIdx.x; mm < N; mm += FT) resp[mm] = 0.0;
-  }
-  wh::sync<FT>();
-
-  // ---- aperiodic response (synthesis.py:86-96) --------------------------------------------------
-  min_phase<N>(asp, buf, tw);
-  wh::fft_lds<N, true, FT>(buf, tw);
-  for (int mm = threadIdx.x; mm < N; mm += FT) ra[mm] = buf[(mm + N / 2) & (N - 1)].x / N;
-  wh::sync<FT>();
-
-  // noise excitation: zero-mean, max(3, noise_size) samples, y[m] = sum_j nz[j] * ra[m-j], m < N
+  // ---- noise for this pulse: max(3, noise_size) samples, zero-mean (synthesis.py:93-95) -----------
   const int64_t nd = noise_size > 3 ? noise_size : 3;
   const int64_t noff = p_noff[m.p_off + i];
   auto noise_at = [&](int64_t j) -> double {
@@ -434,34 +387,92 @@ __global__ __launch_bounds__(FT) void response_kernel(
     }
     return normal_at(m.seed, (uint64_t)(noff + j));
   };
-  double part = 0.0;
-  for (int64_t j = threadIdx.x; j < nd; j += FT) part += noise_at(j);
-  const double mean = wh::block_sum<FT>(part, scratch) / (double)nd;
-  double acc[N / FT];
+  double mean;
+  {
+    double part = 0.0;
+    for (int64_t j = threadIdx.x; j < nd; j += FT) {
+      const double v = noise_at(j);
+      part += v;
+      if (j < NZ) nz[j] = v;  // the usual case nd <= NZ: generate / fetch each sample once
+    }
+    mean = wh::block_sum<FT>(part, scratch) / (double)nd;  // barriers: spec/asp/nz visible
+  }
+
+  // ---- aperiodic response (synthesis.py:86-96): minimum phase → real inverse FFT → fftshift ---------
+  min_phase_half<N>(asp, zb, tw_base);
+  wh::irfft_lds<N, FT>(zb, tw_base);
+  for (int n = threadIdx.x; n < N; n += FT) rap[rap_index(n)] = zr[(n + N / 2) & (N - 1)] / N;
+  wh::sync<FT>();
+
+  // y[m] = sum_j nz[j] * ra[m-j], m < N: each thread owns R consecutive outputs and slides an R-wide
+  // register window over the response, two noise samples (one 16-byte LDS read each side) per step.
+  double acc[R];
 #pragma unroll
-  for (int q = 0; q < N / FT; ++q) acc[q] = 0.0;
+  for (int q = 0; q < R; ++q) acc[q] = 0.0;
+  const int m0 = threadIdx.x * R;
   for (int64_t j0 = 0; j0 < nd; j0 += NZ) {
     const int cnt = (int)(nd - j0 < NZ ? nd - j0 : NZ);
     wh::sync<FT>();
-    for (int j = threadIdx.x; j < cnt; j += FT) nz[j] = noise_at(j0 + j) - mean;
-    wh::sync<FT>();
-#pragma unroll
-    for (int q = 0; q < N / FT; ++q) {
-      const int mm = threadIdx.x + q * FT;
-      double s = 0.0;
-      const int jmax = (int)((int64_t)mm - j0 < cnt - 1 ? (int64_t)mm - j0 : cnt - 1);
-      for (int j = 0; j <= jmax; ++j) s += nz[j] * ra[mm - (int)j0 - j];
-      acc[q] += s;
+    for (int j = threadIdx.x; j < NZ; j += FT) {
+      double v = 0.0;
+      if (j < cnt) v = (j0 == 0 ? nz[j] : noise_at(j0 + j)) - mean;
+      nz[j] = v;  // zero padded to an even count
     }
+    wh::sync<FT>();
+    double r[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int idx = m0 + q - (int)j0;
+      r[q] = idx >= 0 ? rap[rap_index(idx)] : 0.0;
+    }
+    const int steps = (cnt + 1) & ~1;
+    for (int j = 0; j < steps; j += 2) {
+      const double2 nn = *reinterpret_cast<const double2*>(nz + j);
+      const int inew = m0 - (int)j0 - j - 2;  // even: (ra[inew], ra[inew+1]) is an aligned pair
+      double2 fresh = make_double2(0.0, 0.0);
+      if (inew >= 0) fresh = *reinterpret_cast<const double2*>(rap + rap_index(inew));
+#pragma unroll
+      for (int q = 0; q < R; ++q) acc[q] = fma(nn.x, r[q], acc[q]);
+#pragma unroll
+      for (int q = R - 1; q > 0; --q) r[q] = r[q - 1];
+      r[0] = fresh.y;  // ra[m0 - g - 1]
+#pragma unroll
+      for (int q = 0; q < R; ++q) acc[q] = fma(nn.y, r[q], acc[q]);
+#pragma unroll
+      for (int q = R - 1; q > 0; --q) r[q] = r[q - 1];
+      r[0] = fresh.x;  // ra[m0 - g - 2]
+    }
+  }
+
+  // ---- periodic response (synthesis.py:100-116) --------------------------------------------------
+  double dc_total = 0.0;
+  const double gain = sqrt((double)(noise_size > 1 ? noise_size : 1));
+  if (voiced) {
+    wh::sync<FT>();
+    min_phase_half<N>(spec, zb, tw_base);
+    const double coef = 2.0 * M_PI * fs / N;
+    for (int k = threadIdx.x; k <= N / 2; k += FT) {
+      const double th = coef * shift * (double)k;
+      double sn, cs;
+      sincos(th, &sn, &cs);
+      const double2 z = zb[k];
+      zb[k] = make_double2(z.x * cs + z.y * sn, z.y * cs - z.x * sn);  // z * exp(-i th)
+    }
+    wh::sync<FT>();
+    wh::irfft_lds<N, FT>(zb, tw_base);  // zr[n] = N * response[n] (before fftshift)
+    double part = 0.0;
+    for (int n = threadIdx.x; n < N; n += FT) part += zr[n] / N;
+    dc_total = wh::block_sum<FT>(part, scratch);
   }
 
   // ---- overlap-add with the reference's clipped fancy-index semantics (Q8) -----------------------
   double* yu = y + m.y_off;
 #pragma unroll
-  for (int q = 0; q < N / FT; ++q) {
-    const int mm = threadIdx.x + q * FT;
+  for (int q = 0; q < R; ++q) {
+    const int mm = m0 + q;
     const int64_t tgt = pidx - N / 2 + 1 + mm;  // 1-based
-    const double v = resp[mm] + acc[q];
+    double v = acc[q];
+    if (voiced) v += (zr[(mm + N / 2) & (N - 1)] / N + dc_base[mm] * -dc_total) * gain;
     if (tgt < 1) continue;                    // clipped to 1 and overwritten by the in-range tap
     if (tgt < m.ny) atomicAdd(&yu[tgt - 1], v);
     else if (mm == N - 1) atomicAdd(&yu[m.ny - 1], v);  // last duplicate wins on the high side
@@ -483,12 +494,12 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   for (int n = 0; n < N; ++n) dc[n] /= sum;
   const double* d_dc = nullptr;
   if (int rc = wh::const_table(ctx, "dc_base:" + std::to_string(N), dc, &d_dc)) return rc;
-  const size_t lds = sizeof(double2) * N + sizeof(double) * (2 * N + 2 * (N / 2 + 8) + 256 + 16);
+  const size_t lds = sizeof(double) * ((N + 2) + (N + N / 16 + 2) + 2 * (N / 2 + 8) + 256 + 16);
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
   int64_t grid = pcap_max * B;
   if (grid > 256 * 16) grid = 256 * 16;  // persistent-style: workgroups stride over the flat pulse list
   { wh::KernelTimer _kt(ctx, st, "response_kernel"); hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(FT), lds, st, d_meta, tp, spec, ap, fs,
-                     p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, d_dc, wh::twiddle(ctx, N), y); }
+                     p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, d_dc, ctx->d_twiddle, y); }
   WH_LAUNCH_CHECK("response_kernel");
   return 0;
 }
@@ -595,14 +606,15 @@ __global__ __launch_bounds__(256) void req_pulse_kernel(const SynUtt* __restrict
 
 template <int N>
 __global__ __launch_bounds__(FT) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
-                                                              const double* __restrict__ spectrogram,
-                                                              const double* __restrict__ exc,
-                                                              const double2* __restrict__ tw, double* __restrict__ y) {
+                                                        const double* __restrict__ spectrogram,
+                                                        const double* __restrict__ exc,
+                                                        const double2* __restrict__ tw_base, double* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = N / 2 + 1;
-  double2* buf = reinterpret_cast<double2*>(smem);
-  double2* seg = buf + N;
-  double* amp = reinterpret_cast<double*>(seg + N);  // K
+  double2* zb = reinterpret_cast<double2*>(smem);        // minimum-phase half spectrum (N/2+1 complex)
+  double2* sb = zb + (N / 2 + 1);                         // windowed excitation frame / its half spectrum
+  double* sr = reinterpret_cast<double*>(sb);
+  double* amp = reinterpret_cast<double*>(sb + (N / 2 + 1));  // K
   const SynUtt m = meta[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x + 2;  // frames 2 .. F-2  (synthesisRequiem.py:83)
   if (i > m.nf - 2) return;
@@ -616,23 +628,24 @@ __global__ __launch_bounds__(FT) void req_filter_kernel(const SynUtt* __restrict
       int64_t g = origin + j;
       g = g > m.ny ? m.ny : g;
       g = g < 1 ? 1 : g;
-      const double wv = 0.5 - 0.5 * cos(2.0 * M_PI * (double)(j + 1) / (double)(wlen + 1));  // hanning(wlen+2)[1:-1]
+      const double wv = 0.5 - 0.5 * cospi(2.0 * (double)(j + 1) / (double)(wlen + 1));  // hanning(wlen+2)[1:-1]
       v = eu[g - 1] * wv;
     }
-    seg[j] = make_double2(v, 0.0);
+    sr[j] = v;
   }
   const double* sp = spectrogram + (m.f_off + (i - 1)) * K;
   for (int k = threadIdx.x; k < K; k += FT) amp[k] = sp[k];
   wh::sync<FT>();
-  wh::fft_lds<N, false, FT>(seg, tw);
-  min_phase<N>(amp, buf, tw);
-  for (int n = threadIdx.x; n < N; n += FT) buf[n] = wh::cmul(buf[n], seg[n]);
+  wh::rfft_lds<N, FT>(sb, tw_base);
+  min_phase_half<N>(amp, zb, tw_base);
+  for (int k = threadIdx.x; k < K; k += FT) zb[k] = wh::cmul(zb[k], sb[k]);  // both Hermitian → product Hermitian
   wh::sync<FT>();
-  wh::fft_lds<N, true, FT>(buf, tw);
+  wh::irfft_lds<N, FT>(zb, tw_base);
+  const double* zr = reinterpret_cast<const double*>(zb);
   double* yu = y + m.y_off;
   for (int mm = threadIdx.x; mm < N; mm += FT) {
     const int64_t tgt = origin + mm;
-    const double v = buf[mm].x / N;
+    const double v = zr[mm] / N;
     if (tgt < 1) continue;
     if (tgt < m.ny) atomicAdd(&yu[tgt - 1], v);
     else if (mm == N - 1) atomicAdd(&yu[m.ny - 1], v);
@@ -642,10 +655,10 @@ __global__ __launch_bounds__(FT) void req_filter_kernel(const SynUtt* __restrict
 template <int N>
 int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, const SynUtt* d_meta, const ReqUtt* d_rq,
                       const double* spec, const double* exc, double* y) {
-  const size_t lds = sizeof(double2) * 2 * N + sizeof(double) * (N / 2 + 8);
+  const size_t lds = sizeof(double2) * 2 * (N / 2 + 1) + sizeof(double) * (N / 2 + 8);
   if (int rc = wh::allow_lds(&req_filter_kernel<N>, lds)) return rc;
   if (max_nf < 4) return 0;
-  { wh::KernelTimer _kt(ctx, st, "req_filter_kernel"); hipLaunchKernelGGL(req_filter_kernel<N>, dim3((unsigned)(max_nf - 3), B), dim3(FT), lds, st, d_meta, d_rq, spec, exc, wh::twiddle(ctx, N), y); }
+  { wh::KernelTimer _kt(ctx, st, "req_filter_kernel"); hipLaunchKernelGGL(req_filter_kernel<N>, dim3((unsigned)(max_nf - 3), B), dim3(FT), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, y); }
   WH_LAUNCH_CHECK("req_filter_kernel");
   return 0;
 }

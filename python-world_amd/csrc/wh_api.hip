@@ -57,6 +57,29 @@ int const_table(wh_ctx* ctx, const std::string& key, const std::vector<double>& 
   *out = d;
   return 0;
 }
+int persistent_upload(wh_ctx* ctx, const std::string& slot, const void* host, size_t bytes, void** dptr) {
+  wh_ctx::Persist& e = ctx->persist[slot];
+  if (e.d && e.host.size() == bytes && (bytes == 0 || memcmp(e.host.data(), host, bytes) == 0)) {
+    *dptr = e.d;
+    return 0;
+  }
+  if (e.cap < bytes || !e.d) {
+    if (e.d) {
+      WH_CHECK(hipDeviceSynchronize());
+      WH_CHECK(hipFree(e.d));
+      e.d = nullptr;
+    }
+    const size_t want = bytes < 256 ? 256 : bytes + bytes / 4;
+    WH_CHECK(hipMalloc(&e.d, want));
+    e.cap = want;
+  } else {
+    WH_CHECK(hipDeviceSynchronize());  // a kernel of an earlier call may still be reading the old content
+  }
+  if (bytes) WH_CHECK(hipMemcpy(e.d, host, bytes, hipMemcpyHostToDevice));
+  e.host.assign(reinterpret_cast<const char*>(host), reinterpret_cast<const char*>(host) + bytes);
+  *dptr = e.d;
+  return 0;
+}
 }  // namespace wh
 
 extern "C" {
@@ -110,6 +133,7 @@ int wh_ctx_destroy(wh_ctx* ctx) {
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   for (auto& kv : ctx->tables) (void)hipFree(kv.second);
   for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
+  for (auto& kv : ctx->persist) if (kv.second.d) (void)hipFree(kv.second.d);
   delete ctx;
   return 0;
 }

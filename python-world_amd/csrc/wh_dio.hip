@@ -431,7 +431,6 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   const int64_t F = b->total_frames;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
-  const size_t o_meta = off; off += al(sizeof(DioUtt) * B);
   const size_t o_tmp = off; off += al(sizeof(double) * tmp_tot);
   const size_t o_y = off; off += al(sizeof(double) * y_tot);
   const size_t o_z = off; off += al(sizeof(double) * z_tot);
@@ -441,14 +440,9 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   const size_t o_stab = off; off += al(sizeof(double) * F * n_bands);
   const size_t o_sorted = off; off += al(sizeof(double) * F * n_bands);
   const size_t o_work = off; off += al(sizeof(double) * (F * 5 + 8 * B));
-  const size_t o_taps = off; off += al(sizeof(double) * taps_total);
-  const size_t o_lc = off; off += al(sizeof(double) * (2 * lowcut_half + 1));
-  const size_t o_bf = off; off += al(sizeof(double) * n_bands);
-  const size_t o_ti = off; off += al(sizeof(int32_t) * n_bands * 3);
-  const size_t o_jobs = off; off += al(sizeof(wh::BandJob) * (size_t)B * n_bands);
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
-  DioUtt* d_meta = reinterpret_cast<DioUtt*>(ws + o_meta);
+  DioUtt* d_meta = nullptr;
   double* d_tmp = reinterpret_cast<double*>(ws + o_tmp);
   double* d_y = reinterpret_cast<double*>(ws + o_y);
   double* d_z = reinterpret_cast<double*>(ws + o_z);
@@ -458,24 +452,27 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   double* d_stab = reinterpret_cast<double*>(ws + o_stab);
   double* d_sorted = reinterpret_cast<double*>(ws + o_sorted);
   double* d_work = reinterpret_cast<double*>(ws + o_work);
-  double* d_taps = reinterpret_cast<double*>(ws + o_taps);
-  double* d_lc = reinterpret_cast<double*>(ws + o_lc);
-  double* d_bf = reinterpret_cast<double*>(ws + o_bf);
-  int32_t* d_ti = reinterpret_cast<int32_t*>(ws + o_ti);
-  wh::BandJob* d_jobs = reinterpret_cast<wh::BandJob*>(ws + o_jobs);
+  double* d_taps = nullptr;
+  double* d_lc = nullptr;
+  double* d_bf = nullptr;
+  int32_t* d_ti = nullptr;
+  wh::BandJob* d_jobs = nullptr;
   std::vector<int32_t> ti(n_bands * 3);
   for (int i = 0; i < n_bands; ++i) {
     ti[i] = tap_off[i];
     ti[n_bands + i] = h_band_len[i];
     ti[2 * n_bands + i] = h_band_bias[i];
   }
-  // small synchronous-to-host uploads (pageable memory: staged before return)
-  WH_CHECK(hipMemcpyAsync(d_meta, meta.data(), sizeof(DioUtt) * B, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipMemcpyAsync(d_taps, h_band_taps, sizeof(double) * taps_total, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipMemcpyAsync(d_lc, h_lowcut, sizeof(double) * (2 * lowcut_half + 1), hipMemcpyHostToDevice, st));
-  WH_CHECK(hipMemcpyAsync(d_bf, h_band_f0, sizeof(double) * n_bands, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipMemcpyAsync(d_ti, ti.data(), sizeof(int32_t) * n_bands * 3, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipStreamSynchronize(st));  // host vectors die at return
+  // per-call tables live in persistent device buffers: re-uploaded (synchronously) only when they change
+  {
+    std::vector<double> taps(h_band_taps, h_band_taps + taps_total), lc(h_lowcut, h_lowcut + 2 * lowcut_half + 1),
+        bf(h_band_f0, h_band_f0 + n_bands);
+    if (int rc = wh::persistent_upload(ctx, "dio.meta", meta, &d_meta)) return rc;
+    if (int rc = wh::persistent_upload(ctx, "dio.taps", taps, &d_taps)) return rc;
+    if (int rc = wh::persistent_upload(ctx, "dio.lowcut", lc, &d_lc)) return rc;
+    if (int rc = wh::persistent_upload(ctx, "dio.band_f0", bf, &d_bf)) return rc;
+    if (int rc = wh::persistent_upload(ctx, "dio.tapinfo", ti, &d_ti)) return rc;
+  }
 
   // ---- decimation ---------------------------------------------------------------------------------
   const double rad = pole_radius(coef);
@@ -504,8 +501,7 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
         j.cap = meta[u].cap;
         j.counts = d_cnt + ((int64_t)u * n_bands + i) * 4;
       }
-    WH_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(wh::BandJob) * jobs.size(), hipMemcpyHostToDevice, st));
-    WH_CHECK(hipStreamSynchronize(st));
+    if (int rc = wh::persistent_upload(ctx, "dio.jobs", jobs, &d_jobs)) return rc;
   }
   if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands, d_ti + 2 * n_bands,
                                       max_lb, false, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW))

@@ -502,14 +502,12 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   }
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
-  const size_t o_meta = off; off += al(sizeof(HvUtt) * B);
   const size_t o_tmp = off; off += al(sizeof(double) * t_tot);
   const size_t o_y = off; off += al(sizeof(double) * y_tot);
   const size_t o_z = off; off += al(sizeof(double) * z_tot);
   const size_t o_mean = off; off += al(sizeof(double) * B);
   const size_t o_e = off; off += al(sizeof(double) * e_tot);
   const size_t o_cnt = off; off += al(sizeof(int32_t) * (size_t)B * n_bands * 4);
-  const size_t o_jobs = off; off += al(sizeof(wh::BandJob) * (size_t)B * n_bands);
   const size_t o_raw = off; off += al(sizeof(double) * f1_tot * n_bands);
   const size_t o_dc = off; off += al(sizeof(double) * f1_tot * kMaxC);
   const size_t o_dn = off; off += al(sizeof(int32_t) * f1_tot);
@@ -517,20 +515,17 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t o_rsc = off; off += al(sizeof(double) * f1_tot * kRows);
   const size_t o_pf0 = off; off += al(sizeof(double) * f1_tot * kRows);
   const size_t o_psc = off; off += al(sizeof(double) * f1_tot * kRows);
-  const size_t o_taps = off; off += al(sizeof(double) * taps_total);
-  const size_t o_bf = off; off += al(sizeof(double) * n_bands);
-  const size_t o_ti = off; off += al(sizeof(int32_t) * n_bands * 3);
   const size_t o_ct = off; off += al(contour_workspace_bytes(f1_tot, B));
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
-  HvUtt* d_meta = reinterpret_cast<HvUtt*>(ws + o_meta);
+  HvUtt* d_meta = nullptr;
   double* d_tmp = reinterpret_cast<double*>(ws + o_tmp);
   double* d_y = reinterpret_cast<double*>(ws + o_y);
   double* d_z = reinterpret_cast<double*>(ws + o_z);
   double* d_mean = reinterpret_cast<double*>(ws + o_mean);
   double* d_e = reinterpret_cast<double*>(ws + o_e);
   int32_t* d_cnt = reinterpret_cast<int32_t*>(ws + o_cnt);
-  wh::BandJob* d_jobs = reinterpret_cast<wh::BandJob*>(ws + o_jobs);
+  wh::BandJob* d_jobs = nullptr;
   double* d_raw = reinterpret_cast<double*>(ws + o_raw);
   double* d_dc = reinterpret_cast<double*>(ws + o_dc);
   int32_t* d_dn = reinterpret_cast<int32_t*>(ws + o_dn);
@@ -538,9 +533,9 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   double* d_rsc = reinterpret_cast<double*>(ws + o_rsc);
   double* d_pf0 = reinterpret_cast<double*>(ws + o_pf0);
   double* d_psc = reinterpret_cast<double*>(ws + o_psc);
-  double* d_taps = reinterpret_cast<double*>(ws + o_taps);
-  double* d_bf = reinterpret_cast<double*>(ws + o_bf);
-  int32_t* d_ti = reinterpret_cast<int32_t*>(ws + o_ti);
+  double* d_taps = nullptr;
+  double* d_bf = nullptr;
+  int32_t* d_ti = nullptr;
   char* d_ct = ws + o_ct;
   std::vector<wh::BandJob> jobs((size_t)B * n_bands);
   for (int u = 0; u < B; ++u)
@@ -552,12 +547,14 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
       j.cap = e_cap[(size_t)u * n_bands + i];
       j.counts = d_cnt + ((int64_t)u * n_bands + i) * 4;
     }
-  WH_CHECK(hipMemcpyAsync(d_meta, meta.data(), sizeof(HvUtt) * B, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(wh::BandJob) * jobs.size(), hipMemcpyHostToDevice, st));
-  WH_CHECK(hipMemcpyAsync(d_taps, h_band_taps, sizeof(double) * taps_total, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipMemcpyAsync(d_bf, h_band_f0, sizeof(double) * n_bands, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipMemcpyAsync(d_ti, ti.data(), sizeof(int32_t) * n_bands * 3, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipStreamSynchronize(st));
+  {
+    std::vector<double> taps(h_band_taps, h_band_taps + taps_total), bf(h_band_f0, h_band_f0 + n_bands);
+    if (int rc = wh::persistent_upload(ctx, "hv.meta", meta, &d_meta)) return rc;
+    if (int rc = wh::persistent_upload(ctx, "hv.jobs", jobs, &d_jobs)) return rc;
+    if (int rc = wh::persistent_upload(ctx, "hv.taps", taps, &d_taps)) return rc;
+    if (int rc = wh::persistent_upload(ctx, "hv.band_f0", bf, &d_bf)) return rc;
+    if (int rc = wh::persistent_upload(ctx, "hv.tapinfo", ti, &d_ti)) return rc;
+  }
 
   // ---- decimation -----------------------------------------------------------------------------------
   if (r > 1) {

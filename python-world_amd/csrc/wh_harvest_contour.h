@@ -480,21 +480,19 @@ inline int harvest_contour(wh_ctx* ctx, hipStream_t st, int B, const HvUtt* d_me
     max_secs = std::max(max_secs, meta[u].nf1 / 7 + 2);
   }
   size_t off = 0;
-  const size_t o_hc = off; off += al(sizeof(HcUtt) * B);
   const size_t o_rows = off; off += al(sizeof(double) * f1_tot * 6);
   const size_t o_runs = off; off += al(sizeof(int32_t) * run_tot);
   const size_t o_secs = off; off += al(sizeof(HcSec) * sec_tot);
   const size_t o_ns = off; off += al(sizeof(int32_t) * B);
   const size_t o_ch = off; off += al(sizeof(double) * ch_tot);
   (void)off;
-  HcUtt* d_hc = reinterpret_cast<HcUtt*>(d_ws + o_hc);
+  HcUtt* d_hc = nullptr;
   double* d_rows = reinterpret_cast<double*>(d_ws + o_rows);
   int32_t* d_runs = reinterpret_cast<int32_t*>(d_ws + o_runs);
   HcSec* d_secs = reinterpret_cast<HcSec*>(d_ws + o_secs);
   int32_t* d_ns = reinterpret_cast<int32_t*>(d_ws + o_ns);
   double* d_ch = reinterpret_cast<double*>(d_ws + o_ch);
-  WH_CHECK(hipMemcpyAsync(d_hc, hc.data(), sizeof(HcUtt) * B, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipStreamSynchronize(st));
+  if (int rc = wh::persistent_upload(ctx, "hv.contour", hc, &d_hc)) return rc;
   const dim3 gf((unsigned)((max_nf1 + 255) / 256), B);
   { wh::KernelTimer _kt(ctx, st, "hc_base_kernel"); hipLaunchKernelGGL(hc_base_kernel, gf, dim3(256), 0, st, d_meta, d_hc, d_pf0, d_psc, d_rows); }
   WH_LAUNCH_CHECK("hc_base_kernel");

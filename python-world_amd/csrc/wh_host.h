@@ -17,6 +17,14 @@ struct wh_ctx {
   size_t ws_bytes = 0;
   std::map<std::string, double*> tables;  // small constant tables resident on the device (windows, taps)
   int32_t* d_flags = nullptr;             // [16] sticky device-side condition flags (see wh_take_flags)
+  // small per-call tables (utterance metadata, filter taps) kept in their own device buffers together with
+  // the host bytes they were filled from: an identical call re-uses them without any copy or stream sync
+  struct Persist {
+    void* d = nullptr;
+    size_t cap = 0;
+    std::vector<char> host;
+  };
+  std::map<std::string, Persist> persist;
   // optional per-kernel timing (HIP events on the launch stream), see wh_profile_*
   bool prof = false;
   std::vector<hipEvent_t> prof_events;    // pool, two per record
@@ -44,6 +52,16 @@ int ws_reserve(wh_ctx* ctx, size_t bytes);  // grows ctx->ws (hipFree + hipMallo
 inline const double2* twiddle(const wh_ctx* ctx, int n) { return ctx->d_twiddle + n; }
 // Upload-once constant table keyed by name (synchronous on first use, cached afterwards).
 int const_table(wh_ctx* ctx, const std::string& key, const std::vector<double>& host, const double** out);
+// Upload `bytes` from host memory into the persistent device buffer named `slot` unless it already holds
+// exactly these bytes.  Synchronous (and possibly reallocating) only when the content changed.
+int persistent_upload(wh_ctx* ctx, const std::string& slot, const void* host, size_t bytes, void** dptr);
+template <typename T>
+inline int persistent_upload(wh_ctx* ctx, const std::string& slot, const std::vector<T>& v, T** dptr) {
+  void* p = nullptr;
+  const int rc = persistent_upload(ctx, slot, v.data(), v.size() * sizeof(T), &p);
+  *dptr = reinterpret_cast<T*>(p);
+  return rc;
+}
 // Opt a kernel into more than 64 KiB of dynamic LDS (gfx950: up to 160 KiB per workgroup).
 template <typename K>
 inline int allow_lds(K kernel, size_t bytes) {

@@ -30,7 +30,6 @@ struct SynUtt {
   int64_t p_off, pcap;    // pulse slots
   int64_t noise_off, noise_len;  // host-supplied noise stream (if any)
   double t0, dt;          // time axis t_i = t0 + i*dt  (NumPy arange semantics, host-computed)
-  uint64_t seed;          // device RNG stream id when no noise is supplied
 };
 
 __device__ __forceinline__ double lerp_tp(const double* __restrict__ tp, const double* __restrict__ v, int64_t nf, double t) {
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(FT) void response_kernel(
     const double* __restrict__ aperiodicity, double fs, const double* __restrict__ p_time,
     const int64_t* __restrict__ p_idx, const double* __restrict__ p_shift, const int64_t* __restrict__ p_noff,
     const int32_t* __restrict__ p_count, const int64_t* __restrict__ p_base, int n_utt,
-    const uint8_t* __restrict__ vuv_s, const double* __restrict__ noise, const double* __restrict__ dc_base,
+    const uint8_t* __restrict__ vuv_s, const double* __restrict__ noise, uint64_t seed, const double* __restrict__ dc_base,
     const double2* __restrict__ tw_base, double* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = N / 2 + 1;
@@ -385,7 +384,7 @@ __global__ __launch_bounds__(FT) void response_kernel(
       const int64_t q = noff + j;
       return q < m.noise_len ? noise[m.noise_off + q] : 0.0;
     }
-    return normal_at(m.seed, (uint64_t)(noff + j));
+    return normal_at(seed * 0x9E3779B97F4A7C15ull + (uint64_t)u * 0xD1B54A32D192ED03ull + 1, (uint64_t)(noff + j));
   };
   double mean;
   {
@@ -484,7 +483,7 @@ template <int N>
 int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynUtt* d_meta, const double* tp,
                 const double* spec, const double* ap, double fs, const double* p_time, const int64_t* p_idx,
                 const double* p_shift, const int64_t* p_noff, const int32_t* p_count, const int64_t* p_base,
-                const uint8_t* vuv_s, const double* noise, double* y) {
+                const uint8_t* vuv_s, const double* noise, uint64_t seed, double* y) {
   std::vector<double> dc(N);
   double sum = 0.0;
   for (int n = 0; n < N; ++n) {  // hanning(N+2)[1:-1] normalised (synthesis.py:57-58)
@@ -499,7 +498,7 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   int64_t grid = pcap_max * B;
   if (grid > 256 * 16) grid = 256 * 16;  // persistent-style: workgroups stride over the flat pulse list
   { wh::KernelTimer _kt(ctx, st, "response_kernel"); hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(FT), lds, st, d_meta, tp, spec, ap, fs,
-                     p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, d_dc, ctx->d_twiddle, y); }
+                     p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, seed, d_dc, ctx->d_twiddle, y); }
   WH_LAUNCH_CHECK("response_kernel");
   return 0;
 }
@@ -691,13 +690,11 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
     m.noise_len = noise ? h_noise_off[u + 1] - h_noise_off[u] : -1;
     m.t0 = h_t0[u];
     m.dt = h_dt[u];
-    m.seed = seed * 0x9E3779B97F4A7C15ull + (uint64_t)u * 0xD1B54A32D192ED03ull + 1;
     max_ny = std::max(max_ny, m.ny);
   }
   const int64_t ny_tot = h_y_off[B];
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
-  const size_t o_meta = off; off += al(sizeof(SynUtt) * B);
   const size_t o_phase = off; off += al(sizeof(double) * ny_tot);
   const size_t o_vuv = off; off += al((size_t)ny_tot);
   const size_t o_pt = off; off += al(sizeof(double) * B * pulse_cap);
@@ -708,7 +705,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   const size_t o_pb = off; off += al(sizeof(int64_t) * (B + 1));
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
-  SynUtt* d_meta = reinterpret_cast<SynUtt*>(ws + o_meta);
+  SynUtt* d_meta = nullptr;
   double* d_phase = reinterpret_cast<double*>(ws + o_phase);
   uint8_t* d_vuv = reinterpret_cast<uint8_t*>(ws + o_vuv);
   int64_t* d_pb = reinterpret_cast<int64_t*>(ws + o_pb);
@@ -717,8 +714,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   double* d_ps = reinterpret_cast<double*>(ws + o_ps);
   int64_t* d_pn = reinterpret_cast<int64_t*>(ws + o_pn);
   int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
-  WH_CHECK(hipMemcpyAsync(d_meta, meta.data(), sizeof(SynUtt) * B, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipStreamSynchronize(st));
+  if (int rc = wh::persistent_upload(ctx, "syn.meta", meta, &d_meta)) return rc;
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
                      d_phase, d_vuv); }
@@ -732,10 +728,10 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   WH_LAUNCH_CHECK("pulse_base_kernel");
   int rc;
   switch (fft_size) {
-    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, y); break;
-    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, y); break;
-    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, y); break;
-    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, y); break;
+    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y); break;
+    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y); break;
+    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y); break;
+    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y); break;
     default: return wh::fail_msg("wh_synthesis", "fft_size must be a power of two in [512, 4096]");
   }
   if (rc) return rc;
@@ -768,13 +764,11 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
     m.noise_len = -1;
     m.t0 = h_t0[u];
     m.dt = h_dt[u];
-    m.seed = 0;
     max_ny = std::max(max_ny, m.ny);
   }
   const int64_t ny_tot = h_y_off[B];
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
-  const size_t o_meta = off; off += al(sizeof(SynUtt) * B);
   const size_t o_phase = off; off += al(sizeof(double) * ny_tot);
   const size_t o_vuv = off; off += al((size_t)ny_tot);
   const size_t o_pt = off; off += al(sizeof(double) * B * pulse_cap);
@@ -784,13 +778,13 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
   const size_t o_pc = off; off += al(sizeof(int32_t) * B);
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
-  SynUtt* d_meta = reinterpret_cast<SynUtt*>(ws + o_meta);
+  SynUtt* d_meta = nullptr;
   double* d_phase = reinterpret_cast<double*>(ws + o_phase);
   uint8_t* d_vuv = reinterpret_cast<uint8_t*>(ws + o_vuv);
   int64_t* d_pi = reinterpret_cast<int64_t*>(ws + o_pi);
   int64_t* d_pn = reinterpret_cast<int64_t*>(ws + o_pn);
   int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
-  WH_CHECK(hipMemcpyAsync(d_meta, meta.data(), sizeof(SynUtt) * B, hipMemcpyHostToDevice, st));
+  if (int rc = wh::persistent_upload(ctx, "syn.meta", meta, &d_meta)) return rc;
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
                      d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
@@ -845,7 +839,6 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
     m.noise_len = -1;
     m.t0 = h_t0[u];
     m.dt = h_dt[u];
-    m.seed = 0;
     rq[u].hop = h_hop[u];
     if (rq[u].hop < 1) return wh::fail_msg("wh_synthesis_requiem", "frame hop below one sample");
     for (int k = 0; k < 8; ++k) rq[u].cursor[k] = k < n_bands ? ((h_cursor[(int64_t)u * n_bands + k] % noise_len) + noise_len) % noise_len : 0;
@@ -856,8 +849,6 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   const int64_t F = b->total_frames;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
-  const size_t o_meta = off; off += al(sizeof(SynUtt) * B);
-  const size_t o_rq = off; off += al(sizeof(ReqUtt) * B);
   const size_t o_phase = off; off += al(sizeof(double) * ny_tot);
   const size_t o_vuv = off; off += al((size_t)ny_tot);
   const size_t o_pt = off; off += al(sizeof(double) * B * pulse_cap);
@@ -870,8 +861,8 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   const size_t o_exc = off; off += al(sizeof(double) * ny_tot);
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
-  SynUtt* d_meta = reinterpret_cast<SynUtt*>(ws + o_meta);
-  ReqUtt* d_rq = reinterpret_cast<ReqUtt*>(ws + o_rq);
+  SynUtt* d_meta = nullptr;
+  ReqUtt* d_rq = nullptr;
   double* d_phase = reinterpret_cast<double*>(ws + o_phase);
   uint8_t* d_vuv = reinterpret_cast<uint8_t*>(ws + o_vuv);
   double* d_pt = reinterpret_cast<double*>(ws + o_pt);
@@ -882,9 +873,8 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   int64_t* d_pb = reinterpret_cast<int64_t*>(ws + o_pb);
   double* d_lin = reinterpret_cast<double*>(ws + o_lin);
   double* d_exc = reinterpret_cast<double*>(ws + o_exc);
-  WH_CHECK(hipMemcpyAsync(d_meta, meta.data(), sizeof(SynUtt) * B, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipMemcpyAsync(d_rq, rq.data(), sizeof(ReqUtt) * B, hipMemcpyHostToDevice, st));
-  WH_CHECK(hipStreamSynchronize(st));
+  if (int rc = wh::persistent_upload(ctx, "syn.meta", meta, &d_meta)) return rc;
+  if (int rc = wh::persistent_upload(ctx, "syn.req", rq, &d_rq)) return rc;
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs, d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");

@@ -17,8 +17,10 @@ from .synthesis import synthesis_device, time_axis_params
 
 
 class BatchEncoding:
-    def __init__(self, rt, batch, fs, tp, f0, vuv, spectrogram, aperiodicity, fft_size, is_requiem, frame_period):
+    def __init__(self, rt, batch, fs, tp, f0, vuv, spectrogram, aperiodicity, fft_size, is_requiem, frame_period,
+                 tp_host=None):
         self.rt, self.batch, self.fs = rt, batch, fs
+        self.tp_host = tp_host  # host copy of the frame times (kept in step with scale_duration): no D2H in decode
         self.temporal_positions, self.f0, self.vuv = tp, f0, vuv
         self.spectrogram, self.aperiodicity = spectrogram, aperiodicity
         self.fft_size, self.is_requiem, self.frame_period = fft_size, is_requiem, frame_period
@@ -35,6 +37,8 @@ class BatchEncoding:
     def scale_duration(self, factor):
         """world/main.py:170-178, on the device."""
         self.temporal_positions *= factor
+        if self.tp_host is not None:
+            self.tp_host = self.tp_host * factor
         return self
 
     def to_dicts(self):
@@ -64,7 +68,9 @@ class WorldBatch:
         nfs = [_tables.frame_count(n, fs, frame_period) for n in lens]
         batch = rt.make_batch(np.concatenate([[0], np.cumsum(lens)]), np.concatenate([[0], np.cumsum(nfs)]))
         x_d = rt.to_device(np.concatenate(xs))
-        tp_d = rt.to_device(np.concatenate([_tables.frame_times(n, frame_period) for n in nfs]))
+        tp_h = np.concatenate([_tables.frame_times(n, frame_period) for n in nfs])
+        tp_d = rt.to_device(tp_h)
+        self._tp_host = {tp_d.data_ptr(): tp_h}
         return batch, x_d, tp_d
 
     def encode_device(self, batch, x_d, tp_d, fs, f0_method='dio', f0_floor=71, f0_ceil=800, channels_in_octave=2,
@@ -88,7 +94,9 @@ class WorldBatch:
             ap_d = d4c_requiem_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, fft_size)
         else:
             ap_d, _ = d4c_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, ct_fft)
-        return BatchEncoding(rt, batch, fs, tp_d.clone(), f0_d, vuv_d, spec_d, ap_d, ct_fft, is_requiem, frame_period)
+        tp_host = getattr(self, "_tp_host", {}).get(tp_d.data_ptr())
+        return BatchEncoding(rt, batch, fs, tp_d.clone(), f0_d, vuv_d, spec_d, ap_d, ct_fft, is_requiem, frame_period,
+                             tp_host=None if tp_host is None else tp_host.copy())
 
     def encode(self, xs, fs, **kw):
         batch, x_d, tp_d = self.upload(xs, fs, kw.get('frame_period', 5))
@@ -100,7 +108,7 @@ class WorldBatch:
         standard-normal arrays (reference-parity mode); default = on-device Philox stream ``seed``."""
         rt = self.rt
         fo = enc.batch.frame_off
-        tp_h = enc.temporal_positions.cpu().numpy()
+        tp_h = enc.tp_host if enc.tp_host is not None else enc.temporal_positions.cpu().numpy()
         geo = [time_axis_params(tp_h[int(fo[u]):int(fo[u + 1])], enc.fs) for u in range(enc.n_utt)]
         ny = [g[0] for g in geo]
         if enc.is_requiem:

@@ -65,7 +65,7 @@ def synthesis_requiem_device(rt, enc, ny, geo, seeds=None, cursor=None):
     nlen = seeds['noise'].shape[0]
     cur = np.zeros(nb) if cursor is None else np.array(cursor, dtype=np.float64)
     fo = enc.batch.frame_off
-    tp_h = enc.temporal_positions.cpu().numpy()
+    tp_h = enc.tp_host if enc.tp_host is not None else enc.temporal_positions.cpu().numpy()
     hops, cursors = [], []
     for u in range(enc.n_utt):
         t = tp_h[int(fo[u]):int(fo[u + 1])]

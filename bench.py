@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--seconds", type=float, default=SECONDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=12, help="utterances of the batch timed through the CPU oracle")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
+                    help="BASELINE.json config: 2 = DIO path encode+decode (the metric's config, default); "
+                         "3 = Harvest F0 only; 4 = Harvest + CheapTrick + D4C-Requiem encode + Requiem decode")
     return ap.parse_args()
 
 
@@ -101,10 +104,27 @@ def main():
     batch, x_d, tp_d = wb.upload(xs, FS)  # inputs resident in HBM before the timed region
     frames_per_step = batch.total_frames
 
-    def step(seed):
-        enc = wb.encode_device(batch, x_d, tp_d, FS, f0_method="dio")
-        y, _ = wb.decode_device(enc, seed=seed)
-        return y
+    if args.config == 2:
+        def step(seed):
+            enc = wb.encode_device(batch, x_d, tp_d, FS, f0_method="dio")
+            y, _ = wb.decode_device(enc, seed=seed)
+            return y
+    elif args.config == 3:
+        from world.harvest import harvest_device
+
+        def step(seed):
+            return harvest_device(rt, batch, x_d, tp_d, FS)
+    else:
+        from world.get_seeds_signals import get_seeds_signals
+        import random
+        random.seed(0)
+        np.random.seed(0)
+        seeds = get_seeds_signals(FS)
+
+        def step(seed):
+            enc = wb.encode_device(batch, x_d, tp_d, FS, f0_method="harvest", is_requiem=True)
+            y, _ = wb.decode_device(enc, seeds=seeds)
+            return y
 
     def fence():
         if world > 1:
@@ -165,16 +185,18 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "x_realtime": audio_s / elapsed,
-            "config": {"workload": "BASELINE config 2 per GPU: %d x %.0f s synthetic 16 kHz utterances, "
-                                   "DIO+StoneMask+CheapTrick+D4C encode + pulse-wise synthesis decode, HBM-resident"
-                                   % (args.utts, args.seconds),
+            "config": {"workload": {2: "BASELINE config 2 per GPU: %d x %.0f s synthetic 16 kHz utterances, "
+                                       "DIO+StoneMask+CheapTrick+D4C encode + pulse-wise synthesis decode, HBM-resident",
+                                    3: "BASELINE config 3 per GPU: %d x %.0f s synthetic 16 kHz utterances, Harvest F0 only",
+                                    4: "BASELINE config 4 per GPU: %d x %.0f s synthetic 16 kHz utterances, Harvest+CheapTrick+"
+                                       "D4C-Requiem encode + Requiem decode"}[args.config] % (args.utts, args.seconds),
                        "utterances_per_gpu": args.utts, "fs": FS, "frame_period_ms": 5,
                        "frames_per_step_per_gpu": frames_per_step, "sharding": "utterances, no collective"},
             "roofline": roofline,
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
             "device_flags": flags,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 2:
             out["cpu_baseline"] = cpu_baseline(xs, args.cpu_utts)
         print(json.dumps(out))
     if world > 1:

@@ -102,7 +102,7 @@ class WorldBatch:
         batch, x_d, tp_d = self.upload(xs, fs, kw.get('frame_period', 5))
         return self.encode_device(batch, x_d, tp_d, fs, **kw)
 
-    def decode_device(self, enc, noise=None, seed=0, pulse_cap=None):
+    def decode_device(self, enc, noise=None, seed=0, pulse_cap=None, seeds=None):
         """world/main.py:198-214 for a resident encoding.  Returns (y tensor, y_off) — concatenated
         waveforms, peak-normalised per utterance where max|y| > 1.  ``noise``: optional list of per-utterance
         standard-normal arrays (reference-parity mode); default = on-device Philox stream ``seed``."""
@@ -113,7 +113,7 @@ class WorldBatch:
         ny = [g[0] for g in geo]
         if enc.is_requiem:
             from .synthesisRequiem import synthesis_requiem_device
-            y, y_off = synthesis_requiem_device(rt, enc, ny, geo)
+            y, y_off = synthesis_requiem_device(rt, enc, ny, geo, seeds=seeds)
         else:
             noise_d = noise_off = None
             if noise is not None:

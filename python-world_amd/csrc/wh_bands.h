@@ -19,6 +19,9 @@ struct BandJob {
 };
 
 constexpr int kBandTile = 1024;
+// staging index with 2 doubles of padding every 32: keeps the 16-byte pair reads of lanes 4 samples apart on
+// different LDS banks
+__device__ __forceinline__ int zpad(int i) { return i + 2 * (i >> 5); }
 
 // s[g] = sum_k taps[k] * z[(bias + 1 + g) - k], g in [0, M)
 template <bool FMA>
@@ -34,9 +37,9 @@ __global__ __launch_bounds__(256) void band_events_kernel(const BandJob* __restr
   const int lb = tap_len[b];
   double* taps = reinterpret_cast<double*>(smem);      // lb
   double* zt = taps + ((lb + 1) & ~1);                 // kBandTile + 2 + lb
-  double* sig = zt + ((kBandTile + 2 + lb + 1) & ~1);  // kBandTile + 2
+  double* sig = zt + ((zpad(kBandTile + 2 + lb) + 3) & ~1);  // kBandTile + 2
   unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(sig + kBandTile + 2);  // 8
-  for (int k = threadIdx.x; k < lb; k += 256) taps[k] = taps_all[tap_off[b] + k];
+  for (int k = threadIdx.x; k < ((lb + 1) & ~1); k += 256) taps[k] = k < lb ? taps_all[tap_off[b] + k] : 0.0;
   int base_cnt[4] = {0, 0, 0, 0};
   const int64_t M = job.M;
   for (int64_t t0 = 0; t0 < M; t0 += kBandTile) {
@@ -44,27 +47,46 @@ __global__ __launch_bounds__(256) void band_events_kernel(const BandJob* __restr
     const int64_t zlo = t0 + bias[b] + 1 - (lb - 1);
     for (int i = threadIdx.x; i < kBandTile + 2 + lb - 1; i += 256) {
       const int64_t j = zlo + i + pad;
-      zt[i] = (j >= 0 && j < M + 2 * pad) ? job.z[j] : 0.0;
+      zt[zpad(i)] = (j >= 0 && j < M + 2 * pad) ? job.z[j] : 0.0;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kBandTile + 2; i += 256) {
-      double acc = 0.0;
-      if (t0 + i < M) {
-        const double* zp = zt + i + (lb - 1);
-        if (FMA) {
-          double a0 = 0.0, a1 = 0.0;  // two chains hide the FP64 FMA latency
-          int k = 0;
-          for (; k + 1 < lb; k += 2) {
-            a0 = fma(taps[k], zp[-k], a0);
-            a1 = fma(taps[k + 1], zp[-k - 1], a1);
-          }
-          if (k < lb) a0 = fma(taps[k], zp[-k], a0);
-          acc = a0 + a1;
-        } else {
-          for (int k = 0; k < lb; ++k) acc += taps[k] * zp[-k];
-        }
+    if (FMA) {
+      // register-tiled FIR: each thread owns 4 consecutive outputs and slides a 4-wide window over the
+      // staged input, two taps per step (one 16-byte LDS read for the tap pair, one for the two new inputs)
+      const int i0 = threadIdx.x * 4;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      const int top = i0 + (lb - 1);  // input index of output i0 for tap 0
+      double r0 = zt[zpad(top)], r1 = zt[zpad(top + 1)], r2 = zt[zpad(top + 2)], r3 = zt[zpad(top + 3)];
+      const int lbe = (lb + 1) & ~1;  // taps are zero padded to an even count
+      for (int k = 0; k < lbe; k += 2) {
+        const double2 tk = *reinterpret_cast<const double2*>(taps + k);
+        const int inew = top - k - 2;  // even → aligned pair (z[inew], z[inew+1])
+        double2 fresh = make_double2(0.0, 0.0);
+        if (inew >= 0) fresh = *reinterpret_cast<const double2*>(zt + zpad(inew));
+        a0 = fma(tk.x, r0, a0); a1 = fma(tk.x, r1, a1); a2 = fma(tk.x, r2, a2); a3 = fma(tk.x, r3, a3);
+        r3 = r2; r2 = r1; r1 = r0; r0 = fresh.y;
+        a0 = fma(tk.y, r0, a0); a1 = fma(tk.y, r1, a1); a2 = fma(tk.y, r2, a2); a3 = fma(tk.y, r3, a3);
+        r3 = r2; r2 = r1; r1 = r0; r0 = fresh.x;
       }
-      sig[i] = acc;
+      sig[i0] = t0 + i0 < M ? a0 : 0.0;
+      sig[i0 + 1] = t0 + i0 + 1 < M ? a1 : 0.0;
+      sig[i0 + 2] = t0 + i0 + 2 < M ? a2 : 0.0;
+      sig[i0 + 3] = t0 + i0 + 3 < M ? a3 : 0.0;
+      if (threadIdx.x < 2) {  // the two look-ahead samples the crossing detector needs
+        const int i = kBandTile + threadIdx.x;
+        double acc = 0.0;
+        if (t0 + i < M)
+          for (int k = 0; k < lb; ++k) acc = fma(taps[k], zt[zpad(i + (lb - 1) - k)], acc);
+        sig[i] = acc;
+      }
+    } else {
+      for (int i = threadIdx.x; i < kBandTile + 2; i += 256) {
+        double acc = 0.0;
+        if (t0 + i < M) {
+          for (int k = 0; k < lb; ++k) acc += taps[k] * zt[zpad(i + (lb - 1) - k)];
+        }
+        sig[i] = acc;
+      }
     }
     __syncthreads();
     emit_crossings(sig, t0, M, kBandTile, job.edges, job.cap, base_cnt, scan_scratch, flags);
@@ -75,7 +97,8 @@ __global__ __launch_bounds__(256) void band_events_kernel(const BandJob* __restr
 inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs, int nb, int n_utt, int pad,
                               const double* d_taps, const int32_t* d_tap_off, const int32_t* d_tap_len,
                               const int32_t* d_bias, int max_lb, bool use_fma, int32_t* d_flag) {
-  const size_t lds = sizeof(double) * (((max_lb + 1) & ~1) + ((kBandTile + 2 + max_lb + 1) & ~1) + kBandTile + 2) + 64;
+  const int zlen = kBandTile + 2 + max_lb;
+  const size_t lds = sizeof(double) * (((max_lb + 1) & ~1) + ((zlen + 2 * (zlen >> 5) + 3) & ~1) + kBandTile + 2) + 64;
   if (use_fma) {
     if (int rc = allow_lds(&band_events_kernel<true>, lds)) return rc;
     { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_kernel<true>, dim3(nb, n_utt), dim3(256), lds, st, d_jobs, pad, d_taps, d_tap_off, d_tap_len, d_bias, nb, d_flag); }

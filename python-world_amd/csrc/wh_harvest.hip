@@ -337,27 +337,37 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict_
   }
   double* of0 = rf0 + (m.f1_off + f) * kRows;
   double* osc = rsc + (m.f1_off + f) * kRows;
-  for (int e = threadIdx.x; e < kRows; e += 256) {
-    of0[e] = 0.0;
-    osc[e] = 0.0;
-  }
+  // gather this frame's overlapped candidates (one global-memory latency for all 105 rows) and compact the
+  // non-zero ones so that the four waves only iterate over real work
+  __shared__ double cl_val[kRows];
+  __shared__ int cl_row[kRows];
+  __shared__ int cl_n;
+  if (threadIdx.x == 0) cl_n = 0;
   __syncthreads();
-  double* sm = wbuf + (size_t)w * 2 * (2 * hmax + 1);
-  double* sd = sm + (2 * hmax + 1);
-  for (int e = w; e < kRows; e += 4) {  // wave-uniform loop over overlapped rows (shift-major)
+  for (int e = threadIdx.x; e < kRows; e += 256) {
     const int s = e / kMaxC - 3, c = e % kMaxC;
     const int64_t src = f + s;
     double cand = 0.0;
     if (src >= 0 && src < m.nf1 && c < dcount[m.f1_off + src]) cand = dc[(m.f1_off + src) * kMaxC + c];
     if (e == 0 && f < 3) cand = dc[(m.f1_off + f) * kMaxC + 6];  // stray seeding of row 0 (harvest.py:119)
-    if (cand == 0.0) continue;
-    const double hw = ceil(3 * fs / cand / 2);
-    if (!(hw <= (double)hmax)) continue;  // cannot happen for candidates >= f0_floor
+    of0[e] = 0.0;
+    osc[e] = 0.0;
+    if (cand != 0.0 && ceil(3 * fs / cand / 2) <= (double)hmax) {
+      const int p = atomicAdd(&cl_n, 1);  // order is irrelevant: results are written to row e
+      cl_val[p] = cand;
+      cl_row[p] = e;
+    }
+  }
+  __syncthreads();
+  const int n_items = cl_n;
+  double* sm = wbuf + (size_t)w * 2 * (2 * hmax + 1);
+  double* sd = sm + (2 * hmax + 1);
+  for (int it = w; it < n_items; it += 4) {
     double r0, r1;
-    hv_refine_one(yl, ybase, m.ylen, fs, t0, cand, f0_floor, f0_ceil, sm, sd, tw_base, &r0, &r1);
+    hv_refine_one(yl, ybase, m.ylen, fs, t0, cl_val[it], f0_floor, f0_ceil, sm, sd, tw_base, &r0, &r1);
     if (lane == 0) {
-      of0[e] = r0;
-      osc[e] = r1;
+      of0[cl_row[it]] = r0;
+      osc[cl_row[it]] = r1;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -368,25 +378,34 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict_
 __global__ __launch_bounds__(128) void hv_prune_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ rf0,
                                                        const double* __restrict__ rsc, double* __restrict__ pf0,
                                                        double* __restrict__ psc) {
-  __shared__ double nb_prev[kRows], nb_next[kRows];
+  __shared__ double nb_prev[kRows], nb_next[kRows];  // compacted non-zero candidates of frames j-1 / j+1
+  __shared__ int n_prev, n_next;
   const HvUtt m = meta[blockIdx.y];
   const int64_t f = blockIdx.x;
   if (f >= m.nf1) return;
   const int e = threadIdx.x;
   const int64_t o = (m.f1_off + f) * kRows;
   const bool inner = f >= 1 && f <= m.nf1 - 2;
+  if (e == 0) {
+    n_prev = 0;
+    n_next = 0;
+  }
+  __syncthreads();
   if (e < kRows && inner) {
-    nb_prev[e] = rf0[o - kRows + e];
-    nb_next[e] = rf0[o + kRows + e];
+    const double a = rf0[o - kRows + e], b = rf0[o + kRows + e];
+    if (a != 0.0) nb_prev[atomicAdd(&n_prev, 1)] = a;  // zeros can never be the nearest candidate
+    if (b != 0.0) nb_next[atomicAdd(&n_next, 1)] = b;
   }
   __syncthreads();
   if (e >= kRows) return;
   double v = rf0[o + e], s = rsc[o + e];
   if (inner && v != 0.0) {
-    double e1 = 1.0, e2 = 1.0;  // SelectBestF0 with allowed_range = 1
-    for (int k = 0; k < kRows; ++k) {
+    double e1 = 1.0, e2 = 1.0;  // SelectBestF0 with allowed_range = 1 (a zero candidate gives exactly 1)
+    for (int k = 0; k < n_next; ++k) {
       const double a = fabs(v - nb_next[k]) / v;
       if (!(a > e1)) e1 = a;
+    }
+    for (int k = 0; k < n_prev; ++k) {
       const double b = fabs(v - nb_prev[k]) / v;
       if (!(b > e2)) e2 = b;
     }

@@ -59,6 +59,20 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` measured with rocprofv3 PMC passes on this workload (committed under
+    profiles/; bench.py itself cannot run the profiler around its own timed region).  None if unavailable."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic_cfg2_latest.txt")
+    try:
+        for line in open(path):
+            parts = line.split()
+            if parts and parts[0] == kernel:
+                return float(parts[3]) * 1e6, os.path.relpath(path, ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def cpu_baseline(xs, n_utts):
     """The NumPy oracle (a 'port' of the reference path) on a bounded sample of the same workload."""
     from oracle import api as oapi
@@ -166,8 +180,9 @@ def main():
             per_frame = ALGO_BYTES_PER_FRAME.get(dominant, PATH_BYTES_PER_FRAME)
             avg_s = kernel_ms[dominant] / 1e3
             achieved = per_frame * frames_per_step / avg_s / 1e9
+            traffic, traffic_src = pmc_traffic(dominant) if args.config == 2 and args.utts == UTT_PER_GPU else (None, None)
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": per_frame * frames_per_step,
                         "avg_launch_ms": kernel_ms[dominant],
                         "path_algorithmic_GBps": PATH_BYTES_PER_FRAME * frames_per_step * args.steps / elapsed / 1e9}

@@ -41,8 +41,9 @@ def cheaptrick_np(x, fs, f0, vuv, temporal_positions, q1=-0.15, fft_size=None, w
     power = np.abs(ps) ** 2
     power = C.low_band_replica(power, fs, fft_size, f0u, f0u + fs / fft_size)
 
-    # step 2: rectangular smoothing of width 2*f0/3 (cheaptrick.py:103-118); eps dither omitted (Q10)
-    smoothed = C.cumsum_band_mean(power, fs, fft_size, 2.0 * f0u / 3.0) * 1.5 / f0u[:, None]
+    # step 2: rectangular smoothing of width 2*f0/3 (cheaptrick.py:103-118).  The reference adds an unseeded
+    # rand*eps dither so that log() never sees 0 (Q10); its mean eps/2 is added here (deterministic)
+    smoothed = C.cumsum_band_mean(power, fs, fft_size, 2.0 * f0u / 3.0) * 1.5 / f0u[:, None] + 0.5 * C.EPS
 
     # step 3: liftering (cheaptrick.py:136-157)
     envelope = lifter_recover(C.mirror_half(smoothed), f0u, fs, fft_size, q1)

@@ -8,10 +8,10 @@
 
 namespace {
 
-#ifndef WH_FRAME_THREADS
-#define WH_FRAME_THREADS 256
+#ifndef WH_FT_CHEAPTRICK
+#define WH_FT_CHEAPTRICK 256
 #endif
-constexpr int FT = WH_FRAME_THREADS;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
+constexpr int FT = WH_FT_CHEAPTRICK;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
 
 template <int N>
 __global__ __launch_bounds__(FT) void cheaptrick_kernel(
@@ -96,7 +96,9 @@ __global__ __launch_bounds__(FT) void cheaptrick_kernel(
     const double c = (double)k / N * fs;
     const double lo = lk.at(c - f0 / 3);
     const double hi = lk.at(c + f0 / 3);
-    aux[k] = log((hi - lo) * 1.5 / f0);  // the reference's rand*eps dither is omitted (Q10)
+    // the reference adds rand()*eps here "to avoid log(0)" (cheaptrick.py:117, unseeded, Q10); its mean eps/2 keeps
+    // that guarantee (digital silence) deterministically
+    aux[k] = log((hi - lo) * 1.5 / f0 + 0.5 * 2.220446049250313e-16);
   }
   wh::sync<FT>();
 

@@ -13,10 +13,10 @@
 
 namespace {
 
-#ifndef WH_FRAME_THREADS
-#define WH_FRAME_THREADS 256
+#ifndef WH_FT_D4C
+#define WH_FT_D4C 256
 #endif
-constexpr int FT = WH_FRAME_THREADS;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
+constexpr int FT = WH_FT_D4C;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
 
 // Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110).  Values for samples j = tid + q*FT land
 // in the caller's registers v[q] (zero beyond the window; rows longer than N are cropped like

@@ -19,10 +19,10 @@
 
 namespace {
 
-#ifndef WH_FRAME_THREADS
-#define WH_FRAME_THREADS 256
+#ifndef WH_FT_SYNTH
+#define WH_FT_SYNTH 256
 #endif
-constexpr int FT = WH_FRAME_THREADS;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
+constexpr int FT = WH_FT_SYNTH;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
 
 struct SynUtt {
   int64_t f_off, nf;      // frames
@@ -63,33 +63,54 @@ __global__ __launch_bounds__(256) void prep_kernel(const SynUtt* __restrict__ me
 
 // In-place sequential cumulative sum, one 64-lane wave per utterance.  Tiles of 2048 samples are staged
 // through LDS with coalesced loads/stores by all lanes; lane 0 walks the tile with the exact left-to-right
-// float64 additions of np.cumsum (16 values per LDS round trip, so the only serial cost is the add chain).
+// float64 additions of np.cumsum.  The next tile's global loads and the next 16-sample block's LDS reads are
+// issued before the current additions, so the only exposed cost is the add chain itself.
 constexpr int kScanTile = 2048;
 __global__ __launch_bounds__(64) void phase_kernel(const SynUtt* __restrict__ meta, double* __restrict__ phase) {
   __shared__ __attribute__((aligned(16))) double tile[kScanTile];
   const SynUtt m = meta[blockIdx.x];
   double* p = phase + m.y_off;
   const int lane = threadIdx.x;
+  constexpr int PER = kScanTile / 64;
   double carry = 0.0;
+  double pre[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int64_t i = (int64_t)q * 64 + lane;
+    pre[q] = i < m.ny ? p[i] : 0.0;
+  }
   for (int64_t base = 0; base < m.ny; base += kScanTile) {
     const int cnt = (int)(m.ny - base < kScanTile ? m.ny - base : kScanTile);
-    for (int i = lane; i < kScanTile; i += 64) tile[i] = i < cnt ? p[base + i] : 0.0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) tile[q * 64 + lane] = pre[q];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // prefetch the next tile while lane 0 runs the chain
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int64_t i = base + kScanTile + (int64_t)q * 64 + lane;
+      pre[q] = i < m.ny ? p[i] : 0.0;
+    }
     if (lane == 0) {
       double run = carry;
+      double cur[16], nxt[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) cur[q] = tile[q];
       for (int k = 0; k < kScanTile; k += 16) {
-        double v[16];
+        if (k + 16 < kScanTile) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = tile[k + q];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          run += v[q];
-          v[q] = run;
+          for (int q = 0; q < 16; ++q) nxt[q] = tile[k + 16 + q];
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) tile[k + q] = v[q];
+        for (int q = 0; q < 16; ++q) {
+          run += cur[q];
+          cur[q] = run;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tile[k + q] = cur[q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
       }
       carry = run;
     }
@@ -98,6 +119,8 @@ __global__ __launch_bounds__(64) void phase_kernel(const SynUtt* __restrict__ me
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     for (int i = lane; i < cnt; i += 64) p[base + i] = tile[i];
     carry = __shfl(carry, 0, 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
   }
 }
 

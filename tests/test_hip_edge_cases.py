@@ -1,0 +1,87 @@
+"""GPU: edge cases of the batched path — 48 kHz long-form with modifiers (BASELINE config 5 shape, reduced
+count), very short and silent utterances, ragged mixes, odd sampling rates."""
+import numpy as np
+import pytest
+
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config5_shape_48k_modifiers():
+    """48 kHz, harvest, scale_pitch(1.5) + scale_duration(2.0), decode: lengths follow NumPy's float arange
+    (Q9) and the result matches the oracle decode fed with the same noise."""
+    from oracle import api as oapi
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+    from world.synthesis import time_axis_params
+
+    fs = 48000
+    xs = [synth_utterance(70 + i, fs, 1.0 + 0.5 * i) for i in range(2)]
+    wb = WorldBatch()
+    enc = wb.encode(xs, fs, f0_method="harvest")
+    enc.scale_pitch(1.5).scale_duration(2.0)
+    dicts = enc.to_dicts()
+    rng = np.random.RandomState(1)
+    noise = [rng.randn(4 * len(x)) for x in xs]
+    y, y_off = wb.decode_device(enc, noise=noise)
+    y = y.cpu().numpy()
+    for u, x in enumerate(xs):
+        ny = time_axis_params(dicts[u]["temporal_positions"], fs)[0]
+        assert y_off[u + 1] - y_off[u] == ny
+        o = oapi.encode_np(fs, x, f0_method="harvest")
+        assert np.array_equal(dicts[u]["vuv"], o["vuv"])
+        assert rel_rms(dicts[u]["f0"], o["f0"] * 1.5) < 1e-8
+        assert rel_rms(dicts[u]["spectrogram"], o["spectrogram"]) < 1e-8
+        yo = oapi.decode_np(dict(dicts[u]), noise=noise[u])["out"]
+        assert rel_rms(y[y_off[u]:y_off[u + 1]], yo) < 1e-8
+    assert wb.rt.take_flags() == [0] * 16
+
+
+def test_silence_and_short_utterances():
+    """Digital silence and a 60 ms utterance next to a normal one: no NaN, all-unvoiced where there is no
+    signal, frame counts exact, neighbours unaffected."""
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+
+    fs = 16000
+    normal = synth_utterance(80, fs, 0.8)
+    xs = [np.zeros(8000), normal, 1e-3 * np.random.RandomState(0).randn(960), normal[:4000]]
+    wb = WorldBatch()
+    for method in ("dio", "harvest"):
+        enc = wb.encode(xs, fs, f0_method=method)
+        fo = enc.batch.frame_off
+        assert list(np.diff(fo)) == [int(1000 * len(x) / fs / 5 + 1) for x in xs]
+        f0 = enc.f0.cpu().numpy()
+        assert np.all(np.isfinite(f0))
+        assert np.all(f0[fo[0]:fo[1]] == 0)  # silence is unvoiced
+        ref = wb.encode([normal], fs, f0_method=method)
+        assert np.array_equal(enc.f0.cpu().numpy()[fo[1]:fo[2]], ref.f0.cpu().numpy())
+        assert np.array_equal(enc.spectrogram.cpu().numpy()[fo[1]:fo[2]], ref.spectrogram.cpu().numpy())
+        y, y_off = wb.decode_device(enc, seed=1)
+        assert np.all(np.isfinite(y.cpu().numpy()))
+    wb.rt.take_flags()
+
+
+@pytest.mark.parametrize("fs", [8000, 22050, 44100])
+def test_other_sampling_rates_match_oracle(fs):
+    from oracle import api as oapi
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+
+    x = synth_utterance(90, fs, 0.6)
+    wb = WorldBatch()
+    for method, req in (("dio", False), ("harvest", True)):
+        if fs < 16000 and req:
+            continue  # fs/2 - 3000 < 3000: the reference asserts (no Requiem band)
+        enc = wb.encode([x], fs, f0_method=method, is_requiem=req)
+        d = enc.to_dicts()[0]
+        o = oapi.encode_np(fs, x, f0_method=method, is_requiem=req)
+        assert np.array_equal(d["vuv"], o["vuv"])
+        assert rel_rms(d["f0"], o["f0"]) < 1e-8
+        assert rel_rms(d["spectrogram"], o["spectrogram"]) < 1e-8
+        if req:
+            assert np.max(np.abs(d["aperiodicity"] - o["aperiodicity"])) < 1e-6
+        else:
+            assert np.max(np.abs(d["aperiodicity"] - o["aperiodicity"])) < 1e-7
+    wb.rt.take_flags()

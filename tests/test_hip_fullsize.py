@@ -1,0 +1,96 @@
+"""GPU: BASELINE config 2 at FULL size (64 x 10 s, 16 kHz) checked through size-independent properties
+(the oracle would need minutes here): exact frame / sample counts, batch == single-utterance results,
+utterance-permutation equivariance, input-gain scaling laws, and waveform-level resynthesis sanity."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FS = 16000
+
+
+@pytest.fixture(scope="module")
+def full_batch():
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+
+    xs = [synth_utterance(u, FS, 10.0) for u in range(64)]
+    wb = WorldBatch()
+    enc = wb.encode(xs, FS, f0_method="dio")
+    return xs, wb, enc
+
+
+def test_counts_and_flags(full_batch):
+    xs, wb, enc = full_batch
+    assert enc.batch.total_frames == 64 * 2001          # F = int(1000*N/fs/5 + 1), bit-exact
+    y, y_off = wb.decode_device(enc, seed=7)
+    assert list(np.diff(y_off)) == [160001] * 64        # len(np.arange(0, tp[-1]+1/fs, 1/fs))
+    assert wb.rt.take_flags() == [0] * 16
+    y = y.cpu().numpy()
+    assert np.all(np.isfinite(y)) and np.max(np.abs(y)) <= 1.0 + 1e-12   # peak normalisation (main.py:209-212)
+    f0 = enc.f0.cpu().numpy()
+    vuv = enc.vuv.cpu().numpy()
+    assert np.all((f0 == 0) == (vuv == 0)) or np.all(f0[vuv == 0] == 0)   # d4c zeroes unvoiced f0 (Q6)
+    voiced = f0[(vuv != 0) & (f0 != 500.0)]
+    assert 50 < voiced.min() and voiced.max() < 1000   # DIO candidates in [71, 800], StoneMask may move them by <= 20 %
+    sp = enc.spectrogram
+    ap = enc.aperiodicity
+    assert bool((sp > 0).all()) and bool(((ap > 0) & (ap <= 1)).all())   # a 0 dB band gives exactly 1.0, like the reference
+
+
+def test_batch_rows_equal_single_utterance(full_batch):
+    """No cross-utterance state: utterance u inside the 64-batch == the same utterance alone (bitwise)."""
+    from world.batch import WorldBatch
+
+    xs, wb, enc = full_batch
+    fo = enc.batch.frame_off
+    for u in (0, 17, 63):
+        single = WorldBatch().encode([xs[u]], FS, f0_method="dio")
+        s = slice(int(fo[u]), int(fo[u + 1]))
+        for name in ("f0", "vuv", "spectrogram", "aperiodicity"):
+            a = getattr(enc, name)[s].cpu().numpy()
+            b = getattr(single, name).cpu().numpy()
+            assert np.array_equal(a, b), (u, name)
+
+
+def test_permutation_equivariance(full_batch):
+    from world.batch import WorldBatch
+
+    xs, wb, enc = full_batch
+    perm = np.random.RandomState(0).permutation(8)
+    sub = [xs[i] for i in range(8)]
+    e1 = WorldBatch().encode(sub, FS, f0_method="dio")
+    e2 = WorldBatch().encode([sub[i] for i in perm], FS, f0_method="dio")
+    f1 = e1.spectrogram.cpu().numpy().reshape(8, 2001, -1)
+    f2 = e2.spectrogram.cpu().numpy().reshape(8, 2001, -1)
+    assert np.array_equal(f2, f1[perm])
+
+
+def test_gain_scaling_laws(full_batch):
+    """x -> 0.5*x: F0, VUV and aperiodicity are scale-free, the power-spectral envelope scales by 0.25
+    (exact up to rounding because 0.5 is a power of two)."""
+    from world.batch import WorldBatch
+
+    xs, wb, enc = full_batch
+    sub = xs[:4]
+    e1 = WorldBatch().encode(sub, FS, f0_method="dio")
+    e2 = WorldBatch().encode([0.5 * x for x in sub], FS, f0_method="dio")
+    assert np.array_equal(e1.vuv.cpu().numpy(), e2.vuv.cpu().numpy())
+    assert np.allclose(e1.f0.cpu().numpy(), e2.f0.cpu().numpy(), rtol=1e-12, atol=0)
+    assert np.allclose(e1.aperiodicity.cpu().numpy(), e2.aperiodicity.cpu().numpy(), rtol=0, atol=1e-9)
+    s1, s2 = e1.spectrogram.cpu().numpy(), e2.spectrogram.cpu().numpy()
+    # exact up to the eps/2 log-guard (not scale-free): visible only on ~1e-9-level bins
+    assert np.allclose(s2, 0.25 * s1, rtol=1e-6, atol=0)
+    assert np.sqrt(np.mean((s2 - 0.25 * s1) ** 2) / np.mean(s2 ** 2)) < 1e-12
+
+
+def test_resynthesis_tracks_input(full_batch):
+    """encode → decode reproduces the utterance's short-time energy envelope (voiced/unvoiced alternation)."""
+    xs, wb, enc = full_batch
+    y, y_off = wb.decode_device(enc, seed=3)
+    y = y.cpu().numpy()
+    for u in (0, 31):
+        seg = y[y_off[u]:y_off[u + 1]][:160000]
+        ex = np.sqrt(np.mean(xs[u].reshape(-1, 1600) ** 2, axis=1))
+        ey = np.sqrt(np.mean(seg.reshape(-1, 1600) ** 2, axis=1))
+        assert np.corrcoef(ex, ey)[0, 1] > 0.9

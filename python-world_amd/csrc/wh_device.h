@@ -156,12 +156,14 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 
 // One Stockham pass of radix R over N points with NT threads; NS = product of earlier radices.
 // tw[i] = exp(-2*pi*i*sqrt(-1)/N), i in [0,N).  INV conjugates twiddles and butterflies.
-template <int N, int NT, int R, int NS, bool INV>
+// SNT >= NT: the barrier spans SNT threads while NT of them (thread index modulo NT) cooperate on this buffer,
+// so that SNT/NT independent transforms on different buffers advance in lockstep through the same barriers.
+template <int N, int NT, int R, int NS, bool INV, int SNT = NT>
 __device__ __forceinline__ void fft_pass(double2* __restrict__ s, const double2* __restrict__ tw) {
   constexpr int J = N / R;
   constexpr int PER = (J + NT - 1) / NT;
   double2 v[PER][R];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & (NT - 1);
 #pragma unroll
   for (int p = 0; p < PER; ++p) {
     const int j = tid + p * NT;
@@ -170,7 +172,7 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ s, const double2*
       for (int r = 0; r < R; ++r) v[p][r] = s[j + r * J];
     }
   }
-  sync<NT>();
+  sync<SNT>();
 #pragma unroll
   for (int p = 0; p < PER; ++p) {
     const int j = tid + p * NT;
@@ -203,18 +205,18 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ s, const double2*
       }
     }
   }
-  sync<NT>();
+  sync<SNT>();
 }
 
-template <int N, int NT, int NS, bool INV>
+template <int N, int NT, int NS, bool INV, int SNT = NT>
 __device__ __forceinline__ void fft_passes(double2* s, const double2* tw) {
   if constexpr (NS < N) {
     if constexpr (NS * 4 <= N) {
-      fft_pass<N, NT, 4, NS, INV>(s, tw);
-      fft_passes<N, NT, NS * 4, INV>(s, tw);
+      fft_pass<N, NT, 4, NS, INV, SNT>(s, tw);
+      fft_passes<N, NT, NS * 4, INV, SNT>(s, tw);
     } else {
-      fft_pass<N, NT, 2, NS, INV>(s, tw);
-      fft_passes<N, NT, NS * 2, INV>(s, tw);
+      fft_pass<N, NT, 2, NS, INV, SNT>(s, tw);
+      fft_passes<N, NT, NS * 2, INV, SNT>(s, tw);
     }
   }
 }
@@ -222,9 +224,9 @@ __device__ __forceinline__ void fft_passes(double2* s, const double2* tw) {
 // In-place unnormalised DFT of N complex doubles resident in LDS.  Caller guarantees that the
 // buffer is fully written and visible (barrier) on entry; visible on exit.  The inverse does
 // NOT divide by N.
-template <int N, bool INV, int NT = WH_BLOCK>
+template <int N, bool INV, int NT = WH_BLOCK, int SNT = NT>
 __device__ __forceinline__ void fft_lds(double2* s, const double2* tw) {
-  fft_passes<N, NT, 1, INV>(s, tw);
+  fft_passes<N, NT, 1, INV, SNT>(s, tw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -237,11 +239,11 @@ __device__ __forceinline__ void fft_lds(double2* s, const double2* tw) {
 
 // Forward.  in: z[j] = (x[2j], x[2j+1]), j < N/2 (i.e. the real array itself).  out: z[k] = X[k], k = 0..N/2
 // (N/2 + 1 entries).  Buffer must be visible on entry; visible on exit.
-template <int N, int NT = WH_BLOCK>
+template <int N, int NT = WH_BLOCK, int SNT = NT>
 __device__ __forceinline__ void rfft_lds(double2* z, const double2* __restrict__ tw_base) {
-  fft_lds<N / 2, false, NT>(z, tw_base + N / 2);
+  fft_lds<N / 2, false, NT, SNT>(z, tw_base + N / 2);
   const double2* __restrict__ w = tw_base + N;
-  for (int k = threadIdx.x; k <= N / 4; k += NT) {
+  for (int k = threadIdx.x & (NT - 1); k <= N / 4; k += NT) {
     if (k == 0) {
       const double2 a = z[0];
       z[0] = make_double2(a.x + a.y, 0.0);
@@ -257,16 +259,16 @@ __device__ __forceinline__ void rfft_lds(double2* z, const double2* __restrict__
       z[N / 2 - k] = make_double2(er - tr, ti - ei);  // conj(E - T)
     }
   }
-  sync<NT>();
+  sync<SNT>();
 }
 
 // Inverse.  in: z[k] = X[k], k = 0..N/2: the half spectrum; the result is Re(IDFT) of its Hermitian extension
 // (imaginary parts of the DC / Nyquist bins are ignored, as taking .real of a full complex IFFT would).
 // out: z[j] = N * (x[2j], x[2j+1]), j < N/2 (unnormalised like fft_lds<.., true>: divide by N).
-template <int N, int NT = WH_BLOCK>
+template <int N, int NT = WH_BLOCK, int SNT = NT>
 __device__ __forceinline__ void irfft_lds(double2* z, const double2* __restrict__ tw_base) {
   const double2* __restrict__ w = tw_base + N;
-  for (int k = threadIdx.x; k <= N / 4; k += NT) {
+  for (int k = threadIdx.x & (NT - 1); k <= N / 4; k += NT) {
     double2 a = z[k], b = z[N / 2 - k];
     if (k == 0) {  // DC and Nyquist bins: only their real parts reach a real output (Re of the inverse DFT)
       a.y = 0.0;
@@ -280,8 +282,8 @@ __device__ __forceinline__ void irfft_lds(double2* z, const double2* __restrict_
     z[k] = make_double2(er - oi, ei + orr);                      // Z[k]     = 2E + i*2O
     if (k != 0) z[N / 2 - k] = make_double2(er + oi, orr - ei);  // Z[N/2-k] = conj(2E) + i*conj(2O)
   }
-  sync<NT>();
-  fft_lds<N / 2, true, NT>(z, tw_base + N / 2);
+  sync<SNT>();
+  fft_lds<N / 2, true, NT, SNT>(z, tw_base + N / 2);
 }
 
 }  // namespace wh

@@ -269,7 +269,7 @@ __device__ __forceinline__ double normal_at(uint64_t seed, uint64_t q) {
   const double u2 = ((double)c2 * 4294967296.0 + (double)c3 + 0.5) * (1.0 / 18446744073709551616.0);
   const double rr = sqrt(-2.0 * log(u1));
   double s, c;
-  sincos(2 * M_PI * u2, &s, &c);
+  sincospi(2 * u2, &s, &c);  // sin/cos(2*pi*u2) without the large-argument reduction path
   return (q & 1) ? rr * s : rr * c;
 }
 
@@ -277,24 +277,29 @@ __device__ __forceinline__ double normal_at(uint64_t seed, uint64_t q) {
 // log|.|/2 (in place, amp is destroyed) → real FFT → fold the cepstrum onto its upper half (x2, bin 0 kept)
 // → inverse transform of that REAL sequence = conj of its real FFT → complex exp.  Both transforms are
 // N/2-point complex FFTs.  Result: zb[k], k = 0..N/2 (the rest of the spectrum is its Hermitian mirror).
-template <int N>
+// GT threads (thread index modulo GT) work on this (amp, zb) pair; barriers span all FT threads, so FT/GT
+// independent chains on different buffers run side by side through the same barrier phases.
+template <int N, int GT>
 __device__ __forceinline__ void min_phase_half(double* amp, double2* zb, const double2* tw_base) {
   double* zr = reinterpret_cast<double*>(zb);
-  for (int k = threadIdx.x; k <= N / 2; k += FT) amp[k] = log(fabs(amp[k])) / 2;
+  const int gt = threadIdx.x & (GT - 1);
+#pragma unroll 1
+  for (int k = gt; k <= N / 2; k += GT) amp[k] = log(fabs(amp[k])) / 2;
   wh::sync<FT>();
-  for (int n = threadIdx.x; n < N; n += FT) zr[n] = amp[n <= N / 2 ? n : N - n];
+  for (int n = gt; n < N; n += GT) zr[n] = amp[n <= N / 2 ? n : N - n];
   wh::sync<FT>();
-  wh::rfft_lds<N, FT>(zb, tw_base);
-  for (int k = threadIdx.x; k <= N / 2; k += FT) amp[k] = zb[k].x;  // real cepstrum (even)
+  wh::rfft_lds<N, GT, FT>(zb, tw_base);
+  for (int k = gt; k <= N / 2; k += GT) amp[k] = zb[k].x;  // real cepstrum (even)
   wh::sync<FT>();
-  for (int n = threadIdx.x; n < N; n += FT) zr[n] = n == 0 ? amp[0] : (n >= N / 2 ? 2 * amp[N - n] : 0.0);
+  for (int n = gt; n < N; n += GT) zr[n] = n == 0 ? amp[0] : (n >= N / 2 ? 2 * amp[N - n] : 0.0);
   wh::sync<FT>();
-  wh::rfft_lds<N, FT>(zb, tw_base);
-  for (int k = threadIdx.x; k <= N / 2; k += FT) {
+  wh::rfft_lds<N, GT, FT>(zb, tw_base);
+#pragma unroll 1
+  for (int k = gt; k <= N / 2; k += GT) {
     const double2 r = zb[k];  // sum c[n] e^{+i..} = conj(r)
     const double e = exp(r.x / N);
     double sn, cs;
-    sincos(-r.y / N, &sn, &cs);
+    sincospi(-r.y / N * M_1_PI, &sn, &cs);  // small angle in units of pi: cheap exact range reduction
     zb[k] = make_double2(e * cs, e * sn);
   }
   wh::sync<FT>();
@@ -304,29 +309,69 @@ __device__ __forceinline__ void min_phase_half(double* amp, double2* zb, const d
 // keep the 16-byte pair reads of lanes that are 4..8 samples apart on different LDS banks
 __device__ __forceinline__ int rap_index(int i) { return i + 2 * (i >> 5); }
 
+// Everything one pulse needs (kernel arguments bundled so that the per-pulse body can be a real function).
+struct RespArgs {
+  const SynUtt* meta;
+  const double* tp;
+  const double* spectrogram;
+  const double* aperiodicity;
+  double fs;
+  const double* p_time;
+  const int64_t* p_idx;
+  const double* p_shift;
+  const int64_t* p_noff;
+  const int32_t* p_count;
+  const int64_t* p_base;
+  int n_utt;
+  const uint8_t* vuv_s;
+  const double* noise;
+  uint64_t seed;
+  const double* dc_base;
+  const double2* tw_base;
+  double* y;
+};
+
+// One pulse per workgroup.  (A persistent grid-stride loop over pulses was measured first: the compiler then
+// hoists every loop-invariant LDS / twiddle address of the ~15 FFT passes out of the loop and keeps them live
+// across it — 219 VGPRs, 2 workgroups per CU.  Launching one workgroup per pulse slot and letting the surplus
+// ones exit costs < 0.2 ms and more than halves the register count.)
 template <int N>
-__global__ __launch_bounds__(FT) void response_kernel(
-    const SynUtt* __restrict__ meta, const double* __restrict__ tp, const double* __restrict__ spectrogram,
-    const double* __restrict__ aperiodicity, double fs, const double* __restrict__ p_time,
-    const int64_t* __restrict__ p_idx, const double* __restrict__ p_shift, const int64_t* __restrict__ p_noff,
-    const int32_t* __restrict__ p_count, const int64_t* __restrict__ p_base, int n_utt,
-    const uint8_t* __restrict__ vuv_s, const double* __restrict__ noise, uint64_t seed, const double* __restrict__ dc_base,
-    const double2* __restrict__ tw_base, double* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, char* smem) {
+  const SynUtt* __restrict__ meta = A.meta;
+  const double* __restrict__ tp = A.tp;
+  const double* __restrict__ spectrogram = A.spectrogram;
+  const double* __restrict__ aperiodicity = A.aperiodicity;
+  const double fs = A.fs;
+  const double* __restrict__ p_time = A.p_time;
+  const int64_t* __restrict__ p_idx = A.p_idx;
+  const double* __restrict__ p_shift = A.p_shift;
+  const int64_t* __restrict__ p_noff = A.p_noff;
+  const int32_t* __restrict__ p_count = A.p_count;
+  const int64_t* __restrict__ p_base = A.p_base;
+  const int n_utt = A.n_utt;
+  const uint8_t* __restrict__ vuv_s = A.vuv_s;
+  const double* __restrict__ noise = A.noise;
+  const uint64_t seed = A.seed;
+  const double* __restrict__ dc_base = A.dc_base;
+  const double2* __restrict__ tw_base = A.tw_base;
+  double* __restrict__ y = A.y;
   constexpr int K = N / 2 + 1;
   constexpr int NZ = 256;
   constexpr int R = N / FT;  // consecutive output samples per thread
   static_assert(R % 2 == 0, "pairwise reads need an even number of outputs per thread");
-  double2* zb = reinterpret_cast<double2*>(smem);                  // N/2+1 complex
-  double* zr = reinterpret_cast<double*>(smem);                     // = N+2 reals
-  double* rap = zr + (N + 2);                                       // N + N/16 (+2): aperiodic response, padded
-  double* spec = rap + (N + N / 16 + 2);                            // K+7
-  double* asp = spec + (K + 7);                                     // K+7
-  double* nz = asp + (K + 7);                                       // NZ
+  constexpr int GT = FT >= 256 ? FT / 2 : FT;  // threads per chain: the periodic and aperiodic chains run side by side
+  constexpr int NG = FT / GT;
+  double2* zbA = reinterpret_cast<double2*>(smem);                 // N/2+1 complex: aperiodic chain
+  double* zrA = reinterpret_cast<double*>(smem);
+  double2* zbP = zbA + (N / 2 + 1);                                 // N/2+1 complex: periodic chain
+  double* zrP = reinterpret_cast<double*>(zbP);
+  double* rap = zrP + (N + 2);                                      // N + N/16 + 2: padded aperiodic response ...
+  double* spec = rap;                                               // ... aliasing the two K+7 amplitude arrays,
+  double* asp = rap + (K + 7);                                      //     dead once both spectra exist
+  double* nz = rap + (N + N / 16 + 2);                              // NZ
   double* scratch = nz + NZ;                                        // 16
+  static_assert(2 * (K + 7) <= N + N / 16 + 2, "amplitude arrays must fit under the padded response");
 
-  const int64_t total_pulses = p_base[n_utt];
-  for (int64_t gp = blockIdx.x; gp < total_pulses; gp += gridDim.x) {
   wh::sync<FT>();
   int u;
   {
@@ -420,10 +465,40 @@ __global__ __launch_bounds__(FT) void response_kernel(
     mean = wh::block_sum<FT>(part, scratch) / (double)nd;  // barriers: spec/asp/nz visible
   }
 
-  // ---- aperiodic response (synthesis.py:86-96): minimum phase → real inverse FFT → fftshift ---------
-  min_phase_half<N>(asp, zb, tw_base);
-  wh::irfft_lds<N, FT>(zb, tw_base);
-  for (int n = threadIdx.x; n < N; n += FT) rap[rap_index(n)] = zr[(n + N / 2) & (N - 1)] / N;
+  // ---- minimum-phase responses (synthesis.py:86-116): aperiodic chain on thread group 0, periodic chain on
+  //      group 1, advancing through the same barrier phases (with a single group: one after the other) --------
+  const double coef_pi = 2.0 * fs / N;  // coefficient = 2*pi*fs/N (synthesis.py:59), kept in units of pi
+  if constexpr (NG == 2) {
+    const int g = threadIdx.x / GT;
+    min_phase_half<N, GT>(g == 0 ? asp : spec, g == 0 ? zbA : zbP, tw_base);
+    if (g == 1) {
+#pragma unroll 1
+      for (int k = threadIdx.x & (GT - 1); k <= N / 2; k += GT) {
+        double sn, cs;
+        sincospi(coef_pi * shift * (double)k, &sn, &cs);  // angle coef*shift*k expressed in units of pi
+        const double2 z = zbP[k];
+        zbP[k] = make_double2(z.x * cs + z.y * sn, z.y * cs - z.x * sn);  // z * exp(-i th): fractional delay
+      }
+    }
+    wh::sync<FT>();
+    wh::irfft_lds<N, GT, FT>(g == 0 ? zbA : zbP, tw_base);
+  } else {
+    min_phase_half<N, FT>(asp, zbA, tw_base);
+    wh::irfft_lds<N, FT, FT>(zbA, tw_base);
+    if (voiced) {
+      min_phase_half<N, FT>(spec, zbP, tw_base);
+      for (int k = threadIdx.x; k <= N / 2; k += FT) {
+        double sn, cs;
+        sincospi(coef_pi * shift * (double)k, &sn, &cs);  // angle coef*shift*k expressed in units of pi
+        const double2 z = zbP[k];
+        zbP[k] = make_double2(z.x * cs + z.y * sn, z.y * cs - z.x * sn);
+      }
+      wh::sync<FT>();
+      wh::irfft_lds<N, FT, FT>(zbP, tw_base);
+    }
+  }
+  // zrA[n] = N * aperiodic response, zrP[n] = N * periodic response (both before fftshift)
+  for (int n = threadIdx.x; n < N; n += FT) rap[rap_index(n)] = zrA[(n + N / 2) & (N - 1)] / N;
   wh::sync<FT>();
 
   // y[m] = sum_j nz[j] * ra[m-j], m < N: each thread owns R consecutive outputs and slides an R-wide
@@ -466,24 +541,12 @@ __global__ __launch_bounds__(FT) void response_kernel(
     }
   }
 
-  // ---- periodic response (synthesis.py:100-116) --------------------------------------------------
+  // ---- DC removal of the periodic response (synthesis.py:72-73) ------------------------------------
   double dc_total = 0.0;
   const double gain = sqrt((double)(noise_size > 1 ? noise_size : 1));
   if (voiced) {
-    wh::sync<FT>();
-    min_phase_half<N>(spec, zb, tw_base);
-    const double coef = 2.0 * M_PI * fs / N;
-    for (int k = threadIdx.x; k <= N / 2; k += FT) {
-      const double th = coef * shift * (double)k;
-      double sn, cs;
-      sincos(th, &sn, &cs);
-      const double2 z = zb[k];
-      zb[k] = make_double2(z.x * cs + z.y * sn, z.y * cs - z.x * sn);  // z * exp(-i th)
-    }
-    wh::sync<FT>();
-    wh::irfft_lds<N, FT>(zb, tw_base);  // zr[n] = N * response[n] (before fftshift)
     double part = 0.0;
-    for (int n = threadIdx.x; n < N; n += FT) part += zr[n] / N;
+    for (int n = threadIdx.x; n < N; n += FT) part += zrP[n] / N;
     dc_total = wh::block_sum<FT>(part, scratch);
   }
 
@@ -494,13 +557,25 @@ __global__ __launch_bounds__(FT) void response_kernel(
     const int mm = m0 + q;
     const int64_t tgt = pidx - N / 2 + 1 + mm;  // 1-based
     double v = acc[q];
-    if (voiced) v += (zr[(mm + N / 2) & (N - 1)] / N + dc_base[mm] * -dc_total) * gain;
+    if (voiced) v += (zrP[(mm + N / 2) & (N - 1)] / N + dc_base[mm] * -dc_total) * gain;
     if (tgt < 1) continue;                    // clipped to 1 and overwritten by the in-range tap
+#ifdef WH_ABLATE_OLA
+    if (v == 1.2345e300) yu[0] = v;
+#else
     if (tgt < m.ny) atomicAdd(&yu[tgt - 1], v);
     else if (mm == N - 1) atomicAdd(&yu[m.ny - 1], v);  // last duplicate wins on the high side
+#endif
   }
-  }  // pulse loop
 }
+
+template <int N>
+__global__ __launch_bounds__(FT) void response_kernel(RespArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t gp = blockIdx.x;
+  if (gp >= A.p_base[A.n_utt]) return;  // pulse slots beyond the actual pulse count
+  response_pulse<N>(A, gp, smem);
+}
+
 
 template <int N>
 int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynUtt* d_meta, const double* tp,
@@ -516,12 +591,11 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   for (int n = 0; n < N; ++n) dc[n] /= sum;
   const double* d_dc = nullptr;
   if (int rc = wh::const_table(ctx, "dc_base:" + std::to_string(N), dc, &d_dc)) return rc;
-  const size_t lds = sizeof(double) * ((N + 2) + (N + N / 16 + 2) + 2 * (N / 2 + 8) + 256 + 16);
+  const size_t lds = sizeof(double) * (2 * (N + 2) + (N + N / 16 + 2) + 256 + 16);
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
-  int64_t grid = pcap_max * B;
-  if (grid > 256 * 16) grid = 256 * 16;  // persistent-style: workgroups stride over the flat pulse list
-  { wh::KernelTimer _kt(ctx, st, "response_kernel"); hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(FT), lds, st, d_meta, tp, spec, ap, fs,
-                     p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, seed, d_dc, ctx->d_twiddle, y); }
+  const int64_t grid = pcap_max * B;  // one workgroup per pulse slot; slots past the real count exit at once
+  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, seed, d_dc, ctx->d_twiddle, y};
+  hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(FT), lds, st, ra); }
   WH_LAUNCH_CHECK("response_kernel");
   return 0;
 }
@@ -659,7 +733,7 @@ __global__ __launch_bounds__(FT) void req_filter_kernel(const SynUtt* __restrict
   for (int k = threadIdx.x; k < K; k += FT) amp[k] = sp[k];
   wh::sync<FT>();
   wh::rfft_lds<N, FT>(sb, tw_base);
-  min_phase_half<N>(amp, zb, tw_base);
+  min_phase_half<N, FT>(amp, zb, tw_base);
   for (int k = threadIdx.x; k < K; k += FT) zb[k] = wh::cmul(zb[k], sb[k]);  // both Hermitian → product Hermitian
   wh::sync<FT>();
   wh::irfft_lds<N, FT>(zb, tw_base);

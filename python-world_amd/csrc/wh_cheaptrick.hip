@@ -92,13 +92,11 @@ __global__ __launch_bounds__(FT) void cheaptrick_kernel(
   wh::scan_mirrored<FT>(aux, zr, N, fs, scratch);
   wh::BandLookup lk;
   lk.init(zr, N, fs);
+  lk.set_half_width(f0 / 3);
   for (int k = threadIdx.x; k < K; k += FT) {
-    const double c = (double)k / N * fs;
-    const double lo = lk.at(c - f0 / 3);
-    const double hi = lk.at(c + f0 / 3);
     // the reference adds rand()*eps here "to avoid log(0)" (cheaptrick.py:117, unseeded, Q10); its mean eps/2 keeps
     // that guarantee (digital silence) deterministically
-    aux[k] = log((hi - lo) * 1.5 / f0 + 0.5 * 2.220446049250313e-16);
+    aux[k] = log(lk.band(k) * 1.5 / f0 + 0.5 * 2.220446049250313e-16);
   }
   wh::sync<FT>();
 

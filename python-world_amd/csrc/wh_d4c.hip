@@ -291,9 +291,9 @@ __global__ __launch_bounds__(FT) void d4c_kernel(
   wh::scan_mirrored<FT>(pw, cum, N, fs, scratch);
   wh::BandLookup lk;
   lk.init(cum, N, fs);
+  lk.set_half_width(cf / 2);
   for (int k = threadIdx.x; k < K; k += FT) {
-    const double c = (double)k / N * fs;
-    const double sm = (lk.at(c + cf / 2) - lk.at(c - cf / 2)) / cf;
+    const double sm = lk.band(k) / cf;
     cent[k] = cent[k] / sm;  // T_g = centroid / smoothed power (d4c.py:169; no zero guard, Q14)
   }
   wh::sync<FT>();
@@ -302,18 +302,14 @@ __global__ __launch_bounds__(FT) void d4c_kernel(
   lk.init(cum, N, fs);
   {
     const double w2 = cf / 2;
-    for (int k = threadIdx.x; k < K; k += FT) {
-      const double c = (double)k / N * fs;
-      pw[k] = (lk.at(c + w2 / 2) - lk.at(c - w2 / 2)) / w2;  // T_gs
-    }
+    lk.set_half_width(w2 / 2);
+    for (int k = threadIdx.x; k < K; k += FT) pw[k] = lk.band(k) / w2;  // T_gs
   }
   wh::sync<FT>();
   wh::scan_mirrored<FT>(pw, cum, N, fs, scratch);
   lk.init(cum, N, fs);
-  for (int k = threadIdx.x; k < K; k += FT) {
-    const double c = (double)k / N * fs;
-    cent[k] = pw[k] - (lk.at(c + cf / 2) - lk.at(c - cf / 2)) / cf;  // T_D = T_gs - T_gb
-  }
+  lk.set_half_width(cf / 2);
+  for (int k = threadIdx.x; k < K; k += FT) cent[k] = pw[k] - lk.band(k) / cf;  // T_D = T_gs - T_gb
   wh::sync<FT>();
 
   // ---- band-wise aperiodicity (d4c.py:192-209) -----------------------------------------------

@@ -73,6 +73,27 @@ struct BandLookup {
     total = c[n - 1];
   }
   __device__ __forceinline__ double seg(int i) const { return i < N ? cum[i] : total + cum[i - N]; }
+  // Band mean around every bin centre: the look-up positions centre_k +- half sit at a CONSTANT fractional
+  // offset from bin k (q_k = k + const), so base index and fraction are found once per frame instead of by a
+  // divide/floor per bin.  (Differs from evaluating q_k per bin only by rounding of q; the interpolant is
+  // continuous, so the value is unaffected.)  Requires centre +- half inside the doubled axis (always true for
+  // k <= N/2 and half < fs/2 - fs/N).
+  int b_lo, b_hi;
+  double f_lo, f_hi;
+  __device__ __forceinline__ void set_half_width(double half) {
+    const double q_lo = ((0.0 - half) - x0) * inv_dx, q_hi = ((0.0 + half) - x0) * inv_dx;
+    const double fl = floor(q_lo), fh = floor(q_hi);
+    b_lo = (int)fl;
+    b_hi = (int)fh;
+    f_lo = q_lo - fl;
+    f_hi = q_hi - fh;
+  }
+  __device__ __forceinline__ double band(int k) const {  // at(c_k + half) - at(c_k - half)
+    const double l0 = seg(k + b_lo), h0 = seg(k + b_hi);
+    const double lo = l0 + (seg(k + b_lo + 1) - l0) * f_lo;
+    const double hi = h0 + (seg(k + b_hi + 1) - h0) * f_hi;
+    return hi - lo;
+  }
   __device__ __forceinline__ double at(double xi) const {
     xi = fmax(x0, fmin(xlast, xi));
     const double q = (xi - x0) * inv_dx;

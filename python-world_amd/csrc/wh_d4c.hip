@@ -233,11 +233,15 @@ __device__ __forceinline__ void add_centroid(const double* xu, long long xn, dou
   wh::sync<FT>();
 }
 
-template <int N>
+// FUSED (love-train FFT size == D4C FFT size, the case at 16/22.05/44.1/48 kHz for d4c()): the VUV gate's
+// Blackman frame and the Hann frame of the smoothed power spectrum are two real sequences → ONE complex FFT,
+// separated by Hermitian symmetry; the separate love_train_kernel launch and one transform disappear.
+template <int N, bool FUSED>
 __global__ __launch_bounds__(FT) void d4c_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
-    const double* __restrict__ tp, const double* __restrict__ f0_in, const int32_t* __restrict__ gate, double fs,
-    int nap, int interval, const double* __restrict__ window, int wlen, const double2* __restrict__ tw_base,
+    const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv,
+    const int32_t* __restrict__ gate, double threshold, double fs, int nap, int interval,
+    const double* __restrict__ window, int wlen, const double2* __restrict__ tw_base,
     int k_spec,                       // >0: dense amplitude output [F][k_spec]; 0: Requiem band output [F][nap+2]
     double* __restrict__ out, double* __restrict__ coarse_dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -250,7 +254,53 @@ __global__ __launch_bounds__(FT) void d4c_kernel(
   double* band = scratch + 16;                       // nap (<= 8)
 
   const int64_t f = blockIdx.x;
-  if (gate[f] == 0) {
+  const int u = frame_utt[f];
+  const double* xu = x + x_off[u];
+  const long long xn = x_off[u + 1] - x_off[u];
+  const double pos = tp[f];
+  double f0v = f0_io[f];
+  bool voiced;
+  if (FUSED) {
+    if (vuv[f] == 0.0) f0v = 0.0;  // d4c.py:32 — written back (Q6)
+    if (threadIdx.x == 0) f0_io[f] = f0v;
+    voiced = f0v != 0.0;
+  } else {
+    voiced = gate[f] != 0;
+  }
+  const double cf = fmax(47.0, f0v);
+  if (FUSED && voiced) {
+    // love-train frame (Blackman, 3*T0, f0 floored at 40 Hz) and smoothed-power frame (Hann, 4*T0) in one FFT
+    double va[N / FT], vb[N / FT];
+    d4c_window<true, N>(xu, xn, fs, fmax(f0v, 40.0), pos, 1.5, zr, va, scratch);
+    d4c_window<false, N>(xu, xn, fs, cf, pos, 2.0, zr, vb, scratch);
+#pragma unroll
+    for (int q = 0; q < N / FT; ++q) buf[threadIdx.x + q * FT] = make_double2(va[q], vb[q]);
+    wh::sync<FT>();
+    wh::fft_lds<N, false, FT>(buf, tw_base + N);
+    const int b0 = (int)(ceil(100.0 / (fs / N)) + 1);
+    const int b1 = (int)(ceil(4000.0 / (fs / N)) + 1);
+    const int b2 = (int)(ceil(7900.0 / (fs / N)) + 1);
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = threadIdx.x; k < K; k += FT) {
+      const double2 a = buf[k], b = buf[(N - k) & (N - 1)];
+      const double ar = 0.5 * (a.x + b.x), ai = 0.5 * (a.y - b.y);   // love-train spectrum A[k]
+      const double br = 0.5 * (a.y + b.y), bi = -0.5 * (a.x - b.x);  // Hann-frame spectrum B[k]
+      pw[k] = br * br + bi * bi;
+      const double pa = ar * ar + ai * ai;  // |A[k]|^2 = |A[N-k]|^2: bins k and N-k of the full power spectrum
+      if (k >= b0 && k < b2) {
+        s2 += pa;
+        if (k < b1) s1 += pa;
+      }
+      const int km = N - k;  // mirrored bin (only reached when 7.9 kHz lies above fs/2)
+      if (k > 0 && k < N / 2 && km >= b0 && km < b2) {
+        s2 += pa;
+        if (km < b1) s1 += pa;
+      }
+    }
+    wh::block_sum2<FT>(s1, s2, scratch);
+    voiced = s1 / s2 > threshold;  // d4c.py:86
+  }
+  if (!voiced) {
     if (k_spec > 0) {
       double* o = out + f * (int64_t)k_spec;
       for (int k = threadIdx.x; k < k_spec; k += FT) o[k] = 1 - 0.000000000001;
@@ -261,11 +311,6 @@ __global__ __launch_bounds__(FT) void d4c_kernel(
     }
     return;
   }
-  const int u = frame_utt[f];
-  const double* xu = x + x_off[u];
-  const long long xn = x_off[u + 1] - x_off[u];
-  const double pos = tp[f];
-  const double cf = fmax(47.0, f0_in[f]);
 
   // ---- static centroid from two frames at +-T0/4 (d4c.py:132-142) + DC correction ----------
   add_centroid<N>(xu, xn, fs, cf, pos + 1 / cf / 4, buf, cent, true, tw_base, scratch);
@@ -273,19 +318,19 @@ __global__ __launch_bounds__(FT) void d4c_kernel(
   wh::low_band_replica<FT>(cent, zr, N, fs, cf, 1.2 * cf);
 
   // ---- smoothed power spectrum (d4c.py:157-161) ----------------------------------------------
-  {
+  if (!FUSED) {
     double v[N / FT];
     d4c_window<false, N>(xu, xn, fs, cf, pos, 2.0, zr, v, scratch);
 #pragma unroll
     for (int q = 0; q < N / FT; ++q) zr[threadIdx.x + q * FT] = v[q];
     wh::sync<FT>();
+    wh::rfft_lds<N, FT>(buf, tw_base);
+    for (int k = threadIdx.x; k < K; k += FT) {
+      const double2 z = buf[k];
+      pw[k] = z.x * z.x + z.y * z.y;
+    }
+    wh::sync<FT>();
   }
-  wh::rfft_lds<N, FT>(buf, tw_base);
-  for (int k = threadIdx.x; k < K; k += FT) {
-    const double2 z = buf[k];
-    pw[k] = z.x * z.x + z.y * z.y;
-  }
-  wh::sync<FT>();
   double* cum = zr;  // the FFT buffer is idle during the smoothing steps
   wh::low_band_replica<FT>(pw, cum, N, fs, cf, 1.2 * cf);
   wh::scan_mirrored<FT>(pw, cum, N, fs, scratch);
@@ -393,14 +438,14 @@ int launch_lt(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, c
   return 0;
 }
 
-template <int N>
-int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, const double* f0,
-                const int32_t* gate, double fs, int nap, int interval, const double* win, int wlen, int k_spec,
-                double* out, double* coarse) {
+template <int N, bool FUSED>
+int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
+                const double* vuv, const int32_t* gate, double thr, double fs, int nap, int interval, const double* win,
+                int wlen, int k_spec, double* out, double* coarse) {
   const size_t lds = sizeof(double) * (2 * N + 2 * (N / 2 + 8) + 16 + 8);
-  if (int rc = wh::allow_lds(&d4c_kernel<N>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL(d4c_kernel<N>, dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
-                     b->d_frame_utt, tp, f0, gate, fs, nap, interval, win, wlen, ctx->d_twiddle, k_spec, out,
+  if (int rc = wh::allow_lds(&d4c_kernel<N, FUSED>, lds)) return rc;
+  { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL((d4c_kernel<N, FUSED>), dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
+                     b->d_frame_utt, tp, f0, vuv, gate, thr, fs, nap, interval, win, wlen, ctx->d_twiddle, k_spec, out,
                      coarse); }
   WH_LAUNCH_CHECK("d4c_kernel");
   return 0;
@@ -421,6 +466,15 @@ int d4c_common(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, co
   int32_t* gate = reinterpret_cast<int32_t*>(ctx->ws);
   const double* d_win = nullptr;
   if (int rc = wh::const_table(ctx, "nuttall:" + std::to_string(wlen), nuttall(wlen), &d_win)) return rc;
+  if (nlt == nfft) {  // fused love-train + D4C
+    switch (nfft) {
+      case 512: return launch_main<512, true>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+      case 1024: return launch_main<1024, true>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+      case 2048: return launch_main<2048, true>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+      case 4096: return launch_main<4096, true>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+      default: return wh::fail_msg("wh_d4c", "D4C FFT size outside [512, 4096]");
+    }
+  }
   int rc;
   switch (nlt) {
     case 512: rc = launch_lt<512>(ctx, st, b, x, tp, f0, vuv, fs, threshold, gate); break;
@@ -431,10 +485,10 @@ int d4c_common(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, co
   }
   if (rc) return rc;
   switch (nfft) {
-    case 512: return launch_main<512>(ctx, st, b, x, tp, f0, gate, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
-    case 1024: return launch_main<1024>(ctx, st, b, x, tp, f0, gate, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
-    case 2048: return launch_main<2048>(ctx, st, b, x, tp, f0, gate, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
-    case 4096: return launch_main<4096>(ctx, st, b, x, tp, f0, gate, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+    case 512: return launch_main<512, false>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+    case 1024: return launch_main<1024, false>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+    case 2048: return launch_main<2048, false>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+    case 4096: return launch_main<4096, false>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
     default: return wh::fail_msg("wh_d4c", "D4C FFT size outside [512, 4096]");
   }
 }

@@ -209,12 +209,30 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
 }
 
 // ---- candidate refinement ------------------------------------------------------------------------
-// One wave refines one (frame, candidate): GetRefinedF0, harvest.py:169-211.
-__device__ __forceinline__ void hv_refine_one(const double* __restrict__ yl, int64_t ybase, int64_t ylen, double fs,
+// GetRefinedF0 (harvest.py:169-211) for one (frame, candidate), evaluated by a 16-lane DPP row; a wave
+// refines four candidates at once.  No FFT: the Blackman-windowed frame and its derivative-windowed twin are
+// accumulated directly into the <= 6 harmonic bins the reference reads from its two zero-padded FFTs, and the
+// 24 partial sums are reduced inside the row with DPP lane permutes (no LDS, no cross-row traffic).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row, result in every lane: xor-1, xor-2 quad permutes, then the two mirrors
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  return v;
+}
+
+__device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int64_t ybase, int64_t ylen, double fs,
                                               double t0, double f0c, double f0_floor, double f0_ceil,
-                                              double* __restrict__ sm, double* __restrict__ sd,
                                               const double2* __restrict__ tw_base, double* out_f0, double* out_sc) {
-  const int lane = threadIdx.x & 63;
+  const int l16 = threadIdx.x & 15;
   const double hwl_d = ceil(3 * fs / f0c / 2);
   const int hwl = (int)hwl_d;
   const int L = 2 * hwl + 1;
@@ -225,66 +243,56 @@ __device__ __forceinline__ void hv_refine_one(const double* __restrict__ yl, int
     while ((1 << e) < L) ++e;
     nfft = 1 << (e + 1);
   }
-  auto idx_raw_at = [&](int j) -> double {
-    const double bt = (double)(j - hwl) / fs;
-    const double v = (t0 + bt) * fs + 0.001;  // "first-aid treatment", harvest.py:178
-    return v > 0 ? v + 0.5 : v - 0.5;         // round_matlab does not truncate (Q1)
-  };
-  auto main_at = [&](int j) -> double {
-    if (j < 0 || j >= L) return 0.0;
-    const double common = M_PI * ((idx_raw_at(j) - 1) / fs - t0) / wlit;
-    return 0.42 + 0.5 * cos(2 * common) + 0.08 * cos(4 * common);
-  };
-  double prev_last = 0.0;
-  double cur = main_at(lane);
-  for (int base = 0; base < L; base += 64) {
-    const int j = base + lane;
-    const double nxt = main_at(j + 64);
-    double left = __shfl_up(cur, 1, 64);
-    if (lane == 0) left = prev_last;
-    double right = __shfl_down(cur, 1, 64);
-    const double nxt0 = __shfl(nxt, 0, 64);
-    if (lane == 63) right = nxt0;
-    if (j < L) {
-      double dw;
-      if (j == 0) dw = -right / 2;
-      else if (j == L - 1) dw = left / 2;
-      else dw = -((right - cur) + (cur - left)) / 2;
-      double ir = idx_raw_at(j);
-      ir = fmax(1.0, fmin((double)ylen, ir)) - 1;
-      const int64_t gi = (int64_t)ir;  // 0-based sample
-      const double s = yl[gi - ybase];
-      sm[j] = s * cur;
-      sd[j] = s * dw;
-    }
-    prev_last = __shfl(cur, 63, 64);
-    cur = nxt;
-  }
-  // wave-private LDS: no block barrier, just make the writes visible to the other lanes of this wave
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
   const int nh = (int)fmin(floor(fs / 2 / f0c), 6.0);
   const double2* tw = tw_base + nfft;
-  double2 X[6], D[6];
   int bins[6];
-  for (int h = 0; h < 6; ++h) {
-    X[h] = make_double2(0.0, 0.0);
-    D[h] = make_double2(0.0, 0.0);
-    const double b = f0c * nfft / fs * (double)(h + 1);
-    bins[h] = (int)(b + 0.5);
-  }
-  for (int j = lane; j < L; j += 64) {
-    const double a = sm[j], d = sd[j];
+#pragma unroll
+  for (int h = 0; h < 6; ++h) bins[h] = (int)(f0c * nfft / fs * (double)(h + 1) + 0.5);
+  auto idx_raw_at = [&](int j) -> double {
+    const double v = (t0 + (double)(j - hwl) / fs) * fs + 0.001;  // "first-aid treatment", harvest.py:178
+    return v > 0 ? v + 0.5 : v - 0.5;                               // round_matlab does not truncate (Q1)
+  };
+  // window phase: 2*common = pi*xw, xw advances by dx per unit step of idx_raw (steps are 1, or 2 where the
+  // +-0.5 offset flips sign at negative times)
+  const double dx = 2.0 / (fs * wlit);
+  double sd1, cd1, sd2, cd2;
+  sincospi(dx, &sd1, &cd1);
+  sincospi(2 * dx, &sd2, &cd2);
+  double xr[6], xi[6], dr[6], di[6];
+#pragma unroll
+  for (int h = 0; h < 6; ++h) xr[h] = xi[h] = dr[h] = di[h] = 0.0;
+  for (int j = l16; j < L; j += 16) {
+    const double ir = idx_raw_at(j);
+    const double xw = 2 * ((ir - 1) / fs - t0) / wlit;
+    double s2, c2;
+    sincospi(xw, &s2, &c2);  // sin/cos(2*common)
+    const double mj = 0.42 + 0.5 * c2 + 0.08 * (2 * c2 * c2 - 1);  // cos(4c) = 2cos^2(2c) - 1
+    double mn = 0.0, mp = 0.0;
+    if (j + 1 < L) {
+      const bool two = idx_raw_at(j + 1) - ir > 1.5;
+      const double c = two ? c2 * cd2 - s2 * sd2 : c2 * cd1 - s2 * sd1;  // cos(2c + step*pi*dx)
+      mn = 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1);
+    }
+    if (j > 0) {
+      const bool two = ir - idx_raw_at(j - 1) > 1.5;
+      const double c = two ? c2 * cd2 + s2 * sd2 : c2 * cd1 + s2 * sd1;
+      mp = 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1);
+    }
+    double dw;
+    if (j == 0) dw = -mn / 2;
+    else if (j == L - 1) dw = mp / 2;
+    else dw = -((mn - mj) + (mj - mp)) / 2;
+    const double irc = fmax(1.0, fmin((double)ylen, ir)) - 1;
+    const double smp = yl[(int64_t)irc - ybase];
+    const double a = smp * mj, d = smp * dw;
 #pragma unroll
     for (int h = 0; h < 6; ++h) {
       if (h < nh) {
-        const double2 w = tw[(int)(((long long)bins[h] * j) & (nfft - 1))];
-        X[h].x += a * w.x;
-        X[h].y += a * w.y;
-        D[h].x += d * w.x;
-        D[h].y += d * w.y;
+        const double2 w = tw[(bins[h] * j) & (nfft - 1)];
+        xr[h] = fma(a, w.x, xr[h]);
+        xi[h] = fma(a, w.y, xi[h]);
+        dr[h] = fma(d, w.x, dr[h]);
+        di[h] = fma(d, w.y, di[h]);
       }
     }
   }
@@ -292,10 +300,9 @@ __device__ __forceinline__ void hv_refine_one(const double* __restrict__ yl, int
 #pragma unroll
   for (int h = 0; h < 6; ++h) {
     if (h < nh) {
-      const double xr = wh::wave_sum(X[h].x), xi = wh::wave_sum(X[h].y);
-      const double dr = wh::wave_sum(D[h].x), di = wh::wave_sum(D[h].y);
-      const double p = xr * xr + xi * xi;
-      const double nm = xr * di - xi * dr;
+      const double a = row16_sum(xr[h]), b = row16_sum(xi[h]), c = row16_sum(dr[h]), d = row16_sum(di[h]);
+      const double p = a * a + b * b;
+      const double nm = a * d - b * c;
       const double inst = ((double)bins[h] / nfft + nm / p / 2 / M_PI) * fs;
       const double amp = sqrt(p);
       num += amp * inst;
@@ -313,63 +320,62 @@ __device__ __forceinline__ void hv_refine_one(const double* __restrict__ yl, int
   *out_sc = sc;
 }
 
+constexpr int kFramesPerBlock = 4;
+
 __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
                                                         const double* __restrict__ dc, const int32_t* __restrict__ dcount,
-                                                        double fs, double f0_floor, double f0_ceil, int hmax,
+                                                        double fs, double f0_floor, double f0_ceil, int hmax, int seglen,
                                                         const double2* __restrict__ tw_base, double* __restrict__ rf0,
                                                         double* __restrict__ rsc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double cl_val[kFramesPerBlock * kRows];
+  __shared__ int cl_meta[kFramesPerBlock * kRows];
+  __shared__ int cl_n;
   const HvUtt m = meta[blockIdx.y];
-  const int64_t f = blockIdx.x;
-  if (f >= m.nf1) return;
-  const int seglen = 2 * hmax + 8;
-  double* yl = reinterpret_cast<double*>(smem);  // staged signal around the frame centre
-  double* wbuf = yl + seglen;                     // 4 waves x 2 x (2*hmax+1)
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const double t0 = (double)f * 1 / 1000;
-  const int64_t centre = (int64_t)floor(t0 * fs + 0.5);
-  int64_t ybase = centre - hmax - 3;
+  const int64_t f_first = (int64_t)blockIdx.x * kFramesPerBlock;
+  if (f_first >= m.nf1) return;
+  double* yl = reinterpret_cast<double*>(smem);  // staged signal around the block's frames
+  const int64_t centre0 = (int64_t)floor(((double)f_first * 1 / 1000) * fs + 0.5);
+  int64_t ybase = centre0 - hmax - 3;
   if (ybase < 0) ybase = 0;
   const double* yu = y + m.y_off;
   for (int i = threadIdx.x; i < seglen; i += 256) {
     const int64_t g = ybase + i;
     yl[i] = g < m.ylen ? yu[g] : 0.0;
   }
-  double* of0 = rf0 + (m.f1_off + f) * kRows;
-  double* osc = rsc + (m.f1_off + f) * kRows;
-  // gather this frame's overlapped candidates (one global-memory latency for all 105 rows) and compact the
-  // non-zero ones so that the four waves only iterate over real work
-  __shared__ double cl_val[kRows];
-  __shared__ int cl_row[kRows];
-  __shared__ int cl_n;
   if (threadIdx.x == 0) cl_n = 0;
   __syncthreads();
-  for (int e = threadIdx.x; e < kRows; e += 256) {
+  // gather the overlapped candidates of the block's frames (+-3 frames, harvest.py:114-125) and compact the
+  // non-zero ones into a work list; results go back to row e of their frame, so the order is irrelevant
+  for (int q = threadIdx.x; q < kFramesPerBlock * kRows; q += 256) {
+    const int fl = q / kRows, e = q % kRows;
+    const int64_t f = f_first + fl;
+    if (f >= m.nf1) continue;
     const int s = e / kMaxC - 3, c = e % kMaxC;
     const int64_t src = f + s;
     double cand = 0.0;
     if (src >= 0 && src < m.nf1 && c < dcount[m.f1_off + src]) cand = dc[(m.f1_off + src) * kMaxC + c];
     if (e == 0 && f < 3) cand = dc[(m.f1_off + f) * kMaxC + 6];  // stray seeding of row 0 (harvest.py:119)
-    of0[e] = 0.0;
-    osc[e] = 0.0;
+    rf0[(m.f1_off + f) * kRows + e] = 0.0;
+    rsc[(m.f1_off + f) * kRows + e] = 0.0;
     if (cand != 0.0 && ceil(3 * fs / cand / 2) <= (double)hmax) {
-      const int p = atomicAdd(&cl_n, 1);  // order is irrelevant: results are written to row e
+      const int p = atomicAdd(&cl_n, 1);
       cl_val[p] = cand;
-      cl_row[p] = e;
+      cl_meta[p] = q;
     }
   }
   __syncthreads();
   const int n_items = cl_n;
-  double* sm = wbuf + (size_t)w * 2 * (2 * hmax + 1);
-  double* sd = sm + (2 * hmax + 1);
-  for (int it = w; it < n_items; it += 4) {
+  const int grp = threadIdx.x >> 4;  // 16 rows of 16 lanes
+  for (int it = grp; it < n_items; it += 16) {
+    const int q = cl_meta[it];
+    const int64_t f = f_first + q / kRows;
     double r0, r1;
-    hv_refine_one(yl, ybase, m.ylen, fs, t0, cl_val[it], f0_floor, f0_ceil, sm, sd, tw_base, &r0, &r1);
-    if (lane == 0) {
-      of0[cl_row[it]] = r0;
-      osc[cl_row[it]] = r1;
+    hv_refine_row(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[it], f0_floor, f0_ceil, tw_base, &r0, &r1);
+    if ((threadIdx.x & 15) == 0) {
+      rf0[(m.f1_off + f) * kRows + q % kRows] = r0;
+      rsc[(m.f1_off + f) * kRows + q % kRows] = r1;
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -614,9 +620,9 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   WH_LAUNCH_CHECK("hv_detect_kernel");
   // ---- refinement + pruning ------------------------------------------------------------------------------
   {
-    const size_t lds = sizeof(double) * ((size_t)(2 * hmax + 8) + 4 * 2 * (size_t)(2 * hmax + 1));
-    if (int rc = wh::allow_lds(&hv_refine_kernel, lds)) return rc;
-    { wh::KernelTimer _kt(ctx, st, "hv_refine_kernel"); hipLaunchKernelGGL(hv_refine_kernel, dim3((unsigned)max_nf1, B), dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, ctx->d_twiddle, d_rf0, d_rsc); }
+    const int seglen = 2 * hmax + 8 + (kFramesPerBlock - 1) * ((int)ceil(fs_d / 1000.0) + 1);
+    const size_t lds = sizeof(double) * (size_t)seglen;
+    { wh::KernelTimer _kt(ctx, st, "hv_refine_kernel"); hipLaunchKernelGGL(hv_refine_kernel, dim3((unsigned)((max_nf1 + kFramesPerBlock - 1) / kFramesPerBlock), B), dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, d_rf0, d_rsc); }
     WH_LAUNCH_CHECK("hv_refine_kernel");
   }
   { wh::KernelTimer _kt(ctx, st, "hv_prune_kernel"); hipLaunchKernelGGL(hv_prune_kernel, dim3((unsigned)max_nf1, B), dim3(128), 0, st, d_meta, d_rf0, d_rsc, d_pf0, d_psc); }

@@ -40,6 +40,9 @@ ALGO_BYTES_PER_FRAME = {
     "love_train_kernel": 640 + 24 + 4,
     "response_kernel": 24 + 4104 + 4104 + 640,
     "stonemask_kernel": 640 + 24 + 8,
+    # Harvest kernels: the F0-only path reads the hop and writes f0/vuv/tp (664 B/frame)
+    "hv_refine_kernel": 640 + 24,
+    "band_events_kernel": 640 + 24,
 }
 PATH_BYTES_PER_FRAME = 17744  # whole encode+decode path, SURVEY §8(d)
 

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(FT) void cheaptrick_kernel(
   double2* zb = reinterpret_cast<double2*>(smem);   // N/2+1 complex = the N-sample real buffer (+1 bin)
   double* zr = reinterpret_cast<double*>(smem);     // same memory viewed as reals; also the prefix-sum array
   double* aux = zr + (N + 2);                       // K+1 reals
-  double* scratch = aux + (K + 1);                  // 16 doubles
+  double* scratch = aux + (K + 1);                  // 32 doubles
 
   const int64_t f = blockIdx.x;
   const int u = frame_utt[f];
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(FT) void cheaptrick_kernel(
 template <int N>
 int launch(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
            const double* vuv, double fs, double q1, double* spec, double* ps) {
-  const size_t lds = sizeof(double) * ((N + 2) + (N / 2 + 2) + 16);
+  const size_t lds = sizeof(double) * ((N + 2) + (N / 2 + 2) + 32);
   const double low = fs * 3.0 / (N - 3.0);
   if (int rc = wh::allow_lds(&cheaptrick_kernel<N>, lds)) return rc;
   { wh::KernelTimer _kt(ctx, st, "cheaptrick_kernel"); hipLaunchKernelGGL(cheaptrick_kernel<N>, dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,

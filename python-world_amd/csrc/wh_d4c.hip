@@ -251,7 +251,7 @@ __global__ __launch_bounds__(FT) void d4c_kernel(
   double* cent = zr + 2 * N;                         // K (padded to N/2+8)
   double* pw = cent + (N / 2 + 8);                   // K
   double* scratch = pw + (N / 2 + 8);                // 16
-  double* band = scratch + 16;                       // nap (<= 8)
+  double* band = scratch + 32;                       // nap (<= 8)
 
   const int64_t f = blockIdx.x;
   const int u = frame_utt[f];
@@ -430,7 +430,7 @@ std::vector<double> nuttall(int n) {
 template <int NLT>
 int launch_lt(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
               const double* vuv, double fs, double thr, int32_t* gate) {
-  const size_t lds = sizeof(double) * (2 * NLT + 16);
+  const size_t lds = sizeof(double) * (2 * NLT + 32);
   if (int rc = wh::allow_lds(&love_train_kernel<NLT>, lds)) return rc;
   { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, fs, thr, ctx->d_twiddle, gate); }
@@ -442,7 +442,7 @@ template <int N, bool FUSED>
 int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
                 const double* vuv, const int32_t* gate, double thr, double fs, int nap, int interval, const double* win,
                 int wlen, int k_spec, double* out, double* coarse) {
-  const size_t lds = sizeof(double) * (2 * N + 2 * (N / 2 + 8) + 16 + 8);
+  const size_t lds = sizeof(double) * (2 * N + 2 * (N / 2 + 8) + 32 + 8);
   if (int rc = wh::allow_lds(&d4c_kernel<N, FUSED>, lds)) return rc;
   { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL((d4c_kernel<N, FUSED>), dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, gate, thr, fs, nap, interval, win, wlen, ctx->d_twiddle, k_spec, out,

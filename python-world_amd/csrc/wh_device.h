@@ -39,7 +39,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // Sum over the whole 256-thread block; result broadcast to every thread.
-// `scratch` must hold >= 8 doubles of LDS.  Contains two barriers.
+// `scratch` must hold >= 3*NT/64 doubles of LDS (24 for the largest block used, 512).  Contains two barriers.
 template <int NT = WH_BLOCK>
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
   v = wave_sum(v);
@@ -70,14 +70,14 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
   __syncthreads();
   if ((threadIdx.x & 63) == 0) {
     scratch[w] = a;
-    scratch[4 + w] = b;
+    scratch[NT / WH_WAVE + w] = b;
   }
   __syncthreads();
   double ta = 0.0, tb = 0.0;
 #pragma unroll
   for (int i = 0; i < NT / WH_WAVE; ++i) {
     ta += scratch[i];
-    tb += scratch[4 + i];
+    tb += scratch[NT / WH_WAVE + i];
   }
   a = ta;
   b = tb;
@@ -96,16 +96,16 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
   __syncthreads();
   if ((threadIdx.x & 63) == 0) {
     scratch[w] = a;
-    scratch[4 + w] = b;
-    scratch[8 + w] = c;
+    scratch[NT / WH_WAVE + w] = b;
+    scratch[2 * (NT / WH_WAVE) + w] = c;
   }
   __syncthreads();
   double ta = 0.0, tb = 0.0, tc = 0.0;
 #pragma unroll
   for (int i = 0; i < NT / WH_WAVE; ++i) {
     ta += scratch[i];
-    tb += scratch[4 + i];
-    tc += scratch[8 + i];
+    tb += scratch[NT / WH_WAVE + i];
+    tc += scratch[2 * (NT / WH_WAVE) + i];
   }
   a = ta;
   b = tb;

@@ -591,7 +591,7 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   for (int n = 0; n < N; ++n) dc[n] /= sum;
   const double* d_dc = nullptr;
   if (int rc = wh::const_table(ctx, "dc_base:" + std::to_string(N), dc, &d_dc)) return rc;
-  const size_t lds = sizeof(double) * (2 * (N + 2) + (N + N / 16 + 2) + 256 + 16);
+  const size_t lds = sizeof(double) * (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32);
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
   const int64_t grid = pcap_max * B;  // one workgroup per pulse slot; slots past the real count exit at once
   { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, seed, d_dc, ctx->d_twiddle, y};

@@ -56,21 +56,28 @@ def parse():
     ap.add_argument("--seconds", type=float, default=SECONDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=12, help="utterances of the batch timed through the CPU oracle")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="independent sub-batches in flight per GPU, each on its own HIP stream (world.batch."
+                         "WorldBatchLanes).  2 staggered lanes measure ~6%% faster on config 2, but the per-kernel "
+                         "HIP-event durations then include the other lane's overlap, so the default keeps one lane and "
+                         "clean per-kernel attribution")
+    ap.add_argument("--no-stagger", action="store_true", help="start all lanes together (ablation)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
                     help="BASELINE.json config: 2 = DIO path encode+decode (the metric's config, default); "
                          "3 = Harvest F0 only; 4 = Harvest + CheapTrick + D4C-Requiem encode + Requiem decode")
     return ap.parse_args()
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, lanes):
     """HBM bytes per launch of `kernel` measured with rocprofv3 PMC passes on this workload (committed under
-    profiles/; bench.py itself cannot run the profiler around its own timed region).  None if unavailable."""
+    profiles/; bench.py itself cannot run the profiler around its own timed region).  The file holds bytes per
+    pass over the whole 64-utterance batch; one launch covers 1/lanes of it.  None if unavailable."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic_cfg2_latest.txt")
     try:
         for line in open(path):
             parts = line.split()
             if parts and parts[0] == kernel:
-                return float(parts[3]) * 1e6, os.path.relpath(path, ROOT)
+                return float(parts[3]) * 1e6 / lanes, os.path.relpath(path, ROOT)
     except Exception:
         pass
     return None, None
@@ -112,25 +119,30 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from world._synthetic import synth_utterance
-    from world.batch import WorldBatch
+    from world.batch import WorldBatchLanes
 
-    wb = WorldBatch(local_rank)
-    rt = wb.rt
+    # args.lanes independent sub-batches per GPU, each on its own HIP stream and library context; one "step" is
+    # still one pass of the hot path over the whole per-GPU batch
+    wl = WorldBatchLanes(local_rank, lanes=max(1, min(args.lanes, args.utts)))
+    rts = [wb.rt for wb in wl.lanes]
     first = rank * args.utts
     xs = [synth_utterance(first + i, FS, args.seconds) for i in range(args.utts)]
-    batch, x_d, tp_d = wb.upload(xs, FS)  # inputs resident in HBM before the timed region
-    frames_per_step = batch.total_frames
+    wl.upload(xs, FS)  # inputs resident in HBM before the timed region
+    frames_per_step = wl.total_frames
 
     if args.config == 2:
         def step(seed):
-            enc = wb.encode_device(batch, x_d, tp_d, FS, f0_method="dio")
-            y, _ = wb.decode_device(enc, seed=seed)
-            return y
+            encs = wl.encode_device(FS, stagger=not args.no_stagger, f0_method="dio")
+            return wl.decode_device(encs, seed=seed)
     elif args.config == 3:
         from world.harvest import harvest_device
 
         def step(seed):
-            return harvest_device(rt, batch, x_d, tp_d, FS)
+            out = []
+            for wb, r in zip(wl.lanes, wl.resident):
+                with wb.rt.on_stream():
+                    out.append(harvest_device(wb.rt, r[0], r[1], r[2], FS))
+            return out
     else:
         from world.get_seeds_signals import get_seeds_signals
         import random
@@ -139,9 +151,8 @@ def main():
         seeds = get_seeds_signals(FS)
 
         def step(seed):
-            enc = wb.encode_device(batch, x_d, tp_d, FS, f0_method="harvest", is_requiem=True)
-            y, _ = wb.decode_device(enc, seeds=seeds)
-            return y
+            encs = wl.encode_device(FS, stagger=not args.no_stagger, f0_method="harvest", is_requiem=True)
+            return wl.decode_device(encs, seeds=seeds)
 
     def fence():
         if dist.is_initialized():
@@ -151,15 +162,19 @@ def main():
     for w in range(args.warmup):
         step(w)
     fence()
-    rt.profile(True)
+    for rt in rts:
+        rt.profile(True)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(1000 + k)
+    host_enqueue = time.perf_counter() - t0  # the launches are asynchronous: host time to enqueue all K steps
     fence()
     elapsed = time.perf_counter() - t0
-    records = rt.profile_collect()
-    rt.profile(False)
-    flags = rt.take_flags()
+    records, flags = [], [0] * 16
+    for rt in rts:
+        records += rt.profile_collect()
+        rt.profile(False)
+        flags = [a | b for a, b in zip(flags, rt.take_flags())]
 
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -170,7 +185,7 @@ def main():
         total_frames = frames_per_step * world * args.steps
         audio_s = args.utts * args.seconds * world * args.steps
         value = total_frames / elapsed
-        # per-kernel totals from the HIP-event records of the timed region (rank 0's stream)
+        # per-kernel launch durations from the HIP-event records of the timed region (rank 0, each lane's stream)
         agg = {}
         for name, ms in records:
             a = agg.setdefault(name, [0.0, 0])
@@ -182,11 +197,15 @@ def main():
         if dominant:
             per_frame = ALGO_BYTES_PER_FRAME.get(dominant, PATH_BYTES_PER_FRAME)
             avg_s = kernel_ms[dominant] / 1e3
-            achieved = per_frame * frames_per_step / avg_s / 1e9
-            traffic, traffic_src = pmc_traffic(dominant) if args.config == 2 and args.utts == UTT_PER_GPU else (None, None)
+            # every lane launches the kernel once per step on its share of the frames
+            frames_per_launch = frames_per_step * args.steps / agg[dominant][1]
+            achieved = per_frame * frames_per_launch / avg_s / 1e9
+            traffic, traffic_src = (pmc_traffic(dominant, len(rts)) if args.config == 2 and args.utts == UTT_PER_GPU
+                                    else (None, None))
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": per_frame * frames_per_step,
+                        "algorithmic_bytes_per_launch": per_frame * frames_per_launch,
+                        "frames_per_launch": frames_per_launch,
                         "avg_launch_ms": kernel_ms[dominant],
                         "path_algorithmic_GBps": PATH_BYTES_PER_FRAME * frames_per_step * args.steps / elapsed / 1e9}
         out = {
@@ -203,13 +222,15 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "x_realtime": audio_s / elapsed,
+            "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
             "config": {"workload": {2: "BASELINE config 2 per GPU: %d x %.0f s synthetic 16 kHz utterances, "
                                        "DIO+StoneMask+CheapTrick+D4C encode + pulse-wise synthesis decode, HBM-resident",
                                     3: "BASELINE config 3 per GPU: %d x %.0f s synthetic 16 kHz utterances, Harvest F0 only",
                                     4: "BASELINE config 4 per GPU: %d x %.0f s synthetic 16 kHz utterances, Harvest+CheapTrick+"
                                        "D4C-Requiem encode + Requiem decode"}[args.config] % (args.utts, args.seconds),
                        "utterances_per_gpu": args.utts, "fs": FS, "frame_period_ms": 5,
-                       "frames_per_step_per_gpu": frames_per_step, "sharding": "utterances, no collective"},
+                       "frames_per_step_per_gpu": frames_per_step, "sharding": "utterances, no collective",
+                       "lanes_per_gpu": len(rts)},
             "roofline": roofline,
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
             "device_flags": flags,

@@ -4,6 +4,7 @@ streams (torch.cuda tensors are handed to the library as raw device pointers).
 
 There is deliberately NO CPU fallback: if the library or a GPU is missing every stage raises.
 """
+import contextlib
 import ctypes
 import os
 import threading
@@ -90,11 +91,17 @@ def check(rc):
 
 
 class Runtime:
-    """One wh_ctx per device; device buffers are torch tensors."""
+    """One wh_ctx per (device, lane); device buffers are torch tensors.
+
+    Lane 0 launches on torch's current stream.  Every further lane owns a private HIP stream and a private
+    context (workspace, tables, flags), so that independent sub-batches can be in flight on the GPU at the same
+    time: the chip-filling kernels of one lane overlap the latency-bound per-utterance kernels (IIR chains,
+    the exact phase scan, pulse compaction) of another.
+    """
 
     _instances = {}
 
-    def __init__(self, device_index):
+    def __init__(self, device_index, lane=0):
         import torch
 
         if not torch.cuda.is_available():
@@ -108,21 +115,31 @@ class Runtime:
         h = _vp()
         check(self.lib.wh_ctx_create(device_index, ctypes.byref(h)))
         self.ctx = h
+        self.lane = lane
+        self.own_stream = torch.cuda.Stream(device=self.device) if lane else None
 
     @classmethod
-    def get(cls, device_index=None):
+    def get(cls, device_index=None, lane=0):
         import torch
 
         if device_index is None:
             device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
-        rt = cls._instances.get(device_index)
+        rt = cls._instances.get((device_index, lane))
         if rt is None:
-            rt = cls(device_index)
-            cls._instances[device_index] = rt
+            rt = cls(device_index, lane)
+            cls._instances[(device_index, lane)] = rt
         return rt
+
+    def on_stream(self):
+        """Context manager: make this lane's stream torch's current stream (no-op for lane 0)."""
+        if self.own_stream is None:
+            return contextlib.nullcontext()
+        return self.torch.cuda.stream(self.own_stream)
 
     # ---- memory ---------------------------------------------------------------------------
     def stream(self):
+        if self.own_stream is not None:
+            return _vp(self.own_stream.cuda_stream)
         return _vp(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def to_device(self, a, dtype=np.float64):

@@ -56,10 +56,22 @@ class BatchEncoding:
         return out
 
 
-class WorldBatch:
-    def __init__(self, device_index=None):
-        self.rt = _hip.Runtime.get(device_index)
+def _on_lane_stream(fn):
+    """Run a WorldBatch method with its lane's HIP stream as torch's current stream."""
+    import functools
 
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with self.rt.on_stream():
+            return fn(self, *a, **kw)
+    return wrapped
+
+
+class WorldBatch:
+    def __init__(self, device_index=None, lane=0):
+        self.rt = _hip.Runtime.get(device_index, lane)
+
+    @_on_lane_stream
     def upload(self, xs, fs, frame_period=5):
         """Concatenate and upload a list of 1-D waveforms (or a 2-D array).  Returns (batch, x_d, tp_d)."""
         rt = self.rt
@@ -73,9 +85,12 @@ class WorldBatch:
         self._tp_host = {tp_d.data_ptr(): tp_h}
         return batch, x_d, tp_d
 
+    @_on_lane_stream
     def encode_device(self, batch, x_d, tp_d, fs, f0_method='dio', f0_floor=71, f0_ceil=800, channels_in_octave=2,
-                      target_fs=4000, frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False):
-        """world/main.py:106-152 for a resident batch.  tp_d is not modified (a copy is kept in the result)."""
+                      target_fs=4000, frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False,
+                      f0_done=None):
+        """world/main.py:106-152 for a resident batch.  tp_d is not modified (a copy is kept in the result).
+        ``f0_done``: optional callable invoked once the F0 stage has been enqueued (used to stagger lanes)."""
         rt = self.rt
         if fft_size is not None:
             f0_floor = 3.0 * fs / fft_size
@@ -88,6 +103,8 @@ class WorldBatch:
             f0_d, vuv_d = harvest_device(rt, batch, x_d, tp_d, fs, f0_floor, f0_ceil, frame_period)
         else:
             raise Exception
+        if f0_done is not None:
+            f0_done()
         ct_fft = int(fft_size) if fft_size is not None else default_fft_size(fs)
         spec_d, _ = cheaptrick_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, ct_fft)
         if is_requiem:
@@ -102,6 +119,7 @@ class WorldBatch:
         batch, x_d, tp_d = self.upload(xs, fs, kw.get('frame_period', 5))
         return self.encode_device(batch, x_d, tp_d, fs, **kw)
 
+    @_on_lane_stream
     def decode_device(self, enc, noise=None, seed=0, pulse_cap=None, seeds=None):
         """world/main.py:198-214 for a resident encoding.  Returns (y tensor, y_off) — concatenated
         waveforms, peak-normalised per utterance where max|y| > 1.  ``noise``: optional list of per-utterance
@@ -141,3 +159,63 @@ class WorldBatch:
                 m = seg.abs().max()
                 if float(m) > 1.0:
                     seg /= m
+
+
+class WorldBatchLanes:
+    """The same resident pipeline with the utterances dealt to ``lanes`` independent sub-batches, each on its own
+    HIP stream and library context (``_hip.Runtime`` lanes).  Nothing is exchanged between lanes: utterances are
+    independent, so the GPU is free to run one lane's chip-filling kernels (D4C,
+    CheapTrick, the pulse responses) while another lane sits in its per-utterance serial kernels (the IIR chains,
+    the exact phase scan, pulse compaction), which occupy a handful of CUs.  ``lanes=1`` is plain WorldBatch.
+    """
+
+    def __init__(self, device_index=None, lanes=2):
+        self.lanes = [WorldBatch(device_index, lane=(i + 1 if lanes > 1 else 0)) for i in range(lanes)]
+        self.resident = None
+
+    @staticmethod
+    def split(lengths, lanes):
+        """Contiguous utterance ranges per lane, balanced by samples (the rule ranks are sharded by)."""
+        from .distributed import shard_ranges
+        return shard_ranges(lengths, lanes)
+
+    def upload(self, xs, fs, frame_period=5):
+        parts = self.split([len(x) for x in xs], len(self.lanes))
+        self.resident = [wb.upload(xs[a:b], fs, frame_period) if b > a else None
+                         for wb, (a, b) in zip(self.lanes, parts)]
+        return self.resident
+
+    @property
+    def total_frames(self):
+        return sum(r[0].total_frames for r in self.resident if r is not None)
+
+    def encode_device(self, fs, stagger=True, **kw):
+        """One BatchEncoding per lane (None for an empty lane); launches are asynchronous.
+
+        ``stagger``: lane i starts once lane i-1 has finished its F0 stage (a stream-to-stream event wait, no host
+        sync).  Lanes that start together stay in lockstep — all in their serial kernels at once, then all
+        competing for the CUs at once; the offset is what puts one lane's serial stretch under another lane's
+        chip-filling kernels, and it persists from step to step."""
+        torch = self.lanes[0].rt.torch
+        out, prev = [], None
+        for wb, r in zip(self.lanes, self.resident):
+            if r is None:
+                out.append(None)
+                continue
+            if prev is not None and wb.rt.own_stream is not None:
+                wb.rt.own_stream.wait_event(prev)
+            ev = torch.cuda.Event() if stagger and wb.rt.own_stream is not None else None
+            out.append(wb.encode_device(r[0], r[1], r[2], fs, f0_done=(ev.record if ev is not None else None), **kw))
+            prev = ev
+        return out
+
+    def decode_device(self, encs, **kw):
+        """[(y, y_off) per lane]."""
+        return [wb.decode_device(e, **kw) if e is not None else None for wb, e in zip(self.lanes, encs)]
+
+    def synchronize(self):
+        for wb in self.lanes:
+            if wb.rt.own_stream is not None:
+                wb.rt.own_stream.synchronize()
+            else:
+                wb.rt.torch.cuda.current_stream(wb.rt.device).synchronize()

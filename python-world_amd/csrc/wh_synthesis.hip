@@ -61,66 +61,96 @@ __global__ __launch_bounds__(256) void prep_kernel(const SynUtt* __restrict__ me
   vuv_s[m.y_off + i] = v ? 1 : 0;
 }
 
-// In-place sequential cumulative sum, one 64-lane wave per utterance.  Tiles of 2048 samples are staged
-// through LDS with coalesced loads/stores by all lanes; lane 0 walks the tile with the exact left-to-right
-// float64 additions of np.cumsum.  The next tile's global loads and the next 16-sample block's LDS reads are
-// issued before the current additions, so the only exposed cost is the add chain itself.
+// In-place sequential cumulative sum, one workgroup of two waves per utterance, bit-identical to np.cumsum (one
+// rounding per sample, left to right).  Measured on MI355X (tools/ubench/chain.hip): a dependent FP64 add issues
+// every ~2.5 ns and a ds_read_b128 adds ~1.7 ns per sample, but an LDS *store* from a single lane costs ~12 ns —
+// so the serial lane must not write the sums back.  Per tile of 2048 samples:
+//   stage  : the helper wave copies the tile into LDS (coalesced global loads);
+//   chain  : lane 0 of the chain wave walks the tile with the exact adds and stores only the carry-in of every
+//            16-sample segment;
+//   replay : the helper wave replays the segments from those carry-ins — the same adds in the same order, hence
+//            the same bits — 64 segments at a time, and writes the tile out with coalesced stores.
+// The tiles are double-buffered: while the chain runs on tile t the helper replays tile t-1 and stages tile t+1,
+// so the kernel's duration is the add chain itself.  Segments are padded to 18 doubles in LDS: 16-byte alignment
+// for the b128 reads of the chain, spread banks for the segment-strided accesses of the replay.
 constexpr int kScanTile = 2048;
-__global__ __launch_bounds__(64) void phase_kernel(const SynUtt* __restrict__ meta, double* __restrict__ phase) {
-  __shared__ __attribute__((aligned(16))) double tile[kScanTile];
+constexpr int kScanSeg = 16;
+constexpr int kScanSegs = kScanTile / kScanSeg;
+constexpr int kScanPad = kScanSeg + 2;
+__global__ __launch_bounds__(128) void phase_kernel(const SynUtt* __restrict__ meta, double* __restrict__ phase) {
+  __shared__ __attribute__((aligned(16))) double tile[2][kScanSegs * kScanPad];
+  __shared__ double carry_in[2][kScanSegs];
   const SynUtt m = meta[blockIdx.x];
   double* p = phase + m.y_off;
-  const int lane = threadIdx.x;
-  constexpr int PER = kScanTile / 64;
-  double carry = 0.0;
-  double pre[PER];
-#pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    const int64_t i = (int64_t)q * 64 + lane;
-    pre[q] = i < m.ny ? p[i] : 0.0;
-  }
-  for (int64_t base = 0; base < m.ny; base += kScanTile) {
-    const int cnt = (int)(m.ny - base < kScanTile ? m.ny - base : kScanTile);
-#pragma unroll
-    for (int q = 0; q < PER; ++q) tile[q * 64 + lane] = pre[q];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // prefetch the next tile while lane 0 runs the chain
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const int64_t i = base + kScanTile + (int64_t)q * 64 + lane;
-      pre[q] = i < m.ny ? p[i] : 0.0;
+  const int lane = threadIdx.x & 63;
+  const bool helper = threadIdx.x >= 64;
+  auto slot = [](int i) { return i + 2 * (i >> 4); };
+  const int64_t tiles = (m.ny + kScanTile - 1) / kScanTile;
+  auto stage = [&](int64_t t) {
+    double* dst = tile[t & 1];
+    const int64_t base = t * kScanTile;
+#pragma unroll 8
+    for (int q = 0; q < kScanTile / 64; ++q) {
+      const int64_t i = base + (int64_t)q * 64 + lane;
+      dst[slot(q * 64 + lane)] = i < m.ny ? p[i] : 0.0;
     }
-    if (lane == 0) {
-      double run = carry;
-      double cur[16], nxt[16];
+  };
+  if (helper && tiles > 0) stage(0);
+  __syncthreads();
+  double run = 0.0;  // chain wave, lane 0: the running sum
+  for (int64_t t = 0; t <= tiles; ++t) {
+    if (!helper) {
+      if (lane == 0 && t < tiles) {
+        const double2* t2 = reinterpret_cast<const double2*>(tile[t & 1]);
+        double* cin = carry_in[t & 1];
+        double2 a[8], b[8];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) cur[q] = tile[q];
-      for (int k = 0; k < kScanTile; k += 16) {
-        if (k + 16 < kScanTile) {
+        for (int q = 0; q < 8; ++q) a[q] = t2[q];
+        for (int sg = 0; sg < kScanSegs; sg += 2) {
 #pragma unroll
-          for (int q = 0; q < 16; ++q) nxt[q] = tile[k + 16 + q];
+          for (int q = 0; q < 8; ++q) b[q] = t2[(sg + 1) * (kScanPad / 2) + q];
+          cin[sg] = run;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            run += a[q].x;
+            run += a[q].y;
+          }
+          if (sg + 2 < kScanSegs) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = t2[(sg + 2) * (kScanPad / 2) + q];
+          }
+          cin[sg + 1] = run;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            run += b[q].x;
+            run += b[q].y;
+          }
         }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          run += cur[q];
-          cur[q] = run;
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) tile[k + q] = cur[q];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
       }
-      carry = run;
+    } else {
+      if (t >= 1) {  // replay and write out tile t-1
+        double* buf = tile[(t - 1) & 1];
+        const double* cin = carry_in[(t - 1) & 1];
+#pragma unroll
+        for (int h = 0; h < kScanSegs / 64; ++h) {
+          const int sg = lane + h * 64;
+          double r = cin[sg];
+          double* seg = buf + sg * kScanPad;
+#pragma unroll
+          for (int j = 0; j < kScanSeg; ++j) {
+            r += seg[j];
+            seg[j] = r;
+          }
+        }
+        wh::sync<64>();
+        const int64_t base = (t - 1) * kScanTile;
+        const int cnt = (int)(m.ny - base < kScanTile ? m.ny - base : kScanTile);
+        for (int i = lane; i < cnt; i += 64) p[base + i] = buf[slot(i)];
+        wh::sync<64>();
+      }
+      if (t + 1 < tiles) stage(t + 1);  // into the buffer just written out
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int i = lane; i < cnt; i += 64) p[base + i] = tile[i];
-    carry = __shfl(carry, 0, 64);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
+    __syncthreads();
   }
 }
 
@@ -816,7 +846,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
                      d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
-  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(64), 0, st, d_meta, d_phase); }
+  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(128), 0, st, d_meta, d_phase); }
   WH_LAUNCH_CHECK("phase_kernel");
   { wh::KernelTimer _kt(ctx, st, "pulse_kernel"); hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc,
                      ctx->d_flags); }
@@ -885,7 +915,7 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
                      d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
-  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(64), 0, st, d_meta, d_phase); }
+  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(128), 0, st, d_meta, d_phase); }
   WH_LAUNCH_CHECK("phase_kernel");
   { wh::KernelTimer _kt(ctx, st, "pulse_kernel"); hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, reinterpret_cast<double*>(ws + o_pt),
                      d_pi, reinterpret_cast<double*>(ws + o_ps), d_pn, d_pc, ctx->d_flags); }
@@ -975,7 +1005,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs, d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
-  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(64), 0, st, d_meta, d_phase); }
+  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(128), 0, st, d_meta, d_phase); }
   WH_LAUNCH_CHECK("phase_kernel");
   { wh::KernelTimer _kt(ctx, st, "pulse_kernel"); hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ctx->d_flags); }
   WH_LAUNCH_CHECK("pulse_kernel");

@@ -1,18 +1,25 @@
 """Pulse-by-pulse overlap-add synthesis — drop-in for world/synthesis.py:21 of the reference, executed
 by the HIP kernels behind wh_synthesis (include/world_hip.h)."""
 import ctypes
+import functools
 
 import numpy as np
 
 from . import _hip
 
 
+@functools.lru_cache(maxsize=4096)
+def _arange_len(start, stop, step):
+    return len(np.arange(start, stop, step))
+
+
 def time_axis_params(temporal_positions, fs):
     """(ny, t0, dt) of np.arange(tp[0], tp[-1] + 1/fs, 1/fs) — evaluated with NumPy itself so that the
-    float-arange length quirk is reproduced; dt is the step NumPy actually uses."""
+    float-arange length quirk is reproduced (memoised per distinct end points: a batch of equal-length
+    utterances asks once); dt is the step NumPy actually uses."""
     tp0 = float(temporal_positions[0])
     step = 1 / fs
-    ny = len(np.arange(tp0, float(temporal_positions[-1]) + step, step))
+    ny = _arange_len(tp0, float(temporal_positions[-1]) + step, step)
     dt = (tp0 + step) - tp0
     return ny, tp0, dt
 

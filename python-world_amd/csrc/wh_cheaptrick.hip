@@ -1,4 +1,4 @@
-// CheapTrick spectral envelope — one 256-thread workgroup per frame, everything between the
+// CheapTrick spectral envelope — one 128-thread workgroup per frame, everything between the
 // waveform gather and the final envelope stays in LDS (12*N bytes): window → real FFT → power →
 // low-band replica → block-scan smoothing → log → real FFT → lifter → inverse real FFT → exp.
 // All three transforms run as N/2-point complex FFTs on sample pairs (wh_device.h: rfft_lds / irfft_lds).
@@ -9,7 +9,7 @@
 namespace {
 
 #ifndef WH_FT_CHEAPTRICK
-#define WH_FT_CHEAPTRICK 256
+#define WH_FT_CHEAPTRICK 128
 #endif
 constexpr int FT = WH_FT_CHEAPTRICK;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
 

@@ -11,6 +11,15 @@
 #include "wh_host.h"
 #include "wh_spectral.h"
 
+#ifndef WH_D4C_MAXR
+#define WH_D4C_MAXR 4
+#endif
+#ifndef WH_D4C_MINBLK
+#define WH_D4C_MINBLK 1
+#endif
+#ifndef WH_D4C_REGFFT
+#define WH_D4C_REGFFT 1
+#endif
 namespace {
 
 #ifndef WH_FT_D4C
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(FT) void love_train_kernel(
 #pragma unroll
   for (int q = 0; q < NLT / FT; ++q) zr[threadIdx.x + q * FT] = v[q];
   wh::sync<FT>();
-  wh::rfft_lds<NLT, FT>(zb, tw_base);
+  wh::rfft_lds<NLT, FT, FT, WH_D4C_MAXR>(zb, tw_base);
   const int b0 = (int)(ceil(100.0 / (fs / NLT)) + 1);
   const int b1 = (int)(ceil(4000.0 / (fs / NLT)) + 1);
   const int b2 = (int)(ceil(7900.0 / (fs / NLT)) + 1);
@@ -213,14 +222,21 @@ __device__ __forceinline__ void add_centroid(const double* xu, long long xn, dou
   double v[N / FT];
   const double energy = d4c_window<true, N>(xu, xn, fs, cf, pos, 2.0, reinterpret_cast<double*>(buf), v, scratch);
   const double nrm = sqrt(energy);
+  double2 zin[N / FT];
 #pragma unroll
   for (int q = 0; q < N / FT; ++q) {
     const int j = threadIdx.x + q * FT;
     const double val = v[q] / nrm;
-    buf[j] = make_double2(val, val * (double)(j + 1));  // n is 1-based
+    zin[q] = make_double2(val, val * (double)(j + 1));  // n is 1-based
   }
-  wh::sync<FT>();
-  wh::fft_lds<N, false, FT>(buf, tw_base + N);
+  if constexpr (N >= WH_D4C_MAXR * FT && WH_D4C_REGFFT) {
+    wh::fft_lds_from_regs<N, false, FT, WH_D4C_MAXR>(zin, buf, tw_base + N);  // first radix-8 pass straight from registers
+  } else {
+#pragma unroll
+    for (int q = 0; q < N / FT; ++q) buf[threadIdx.x + q * FT] = zin[q];
+    wh::sync<FT>();
+    wh::fft_lds<N, false, FT, FT, WH_D4C_MAXR>(buf, tw_base + N);
+  }
   for (int k = threadIdx.x; k <= N / 2; k += FT) {
     const double2 a = buf[k];
     const double2 b = buf[(N - k) & (N - 1)];
@@ -237,7 +253,7 @@ __device__ __forceinline__ void add_centroid(const double* xu, long long xn, dou
 // Blackman frame and the Hann frame of the smoothed power spectrum are two real sequences → ONE complex FFT,
 // separated by Hermitian symmetry; the separate love_train_kernel launch and one transform disappear.
 template <int N, bool FUSED>
-__global__ __launch_bounds__(FT) void d4c_kernel(
+__global__ __launch_bounds__(FT, WH_D4C_MINBLK) void d4c_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv,
     const int32_t* __restrict__ gate, double threshold, double fs, int nap, int interval,
@@ -273,10 +289,17 @@ __global__ __launch_bounds__(FT) void d4c_kernel(
     double va[N / FT], vb[N / FT];
     d4c_window<true, N>(xu, xn, fs, fmax(f0v, 40.0), pos, 1.5, zr, va, scratch);
     d4c_window<false, N>(xu, xn, fs, cf, pos, 2.0, zr, vb, scratch);
+    double2 zin[N / FT];
 #pragma unroll
-    for (int q = 0; q < N / FT; ++q) buf[threadIdx.x + q * FT] = make_double2(va[q], vb[q]);
-    wh::sync<FT>();
-    wh::fft_lds<N, false, FT>(buf, tw_base + N);
+    for (int q = 0; q < N / FT; ++q) zin[q] = make_double2(va[q], vb[q]);
+    if constexpr (N >= WH_D4C_MAXR * FT && WH_D4C_REGFFT) {
+      wh::fft_lds_from_regs<N, false, FT, WH_D4C_MAXR>(zin, buf, tw_base + N);
+    } else {
+#pragma unroll
+      for (int q = 0; q < N / FT; ++q) buf[threadIdx.x + q * FT] = zin[q];
+      wh::sync<FT>();
+      wh::fft_lds<N, false, FT, FT, WH_D4C_MAXR>(buf, tw_base + N);
+    }
     const int b0 = (int)(ceil(100.0 / (fs / N)) + 1);
     const int b1 = (int)(ceil(4000.0 / (fs / N)) + 1);
     const int b2 = (int)(ceil(7900.0 / (fs / N)) + 1);
@@ -324,7 +347,7 @@ __global__ __launch_bounds__(FT) void d4c_kernel(
 #pragma unroll
     for (int q = 0; q < N / FT; ++q) zr[threadIdx.x + q * FT] = v[q];
     wh::sync<FT>();
-    wh::rfft_lds<N, FT>(buf, tw_base);
+    wh::rfft_lds<N, FT, FT, WH_D4C_MAXR>(buf, tw_base);
     for (int k = threadIdx.x; k < K; k += FT) {
       const double2 z = buf[k];
       pw[k] = z.x * z.x + z.y * z.y;
@@ -373,7 +396,7 @@ __global__ __launch_bounds__(FT) void d4c_kernel(
       zr[j] = val;
     }
     wh::sync<FT>();
-    wh::rfft_lds<N, FT>(buf, tw_base);
+    wh::rfft_lds<N, FT, FT, WH_D4C_MAXR>(buf, tw_base);
     for (int k = threadIdx.x; k < K; k += FT) {
       const double2 z = buf[k];
       pw[k] = z.x * z.x + z.y * z.y;

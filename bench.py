@@ -31,20 +31,24 @@ SECONDS = 10.0
 UTT_PER_GPU = 64
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
-# Algorithmic (compulsory) HBM bytes per 5 ms frame of each dominant-kernel candidate at 16 kHz,
-# fft 1024, float64 API dtypes — SURVEY.md §8(d) components: x hop 640 B, f0+vuv+tp 24 B,
-# spectrogram 4104 B, aperiodicity 4104 B, output hop 640 B.
-ALGO_BYTES_PER_FRAME = {
-    "cheaptrick_kernel": 640 + 24 + 4104,
-    "d4c_kernel": 640 + 24 + 4104,
-    "love_train_kernel": 640 + 24 + 4,
-    "response_kernel": 24 + 4104 + 4104 + 640,
-    "stonemask_kernel": 640 + 24 + 8,
-    # Harvest kernels: the F0-only path reads the hop and writes f0/vuv/tp (664 B/frame)
-    "hv_refine_kernel": 640 + 24,
-    "band_events_kernel": 640 + 24,
-}
-PATH_BYTES_PER_FRAME = 17744  # whole encode+decode path, SURVEY §8(d)
+# Algorithmic (compulsory) HBM bytes per 5 ms frame of each dominant-kernel candidate, float64 API dtypes —
+# SURVEY.md §8(d) components: x hop (640 B at 16 kHz), f0+vuv+tp 24 B, spectrogram and aperiodicity
+# (fft/2+1)*8 B each (4104 B at fft 1024), output hop.
+def algo_bytes_per_frame(fs, fft_size, out_hop_scale=1.0):
+    hop = int(fs * 5 // 1000) * 8
+    kb = (fft_size // 2 + 1) * 8
+    per_kernel = {
+        "cheaptrick_kernel": hop + 24 + kb,
+        "d4c_kernel": hop + 24 + kb,
+        "love_train_kernel": hop + 24 + 4,
+        "response_kernel": 24 + kb + kb + int(hop * out_hop_scale),
+        "stonemask_kernel": hop + 24 + 8,
+        # Harvest kernels: the F0-only path reads the hop and writes f0/vuv/tp (664 B/frame)
+        "hv_refine_kernel": hop + 24,
+        "band_events_kernel": hop + 24,
+    }
+    path = hop + int(hop * out_hop_scale) + 48 + 4 * kb  # whole encode+decode path: 17744 B at 16 kHz
+    return per_kernel, path
 
 
 def parse():
@@ -52,8 +56,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--utts", type=int, default=UTT_PER_GPU, help="utterances per GPU (default: BASELINE config 2)")
-    ap.add_argument("--seconds", type=float, default=SECONDS)
+    ap.add_argument("--utts", type=int, default=None,
+                    help="utterances per GPU (default: 64 = BASELINE config 2; 16 for config 5)")
+    ap.add_argument("--seconds", type=float, default=None, help="utterance length (default 10 s; 60 s for config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=12, help="utterances of the batch timed through the CPU oracle")
     ap.add_argument("--lanes", type=int, default=1,
@@ -62,10 +67,16 @@ def parse():
                          "HIP-event durations then include the other lane's overlap, so the default keeps one lane and "
                          "clean per-kernel attribution")
     ap.add_argument("--no-stagger", action="store_true", help="start all lanes together (ablation)")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config: 2 = DIO path encode+decode (the metric's config, default); "
-                         "3 = Harvest F0 only; 4 = Harvest + CheapTrick + D4C-Requiem encode + Requiem decode")
-    return ap.parse_args()
+                         "3 = Harvest F0 only; 4 = Harvest + CheapTrick + D4C-Requiem encode + Requiem decode; "
+                         "5 = 48 kHz long-form: encode, scale_pitch(1.5), scale_duration(2.0), decode")
+    args = ap.parse_args()
+    if args.utts is None:
+        args.utts = 16 if args.config == 5 else UTT_PER_GPU
+    if args.seconds is None:
+        args.seconds = 60.0 if args.config == 5 else SECONDS
+    return args
 
 
 def pmc_traffic(kernel, lanes):
@@ -103,7 +114,10 @@ def cpu_baseline(xs, n_utts):
 
 
 def main():
+    global FS
     args = parse()
+    if args.config == 5:
+        FS = 48000
     import torch
     import torch.distributed as dist
 
@@ -143,6 +157,13 @@ def main():
                 with wb.rt.on_stream():
                     out.append(harvest_device(wb.rt, r[0], r[1], r[2], FS))
             return out
+    elif args.config == 5:
+        def step(seed):
+            encs = wl.encode_device(FS, stagger=not args.no_stagger, f0_method="dio")
+            for e in encs:
+                with e.rt.on_stream():
+                    e.scale_pitch(1.5).scale_duration(2.0)
+            return wl.decode_device(encs, seed=seed)
     else:
         from world.get_seeds_signals import get_seeds_signals
         import random
@@ -195,6 +216,9 @@ def main():
         dominant = max(agg.items(), key=lambda kv: kv[1][0])[0] if agg else None
         roofline = None
         if dominant:
+            from world.cheaptrick import default_fft_size
+            ALGO_BYTES_PER_FRAME, PATH_BYTES_PER_FRAME = algo_bytes_per_frame(FS, default_fft_size(FS),
+                                                                              2.0 if args.config == 5 else 1.0)
             per_frame = ALGO_BYTES_PER_FRAME.get(dominant, PATH_BYTES_PER_FRAME)
             avg_s = kernel_ms[dominant] / 1e3
             # every lane launches the kernel once per step on its share of the frames
@@ -209,7 +233,7 @@ def main():
                         "avg_launch_ms": kernel_ms[dominant],
                         "path_algorithmic_GBps": PATH_BYTES_PER_FRAME * frames_per_step * args.steps / elapsed / 1e9}
         out = {
-            "metric": "analysis+synthesis frames/sec (and xRT), 16 kHz / 5 ms hop",
+            "metric": "analysis+synthesis frames/sec (and xRT), %d kHz / 5 ms hop" % (FS // 1000),
             "value": value,
             "unit": "frames/s",
             "n_gpus": world,
@@ -227,7 +251,10 @@ def main():
                                        "DIO+StoneMask+CheapTrick+D4C encode + pulse-wise synthesis decode, HBM-resident",
                                     3: "BASELINE config 3 per GPU: %d x %.0f s synthetic 16 kHz utterances, Harvest F0 only",
                                     4: "BASELINE config 4 per GPU: %d x %.0f s synthetic 16 kHz utterances, Harvest+CheapTrick+"
-                                       "D4C-Requiem encode + Requiem decode"}[args.config] % (args.utts, args.seconds),
+                                       "D4C-Requiem encode + Requiem decode",
+                                    5: "BASELINE config 5 per GPU: %d x %.0f s synthetic 48 kHz utterances, DIO+StoneMask+"
+                                       "CheapTrick+D4C encode, scale_pitch(1.5), scale_duration(2.0), pulse-wise decode"
+                                    }[args.config] % (args.utts, args.seconds),
                        "utterances_per_gpu": args.utts, "fs": FS, "frame_period_ms": 5,
                        "frames_per_step_per_gpu": frames_per_step, "sharding": "utterances, no collective",
                        "lanes_per_gpu": len(rts)},

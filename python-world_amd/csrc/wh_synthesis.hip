@@ -2,13 +2,13 @@
 //
 //   prep_kernel     : per output sample: f0/vuv linear interpolation at t_i, phase increment
 //                     2*pi*f0/fs (synthesis.py:121-128).  Embarrassingly parallel.
-//   phase_kernel    : one wave per utterance: the cumulative phase is a SEQUENTIAL float64 sum in the
-//                     reference (np.cumsum); each lane rebuilds exactly that left-to-right sum for its
-//                     element from wave-broadcast values, so loads/stores are coalesced and the pulse
-//                     positions derived from the phase are bit-identical to NumPy's.
-//   pulse_kernel    : per utterance: wrap phase, detect pulses (|d wrap| > pi), ordered compaction,
-//                     1-based sample index and fractional shift per pulse, noise-stream offsets
-//                     (synthesis.py:129-138, 65).
+//   phase_kernel    : per utterance: the cumulative phase is a SEQUENTIAL float64 sum in the reference
+//                     (np.cumsum); one lane walks exactly that left-to-right sum and checkpoints it every 16
+//                     samples, a helper wave replays the segments in parallel, so the pulse positions
+//                     derived from the phase are bit-identical to NumPy's.
+//   pulse_*_kernel  : wrap phase, detect pulses (|d wrap| > pi), ordered compaction, 1-based sample index and
+//                     fractional shift per pulse, noise-stream offsets (synthesis.py:129-138, 65): tile-parallel
+//                     mark / scan / emit, then a per-utterance finish.
 //   response_kernel : one workgroup per pulse: interpolate the two neighbouring frames, build the
 //                     minimum-phase periodic and aperiodic responses with six LDS FFTs
 //                     (synthesis.py:86-116,144-180), excite the aperiodic one with zero-mean noise
@@ -64,10 +64,11 @@ __global__ __launch_bounds__(256) void prep_kernel(const SynUtt* __restrict__ me
 // In-place sequential cumulative sum, one workgroup of two waves per utterance, bit-identical to np.cumsum (one
 // rounding per sample, left to right).  Measured on MI355X (tools/ubench/chain.hip): a dependent FP64 add issues
 // every ~2.5 ns and a ds_read_b128 adds ~1.7 ns per sample, but an LDS *store* from a single lane costs ~12 ns —
-// so the serial lane must not write the sums back.  Per tile of 2048 samples:
+// so the serial chain must not write the sums back.  Per tile of 2048 samples:
 //   stage  : the helper wave copies the tile into LDS (coalesced global loads);
-//   chain  : lane 0 of the chain wave walks the tile with the exact adds and stores only the carry-in of every
-//            16-sample segment;
+//   chain  : the chain wave walks the tile with the exact adds (all lanes redundantly, on broadcast operands) and
+//            keeps only the carry-in of every 16-sample segment, lane g that of segment g: no LDS store sits on
+//            the add chain;
 //   replay : the helper wave replays the segments from those carry-ins — the same adds in the same order, hence
 //            the same bits — 64 segments at a time, and writes the tile out with coalesced stores.
 // The tiles are double-buffered: while the chain runs on tile t the helper replays tile t-1 and stages tile t+1,
@@ -86,48 +87,73 @@ __global__ __launch_bounds__(128) void phase_kernel(const SynUtt* __restrict__ m
   const bool helper = threadIdx.x >= 64;
   auto slot = [](int i) { return i + 2 * (i >> 4); };
   const int64_t tiles = (m.ny + kScanTile - 1) / kScanTile;
-  auto stage = [&](int64_t t) {
-    double* dst = tile[t & 1];
+  constexpr int PER = kScanTile / 64;
+  double pre[PER];  // helper wave: the next tile, in flight from global memory
+  auto fetch = [&](int64_t t) {
     const int64_t base = t * kScanTile;
-#pragma unroll 8
-    for (int q = 0; q < kScanTile / 64; ++q) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
       const int64_t i = base + (int64_t)q * 64 + lane;
-      dst[slot(q * 64 + lane)] = i < m.ny ? p[i] : 0.0;
+      pre[q] = i < m.ny ? p[i] : 0.0;
     }
   };
-  if (helper && tiles > 0) stage(0);
-  __syncthreads();
-  double run = 0.0;  // chain wave, lane 0: the running sum
+  auto stage = [&](int64_t t) {
+    double* dst = tile[t & 1];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) dst[slot(q * 64 + lane)] = pre[q];
+  };
+  // the two waves only ever hand LDS contents to each other: a barrier that orders LDS alone does not make the
+  // helper wait for its global stores to drain
+  auto lds_barrier = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  };
+  if (helper && tiles > 0) {
+    fetch(0);
+    stage(0);
+  }
+  lds_barrier();
+  double run = 0.0;  // chain wave: the running sum (the same value in every lane)
   for (int64_t t = 0; t <= tiles; ++t) {
     if (!helper) {
-      if (lane == 0 && t < tiles) {
+      if (t < tiles) {
+        // Every lane of the chain wave runs the same adds on the same (broadcast) LDS operands, so `run` is
+        // identical in all of them and lane g can simply keep the value it sees before segment g: the carry-ins
+        // leave the chain through one wave-wide store per 64 segments instead of a single-lane LDS store (whose
+        // latency would sit on the critical path) per segment.
         const double2* t2 = reinterpret_cast<const double2*>(tile[t & 1]);
         double* cin = carry_in[t & 1];
         double2 a[8], b[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) a[q] = t2[q];
-        for (int sg = 0; sg < kScanSegs; sg += 2) {
+        for (int sb = 0; sb < kScanSegs; sb += 64) {
+          double keep = 0.0;
+          for (int sg = sb; sg < sb + 64; sg += 2) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) b[q] = t2[(sg + 1) * (kScanPad / 2) + q];
-          cin[sg] = run;
+            for (int q = 0; q < 8; ++q) b[q] = t2[(sg + 1) * (kScanPad / 2) + q];
+            keep = lane == sg - sb ? run : keep;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            run += a[q].x;
-            run += a[q].y;
+            for (int q = 0; q < 8; ++q) {
+              run += a[q].x;
+              run += a[q].y;
+            }
+            if (sg + 2 < kScanSegs) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) a[q] = t2[(sg + 2) * (kScanPad / 2) + q];
+            }
+            keep = lane == sg + 1 - sb ? run : keep;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              run += b[q].x;
+              run += b[q].y;
+            }
           }
-          if (sg + 2 < kScanSegs) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] = t2[(sg + 2) * (kScanPad / 2) + q];
-          }
-          cin[sg + 1] = run;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            run += b[q].x;
-            run += b[q].y;
-          }
+          cin[sb + lane] = keep;
         }
       }
     } else {
+      if (t + 1 < tiles) fetch(t + 1);  // issued first: in flight under the replay below
       if (t >= 1) {  // replay and write out tile t-1
         double* buf = tile[(t - 1) & 1];
         const double* cin = carry_in[(t - 1) & 1];
@@ -150,84 +176,135 @@ __global__ __launch_bounds__(128) void phase_kernel(const SynUtt* __restrict__ m
       }
       if (t + 1 < tiles) stage(t + 1);  // into the buffer just written out
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
+// Pulse detection (synthesis.py:129-138) in four launches, none of them serial in the utterance length:
+//   pulse_mark_kernel   : one workgroup per 1024-sample tile: wrap the phase, mark |d wrap| > pi, count;
+//   pulse_scan_kernel   : one workgroup per utterance: exclusive scan of its tile counts, pulse count;
+//   pulse_emit_kernel   : one workgroup per tile: ordered compaction into the utterance's pulse slots;
+//   pulse_finish_kernel : one workgroup per utterance: fractional shifts and the noise-stream offsets
+//                         (exclusive prefix sum of max(3, noise_size), synthesis.py:65).
 constexpr int kPTile = 1024;
+constexpr int kPFinish = 1024;
 
-__global__ __launch_bounds__(256) void pulse_kernel(const SynUtt* __restrict__ meta, const double* __restrict__ phase,
-                                                    double fs, double* __restrict__ p_time, int64_t* __restrict__ p_idx,
-                                                    double* __restrict__ p_shift, int64_t* __restrict__ p_noff,
-                                                    int32_t* __restrict__ p_count, int32_t* __restrict__ flags) {
+__device__ __forceinline__ int block_excl_scan_256(int c, int* wsum, int* total) {
+  int incl = c;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int uu = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += uu;
+  }
+  __syncthreads();
+  if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int excl = incl - c, tot = 0;
+  for (int w = 0; w < 4; ++w) {
+    if (w < (int)(threadIdx.x >> 6)) excl += wsum[w];
+    tot += wsum[w];
+  }
+  *total = tot;
+  return excl;
+}
+
+__global__ __launch_bounds__(256) void pulse_mark_kernel(const SynUtt* __restrict__ meta, const double* __restrict__ phase,
+                                                         int max_tiles, uint8_t* __restrict__ masks,
+                                                         int32_t* __restrict__ tile_cnt) {
   __shared__ double wr[kPTile + 1];
-  __shared__ int wsum[8];
-  __shared__ long long wsum64[8];
-  const SynUtt m = meta[blockIdx.x];
+  __shared__ int wsum[4];
+  const SynUtt m = meta[blockIdx.y];
+  const int64_t t0 = (int64_t)blockIdx.x * kPTile;
+  if (t0 >= m.ny - 1) return;
   const double* ph = phase + m.y_off;
+  const double two_pi = 2 * M_PI;
+  for (int i = threadIdx.x; i < kPTile + 1; i += 256) {
+    const int64_t g = t0 + i;
+    wr[i] = g < m.ny ? fmod(ph[g], two_pi) : 0.0;  // np.remainder of a non-negative value
+  }
+  __syncthreads();
+  unsigned mask = 0;  // 4 consecutive samples per thread
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = threadIdx.x * 4 + q;
+    const int64_t g = t0 + i;
+    if (g < m.ny - 1 && fabs(wr[i + 1] - wr[i]) > M_PI) mask |= 1u << q;
+  }
+  int total;
+  (void)block_excl_scan_256(__popc(mask), wsum, &total);
+  const int64_t slot = (int64_t)blockIdx.y * max_tiles + blockIdx.x;
+  masks[slot * 256 + threadIdx.x] = (uint8_t)mask;
+  if (threadIdx.x == 0) tile_cnt[slot] = total;
+}
+
+__global__ __launch_bounds__(256) void pulse_scan_kernel(const SynUtt* __restrict__ meta, int max_tiles,
+                                                         int32_t* __restrict__ tile_cnt, int32_t* __restrict__ p_count,
+                                                         int32_t* __restrict__ flags) {
+  __shared__ int wsum[4];
+  const SynUtt m = meta[blockIdx.x];
+  const int tiles = m.ny > 1 ? (int)((m.ny - 1 + kPTile - 1) / kPTile) : 0;
+  int32_t* tc = tile_cnt + (int64_t)blockIdx.x * max_tiles;
+  int run = 0;
+  for (int base = 0; base < tiles; base += 256) {
+    const int i = base + threadIdx.x;
+    const int c = i < tiles ? tc[i] : 0;
+    int total;
+    const int excl = block_excl_scan_256(c, wsum, &total);
+    if (i < tiles) tc[i] = run + excl;
+    run += total;
+  }
+  if (threadIdx.x == 0) {
+    if (run > m.pcap) atomicOr(flags + WH_FLAG_PULSE_OVERFLOW, 1);
+    if (run == 0) atomicOr(flags + WH_FLAG_NO_PULSE, 1);
+    p_count[blockIdx.x] = run > m.pcap ? (int)m.pcap : run;
+  }
+}
+
+__global__ __launch_bounds__(256) void pulse_emit_kernel(const SynUtt* __restrict__ meta, int max_tiles,
+                                                         const uint8_t* __restrict__ masks,
+                                                         const int32_t* __restrict__ tile_pos, double fs,
+                                                         double* __restrict__ p_time, int64_t* __restrict__ p_idx) {
+  __shared__ int wsum[4];
+  const SynUtt m = meta[blockIdx.y];
+  const int64_t t0 = (int64_t)blockIdx.x * kPTile;
+  if (t0 >= m.ny - 1) return;
+  const int64_t slot = (int64_t)blockIdx.y * max_tiles + blockIdx.x;
+  const unsigned mask = masks[slot * 256 + threadIdx.x];
+  int total;
+  int pos = tile_pos[slot] + block_excl_scan_256(__popc(mask), wsum, &total);
   double* pt = p_time + m.p_off;
   int64_t* pi = p_idx + m.p_off;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (mask & (1u << q)) {
+      if (pos < m.pcap) {
+        const int64_t g = t0 + threadIdx.x * 4 + q;
+        const double tt = m.t0 + (double)g * m.dt;
+        pt[pos] = tt;
+        pi[pos] = (int64_t)floor(tt * fs + 0.5) + 1;  // Decimal ROUND_HALF_UP then +1 (synthesis.py:132)
+      }
+      ++pos;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kPFinish) void pulse_finish_kernel(const SynUtt* __restrict__ meta,
+                                                                const double* __restrict__ phase, double fs,
+                                                                const int64_t* __restrict__ p_idx,
+                                                                const int32_t* __restrict__ p_count,
+                                                                double* __restrict__ p_shift, int64_t* __restrict__ p_noff,
+                                                                int32_t* __restrict__ flags) {
+  __shared__ long long wsum64[kPFinish / 64];
+  const SynUtt m = meta[blockIdx.x];
+  const double* ph = phase + m.y_off;
+  const int64_t* pi = p_idx + m.p_off;
   double* psh = p_shift + m.p_off;
   int64_t* pn = p_noff + m.p_off;
   const double two_pi = 2 * M_PI;
-  int count = 0;
-  for (int64_t t0 = 0; t0 < m.ny - 1; t0 += kPTile) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < kPTile + 1; i += 256) {
-      const int64_t g = t0 + i;
-      wr[i] = g < m.ny ? fmod(ph[g], two_pi) : 0.0;  // np.remainder of a non-negative value
-    }
-    __syncthreads();
-    // 4 consecutive samples per thread
-    unsigned mask = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = threadIdx.x * 4 + q;
-      const int64_t g = t0 + i;
-      if (g < m.ny - 1 && fabs(wr[i + 1] - wr[i]) > M_PI) mask |= 1u << q;
-    }
-    int c = __popc(mask);
-    int incl = c;
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int uu = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += uu;
-    }
-    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    int excl = incl - c, total = 0;
-    for (int w = 0; w < 4; ++w) {
-      if (w < (int)(threadIdx.x >> 6)) excl += wsum[w];
-      total += wsum[w];
-    }
-    int pos = count + excl;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (mask & (1u << q)) {
-        const int64_t g = t0 + threadIdx.x * 4 + q;
-        if (pos < m.pcap) {
-          const double tt = m.t0 + (double)g * m.dt;
-          pt[pos] = tt;
-          pi[pos] = (int64_t)floor(tt * fs + 0.5) + 1;  // Decimal ROUND_HALF_UP then +1 (synthesis.py:132)
-        } else {
-          atomicOr(flags + WH_FLAG_PULSE_OVERFLOW, 1);
-        }
-        ++pos;
-      }
-    }
-    count += total;
-  }
-  __threadfence_block();
-  __syncthreads();
-  if (count > m.pcap) count = (int)m.pcap;
-  if (threadIdx.x == 0) {
-    p_count[blockIdx.x] = count;
-    if (count == 0) atomicOr(flags + WH_FLAG_NO_PULSE, 1);
-  }
-  // fractional shift and noise-stream offsets (exclusive prefix sum of max(3, noise_size))
+  const int count = p_count[blockIdx.x];
   long long run = 0;
-  for (int base = 0; base < count; base += 256) {
+  for (int base = 0; base < count; base += kPFinish) {
     const int i = base + threadIdx.x;
     long long d = 0;
     if (i < count) {
@@ -253,7 +330,7 @@ __global__ __launch_bounds__(256) void pulse_kernel(const SynUtt* __restrict__ m
     if (lane == 63) wsum64[threadIdx.x >> 6] = incl;
     __syncthreads();
     long long excl = incl - d, total = 0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < kPFinish / 64; ++w) {
       if (w < (int)(threadIdx.x >> 6)) excl += wsum64[w];
       total += wsum64[w];
     }
@@ -273,6 +350,28 @@ __global__ void pulse_base_kernel(const int32_t* __restrict__ p_count, int n_utt
     }
     base[n_utt] = run;
   }
+}
+
+inline int pulse_tiles(int64_t max_ny) { return max_ny > 1 ? (int)((max_ny - 1 + kPTile - 1) / kPTile) : 1; }
+// scratch of the pulse stage: crossing masks (one byte per 4 samples) and per-tile counts
+inline size_t pulse_scratch_bytes(int B, int64_t max_ny) {
+  const size_t mt = (size_t)pulse_tiles(max_ny);
+  return (((size_t)B * mt * 256 + 255) & ~(size_t)255) + (((size_t)B * mt * sizeof(int32_t) + 255) & ~(size_t)255);
+}
+int launch_pulses(wh_ctx* ctx, hipStream_t st, int B, int64_t max_ny, const SynUtt* d_meta, const double* d_phase,
+                  double fs, double* d_pt, int64_t* d_pi, double* d_ps, int64_t* d_pn, int32_t* d_pc, char* scratch) {
+  const int mt = pulse_tiles(max_ny);
+  uint8_t* d_masks = reinterpret_cast<uint8_t*>(scratch);
+  int32_t* d_tc = reinterpret_cast<int32_t*>(scratch + (((size_t)B * mt * 256 + 255) & ~(size_t)255));
+  { wh::KernelTimer _kt(ctx, st, "pulse_mark_kernel"); hipLaunchKernelGGL(pulse_mark_kernel, dim3(mt, B), dim3(256), 0, st, d_meta, d_phase, mt, d_masks, d_tc); }
+  WH_LAUNCH_CHECK("pulse_mark_kernel");
+  { wh::KernelTimer _kt(ctx, st, "pulse_scan_kernel"); hipLaunchKernelGGL(pulse_scan_kernel, dim3(B), dim3(256), 0, st, d_meta, mt, d_tc, d_pc, ctx->d_flags); }
+  WH_LAUNCH_CHECK("pulse_scan_kernel");
+  { wh::KernelTimer _kt(ctx, st, "pulse_emit_kernel"); hipLaunchKernelGGL(pulse_emit_kernel, dim3(mt, B), dim3(256), 0, st, d_meta, mt, d_masks, d_tc, fs, d_pt, d_pi); }
+  WH_LAUNCH_CHECK("pulse_emit_kernel");
+  { wh::KernelTimer _kt(ctx, st, "pulse_finish_kernel"); hipLaunchKernelGGL(pulse_finish_kernel, dim3(B), dim3(kPFinish), 0, st, d_meta, d_phase, fs, d_pi, d_pc, d_ps, d_pn, ctx->d_flags); }
+  WH_LAUNCH_CHECK("pulse_finish_kernel");
+  return 0;
 }
 
 // ---- counter-based normal generator (Philox-4x32-10 + Box-Muller) for the no-host-noise mode ----
@@ -829,6 +928,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   const size_t o_ps = off; off += al(sizeof(double) * B * pulse_cap);
   const size_t o_pn = off; off += al(sizeof(int64_t) * B * pulse_cap);
   const size_t o_pc = off; off += al(sizeof(int32_t) * B);
+  const size_t o_px = off; off += pulse_scratch_bytes(B, max_ny);
   const size_t o_pb = off; off += al(sizeof(int64_t) * (B + 1));
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
@@ -848,9 +948,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   WH_LAUNCH_CHECK("prep_kernel");
   { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(128), 0, st, d_meta, d_phase); }
   WH_LAUNCH_CHECK("phase_kernel");
-  { wh::KernelTimer _kt(ctx, st, "pulse_kernel"); hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc,
-                     ctx->d_flags); }
-  WH_LAUNCH_CHECK("pulse_kernel");
+  if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ws + o_px)) return rc;
   { wh::KernelTimer _kt(ctx, st, "pulse_base_kernel"); hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb); }
   WH_LAUNCH_CHECK("pulse_base_kernel");
   int rc;
@@ -903,6 +1001,7 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
   const size_t o_ps = off; off += al(sizeof(double) * B * pulse_cap);
   const size_t o_pn = off; off += al(sizeof(int64_t) * B * pulse_cap);
   const size_t o_pc = off; off += al(sizeof(int32_t) * B);
+  const size_t o_px = off; off += pulse_scratch_bytes(B, max_ny);
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
   SynUtt* d_meta = nullptr;
@@ -917,9 +1016,8 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
   WH_LAUNCH_CHECK("prep_kernel");
   { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(128), 0, st, d_meta, d_phase); }
   WH_LAUNCH_CHECK("phase_kernel");
-  { wh::KernelTimer _kt(ctx, st, "pulse_kernel"); hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, reinterpret_cast<double*>(ws + o_pt),
-                     d_pi, reinterpret_cast<double*>(ws + o_ps), d_pn, d_pc, ctx->d_flags); }
-  WH_LAUNCH_CHECK("pulse_kernel");
+  if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, reinterpret_cast<double*>(ws + o_pt), d_pi,
+                             reinterpret_cast<double*>(ws + o_ps), d_pn, d_pc, ws + o_px)) return rc;
   WH_CHECK(hipMemcpyAsync(h_pulse_count, d_pc, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
   WH_CHECK(hipStreamSynchronize(st));
   // total draws = noff[last] + max(3, 0)
@@ -983,6 +1081,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   const size_t o_ps = off; off += al(sizeof(double) * B * pulse_cap);
   const size_t o_pn = off; off += al(sizeof(int64_t) * B * pulse_cap);
   const size_t o_pc = off; off += al(sizeof(int32_t) * B);
+  const size_t o_px = off; off += pulse_scratch_bytes(B, max_ny);
   const size_t o_pb = off; off += al(sizeof(int64_t) * (B + 1));
   const size_t o_lin = off; off += al(sizeof(double) * F * n_bands);
   const size_t o_exc = off; off += al(sizeof(double) * ny_tot);
@@ -1007,8 +1106,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   WH_LAUNCH_CHECK("prep_kernel");
   { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(128), 0, st, d_meta, d_phase); }
   WH_LAUNCH_CHECK("phase_kernel");
-  { wh::KernelTimer _kt(ctx, st, "pulse_kernel"); hipLaunchKernelGGL(pulse_kernel, dim3(B), dim3(256), 0, st, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ctx->d_flags); }
-  WH_LAUNCH_CHECK("pulse_kernel");
+  if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ws + o_px)) return rc;
   { wh::KernelTimer _kt(ctx, st, "pulse_base_kernel"); hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb); }
   WH_LAUNCH_CHECK("pulse_base_kernel");
   { wh::KernelTimer _kt(ctx, st, "req_linap_kernel"); hipLaunchKernelGGL(req_linap_kernel, dim3((unsigned)((F * n_bands + 255) / 256)), dim3(256), 0, st, band_aperiodicity, F * n_bands, d_lin); }

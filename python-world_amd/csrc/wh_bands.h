@@ -1,6 +1,6 @@
 // Band FIR + zero-crossing event extraction kernel shared by DIO (7 Nuttall low-pass bands on the
 // low-cut filtered 4 kHz signal) and Harvest (152 cosine-modulated Nuttall band-pass channels on the
-// 8 kHz signal).  One workgroup per (band, utterance): the signal is walked in 1024-sample tiles, each
+// 8 kHz signal).  One workgroup per (band, utterance[, segment]): the signal is walked in 1024-sample tiles, each
 // tile's FIR input window and the taps live in LDS, outputs go straight into the crossing detector
 // (wh_events.h) — the filtered signal itself never touches HBM.
 // Reference: get_raw_event (world/dio.py:128-140) / CalculateRawEvent (world/harvest.py:252-269).
@@ -16,6 +16,11 @@ struct BandJob {
   double* edges;    // [4][cap] fine edge positions (1-based sample units)
   int64_t cap;
   int32_t* counts;  // [4]
+  // segmented mode (launch_band_events nseg > 1): the signal is cut into nseg runs of whole tiles, each with its
+  // own workgroup and private lists, concatenated afterwards (band_concat_kernel)
+  double* seg_edges;    // [nseg][4][seg_cap]
+  int32_t* seg_counts;  // [nseg][4]
+  int64_t seg_cap;
 };
 
 constexpr int kBandTile = 1024;
@@ -42,7 +47,17 @@ __global__ __launch_bounds__(256) void band_events_kernel(const BandJob* __restr
   for (int k = threadIdx.x; k < ((lb + 1) & ~1); k += 256) taps[k] = k < lb ? taps_all[tap_off[b] + k] : 0.0;
   int base_cnt[4] = {0, 0, 0, 0};
   const int64_t M = job.M;
-  for (int64_t t0 = 0; t0 < M; t0 += kBandTile) {
+  // segment blockIdx.z of gridDim.z: a run of whole tiles with its own lists (gridDim.z == 1: the whole signal,
+  // straight into the final lists)
+  const int nseg = gridDim.z;
+  const int64_t tiles = (M + kBandTile - 1) / kBandTile;
+  const int64_t tps = (tiles + nseg - 1) / nseg;
+  const int64_t t_begin = (int64_t)blockIdx.z * tps * kBandTile;
+  const int64_t t_end = (t_begin + tps * kBandTile) < M ? t_begin + tps * kBandTile : M;
+  double* edges_out = nseg > 1 ? job.seg_edges + (int64_t)blockIdx.z * 4 * job.seg_cap : job.edges;
+  const int64_t cap_out = nseg > 1 ? job.seg_cap : job.cap;
+  int32_t* counts_out = nseg > 1 ? job.seg_counts + blockIdx.z * 4 : job.counts;
+  for (int64_t t0 = t_begin; t0 < t_end; t0 += kBandTile) {
     __syncthreads();
     const int64_t zlo = t0 + bias[b] + 1 - (lb - 1);
     for (int i = threadIdx.x; i < kBandTile + 2 + lb - 1; i += 256) {
@@ -89,25 +104,50 @@ __global__ __launch_bounds__(256) void band_events_kernel(const BandJob* __restr
       }
     }
     __syncthreads();
-    emit_crossings(sig, t0, M, kBandTile, job.edges, job.cap, base_cnt, scan_scratch, flags);
+    emit_crossings(sig, t0, M, kBandTile, edges_out, cap_out, base_cnt, scan_scratch, flags);
   }
-  if (threadIdx.x < 4) job.counts[threadIdx.x] = base_cnt[threadIdx.x];
+  if (threadIdx.x < 4) counts_out[threadIdx.x] = base_cnt[threadIdx.x];
+}
+
+// Segment lists -> the final ordered lists of each (band, utterance) job.
+static __global__ __launch_bounds__(256) void band_concat_kernel(const BandJob* __restrict__ jobs, int nseg,
+                                                          int32_t* __restrict__ flags) {
+  const BandJob job = jobs[blockIdx.x];
+  for (int t = 0; t < 4; ++t) {
+    int64_t off = 0;
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+      const int c = job.seg_counts[sgm * 4 + t];
+      const double* src = job.seg_edges + ((int64_t)sgm * 4 + t) * job.seg_cap;
+      for (int i = threadIdx.x; i < c; i += 256)
+        if (off + i < job.cap) job.edges[(int64_t)t * job.cap + off + i] = src[i];
+      off += c;
+    }
+    if (threadIdx.x == 0) {
+      if (off > job.cap) atomicOr(flags, 1);
+      job.counts[t] = (int32_t)(off > job.cap ? job.cap : off);
+    }
+  }
 }
 
 inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs, int nb, int n_utt, int pad,
                               const double* d_taps, const int32_t* d_tap_off, const int32_t* d_tap_len,
-                              const int32_t* d_bias, int max_lb, bool use_fma, int32_t* d_flag) {
+                              const int32_t* d_bias, int max_lb, bool use_fma, int32_t* d_flag, int nseg = 1) {
   const int zlen = kBandTile + 2 + max_lb;
   const size_t lds = sizeof(double) * (((max_lb + 1) & ~1) + ((zlen + 2 * (zlen >> 5) + 3) & ~1) + kBandTile + 2) + 64;
   if (use_fma) {
     if (int rc = allow_lds(&band_events_kernel<true>, lds)) return rc;
-    { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_kernel<true>, dim3(nb, n_utt), dim3(256), lds, st, d_jobs, pad, d_taps, d_tap_off, d_tap_len, d_bias, nb, d_flag); }
+    { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_kernel<true>, dim3(nb, n_utt, nseg), dim3(256), lds, st, d_jobs, pad, d_taps, d_tap_off, d_tap_len, d_bias, nb, d_flag); }
   } else {
     if (int rc = allow_lds(&band_events_kernel<false>, lds)) return rc;
-    { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_kernel<false>, dim3(nb, n_utt), dim3(256), lds, st, d_jobs, pad, d_taps, d_tap_off, d_tap_len, d_bias, nb, d_flag); }
+    { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_kernel<false>, dim3(nb, n_utt, nseg), dim3(256), lds, st, d_jobs, pad, d_taps, d_tap_off, d_tap_len, d_bias, nb, d_flag); }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("band_events_kernel", e);
+  if (nseg > 1) {
+    { KernelTimer _kt(ctx, st, "band_concat_kernel"); hipLaunchKernelGGL(band_concat_kernel, dim3(nb * n_utt), dim3(256), 0, st, d_jobs, nseg, d_flag); }
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail("band_concat_kernel", e);
+  }
   return 0;
 }
 

@@ -25,7 +25,9 @@ namespace {
 #ifndef WH_FT_D4C
 #define WH_FT_D4C 256
 #endif
-constexpr int FT = WH_FT_D4C;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
+// Threads cooperating on one frame: 256 up to N = 2048; 512 at N = 4096 (48 kHz), where the 96 KB of LDS per frame
+// leave one workgroup per CU and the thread count is the only occupancy there is.
+constexpr int ft_of(int n) { return n >= 4096 ? 2 * WH_FT_D4C : WH_FT_D4C; }
 
 // Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110).  Values for samples j = tid + q*FT land
 // in the caller's registers v[q] (zero beyond the window; rows longer than N are cropped like
@@ -33,8 +35,9 @@ constexpr int FT = WH_FT_D4C;  // threads cooperating on one frame / pulse (64 =
 // BLACKMAN selects window type 2, else Hann.
 template <bool BLACKMAN, int N>
 __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long long xn, double fs, double cf,
-                                             double pos, double half_length, double* tmp, double (&v)[N / FT],
+                                             double pos, double half_length, double* tmp, double (&v)[N / ft_of(N)],
                                              double* scratch) {
+  constexpr int FT = ft_of(N);
   const int hwl = (int)(half_length * fs / cf + 0.5);
   const int L = 2 * hwl + 1;
   const long long centre = wh::frame_centre(pos, fs);
@@ -77,10 +80,11 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
 }
 
 template <int NLT>
-__global__ __launch_bounds__(FT) void love_train_kernel(
+__global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv, double fs,
     double threshold, const double2* __restrict__ tw_base, int32_t* __restrict__ gate) {
+  constexpr int FT = ft_of(NLT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2* zb = reinterpret_cast<double2*>(smem);  // NLT/2+1 complex after the real FFT
   double* zr = reinterpret_cast<double*>(smem);    // 2*NLT doubles while windowing
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(FT) void love_train_kernel(
 template <int K>
 __device__ __forceinline__ void sum_smallest(const double* __restrict__ p, int m, void* work, double* scratch,
                                              double* s_small, double* s_total) {
+  constexpr int FT = ft_of(2 * (K - 1));
   constexpr int PER = (K + FT - 1) / FT;
   constexpr int BINS = 2048;
   int* hist = reinterpret_cast<int*>(work);
@@ -219,6 +224,7 @@ template <int N>
 __device__ __forceinline__ void add_centroid(const double* xu, long long xn, double fs, double cf, double pos,
                                              double2* buf, double* cent, bool first, const double2* tw_base,
                                              double* scratch) {
+  constexpr int FT = ft_of(N);
   double v[N / FT];
   const double energy = d4c_window<true, N>(xu, xn, fs, cf, pos, 2.0, reinterpret_cast<double*>(buf), v, scratch);
   const double nrm = sqrt(energy);
@@ -253,13 +259,14 @@ __device__ __forceinline__ void add_centroid(const double* xu, long long xn, dou
 // Blackman frame and the Hann frame of the smoothed power spectrum are two real sequences → ONE complex FFT,
 // separated by Hermitian symmetry; the separate love_train_kernel launch and one transform disappear.
 template <int N, bool FUSED>
-__global__ __launch_bounds__(FT, WH_D4C_MINBLK) void d4c_kernel(
+__global__ __launch_bounds__(ft_of(N), WH_D4C_MINBLK) void d4c_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv,
     const int32_t* __restrict__ gate, double threshold, double fs, int nap, int interval,
     const double* __restrict__ window, int wlen, const double2* __restrict__ tw_base,
     int k_spec,                       // >0: dense amplitude output [F][k_spec]; 0: Requiem band output [F][nap+2]
     double* __restrict__ out, double* __restrict__ coarse_dbg) {
+  constexpr int FT = ft_of(N);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = N / 2 + 1;
   double2* buf = reinterpret_cast<double2*>(smem);   // N complex (centroid FFT) / N/2+1 complex (real FFTs)
@@ -455,7 +462,7 @@ int launch_lt(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, c
               const double* vuv, double fs, double thr, int32_t* gate) {
   const size_t lds = sizeof(double) * (2 * NLT + 32);
   if (int rc = wh::allow_lds(&love_train_kernel<NLT>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
+  { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)b->total_frames), dim3(ft_of(NLT)), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, fs, thr, ctx->d_twiddle, gate); }
   WH_LAUNCH_CHECK("love_train_kernel");
   return 0;
@@ -467,7 +474,7 @@ int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x,
                 int wlen, int k_spec, double* out, double* coarse) {
   const size_t lds = sizeof(double) * (2 * N + 2 * (N / 2 + 8) + 32 + 8);
   if (int rc = wh::allow_lds(&d4c_kernel<N, FUSED>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL((d4c_kernel<N, FUSED>), dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
+  { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL((d4c_kernel<N, FUSED>), dim3((unsigned)b->total_frames), dim3(ft_of(N)), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, gate, thr, fs, nap, interval, win, wlen, ctx->d_twiddle, k_spec, out,
                      coarse); }
   WH_LAUNCH_CHECK("d4c_kernel");

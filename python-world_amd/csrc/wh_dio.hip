@@ -54,7 +54,10 @@ const IirCoef kDecimate[13] = {
     {2.4981398605924205, -2.1368928194784025, 0.62187513816221485, 0.0021097275904709001, 0.0063291827714127002}};
 
 constexpr int kPad = 9;       // kNFact, dio.py:452
-constexpr int kChunk = 1024;  // samples of IIR output per lane
+#ifndef WH_IIR_CHUNK
+#define WH_IIR_CHUNK 256
+#endif
+constexpr int kChunk = WH_IIR_CHUNK;  // samples of IIR output per lane (each lane also re-runs `warm` samples before its chunk)
 
 // mirror-padded input of the first pass (dio.py:458-463)
 __device__ __forceinline__ double padded(const double* __restrict__ x, int64_t n, int64_t i) {
@@ -120,21 +123,28 @@ __global__ __launch_bounds__(64) void iir_bwd_kernel(const DioUtt* __restrict__ 
 }
 
 // z[m mod fft] = sum_k h[k] * yext[(m-k) mod fft], stored for m in [-pad, ylen+pad)   (dio.py:74-88)
+// One workgroup per 256 outputs: the 256 + 2*half circularly indexed inputs they touch are staged in LDS once
+// (one 64-bit modulo per staged sample instead of one per tap), taps in ascending k like the direct sum.
 __global__ __launch_bounds__(256) void lowcut_kernel(const DioUtt* __restrict__ meta, const double* __restrict__ y,
                                                      const double* __restrict__ h, int half, int pad,
                                                      double* __restrict__ z) {
+  extern __shared__ __attribute__((aligned(16))) double lc_sh[];  // 256 + 2*half
   const DioUtt m = meta[blockIdx.y];
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= m.ylen + 2 * pad) return;
-  const int64_t mm = j - pad;
+  const int64_t j0 = (int64_t)blockIdx.x * 256;
+  if (j0 >= m.ylen + 2 * pad) return;
   const double* yu = y + m.y_off;
-  double acc = 0.0;
-  for (int k = -half; k <= half; ++k) {
-    int64_t idx = (mm - k) % m.fftmod;
+  const int64_t lo = j0 - pad - half;  // first staged index (before the modulo)
+  for (int i = threadIdx.x; i < 256 + 2 * half; i += 256) {
+    int64_t idx = (lo + i) % m.fftmod;
     if (idx < 0) idx += m.fftmod;
-    const double v = idx < m.ylen ? yu[idx] : 0.0;
-    acc += h[k + half] * v;
+    lc_sh[i] = idx < m.ylen ? yu[idx] : 0.0;
   }
+  __syncthreads();
+  const int64_t j = j0 + threadIdx.x;
+  if (j >= m.ylen + 2 * pad) return;
+  double acc = 0.0;
+  const double* sh = lc_sh + threadIdx.x + 2 * half;  // (mm - k) - lo = tid + half - k + half... k = -half → +2*half
+  for (int t = 0; t <= 2 * half; ++t) acc += h[t] * sh[-t];
   z[m.z_off + j] = acc;
 }
 
@@ -161,6 +171,10 @@ __global__ __launch_bounds__(256) void cand_kernel(const DioUtt* __restrict__ me
 }
 
 constexpr int kMaxBands = 32;
+#ifndef WH_DIO_BAND_SEGS
+#define WH_DIO_BAND_SEGS 4
+#endif
+constexpr int kBandSegs = WH_DIO_BAND_SEGS;  // workgroups per (band, utterance) in the event extraction
 
 __global__ __launch_bounds__(256) void sort_kernel(const DioUtt* __restrict__ meta, int nb, const double* __restrict__ raw,
                                                    const double* __restrict__ stab, double* __restrict__ sorted,
@@ -436,6 +450,17 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   const size_t o_z = off; off += al(sizeof(double) * z_tot);
   const size_t o_e = off; off += al(sizeof(double) * e_tot);
   const size_t o_cnt = off; off += al(sizeof(int32_t) * (size_t)B * n_bands * 4);
+  // segment-private event lists: 7 bands x B utterances alone cannot fill 256 CUs with their serial tile loops
+  std::vector<int64_t> seg_cap(B), seg_off(B);
+  int64_t se_tot = 0;
+  for (int u = 0; u < B; ++u) {
+    const int64_t tiles = (meta[u].ylen + wh::kBandTile - 1) / wh::kBandTile;
+    seg_cap[u] = ((tiles + kBandSegs - 1) / kBandSegs) * (wh::kBandTile / 2) + 2;
+    seg_off[u] = se_tot;
+    se_tot += (int64_t)n_bands * kBandSegs * 4 * seg_cap[u];
+  }
+  const size_t o_se = off; off += al(sizeof(double) * se_tot);
+  const size_t o_scnt = off; off += al(sizeof(int32_t) * (size_t)B * n_bands * kBandSegs * 4);
   const size_t o_raw = off; off += al(sizeof(double) * F * n_bands);
   const size_t o_stab = off; off += al(sizeof(double) * F * n_bands);
   const size_t o_sorted = off; off += al(sizeof(double) * F * n_bands);
@@ -448,6 +473,8 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   double* d_z = reinterpret_cast<double*>(ws + o_z);
   double* d_e = reinterpret_cast<double*>(ws + o_e);
   int32_t* d_cnt = reinterpret_cast<int32_t*>(ws + o_cnt);
+  double* d_se = reinterpret_cast<double*>(ws + o_se);
+  int32_t* d_scnt = reinterpret_cast<int32_t*>(ws + o_scnt);
   double* d_raw = raw_out ? raw_out : reinterpret_cast<double*>(ws + o_raw);
   double* d_stab = reinterpret_cast<double*>(ws + o_stab);
   double* d_sorted = reinterpret_cast<double*>(ws + o_sorted);
@@ -487,7 +514,7 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   { wh::KernelTimer _kt(ctx, st, "iir_bwd_kernel"); hipLaunchKernelGGL(iir_bwd_kernel, gi, dim3(64), 0, st, d_meta, coef, warm, r, d_tmp, d_y); }
   WH_LAUNCH_CHECK("iir_bwd_kernel");
   // ---- low-cut + band events ----------------------------------------------------------------------
-  { wh::KernelTimer _kt(ctx, st, "lowcut_kernel"); hipLaunchKernelGGL(lowcut_kernel, dim3((unsigned)((max_ylen + 2 * pad + 255) / 256), B), dim3(256), 0, st, d_meta, d_y,
+  { wh::KernelTimer _kt(ctx, st, "lowcut_kernel"); hipLaunchKernelGGL(lowcut_kernel, dim3((unsigned)((max_ylen + 2 * pad + 255) / 256), B), dim3(256), sizeof(double) * (256 + 2 * lowcut_half), st, d_meta, d_y,
                      d_lc, lowcut_half, pad, d_z); }
   WH_LAUNCH_CHECK("lowcut_kernel");
   {
@@ -500,11 +527,14 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
         j.edges = d_e + meta[u].e_off + (int64_t)i * 4 * meta[u].cap;
         j.cap = meta[u].cap;
         j.counts = d_cnt + ((int64_t)u * n_bands + i) * 4;
+        j.seg_edges = d_se + seg_off[u] + (int64_t)i * kBandSegs * 4 * seg_cap[u];
+        j.seg_counts = d_scnt + ((int64_t)u * n_bands + i) * kBandSegs * 4;
+        j.seg_cap = seg_cap[u];
       }
     if (int rc = wh::persistent_upload(ctx, "dio.jobs", jobs, &d_jobs)) return rc;
   }
   if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands, d_ti + 2 * n_bands,
-                                      max_lb, false, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW))
+                                      max_lb, false, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW, kBandSegs))
     return rc;
   // ---- candidates, sort, contour ------------------------------------------------------------------
   { wh::KernelTimer _kt(ctx, st, "cand_kernel"); hipLaunchKernelGGL(cand_kernel, dim3((unsigned)((max_nf + 255) / 256), n_bands, B), dim3(256), 0, st, d_meta, tp, d_e,

@@ -11,6 +11,9 @@
 #include "wh_host.h"
 #include "wh_spectral.h"
 
+#ifndef WH_D4C_ABLATE
+#define WH_D4C_ABLATE 0
+#endif
 #ifndef WH_D4C_MAXR
 #define WH_D4C_MAXR 4
 #endif
@@ -342,11 +345,19 @@ __global__ __launch_bounds__(ft_of(N), WH_D4C_MINBLK) void d4c_kernel(
     return;
   }
 
+#if WH_D4C_ABLATE == 1
+  if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = pw[threadIdx.x];
+  return;
+#endif
   // ---- static centroid from two frames at +-T0/4 (d4c.py:132-142) + DC correction ----------
   add_centroid<N>(xu, xn, fs, cf, pos + 1 / cf / 4, buf, cent, true, tw_base, scratch);
   add_centroid<N>(xu, xn, fs, cf, pos - 1 / cf / 4, buf, cent, false, tw_base, scratch);
   wh::low_band_replica<FT>(cent, zr, N, fs, cf, 1.2 * cf);
 
+#if WH_D4C_ABLATE == 2
+  if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = cent[threadIdx.x] + pw[3];
+  return;
+#endif
   // ---- smoothed power spectrum (d4c.py:157-161) ----------------------------------------------
   if (!FUSED) {
     double v[N / FT];
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(ft_of(N), WH_D4C_MINBLK) void d4c_kernel(
   }
   double* cum = zr;  // the FFT buffer is idle during the smoothing steps
   wh::low_band_replica<FT>(pw, cum, N, fs, cf, 1.2 * cf);
-  wh::scan_mirrored<FT>(pw, cum, N, fs, scratch);
+  wh::scan_mirrored<FT, N>(pw, cum, fs, scratch);
   wh::BandLookup lk;
   lk.init(cum, N, fs);
   lk.set_half_width(cf / 2);
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(ft_of(N), WH_D4C_MINBLK) void d4c_kernel(
   }
   wh::sync<FT>();
   // ---- group-delay shaping (d4c.py:165-174) --------------------------------------------------
-  wh::scan_mirrored<FT>(cent, cum, N, fs, scratch);
+  wh::scan_mirrored<FT, N>(cent, cum, fs, scratch);
   lk.init(cum, N, fs);
   {
     const double w2 = cf / 2;
@@ -381,12 +392,16 @@ __global__ __launch_bounds__(ft_of(N), WH_D4C_MINBLK) void d4c_kernel(
     for (int k = threadIdx.x; k < K; k += FT) pw[k] = lk.band(k) / w2;  // T_gs
   }
   wh::sync<FT>();
-  wh::scan_mirrored<FT>(pw, cum, N, fs, scratch);
+  wh::scan_mirrored<FT, N>(pw, cum, fs, scratch);
   lk.init(cum, N, fs);
   lk.set_half_width(cf / 2);
   for (int k = threadIdx.x; k < K; k += FT) cent[k] = pw[k] - lk.band(k) / cf;  // T_D = T_gs - T_gb
   wh::sync<FT>();
 
+#if WH_D4C_ABLATE == 3
+  if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = cent[threadIdx.x] + pw[3];
+  return;
+#endif
   // ---- band-wise aperiodicity (d4c.py:192-209) -----------------------------------------------
   const int boundary = (int)((double)N / wlen * 8 + 0.5);
   const int half = wlen / 2;
@@ -415,6 +430,10 @@ __global__ __launch_bounds__(ft_of(N), WH_D4C_MINBLK) void d4c_kernel(
     wh::sync<FT>();
   }
 
+#if WH_D4C_ABLATE == 4
+  if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = band[0];
+  return;
+#endif
   // ---- outputs (d4c.py:56-59 / d4cRequiem.py:40) ---------------------------------------------
   const double tilt = (cf - 100) * 2 / 100;
   if (k_spec > 0) {

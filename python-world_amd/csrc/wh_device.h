@@ -122,30 +122,6 @@ __device__ __forceinline__ double wave_scan_incl(double v) {
   return v;
 }
 
-// In-place inclusive prefix sum of n doubles in LDS (n a multiple of NT).  Each thread
-// owns a contiguous run of n/256 elements.  `scratch` >= 8 doubles.  Ends with a barrier.
-template <int NT = WH_BLOCK>
-__device__ __forceinline__ void block_scan_lds(double* a, int n, double* scratch) {
-  const int per = n / NT;
-  const int base = threadIdx.x * per;
-  double run = 0.0;
-  for (int i = 0; i < per; ++i) {
-    run += a[base + i];
-    a[base + i] = run;
-  }
-  double incl = wave_scan_incl(run);
-  double off = incl - run;
-  if constexpr (NT > WH_WAVE) {
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 63) scratch[w] = incl;
-    __syncthreads();
-    for (int i = 0; i < w; ++i) off += scratch[i];
-  }
-  for (int i = 0; i < per; ++i) a[base + i] += off;
-  sync<NT>();
-}
-
 // ------------------------------------------------------------------------------------------
 // FFT
 // ------------------------------------------------------------------------------------------

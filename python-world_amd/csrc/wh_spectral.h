@@ -31,9 +31,14 @@ __device__ __forceinline__ void low_band_replica(double* p, double* tmp, int N, 
     for (int kk = threadIdx.x; kk < nlow; kk += NT) {
       const double fk = (double)kk / N * fs;
       if (fk < f0) {
-        // ascending nodes a_m = f0 - f_{nlow-1-m}; hi = clamp(#nodes < fk, 1, nlow-1)
-        int cnt = 0;
-        for (int m = 0; m < nlow; ++m) cnt += ((f0 - ((double)(nlow - 1 - m) / N * fs)) < fk) ? 1 : 0;
+        // ascending nodes a_m = f0 - f_{nlow-1-m}; hi = clamp(#nodes < fk, 1, nlow-1).  The node predicate
+        // a_m < fk is monotone in m, so the count is its boundary: estimated in closed form, then settled with
+        // the exact floating-point predicate (the estimate is within one of the truth).
+        auto below = [&](int mm) { return (f0 - ((double)(nlow - 1 - mm) / N * fs)) < fk; };
+        int cnt = (int)ceil((double)(nlow - 1) - (f0 - fk) / fs * N);
+        cnt = cnt < 0 ? 0 : (cnt > nlow ? nlow : cnt);
+        while (cnt > 0 && !below(cnt - 1)) --cnt;
+        while (cnt < nlow && below(cnt)) ++cnt;
         const int hi = cnt < 1 ? 1 : (cnt > nlow - 1 ? nlow - 1 : cnt);
         const int lo = hi - 1;
         const double a_lo = f0 - ((double)(nlow - 1 - lo) / N * fs);
@@ -55,8 +60,13 @@ __device__ __forceinline__ void low_band_replica(double* p, double* tmp, int N, 
   sync<NT>();
 }
 
+// The prefix-sum array is stored with one double of padding after every 8 (element i at i + i/8, N + N/8 doubles):
+// the scan gives each thread a contiguous run, and with an unpadded layout the lanes of a wave would walk LDS at a
+// stride of 8 doubles, 8 of them on every bank.
+__device__ __forceinline__ int scan_pad(int i) { return i + (i >> 3); }
+
 // Doubled-spectrum cumulative lookup (cheaptrick.py:103-131 / d4c.py:178-233).
-// cum[i], i<N: inclusive prefix sum of the Hermitian-symmetric spectrum times fs/N.
+// cum[scan_pad(i)], i<N: inclusive prefix sum of the Hermitian-symmetric spectrum times fs/N.
 struct BandLookup {
   const double* cum;
   int N;
@@ -70,9 +80,9 @@ struct BandLookup {
     dx = x1 - x0;
     inv_dx = 1.0 / dx;  // the interpolant is continuous across bins, so a last-bit change of q is harmless
     xlast = ((double)(2 * n - 1) / n * fs - fs) + half;
-    total = c[n - 1];
+    total = c[scan_pad(n - 1)];
   }
-  __device__ __forceinline__ double seg(int i) const { return i < N ? cum[i] : total + cum[i - N]; }
+  __device__ __forceinline__ double seg(int i) const { return i < N ? cum[scan_pad(i)] : total + cum[scan_pad(i - N)]; }
   // Band mean around every bin centre: the look-up positions centre_k +- half sit at a CONSTANT fractional
   // offset from bin k (q_k = k + const), so base index and fraction are found once per frame instead of by a
   // divide/floor per bin.  (Differs from evaluating q_k per bin only by rounding of q; the interpolant is
@@ -106,17 +116,40 @@ struct BandLookup {
   }
 };
 
-// p_half[0..N/2] (LDS) → cum[0..N) (LDS) = inclusive scan of the mirrored full spectrum × fs/N.
-// Contains barriers; p_half must be visible on entry; cum visible on exit.
-template <int NT = WH_BLOCK>
-__device__ __forceinline__ void scan_mirrored(const double* p_half, double* cum, int N, double fs, double* scratch) {
+// p_half[0..N/2] (LDS) → cum (LDS, scan_pad layout, N + N/8 doubles) = inclusive scan of the mirrored full
+// spectrum × fs/N.  Fill with thread-strided ownership (neighbouring lanes on neighbouring addresses), scan with
+// thread-contiguous runs held in registers (read once, written once).  Contains barriers; p_half must be visible
+// on entry; cum visible on exit.  `scratch` >= NT/64 doubles.
+template <int NT, int N>
+__device__ __forceinline__ void scan_mirrored(const double* p_half, double* cum, double fs, double* scratch) {
+  static_assert(N % NT == 0, "scan_mirrored: N must be a multiple of the thread count");
+  constexpr int PER = N / NT;
   const double df = fs / N;
   for (int i = threadIdx.x; i < N; i += NT) {
     const int k = i <= N / 2 ? i : N - i;
-    cum[i] = p_half[k] * df;
+    cum[scan_pad(i)] = p_half[k] * df;
   }
   sync<NT>();
-  block_scan_lds<NT>(cum, N, scratch);
+  const int base = threadIdx.x * PER;
+  double r[PER];
+  double run = 0.0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    run += cum[scan_pad(base + i)];
+    r[i] = run;
+  }
+  const double incl = wave_scan_incl(run);
+  double off = incl - run;
+  if constexpr (NT > WH_WAVE) {
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) scratch[w] = incl;
+    __syncthreads();
+    for (int i = 0; i < w; ++i) off += scratch[i];
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) cum[scan_pad(base + i)] = r[i] + off;
+  sync<NT>();
 }
 
 }  // namespace wh

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""HBM traffic per kernel launch from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected separately,
+as /opt/skills/guides/MI355X_MICROARCH.md prescribes), written in the table bench.py's `roofline.traffic` reads.
+
+usage: tools/pmc_traffic_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <frames_per_launch>
+       > profiles/hbm_traffic_cfg2_latest.txt
+
+rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (the guide's
+HBM section), so corrected_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Values are averaged over the launches of each
+kernel in the run.  algorithmic_MB uses bench.algo_bytes_per_frame (SURVEY 8(d) components) for 16 kHz / fft 1024.
+"""
+import collections
+import csv
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "python-world_amd"))
+
+
+def per_launch(path, counter):
+    tot = collections.defaultdict(float)
+    n = collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        mt = re.search(r"(\w+_kernel)\b", r["Kernel_Name"])
+        if not mt or "at::native" in r["Kernel_Name"]:
+            continue
+        name = mt.group(1)
+        tot[name] += float(r["Counter_Value"])
+        n[name] += 1
+    return {k: tot[k] / n[k] for k in tot}, n
+
+
+def main():
+    fetch, nf = per_launch(sys.argv[1], "FETCH_SIZE")
+    write, _ = per_launch(sys.argv[2], "WRITE_SIZE")
+    frames = int(sys.argv[3])
+    import bench
+    algo, _ = bench.algo_bytes_per_frame(16000, 1024)
+    print("# HBM traffic per launch from rocprofv3 PMC (separate --pmc passes for FETCH_SIZE and WRITE_SIZE), "
+          "config 2 (64 x 10 s, %d frames per launch)" % frames)
+    print("# rocprofv3 reports KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md "
+          "HBM section), so")
+    print("# corrected_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  algorithmic_MB = DESIGN.md bytes/frame x frames per launch.")
+    print("%-24s %12s %12s %14s %16s %8s" % ("kernel", "FETCH_KiB", "WRITE_KiB", "corrected_MB", "algorithmic_MB", "ratio"))
+    rows = []
+    for k in fetch:
+        f, w = fetch[k], write.get(k, 0.0)
+        corr = (2 * f + w) * 1024 / 1e6
+        rows.append((corr, k, f, w))
+    for corr, k, f, w in sorted(rows, reverse=True):
+        if k in algo:
+            a = algo[k] * frames / 1e6
+            print("%-24s %12.0f %12.0f %14.1f %16.1f %8.2f" % (k, f, w, corr, a, corr / a))
+        else:
+            print("%-24s %12.0f %12.0f %14.1f %16s %8s" % (k, f, w, corr, "-", "-"))
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@
 #define WH_D4C_MAXR 4
 #endif
 #ifndef WH_D4C_MINBLK
-#define WH_D4C_MINBLK 1
+#define WH_D4C_MINBLK 3
 #endif
 #ifndef WH_D4C_REGFFT
 #define WH_D4C_REGFFT 1
@@ -31,10 +31,12 @@ namespace {
 // Threads cooperating on one frame: 256 up to N = 2048; 512 at N = 4096 (48 kHz), where the 96 KB of LDS per frame
 // leave one workgroup per CU and the thread count is the only occupancy there is.
 constexpr int ft_of(int n) { return n >= 4096 ? 2 * WH_FT_D4C : WH_FT_D4C; }
+// Workgroups per CU the register allocation must leave room for: LDS allows 3 up to N = 2048 (<= 168 VGPRs).
+constexpr int minblk_of(int n) { return n >= 4096 ? 1 : WH_D4C_MINBLK; }
 
 // Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110).  Values for samples j = tid + q*FT land
 // in the caller's registers v[q] (zero beyond the window; rows longer than N are cropped like
-// np.fft.fft(x, n), Q7).  tmp: 2N doubles of LDS scratch.  Returns sum(wave^2) over the FULL window.
+// np.fft.fft(x, n), Q7).  tmp: unused (kept for the call sites).  Returns sum(wave^2) over the FULL window.
 // BLACKMAN selects window type 2, else Hann.
 template <bool BLACKMAN, int N>
 __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long long xn, double fs, double cf,
@@ -49,16 +51,27 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
     const double c1 = cospi(((double)(j - hwl) / fs / half_length + phase) * cf);  // cos(pi*t*f0)
     return BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);  // cos(2a) = 2cos^2(a)-1
   };
+  // samples j = tid + q*FT of the window stay in this thread's registers from the gather to the DC removal
   double s_sw = 0.0, s_w = 0.0;
-  for (int j = threadIdx.x; j < L; j += FT) {
-    const double w = win(j);
-    const double sw = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w;
-    s_sw += sw;
-    s_w += w;
-    if (j < N) {
-      tmp[j] = sw;
-      tmp[N + j] = w;
+  double swq[N / FT], wq[N / FT];
+#pragma unroll
+  for (int q = 0; q < N / FT; ++q) {
+    const int j = threadIdx.x + q * FT;
+    swq[q] = 0.0;
+    wq[q] = 0.0;
+    if (j < L) {
+      const double w = win(j);
+      const double sw = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w;
+      s_sw += sw;
+      s_w += w;
+      swq[q] = sw;
+      wq[q] = w;
     }
+  }
+  for (int j = N + threadIdx.x; j < L; j += FT) {  // rows longer than N: cropped, but they count in the means
+    const double w = win(j);
+    s_sw += wh::sample_clamped(xu, xn, centre + (j - hwl)) * w;
+    s_w += w;
   }
   wh::block_sum2<FT>(s_sw, s_w, scratch);
   const double mean_sw = s_sw / (double)L;
@@ -69,7 +82,7 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
     const int j = threadIdx.x + q * FT;
     double val = 0.0;
     if (j < L) {
-      val = tmp[j] - tmp[N + j] * mean_sw / mean_w;
+      val = swq[q] - wq[q] * mean_sw / mean_w;
       e += val * val;
     }
     v[q] = val;
@@ -79,7 +92,7 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
     const double val = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w - w * mean_sw / mean_w;
     e += val * val;
   }
-  return wh::block_sum<FT>(e, scratch);  // barriers inside: every thread is done reading tmp
+  return wh::block_sum<FT>(e, scratch);
 }
 
 template <int NLT>
@@ -262,7 +275,7 @@ __device__ __forceinline__ void add_centroid(const double* xu, long long xn, dou
 // Blackman frame and the Hann frame of the smoothed power spectrum are two real sequences → ONE complex FFT,
 // separated by Hermitian symmetry; the separate love_train_kernel launch and one transform disappear.
 template <int N, bool FUSED>
-__global__ __launch_bounds__(ft_of(N), WH_D4C_MINBLK) void d4c_kernel(
+__global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv,
     const int32_t* __restrict__ gate, double threshold, double fs, int nap, int interval,

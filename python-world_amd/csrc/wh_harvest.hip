@@ -231,7 +231,8 @@ __device__ __forceinline__ double row16_sum(double v) {
 
 __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int64_t ybase, int64_t ylen, double fs,
                                               double t0, double f0c, double f0_floor, double f0_ceil,
-                                              const double2* __restrict__ tw_base, double* out_f0, double* out_sc) {
+                                              const double2* __restrict__ tw_base, const double2* tw_lds, int tw_n,
+                                              double* out_f0, double* out_sc) {
   const int l16 = threadIdx.x & 15;
   const double hwl_d = ceil(3 * fs / f0c / 2);
   const int hwl = (int)hwl_d;
@@ -244,7 +245,10 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
     nfft = 1 << (e + 1);
   }
   const int nh = (int)fmin(floor(fs / 2 / f0c), 6.0);
-  const double2* tw = tw_base + nfft;
+  // twiddles exp(-2*pi*i*k/nfft): from the workgroup's LDS copy of the largest table any of its candidates can
+  // need (the smaller tables are its subsamples, bit for bit), else from the global table
+  const double2* tw = tw_lds ? tw_lds : tw_base + nfft;
+  const int tw_sh = tw_lds ? (__ffs(tw_n) - __ffs(nfft)) : 0;
   int bins[6];
 #pragma unroll
   for (int h = 0; h < 6; ++h) bins[h] = (int)(f0c * nfft / fs * (double)(h + 1) + 0.5);
@@ -261,21 +265,16 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   double xr[6], xi[6], dr[6], di[6];
 #pragma unroll
   for (int h = 0; h < 6; ++h) xr[h] = xi[h] = dr[h] = di[h] = 0.0;
-  for (int j = l16; j < L; j += 16) {
-    const double ir = idx_raw_at(j);
-    const double xw = 2 * ((ir - 1) / fs - t0) / wlit;
-    double s2, c2;
-    sincospi(xw, &s2, &c2);  // sin/cos(2*common)
+  // one sample of the frame: (s2, c2) = sin/cos(pi*xw(j)); two_next / two_prev: the index step to the neighbour is 2
+  auto sample = [&](int j, double ir, double s2, double c2, bool two_next, bool two_prev) {
     const double mj = 0.42 + 0.5 * c2 + 0.08 * (2 * c2 * c2 - 1);  // cos(4c) = 2cos^2(2c) - 1
     double mn = 0.0, mp = 0.0;
     if (j + 1 < L) {
-      const bool two = idx_raw_at(j + 1) - ir > 1.5;
-      const double c = two ? c2 * cd2 - s2 * sd2 : c2 * cd1 - s2 * sd1;  // cos(2c + step*pi*dx)
+      const double c = two_next ? c2 * cd2 - s2 * sd2 : c2 * cd1 - s2 * sd1;  // cos(2c + step*pi*dx)
       mn = 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1);
     }
     if (j > 0) {
-      const bool two = ir - idx_raw_at(j - 1) > 1.5;
-      const double c = two ? c2 * cd2 + s2 * sd2 : c2 * cd1 + s2 * sd1;
+      const double c = two_prev ? c2 * cd2 + s2 * sd2 : c2 * cd1 + s2 * sd1;
       mp = 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1);
     }
     double dw;
@@ -288,12 +287,39 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
 #pragma unroll
     for (int h = 0; h < 6; ++h) {
       if (h < nh) {
-        const double2 w = tw[(bins[h] * j) & (nfft - 1)];
+        const double2 w = tw[((bins[h] * j) & (nfft - 1)) << tw_sh];
         xr[h] = fma(a, w.x, xr[h]);
         xi[h] = fma(a, w.y, xi[h]);
         dr[h] = fma(d, w.x, dr[h]);
         di[h] = fma(d, w.y, di[h]);
       }
+    }
+  };
+  if (idx_raw_at(0) > 1.0) {
+    // Every index of the frame is positive (all frames but the first few of an utterance): idx_raw, and with it the
+    // window phase xw, is linear in j, so this lane's samples j = l16 + 16 i are a fixed rotation of 16*pi*dx apart —
+    // one sincospi to start, a 4-flop rotation per sample after that (<= 43 steps: error growth ~1e-15).
+    double s16, c16, s2, c2;
+    sincospi(16 * dx, &s16, &c16);
+    {
+      const double ir0 = idx_raw_at(l16);
+      sincospi(2 * ((ir0 - 1) / fs - t0) / wlit, &s2, &c2);
+    }
+    for (int j = l16; j < L; j += 16) {
+      sample(j, idx_raw_at(j), s2, c2, false, false);
+      const double cn = c2 * c16 - s2 * s16;
+      s2 = s2 * c16 + c2 * s16;
+      c2 = cn;
+    }
+  } else {
+    for (int j = l16; j < L; j += 16) {
+      const double ir = idx_raw_at(j);
+      const double xw = 2 * ((ir - 1) / fs - t0) / wlit;
+      double s2, c2;
+      sincospi(xw, &s2, &c2);  // sin/cos(2*common)
+      const bool two_next = (j + 1 < L) && (idx_raw_at(j + 1) - ir > 1.5);
+      const bool two_prev = (j > 0) && (ir - idx_raw_at(j - 1) > 1.5);
+      sample(j, ir, s2, c2, two_next, two_prev);
     }
   }
   double num = 0.0, den = 0.0, var = 0.0;
@@ -325,8 +351,8 @@ constexpr int kFramesPerBlock = 4;
 __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
                                                         const double* __restrict__ dc, const int32_t* __restrict__ dcount,
                                                         double fs, double f0_floor, double f0_ceil, int hmax, int seglen,
-                                                        const double2* __restrict__ tw_base, double* __restrict__ rf0,
-                                                        double* __restrict__ rsc) {
+                                                        const double2* __restrict__ tw_base, int tw_n,
+                                                        double* __restrict__ rf0, double* __restrict__ rsc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double cl_val[kFramesPerBlock * kRows];
   __shared__ int cl_meta[kFramesPerBlock * kRows];
@@ -335,6 +361,10 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict_
   const int64_t f_first = (int64_t)blockIdx.x * kFramesPerBlock;
   if (f_first >= m.nf1) return;
   double* yl = reinterpret_cast<double*>(smem);  // staged signal around the block's frames
+  // ... followed by the twiddle table of the largest transform length (tw_n points; 0: read the global tables):
+  // every sample of every refinement gathers up to 6 twiddles at scattered indices — LDS serves those, the L1 does not
+  double2* twl = tw_n ? reinterpret_cast<double2*>(yl + ((seglen + 1) & ~1)) : nullptr;
+  for (int i = threadIdx.x; i < tw_n; i += 256) twl[i] = tw_base[tw_n + i];
   const int64_t centre0 = (int64_t)floor(((double)f_first * 1 / 1000) * fs + 0.5);
   int64_t ybase = centre0 - hmax - 3;
   if (ybase < 0) ybase = 0;
@@ -371,7 +401,7 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict_
     const int q = cl_meta[it];
     const int64_t f = f_first + q / kRows;
     double r0, r1;
-    hv_refine_row(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[it], f0_floor, f0_ceil, tw_base, &r0, &r1);
+    hv_refine_row(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[it], f0_floor, f0_ceil, tw_base, twl, tw_n, &r0, &r1);
     if ((threadIdx.x & 15) == 0) {
       rf0[(m.f1_off + f) * kRows + q % kRows] = r0;
       rsc[(m.f1_off + f) * kRows + q % kRows] = r1;
@@ -621,8 +651,13 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   // ---- refinement + pruning ------------------------------------------------------------------------------
   {
     const int seglen = 2 * hmax + 8 + (kFramesPerBlock - 1) * ((int)ceil(fs_d / 1000.0) + 1);
-    const size_t lds = sizeof(double) * (size_t)seglen;
-    { wh::KernelTimer _kt(ctx, st, "hv_refine_kernel"); hipLaunchKernelGGL(hv_refine_kernel, dim3((unsigned)((max_nf1 + kFramesPerBlock - 1) / kFramesPerBlock), B), dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, d_rf0, d_rsc); }
+    int tw_n = 1;  // transform length of the longest window (harvest.py:171-172): 2 * 2^ceil(log2(2*hmax+1))
+    while (tw_n < 2 * hmax + 1) tw_n <<= 1;
+    tw_n <<= 1;
+    if (tw_n > 2048) tw_n = 0;  // 32 KB of LDS at most for the table; beyond that gather from the global tables
+    const size_t lds = sizeof(double) * (size_t)((seglen + 1) & ~1) + sizeof(double2) * (size_t)tw_n;
+    if (int rc = wh::allow_lds(&hv_refine_kernel, lds)) return rc;
+    { wh::KernelTimer _kt(ctx, st, "hv_refine_kernel"); hipLaunchKernelGGL(hv_refine_kernel, dim3((unsigned)((max_nf1 + kFramesPerBlock - 1) / kFramesPerBlock), B), dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rf0, d_rsc); }
     WH_LAUNCH_CHECK("hv_refine_kernel");
   }
   { wh::KernelTimer _kt(ctx, st, "hv_prune_kernel"); hipLaunchKernelGGL(hv_prune_kernel, dim3((unsigned)max_nf1, B), dim3(128), 0, st, d_meta, d_rf0, d_rsc, d_pf0, d_psc); }

@@ -19,6 +19,9 @@
 
 namespace {
 
+#ifndef WH_RESP_ABLATE
+#define WH_RESP_ABLATE 0
+#endif
 #ifndef WH_FT_SYNTH
 #define WH_FT_SYNTH 256
 #endif
@@ -596,6 +599,10 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
 
   // ---- minimum-phase responses (synthesis.py:86-116): aperiodic chain on thread group 0, periodic chain on
   //      group 1, advancing through the same barrier phases (with a single group: one after the other) --------
+#if WH_RESP_ABLATE == 2
+  if (threadIdx.x == 0) A.y[m.y_off] = spec[3] + asp[5] + mean;
+  return;
+#endif
   const double coef_pi = 2.0 * fs / N;  // coefficient = 2*pi*fs/N (synthesis.py:59), kept in units of pi
   if constexpr (NG == 2) {
     const int g = threadIdx.x / GT;
@@ -636,7 +643,11 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
 #pragma unroll
   for (int q = 0; q < R; ++q) acc[q] = 0.0;
   const int m0 = threadIdx.x * R;
+#if WH_RESP_ABLATE == 1
+  for (int64_t j0 = 0; j0 < 0; j0 += NZ) {
+#else
   for (int64_t j0 = 0; j0 < nd; j0 += NZ) {
+#endif
     const int cnt = (int)(nd - j0 < NZ ? nd - j0 : NZ);
     wh::sync<FT>();
     for (int j = threadIdx.x; j < NZ; j += FT) {

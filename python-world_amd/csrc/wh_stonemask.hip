@@ -99,7 +99,8 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
     const double v = (t0 + bt) * fs;
     const double idx_raw = v > 0 ? v + 0.5 : v - 0.5;
     const double wt = (idx_raw - 1) / fs - t0;
-    return 0.42 + 0.5 * cos(2 * M_PI * wt / wlit) + 0.08 * cos(4 * M_PI * wt / wlit);
+    const double c = cospi(2 * wt / wlit);           // cos(2*pi*wt/wlit) without the generic range reduction
+    return 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1);  // cos(4a) = 2cos^2(2a) - 1
   };
   double prev_last = 0.0;
   double cur = main_at(lane);

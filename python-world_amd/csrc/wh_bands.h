@@ -23,10 +23,28 @@ struct BandJob {
   int64_t seg_cap;
 };
 
-constexpr int kBandTile = 1024;
-// staging index with 2 doubles of padding every 32: keeps the 16-byte pair reads of lanes 4 samples apart on
-// different LDS banks
-__device__ __forceinline__ int zpad(int i) { return i + 2 * (i >> 5); }
+constexpr int kBandTile = 1024;   // outputs per tile of the plain path (and the unit of the segment split)
+constexpr int kBandTileR = 2048;  // outputs per tile of the register-tiled path: 8 consecutive outputs per thread
+constexpr int kBandR = 8;
+constexpr int kBandPlanes = kBandR / 2;
+
+// Register-tiled path: the staged input window is kept as 16-byte pairs dealt round-robin to kBandPlanes planes:
+// pair q = (z[2q], z[2q+1]) sits in plane q % 4 at slot q / 4.  Lane t (outputs 8t .. 8t+7) reads pair 4t + e with e
+// uniform, i.e. slot t + e/4 of plane e % 4: neighbouring lanes on neighbouring 16-byte slots (no bank conflicts)
+// and an address linear in t (no per-read index arithmetic, no bounds guard).
+// LDS arithmetic (MI355X_MICROARCH.md): a CU has ONE LDS pipe for its four SIMDs, so a wave may spend at most a
+// quarter as many LDS cycles as FP64-FMA cycles before LDS becomes the bound.  4 outputs per thread with the tap
+// pair read from LDS is exactly at that limit (2 x 4 LDS cycles per 8 FMAs x 4 cycles, measured 17 TFLOP/s);
+// 8 outputs per thread and the taps through the scalar unit (uniform address -> s_load -> SGPR operand of
+// v_fmac_f64) is 4 LDS cycles per 64 FMA cycles.
+__host__ __device__ __forceinline__ int band_plane_len(int zlen) {
+  const int slots = ((zlen + 1) / 2 + kBandPlanes - 1) / kBandPlanes + 1;
+  return 2 * slots + 2;  // +2 doubles: successive planes start 16 bytes further round the bank row
+}
+__device__ __forceinline__ int zmap(int i, int pl) {
+  const int q = i >> 1;
+  return (q & (kBandPlanes - 1)) * pl + ((q / kBandPlanes) << 1) + (i & 1);
+}
 
 // s[g] = sum_k taps[k] * z[(bias + 1 + g) - k], g in [0, M)
 template <bool FMA>
@@ -40,15 +58,21 @@ __global__ __launch_bounds__(256) void band_events_kernel(const BandJob* __restr
   const int b = blockIdx.x;
   const BandJob job = jobs[(int64_t)blockIdx.y * nb + b];
   const int lb = tap_len[b];
+  // register-tiled FIR on the plane layout (odd tap counts — every filter of the reference — keep the input pairs
+  // 16-byte aligned), else the plain sum on a linear layout
+  const bool tiled = FMA && (lb & 1);
+  const int tile = tiled ? kBandTileR : kBandTile;
   double* taps = reinterpret_cast<double*>(smem);      // lb
-  double* zt = taps + ((lb + 1) & ~1);                 // kBandTile + 2 + lb
-  double* sig = zt + ((zpad(kBandTile + 2 + lb) + 3) & ~1);  // kBandTile + 2
-  unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(sig + kBandTile + 2);  // 8
+  double* zt = taps + ((lb + 1) & ~1);                 // tile + 2 + lb - 1 staged inputs
+  const int pl = band_plane_len(kBandTileR + 2 + lb);
+  double* sig = zt + (FMA ? kBandPlanes * pl : ((kBandTile + 2 + lb + 1) & ~1));  // tile + 2 filtered samples
+  unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(sig + (FMA ? kBandTileR : kBandTile) + 2);  // 8
   for (int k = threadIdx.x; k < ((lb + 1) & ~1); k += 256) taps[k] = k < lb ? taps_all[tap_off[b] + k] : 0.0;
+  const double* __restrict__ tg = taps_all + tap_off[b];  // the same taps through the scalar unit (uniform address)
   int base_cnt[4] = {0, 0, 0, 0};
   const int64_t M = job.M;
-  // segment blockIdx.z of gridDim.z: a run of whole tiles with its own lists (gridDim.z == 1: the whole signal,
-  // straight into the final lists)
+  // segment blockIdx.z of gridDim.z: a run of whole kBandTile tiles with its own lists (gridDim.z == 1: the whole
+  // signal, straight into the final lists)
   const int nseg = gridDim.z;
   const int64_t tiles = (M + kBandTile - 1) / kBandTile;
   const int64_t tps = (tiles + nseg - 1) / nseg;
@@ -57,54 +81,83 @@ __global__ __launch_bounds__(256) void band_events_kernel(const BandJob* __restr
   double* edges_out = nseg > 1 ? job.seg_edges + (int64_t)blockIdx.z * 4 * job.seg_cap : job.edges;
   const int64_t cap_out = nseg > 1 ? job.seg_cap : job.cap;
   int32_t* counts_out = nseg > 1 ? job.seg_counts + blockIdx.z * 4 : job.counts;
-  for (int64_t t0 = t_begin; t0 < t_end; t0 += kBandTile) {
+  for (int64_t t0 = t_begin; t0 < t_end; t0 += tile) {
     __syncthreads();
     const int64_t zlo = t0 + bias[b] + 1 - (lb - 1);
-    for (int i = threadIdx.x; i < kBandTile + 2 + lb - 1; i += 256) {
+    for (int i = threadIdx.x; i < tile + 2 + lb - 1; i += 256) {
       const int64_t j = zlo + i + pad;
-      zt[zpad(i)] = (j >= 0 && j < M + 2 * pad) ? job.z[j] : 0.0;
+      zt[tiled ? zmap(i, pl) : i] = (j >= 0 && j < M + 2 * pad) ? job.z[j] : 0.0;
     }
     __syncthreads();
-    if (FMA) {
-      // register-tiled FIR: each thread owns 4 consecutive outputs and slides a 4-wide window over the
-      // staged input, two taps per step (one 16-byte LDS read for the tap pair, one for the two new inputs)
-      const int i0 = threadIdx.x * 4;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      const int top = i0 + (lb - 1);  // input index of output i0 for tap 0
-      double r0 = zt[zpad(top)], r1 = zt[zpad(top + 1)], r2 = zt[zpad(top + 2)], r3 = zt[zpad(top + 3)];
-      const int lbe = (lb + 1) & ~1;  // taps are zero padded to an even count
-      for (int k = 0; k < lbe; k += 2) {
-        const double2 tk = *reinterpret_cast<const double2*>(taps + k);
-        const int inew = top - k - 2;  // even → aligned pair (z[inew], z[inew+1])
-        double2 fresh = make_double2(0.0, 0.0);
-        if (inew >= 0) fresh = *reinterpret_cast<const double2*>(zt + zpad(inew));
-        a0 = fma(tk.x, r0, a0); a1 = fma(tk.x, r1, a1); a2 = fma(tk.x, r2, a2); a3 = fma(tk.x, r3, a3);
-        r3 = r2; r2 = r1; r1 = r0; r0 = fresh.y;
-        a0 = fma(tk.y, r0, a0); a1 = fma(tk.y, r1, a1); a2 = fma(tk.y, r2, a2); a3 = fma(tk.y, r3, a3);
-        r3 = r2; r2 = r1; r1 = r0; r0 = fresh.x;
+    if (tiled) {
+      constexpr int R = kBandR;
+      const int i0 = threadIdx.x * R;
+      double acc[R], r[R];
+      const int top = i0 + (lb - 1);  // input index of output i0 for tap 0 (even)
+      const double2* zt2 = reinterpret_cast<const double2*>(zt);
+      const int pl2 = pl >> 1;
+      const int full = (lb - 1) >> 1;  // steps with two real taps; one last tap follows (lb is odd)
+#pragma unroll
+      for (int q = 0; q < R; q += 2) {  // the window of tap 0: pairs top/2 + q/2 = 4*tid + full + q/2
+        const int eq = full + (q >> 1);
+        const double2 v = zt2[(eq & (kBandPlanes - 1)) * pl2 + (eq >> 2) + threadIdx.x];
+        acc[q] = 0.0;
+        acc[q + 1] = 0.0;
+        r[q] = v.x;
+        r[q + 1] = v.y;
       }
-      sig[i0] = t0 + i0 < M ? a0 : 0.0;
-      sig[i0 + 1] = t0 + i0 + 1 < M ? a1 : 0.0;
-      sig[i0 + 2] = t0 + i0 + 2 < M ? a2 : 0.0;
-      sig[i0 + 3] = t0 + i0 + 3 < M ? a3 : 0.0;
-      if (threadIdx.x < 2) {  // the two look-ahead samples the crossing detector needs
-        const int i = kBandTile + threadIdx.x;
-        double acc = 0.0;
+      // step s consumes taps 2s, 2s+1 and the input pair top/2 - 1 - s = 4*tid + e, e = (lb-1)/2 - 1 - s >= 0
+      int e = full - 1;
+#pragma unroll 4
+      for (int sidx = 0; sidx < full; ++sidx, --e) {
+        const double tx = tg[2 * sidx], ty = tg[2 * sidx + 1];
+        const double2 fresh = zt2[(e & (kBandPlanes - 1)) * pl2 + (e >> 2) + threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] = fma(tx, r[q], acc[q]);
+#pragma unroll
+        for (int q = R - 1; q > 0; --q) r[q] = r[q - 1];
+        r[0] = fresh.y;
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] = fma(ty, r[q], acc[q]);
+#pragma unroll
+        for (int q = R - 1; q > 0; --q) r[q] = r[q - 1];
+        r[0] = fresh.x;
+      }
+      {
+        const double tx = tg[lb - 1];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] = fma(tx, r[q], acc[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) sig[i0 + q] = t0 + i0 + q < M ? acc[q] : 0.0;
+      {  // the two look-ahead samples the crossing detector needs: 128 threads each, taps strided, then reduced
+        const int i = tile + (threadIdx.x >> 7);
+        double a = 0.0;
         if (t0 + i < M)
-          for (int k = 0; k < lb; ++k) acc = fma(taps[k], zt[zpad(i + (lb - 1) - k)], acc);
-        sig[i] = acc;
+          for (int k = threadIdx.x & 127; k < lb; k += 128) a = fma(taps[k], zt[zmap(i + (lb - 1) - k, pl)], a);
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) reinterpret_cast<double*>(scan_scratch)[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x < 2) {
+          const double* la = reinterpret_cast<const double*>(scan_scratch);
+          sig[tile + threadIdx.x] = la[2 * threadIdx.x] + la[2 * threadIdx.x + 1];
+        }
       }
     } else {
       for (int i = threadIdx.x; i < kBandTile + 2; i += 256) {
-        double acc = 0.0;
+        double a = 0.0;
         if (t0 + i < M) {
-          for (int k = 0; k < lb; ++k) acc += taps[k] * zt[zpad(i + (lb - 1) - k)];
+          for (int k = 0; k < lb; ++k) a += taps[k] * zt[i + (lb - 1) - k];
         }
-        sig[i] = acc;
+        sig[i] = a;
       }
     }
     __syncthreads();
     emit_crossings(sig, t0, M, kBandTile, edges_out, cap_out, base_cnt, scan_scratch, flags);
+    if (tiled && t0 + kBandTile < t_end) {  // second half of the 2048-sample tile (its look-ahead is sig[2048..2049])
+      __syncthreads();
+      emit_crossings(sig + kBandTile, t0 + kBandTile, M, kBandTile, edges_out, cap_out, base_cnt, scan_scratch, flags);
+    }
   }
   if (threadIdx.x < 4) counts_out[threadIdx.x] = base_cnt[threadIdx.x];
 }
@@ -132,8 +185,10 @@ static __global__ __launch_bounds__(256) void band_concat_kernel(const BandJob* 
 inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs, int nb, int n_utt, int pad,
                               const double* d_taps, const int32_t* d_tap_off, const int32_t* d_tap_len,
                               const int32_t* d_bias, int max_lb, bool use_fma, int32_t* d_flag, int nseg = 1) {
-  const int zlen = kBandTile + 2 + max_lb;
-  const size_t lds = sizeof(double) * (((max_lb + 1) & ~1) + ((zlen + 2 * (zlen >> 5) + 3) & ~1) + kBandTile + 2) + 64;
+  const size_t lds_tiled = sizeof(double) * (((max_lb + 1) & ~1) + kBandPlanes * band_plane_len(kBandTileR + 2 + max_lb) +
+                                             kBandTileR + 2) + 64;
+  const size_t lds_plain = sizeof(double) * (((max_lb + 1) & ~1) + ((kBandTile + 2 + max_lb + 1) & ~1) + kBandTile + 2) + 64;
+  const size_t lds = use_fma ? lds_tiled : lds_plain;
   if (use_fma) {
     if (int rc = allow_lds(&band_events_kernel<true>, lds)) return rc;
     { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_kernel<true>, dim3(nb, n_utt, nseg), dim3(256), lds, st, d_jobs, pad, d_taps, d_tap_off, d_tap_len, d_bias, nb, d_flag); }

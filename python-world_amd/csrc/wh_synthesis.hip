@@ -355,6 +355,37 @@ __global__ void pulse_base_kernel(const int32_t* __restrict__ p_count, int n_utt
   }
 }
 
+// Per pulse: the two frames it interpolates between and the weight of the later one (synthesis.py:49-51,144-180).
+// One thread per pulse here, so that the 256-thread response workgroups do not each walk the same 11-deep chain of
+// dependent loads (binary search over the frame times) before they can start.
+__global__ __launch_bounds__(256) void pulse_frames_kernel(const SynUtt* __restrict__ meta, const double* __restrict__ tp,
+                                                           const double* __restrict__ p_time,
+                                                           const int32_t* __restrict__ p_count,
+                                                           int64_t* __restrict__ p_frames, double* __restrict__ p_weight) {
+  const SynUtt m = meta[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p_count[blockIdx.y]) return;
+  const double* tpu = tp + m.f_off;
+  const double ptime = p_time[m.p_off + i];
+  // temporal_position_index = interp(tp -> 1..F)(time), clipped to [1, F]
+  int64_t lo = 0, hi = m.nf;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (tpu[mid] < ptime) lo = mid + 1; else hi = mid;
+  }
+  const int64_t ih = lo < 1 ? 1 : (lo > m.nf - 1 ? m.nf - 1 : lo);
+  const int64_t il = ih - 1;
+  const double slope = ((double)(ih + 1) - (double)(il + 1)) / (tpu[ih] - tpu[il]);
+  double pos = slope * (ptime - tpu[il]) + (double)(il + 1);
+  pos = fmax(1.0, fmin((double)m.nf, pos));
+  const int64_t flo = (int64_t)floor(pos) - 1;
+  const int64_t fhi = (int64_t)ceil(pos) - 1;
+  const double t1 = tpu[flo], t2 = tpu[fhi];
+  const double xq = fmax(t1, fmin(t2, ptime));
+  p_frames[m.p_off + i] = flo | (fhi << 32);
+  p_weight[m.p_off + i] = (t1 == t2) ? -1.0 : (xq - t1) / (t2 - t1);  // -1: both frames are the same one
+}
+
 inline int pulse_tiles(int64_t max_ny) { return max_ny > 1 ? (int)((max_ny - 1 + kPTile - 1) / kPTile) : 1; }
 // scratch of the pulse stage: crossing masks (one byte per 4 samples) and per-tile counts
 inline size_t pulse_scratch_bytes(int B, int64_t max_ny) {
@@ -452,6 +483,8 @@ struct RespArgs {
   const int64_t* p_idx;
   const double* p_shift;
   const int64_t* p_noff;
+  const int64_t* p_frames;
+  const double* p_weight;
   const int32_t* p_count;
   const int64_t* p_base;
   int n_utt;
@@ -517,37 +550,19 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   const SynUtt m = meta[u];
   const int i = (int)(gp - p_base[u]);
   const int count = p_count[u];
-  const double ptime = p_time[m.p_off + i];
   const int64_t pidx = p_idx[m.p_off + i];
   const double shift = p_shift[m.p_off + i];
   const int64_t pidx_next = p_idx[m.p_off + (i + 1 < count ? i + 1 : count - 1)];
   const int64_t noise_size = pidx_next - pidx;
-  const double* tpu = tp + m.f_off;
 
   // ---- spectral parameters of this pulse (synthesis.py:49-51,144-180) -------------------------
-  int64_t flo, fhi;
-  double a, b;
-  bool same;
-  {
-    // temporal_position_index = interp(tp -> 1..F)(time), clipped to [1, F]
-    int64_t lo = 0, hi = m.nf;
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (tpu[mid] < ptime) lo = mid + 1; else hi = mid;
-    }
-    int64_t ih = lo < 1 ? 1 : (lo > m.nf - 1 ? m.nf - 1 : lo);
-    const int64_t il = ih - 1;
-    const double slope = ((double)(ih + 1) - (double)(il + 1)) / (tpu[ih] - tpu[il]);
-    double pos = slope * (ptime - tpu[il]) + (double)(il + 1);
-    pos = fmax(1.0, fmin((double)m.nf, pos));
-    flo = (int64_t)floor(pos) - 1;
-    fhi = (int64_t)ceil(pos) - 1;
-    const double t1 = tpu[flo], t2 = tpu[fhi];
-    const double xq = fmax(t1, fmin(t2, ptime));
-    same = (t1 == t2);
-    b = same ? 0.0 : (xq - t1) / (t2 - t1);
-    a = 1 - b;
-  }
+  // the two neighbouring frames and the interpolation weight, from pulse_frames_kernel
+  const int64_t fpair = A.p_frames[m.p_off + i];
+  const int64_t flo = fpair & 0xffffffffll, fhi = fpair >> 32;
+  const double bw = A.p_weight[m.p_off + i];
+  const bool same = bw < 0.0;
+  const double b = same ? 0.0 : bw;
+  const double a = 1 - b;
   const double* s_lo = spectrogram + (m.f_off + flo) * K;
   const double* s_hi = spectrogram + (m.f_off + fhi) * K;
   const double* a_lo = aperiodicity + (m.f_off + flo) * K;
@@ -721,7 +736,10 @@ template <int N>
 int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynUtt* d_meta, const double* tp,
                 const double* spec, const double* ap, double fs, const double* p_time, const int64_t* p_idx,
                 const double* p_shift, const int64_t* p_noff, const int32_t* p_count, const int64_t* p_base,
-                const uint8_t* vuv_s, const double* noise, uint64_t seed, double* y) {
+                const uint8_t* vuv_s, const double* noise, uint64_t seed, double* y, int64_t* p_frames,
+                double* p_weight) {
+  { wh::KernelTimer _kt(ctx, st, "pulse_frames_kernel"); hipLaunchKernelGGL(pulse_frames_kernel, dim3((unsigned)((pcap_max + 255) / 256), B), dim3(256), 0, st, d_meta, tp, p_time, p_count, p_frames, p_weight); }
+  WH_LAUNCH_CHECK("pulse_frames_kernel");
   std::vector<double> dc(N);
   double sum = 0.0;
   for (int n = 0; n < N; ++n) {  // hanning(N+2)[1:-1] normalised (synthesis.py:57-58)
@@ -734,7 +752,7 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   const size_t lds = sizeof(double) * (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32);
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
   const int64_t grid = pcap_max * B;  // one workgroup per pulse slot; slots past the real count exit at once
-  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_time, p_idx, p_shift, p_noff, p_count, p_base, B, vuv_s, noise, seed, d_dc, ctx->d_twiddle, y};
+  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_time, p_idx, p_shift, p_noff, p_frames, p_weight, p_count, p_base, B, vuv_s, noise, seed, d_dc, ctx->d_twiddle, y};
   hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(FT), lds, st, ra); }
   WH_LAUNCH_CHECK("response_kernel");
   return 0;
@@ -941,6 +959,8 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   const size_t o_pc = off; off += al(sizeof(int32_t) * B);
   const size_t o_px = off; off += pulse_scratch_bytes(B, max_ny);
   const size_t o_pb = off; off += al(sizeof(int64_t) * (B + 1));
+  const size_t o_pf = off; off += al(sizeof(int64_t) * B * pulse_cap);
+  const size_t o_pw = off; off += al(sizeof(double) * B * pulse_cap);
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
   SynUtt* d_meta = nullptr;
@@ -951,6 +971,8 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   int64_t* d_pi = reinterpret_cast<int64_t*>(ws + o_pi);
   double* d_ps = reinterpret_cast<double*>(ws + o_ps);
   int64_t* d_pn = reinterpret_cast<int64_t*>(ws + o_pn);
+  int64_t* d_pf = reinterpret_cast<int64_t*>(ws + o_pf);
+  double* d_pw = reinterpret_cast<double*>(ws + o_pw);
   int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
   if (int rc = wh::persistent_upload(ctx, "syn.meta", meta, &d_meta)) return rc;
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
@@ -964,10 +986,10 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   WH_LAUNCH_CHECK("pulse_base_kernel");
   int rc;
   switch (fft_size) {
-    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y); break;
-    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y); break;
-    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y); break;
-    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y); break;
+    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw); break;
+    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw); break;
+    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw); break;
+    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw); break;
     default: return wh::fail_msg("wh_synthesis", "fft_size must be a power of two in [512, 4096]");
   }
   if (rc) return rc;

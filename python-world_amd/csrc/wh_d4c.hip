@@ -14,6 +14,9 @@
 #ifndef WH_D4C_ABLATE
 #define WH_D4C_ABLATE 0
 #endif
+#ifndef WH_D4C_RMAXR
+#define WH_D4C_RMAXR 4
+#endif
 #ifndef WH_D4C_MAXR
 #define WH_D4C_MAXR 4
 #endif
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
 #pragma unroll
     for (int q = 0; q < N / FT; ++q) zr[threadIdx.x + q * FT] = v[q];
     wh::sync<FT>();
-    wh::rfft_lds<N, FT, FT, WH_D4C_MAXR>(buf, tw_base);
+    wh::rfft_lds<N, FT, FT, WH_D4C_RMAXR>(buf, tw_base);
     for (int k = threadIdx.x; k < K; k += FT) {
       const double2 z = buf[k];
       pw[k] = z.x * z.x + z.y * z.y;
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
       zr[j] = val;
     }
     wh::sync<FT>();
-    wh::rfft_lds<N, FT, FT, WH_D4C_MAXR>(buf, tw_base);
+    wh::rfft_lds<N, FT, FT, WH_D4C_RMAXR>(buf, tw_base);
     for (int k = threadIdx.x; k < K; k += FT) {
       const double2 z = buf[k];
       pw[k] = z.x * z.x + z.y * z.y;

@@ -162,6 +162,12 @@ int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, const double
                       const double* vuv, double fs, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
                       int64_t pulse_cap, int32_t* h_pulse_count, int64_t* h_noise_total);
 
+/* The phase accumulator of synthesis() is np.cumsum over the per-sample phase increments (world/synthesis.py:128):
+ * a sequential float64 sum whose rounding decides the pulse positions.  This entry exposes the routine that
+ * reproduces it bit for bit (in place, n_seg independent segments of NON-NEGATIVE doubles, h_off[n_seg + 1] element
+ * offsets into d_data) so that the agreement can be tested directly. */
+int wh_cumsum_exact(wh_ctx* ctx, void* stream, double* d_data, const int64_t* h_off, int n_seg);
+
 /* ---- Requiem synthesis: replaces synthesisRequiem()  (world/synthesisRequiem.py:12-25) ------------ */
 /* band_aperiodicity[total_frames][n_bands] in dB as produced by wh_d4c_requiem (n_bands = bands+2 <= 8).
  * Seed tables (DEVICE, row-major like the reference's NumPy arrays): pulse_seed[pulse_fft][n_bands],

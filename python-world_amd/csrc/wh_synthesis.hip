@@ -3,9 +3,8 @@
 //   prep_kernel     : per output sample: f0/vuv linear interpolation at t_i, phase increment
 //                     2*pi*f0/fs (synthesis.py:121-128).  Embarrassingly parallel.
 //   phase_kernel    : per utterance: the cumulative phase is a SEQUENTIAL float64 sum in the reference
-//                     (np.cumsum); one lane walks exactly that left-to-right sum and checkpoints it every 16
-//                     samples, a helper wave replays the segments in parallel, so the pulse positions
-//                     derived from the phase are bit-identical to NumPy's.
+//                     (np.cumsum); reproduced bit for bit by an integer prefix sum per binade of the running
+//                     sum (exact_cumsum_block), so the pulse positions derived from it are NumPy's.
 //   pulse_*_kernel  : wrap phase, detect pulses (|d wrap| > pi), ordered compaction, 1-based sample index and
 //                     fractional shift per pulse, noise-stream offsets (synthesis.py:129-138, 65): tile-parallel
 //                     mark / scan / emit, then a per-utterance finish.
@@ -64,123 +63,153 @@ __global__ __launch_bounds__(256) void prep_kernel(const SynUtt* __restrict__ me
   vuv_s[m.y_off + i] = v ? 1 : 0;
 }
 
-// In-place sequential cumulative sum, one workgroup of two waves per utterance, bit-identical to np.cumsum (one
-// rounding per sample, left to right).  Measured on MI355X (tools/ubench/chain.hip): a dependent FP64 add issues
-// every ~2.5 ns and a ds_read_b128 adds ~1.7 ns per sample, but an LDS *store* from a single lane costs ~12 ns —
-// so the serial chain must not write the sums back.  Per tile of 2048 samples:
-//   stage  : the helper wave copies the tile into LDS (coalesced global loads);
-//   chain  : the chain wave walks the tile with the exact adds (all lanes redundantly, on broadcast operands) and
-//            keeps only the carry-in of every 16-sample segment, lane g that of segment g: no LDS store sits on
-//            the add chain;
-//   replay : the helper wave replays the segments from those carry-ins — the same adds in the same order, hence
-//            the same bits — 64 segments at a time, and writes the tile out with coalesced stores.
-// The tiles are double-buffered: while the chain runs on tile t the helper replays tile t-1 and stages tile t+1,
-// so the kernel's duration is the add chain itself.  Segments are padded to 18 doubles in LDS: 16-byte alignment
-// for the b128 reads of the chain, spread banks for the segment-strided accesses of the replay.
-constexpr int kScanTile = 2048;
-constexpr int kScanSeg = 16;
-constexpr int kScanSegs = kScanTile / kScanSeg;
-constexpr int kScanPad = kScanSeg + 2;
-__global__ __launch_bounds__(128) void phase_kernel(const SynUtt* __restrict__ meta, double* __restrict__ phase) {
-  __shared__ __attribute__((aligned(16))) double tile[2][kScanSegs * kScanPad];
-  __shared__ double carry_in[2][kScanSegs];
+// In-place cumulative sum of NON-NEGATIVE doubles, bit-identical to the sequential float64 sum (np.cumsum: one
+// rounding per sample, left to right) — without being sequential.
+//
+// While the running sum a stays inside one binade [2^k, 2^(k+1)) every partial sum is a multiple of the binade's
+// ulp q = 2^(k-52), and fl(a + x) = a + RN_q(x): the rounding of each addend to a multiple of q does not depend on
+// a (except for exact ties, which round to the even neighbour of a + x).  So inside a binade the sequence is an
+// INTEGER prefix sum of r_j = RN(x_j / q), exact in any order.  One workgroup per utterance walks 2048-sample tiles:
+//   * r_j for its 8 samples per thread, thread-local prefix, block scan  -> V_j = a/q + sum r;
+//   * the first stop point of the pass — an exact tie, or V_j >= 2^53 (the sum leaves the binade) — is found with
+//     min-reductions; everything before it is final (value V_j * q);
+//   * the stop element itself is done as the true floating-point add, becomes the new carry, and the pass
+//     repeats behind it.  There are ~17 binade crossings and ~1 tie per binade in a whole utterance, so a tile
+//     takes one pass almost always.
+// 5 ns per sample for the sequential add chain (tools/ubench/chain.hip) becomes ~0.5 ns.
+#ifndef WH_XTILE
+#define WH_XTILE 2048
+#endif
+constexpr int kXTile = WH_XTILE;
+constexpr int kXThreads = 256;
+constexpr int kXPer = kXTile / kXThreads;
+__device__ __forceinline__ int xpad(int i) { return i + (i >> 3); }  // thread-contiguous runs of 8: stride 9 doubles
+
+__device__ __forceinline__ int wave_min_int(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int u = __shfl_xor(v, o, 64);
+    v = u < v ? u : v;
+  }
+  return v;
+}
+
+// p[0..n): in place.  xin / xout: kXTile + kXTile/8 doubles of LDS each; scr: 16 doubles.  One workgroup of 256.
+// All integer quantities (r_j, their prefix sums, V_j < 2^53) are carried as integer-valued doubles: exact, and
+// the whole pass stays on the FP64 pipe.
+__device__ __forceinline__ void exact_cumsum_block(double* __restrict__ p, int64_t n, double* xin, double* xout,
+                                                   double* scr) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  constexpr double kTop = 0x1p53;  // V reaches this: the sum has left the binade
+  double carry = 0.0;              // the running sum before the current tile (uniform)
+  double pre[kXPer];               // the next tile, in flight from global memory while this one is scanned
+#pragma unroll
+  for (int q = 0; q < kXPer; ++q) {
+    const int64_t i = (int64_t)q * kXThreads + tid;
+    pre[q] = i < n ? p[i] : 0.0;
+  }
+  for (int64_t base = 0; base < n; base += kXTile) {
+    const int cnt = (int)(n - base < kXTile ? n - base : kXTile);
+#pragma unroll
+    for (int q = 0; q < kXPer; ++q) xin[xpad(q * kXThreads + tid)] = pre[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kXPer; ++q) {
+      const int64_t i = base + kXTile + (int64_t)q * kXThreads + tid;
+      pre[q] = i < n ? p[i] : 0.0;
+    }
+    double x[kXPer];
+#pragma unroll
+    for (int j = 0; j < kXPer; ++j) x[j] = xin[xpad(tid * kXPer + j)];
+    int s = 0;  // first element of the tile that is not final yet (uniform)
+    while (s < cnt) {
+      const int ebits = (int)((__double_as_longlong(carry) >> 52) & 0x7ff);
+      int jstop = s;  // carry == 0 (or subnormal): fl(carry + x) straight away
+      if (ebits != 0) {
+        const int sh = 52 - (ebits - 1023);     // x / q = x * 2^sh, exact
+        const double c_int = ldexp(carry, sh);  // in [2^52, 2^53)
+        double r[kXPer];
+        double run = 0.0;
+        int first_tie = kXTile;
+#pragma unroll
+        for (int j = 0; j < kXPer; ++j) {
+          const int idx = tid * kXPer + j;
+          double rj = 0.0;
+          if (idx >= s && idx < cnt) {
+            const double sc = fmin(ldexp(x[j], sh), 0x1p54);
+            const double fl = floor(sc);
+            const double fr = sc - fl;  // exact: sc has at most 53 significant bits
+            rj = fl + (fr > 0.5 ? 1.0 : 0.0);
+            if (fr == 0.5 && first_tie == kXTile) first_tie = idx;
+          }
+          run += rj;   // exact while < 2^53; beyond that only "it is >= 2^53" matters, and that it stays
+          r[j] = run;  // thread-local inclusive prefix
+        }
+        double incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const double u = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += u;
+        }
+        if (lane == 63) scr[w] = incl;
+        __syncthreads();
+        // exclusive prefix from the lanes below only: incl - run would go through this thread's own run, which is
+        // inexact (>= 2^53) once the thread lies behind a binade crossing — and would spoil lanes that do not
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 0.0;
+        double before = c_int + excl;  // V just before this thread's first element
+        for (int i = 0; i < w; ++i) before += scr[i];
+        int first_x = kXTile;
+#pragma unroll
+        for (int j = 0; j < kXPer; ++j) {
+          const int idx = tid * kXPer + j;
+          if (idx >= s && idx < cnt && before + r[j] >= kTop && first_x == kXTile) first_x = idx;
+        }
+        const int mine = wave_min_int(first_tie < first_x ? first_tie : first_x);
+        int* iscr = reinterpret_cast<int*>(scr + 8);
+        if (lane == 0) iscr[w] = mine;
+        __syncthreads();
+        jstop = iscr[0];
+#pragma unroll
+        for (int i = 1; i < kXThreads / 64; ++i) jstop = iscr[i] < jstop ? iscr[i] : jstop;
+        if (jstop > cnt) jstop = cnt;
+        const double q = ldexp(1.0, -sh);
+#pragma unroll
+        for (int j = 0; j < kXPer; ++j) {
+          const int idx = tid * kXPer + j;
+          if (idx >= s && idx < jstop) xout[xpad(idx)] = (before + r[j]) * q;  // V < 2^53 times a power of two: exact
+        }
+        __syncthreads();
+      }
+      if (jstop < cnt) {  // the stop element: the floating-point add itself
+        const double a = jstop == s ? carry : xout[xpad(jstop - 1)];
+        const double res = a + xin[xpad(jstop)];
+        __syncthreads();  // everyone has read xout[jstop - 1] / scr before they change
+        if (tid == 0) xout[xpad(jstop)] = res;
+        carry = res;
+        s = jstop + 1;
+      } else {
+        carry = xout[xpad(cnt - 1)];
+        s = cnt;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < cnt; i += kXThreads) p[base + i] = xout[xpad(i)];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kXThreads) void phase_kernel(const SynUtt* __restrict__ meta, double* __restrict__ phase) {
+  __shared__ double xin[kXTile + kXTile / 8], xout[kXTile + kXTile / 8], scr[16];
   const SynUtt m = meta[blockIdx.x];
-  double* p = phase + m.y_off;
-  const int lane = threadIdx.x & 63;
-  const bool helper = threadIdx.x >= 64;
-  auto slot = [](int i) { return i + 2 * (i >> 4); };
-  const int64_t tiles = (m.ny + kScanTile - 1) / kScanTile;
-  constexpr int PER = kScanTile / 64;
-  double pre[PER];  // helper wave: the next tile, in flight from global memory
-  auto fetch = [&](int64_t t) {
-    const int64_t base = t * kScanTile;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const int64_t i = base + (int64_t)q * 64 + lane;
-      pre[q] = i < m.ny ? p[i] : 0.0;
-    }
-  };
-  auto stage = [&](int64_t t) {
-    double* dst = tile[t & 1];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) dst[slot(q * 64 + lane)] = pre[q];
-  };
-  // the two waves only ever hand LDS contents to each other: a barrier that orders LDS alone does not make the
-  // helper wait for its global stores to drain
-  auto lds_barrier = [] {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-  };
-  if (helper && tiles > 0) {
-    fetch(0);
-    stage(0);
-  }
-  lds_barrier();
-  double run = 0.0;  // chain wave: the running sum (the same value in every lane)
-  for (int64_t t = 0; t <= tiles; ++t) {
-    if (!helper) {
-      if (t < tiles) {
-        // Every lane of the chain wave runs the same adds on the same (broadcast) LDS operands, so `run` is
-        // identical in all of them and lane g can simply keep the value it sees before segment g: the carry-ins
-        // leave the chain through one wave-wide store per 64 segments instead of a single-lane LDS store (whose
-        // latency would sit on the critical path) per segment.
-        const double2* t2 = reinterpret_cast<const double2*>(tile[t & 1]);
-        double* cin = carry_in[t & 1];
-        double2 a[8], b[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] = t2[q];
-        for (int sb = 0; sb < kScanSegs; sb += 64) {
-          double keep = 0.0;
-          for (int sg = sb; sg < sb + 64; sg += 2) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) b[q] = t2[(sg + 1) * (kScanPad / 2) + q];
-            keep = lane == sg - sb ? run : keep;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              run += a[q].x;
-              run += a[q].y;
-            }
-            if (sg + 2 < kScanSegs) {
-#pragma unroll
-              for (int q = 0; q < 8; ++q) a[q] = t2[(sg + 2) * (kScanPad / 2) + q];
-            }
-            keep = lane == sg + 1 - sb ? run : keep;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              run += b[q].x;
-              run += b[q].y;
-            }
-          }
-          cin[sb + lane] = keep;
-        }
-      }
-    } else {
-      if (t + 1 < tiles) fetch(t + 1);  // issued first: in flight under the replay below
-      if (t >= 1) {  // replay and write out tile t-1
-        double* buf = tile[(t - 1) & 1];
-        const double* cin = carry_in[(t - 1) & 1];
-#pragma unroll
-        for (int h = 0; h < kScanSegs / 64; ++h) {
-          const int sg = lane + h * 64;
-          double r = cin[sg];
-          double* seg = buf + sg * kScanPad;
-#pragma unroll
-          for (int j = 0; j < kScanSeg; ++j) {
-            r += seg[j];
-            seg[j] = r;
-          }
-        }
-        wh::sync<64>();
-        const int64_t base = (t - 1) * kScanTile;
-        const int cnt = (int)(m.ny - base < kScanTile ? m.ny - base : kScanTile);
-        for (int i = lane; i < cnt; i += 64) p[base + i] = buf[slot(i)];
-        wh::sync<64>();
-      }
-      if (t + 1 < tiles) stage(t + 1);  // into the buffer just written out
-    }
-    lds_barrier();
-  }
+  exact_cumsum_block(phase + m.y_off, m.ny, xin, xout, scr);
+}
+
+// Test / utility entry: the same scan over independent segments off[i] .. off[i+1].
+__global__ __launch_bounds__(kXThreads) void exact_cumsum_kernel(double* __restrict__ data, const int64_t* __restrict__ off) {
+  __shared__ double xin[kXTile + kXTile / 8], xout[kXTile + kXTile / 8], scr[16];
+  exact_cumsum_block(data + off[blockIdx.x], off[blockIdx.x + 1] - off[blockIdx.x], xin, xout, scr);
 }
 
 // Pulse detection (synthesis.py:129-138) in four launches, none of them serial in the utterance length:
@@ -979,7 +1008,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
                      d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
-  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(128), 0, st, d_meta, d_phase); }
+  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(kXThreads), 0, st, d_meta, d_phase); }
   WH_LAUNCH_CHECK("phase_kernel");
   if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ws + o_px)) return rc;
   { wh::KernelTimer _kt(ctx, st, "pulse_base_kernel"); hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb); }
@@ -994,6 +1023,21 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   }
   if (rc) return rc;
   if (pulse_count_out) WH_CHECK(hipMemcpyAsync(pulse_count_out, d_pc, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// In-place exact sequential cumulative sum of n_seg independent segments of NON-NEGATIVE doubles
+// (h_off[n_seg + 1] element offsets into d_data) — the routine behind the phase accumulator, exposed so that its
+// bit-for-bit agreement with np.cumsum can be tested directly.
+extern "C" int wh_cumsum_exact(wh_ctx* ctx, void* stream, double* d_data, const int64_t* h_off, int n_seg) {
+  if (!ctx || !d_data || !h_off || n_seg < 0) return wh::fail_msg("wh_cumsum_exact", "bad argument");
+  if (n_seg == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<int64_t> off(h_off, h_off + n_seg + 1);
+  int64_t* d_off = nullptr;
+  if (int rc = wh::persistent_upload(ctx, "cumsum.off", off, &d_off)) return rc;
+  { wh::KernelTimer _kt(ctx, st, "exact_cumsum_kernel"); hipLaunchKernelGGL(exact_cumsum_kernel, dim3(n_seg), dim3(kXThreads), 0, st, d_data, d_off); }
+  WH_LAUNCH_CHECK("exact_cumsum_kernel");
   return 0;
 }
 
@@ -1047,7 +1091,7 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
                      d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
-  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(128), 0, st, d_meta, d_phase); }
+  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(kXThreads), 0, st, d_meta, d_phase); }
   WH_LAUNCH_CHECK("phase_kernel");
   if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, reinterpret_cast<double*>(ws + o_pt), d_pi,
                              reinterpret_cast<double*>(ws + o_ps), d_pn, d_pc, ws + o_px)) return rc;
@@ -1137,7 +1181,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs, d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
-  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(128), 0, st, d_meta, d_phase); }
+  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(kXThreads), 0, st, d_meta, d_phase); }
   WH_LAUNCH_CHECK("phase_kernel");
   if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ws + o_px)) return rc;
   { wh::KernelTimer _kt(ctx, st, "pulse_base_kernel"); hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb); }

@@ -174,7 +174,9 @@ constexpr int kMaxBands = 32;
 #ifndef WH_DIO_BAND_SEGS
 #define WH_DIO_BAND_SEGS 4
 #endif
-constexpr int kBandSegs = WH_DIO_BAND_SEGS;  // workgroups per (band, utterance) in the event extraction
+constexpr int kBandSegsMin = WH_DIO_BAND_SEGS;  // workgroups per (band, utterance) in the event extraction, at least
+constexpr int kBandSegsMax = 32;
+constexpr int kBandTilesPerSeg = 10;  // long signals: more segments, about this many 1024-sample tiles each
 
 __global__ __launch_bounds__(256) void sort_kernel(const DioUtt* __restrict__ meta, int nb, const double* __restrict__ raw,
                                                    const double* __restrict__ stab, double* __restrict__ sorted,
@@ -453,6 +455,12 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   // segment-private event lists: 7 bands x B utterances alone cannot fill 256 CUs with their serial tile loops
   std::vector<int64_t> seg_cap(B), seg_off(B);
   int64_t se_tot = 0;
+  int kBandSegs = kBandSegsMin;
+  {
+    const int64_t max_tiles = (max_ylen + wh::kBandTile - 1) / wh::kBandTile;
+    const int64_t want = (max_tiles + kBandTilesPerSeg - 1) / kBandTilesPerSeg;
+    if (want > kBandSegs) kBandSegs = (int)(want < kBandSegsMax ? want : kBandSegsMax);
+  }
   for (int u = 0; u < B; ++u) {
     const int64_t tiles = (meta[u].ylen + wh::kBandTile - 1) / wh::kBandTile;
     seg_cap[u] = ((tiles + kBandSegs - 1) / kBandSegs) * (wh::kBandTile / 2) + 2;

@@ -39,9 +39,10 @@ constexpr int minblk_of(int n) { return n >= 4096 ? 1 : WH_D4C_MINBLK; }
 
 // Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110).  Values for samples j = tid + q*FT land
 // in the caller's registers v[q] (zero beyond the window; rows longer than N are cropped like
-// np.fft.fft(x, n), Q7).  tmp: unused (kept for the call sites).  Returns sum(wave^2) over the FULL window.
+// np.fft.fft(x, n), Q7).  tmp: unused (kept for the call sites).  Returns sum(wave^2) over the FULL window
+// (ENERGY = false: 0, and one block reduction less).
 // BLACKMAN selects window type 2, else Hann.
-template <bool BLACKMAN, int N>
+template <bool BLACKMAN, int N, bool ENERGY = true>
 __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long long xn, double fs, double cf,
                                              double pos, double half_length, double* tmp, double (&v)[N / ft_of(N)],
                                              double* scratch) {
@@ -90,6 +91,7 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
     }
     v[q] = val;
   }
+  if (!ENERGY) return 0.0;  // callers that do not normalise skip the second reduction (two barriers)
   for (int j = N + threadIdx.x; j < L; j += FT) {  // cropped tail still counts in the energy
     const double w = win(j);
     const double val = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w - w * mean_sw / mean_w;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
   const long long xn = x_off[u + 1] - x_off[u];
   const double cf = fmax(f0, 40.0);
   double v[NLT / FT];
-  d4c_window<true, NLT>(xu, xn, fs, cf, tp[f], 1.5, zr, v, scratch);
+  d4c_window<true, NLT, false>(xu, xn, fs, cf, tp[f], 1.5, zr, v, scratch);
 #pragma unroll
   for (int q = 0; q < NLT / FT; ++q) zr[threadIdx.x + q * FT] = v[q];
   wh::sync<FT>();
@@ -313,8 +315,8 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   if (FUSED && voiced) {
     // love-train frame (Blackman, 3*T0, f0 floored at 40 Hz) and smoothed-power frame (Hann, 4*T0) in one FFT
     double va[N / FT], vb[N / FT];
-    d4c_window<true, N>(xu, xn, fs, fmax(f0v, 40.0), pos, 1.5, zr, va, scratch);
-    d4c_window<false, N>(xu, xn, fs, cf, pos, 2.0, zr, vb, scratch);
+    d4c_window<true, N, false>(xu, xn, fs, fmax(f0v, 40.0), pos, 1.5, zr, va, scratch);
+    d4c_window<false, N, false>(xu, xn, fs, cf, pos, 2.0, zr, vb, scratch);
     double2 zin[N / FT];
 #pragma unroll
     for (int q = 0; q < N / FT; ++q) zin[q] = make_double2(va[q], vb[q]);
@@ -377,7 +379,8 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   // ---- smoothed power spectrum (d4c.py:157-161) ----------------------------------------------
   if (!FUSED) {
     double v[N / FT];
-    d4c_window<false, N>(xu, xn, fs, cf, pos, 2.0, zr, v, scratch);
+    d4c_window<false, N, false>(xu, xn, fs, cf, pos, 2.0, zr, v, scratch);
+    wh::sync<FT>();
 #pragma unroll
     for (int q = 0; q < N / FT; ++q) zr[threadIdx.x + q * FT] = v[q];
     wh::sync<FT>();

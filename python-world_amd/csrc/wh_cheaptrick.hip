@@ -18,7 +18,7 @@ __global__ __launch_bounds__(FT) void cheaptrick_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv, double fs, double q1,
     double f0_low_limit, const double2* __restrict__ tw_base, double* __restrict__ spec_out,
-    double2* __restrict__ ps_out) {
+    double2* __restrict__ ps_out, long long n_frames) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = N / 2 + 1;
   double2* zb = reinterpret_cast<double2*>(smem);   // N/2+1 complex = the N-sample real buffer (+1 bin)
@@ -26,7 +26,8 @@ __global__ __launch_bounds__(FT) void cheaptrick_kernel(
   double* aux = zr + (N + N / 8 + 2);               // K+1 reals (zr doubles as the padded prefix-sum array)
   double* scratch = aux + (K + 1);                  // 32 doubles
 
-  const int64_t f = blockIdx.x;
+  const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
+  if (f >= n_frames) return;
   const int u = frame_utt[f];
   const double* xu = x + x_off[u];
   const long long xn = x_off[u + 1] - x_off[u];
@@ -135,9 +136,9 @@ int launch(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, cons
   const size_t lds = sizeof(double) * ((N + N / 8 + 2) + (N / 2 + 2) + 32);
   const double low = fs * 3.0 / (N - 3.0);
   if (int rc = wh::allow_lds(&cheaptrick_kernel<N>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "cheaptrick_kernel"); hipLaunchKernelGGL(cheaptrick_kernel<N>, dim3((unsigned)b->total_frames), dim3(FT), lds, st, x, b->d_x_off,
+  { wh::KernelTimer _kt(ctx, st, "cheaptrick_kernel"); hipLaunchKernelGGL(cheaptrick_kernel<N>, dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(FT), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, fs, q1, low, ctx->d_twiddle, spec,
-                     reinterpret_cast<double2*>(ps)); }
+                     reinterpret_cast<double2*>(ps), (long long)b->total_frames); }
   WH_LAUNCH_CHECK("cheaptrick_kernel");
   return 0;
 }

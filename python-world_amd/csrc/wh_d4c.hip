@@ -104,13 +104,14 @@ template <int NLT>
 __global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv, double fs,
-    double threshold, const double2* __restrict__ tw_base, int32_t* __restrict__ gate) {
+    double threshold, const double2* __restrict__ tw_base, int32_t* __restrict__ gate, long long n_frames) {
   constexpr int FT = ft_of(NLT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2* zb = reinterpret_cast<double2*>(smem);  // NLT/2+1 complex after the real FFT
   double* zr = reinterpret_cast<double*>(smem);    // 2*NLT doubles while windowing
   double* scratch = zr + 2 * NLT;
-  const int64_t f = blockIdx.x;
+  const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
+  if (f >= n_frames) return;
   double f0 = f0_io[f];
   if (vuv[f] == 0.0) f0 = 0.0;  // d4c.py:32 — written back (Q6)
   if (threadIdx.x == 0) f0_io[f] = f0;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     const int32_t* __restrict__ gate, double threshold, double fs, int nap, int interval,
     const double* __restrict__ window, int wlen, const double2* __restrict__ tw_base,
     int k_spec,                       // >0: dense amplitude output [F][k_spec]; 0: Requiem band output [F][nap+2]
-    double* __restrict__ out, double* __restrict__ coarse_dbg) {
+    double* __restrict__ out, double* __restrict__ coarse_dbg, long long n_frames) {
   constexpr int FT = ft_of(N);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = N / 2 + 1;
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   double* scratch = pw + (N / 2 + 8);                // 16
   double* band = scratch + 32;                       // nap (<= 8)
 
-  const int64_t f = blockIdx.x;
+  const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
+  if (f >= n_frames) return;
   const int u = frame_utt[f];
   const double* xu = x + x_off[u];
   const long long xn = x_off[u + 1] - x_off[u];
@@ -500,8 +502,8 @@ int launch_lt(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, c
               const double* vuv, double fs, double thr, int32_t* gate) {
   const size_t lds = sizeof(double) * (2 * NLT + 32);
   if (int rc = wh::allow_lds(&love_train_kernel<NLT>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)b->total_frames), dim3(ft_of(NLT)), lds, st, x, b->d_x_off,
-                     b->d_frame_utt, tp, f0, vuv, fs, thr, ctx->d_twiddle, gate); }
+  { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_of(NLT)), lds, st, x, b->d_x_off,
+                     b->d_frame_utt, tp, f0, vuv, fs, thr, ctx->d_twiddle, gate, (long long)b->total_frames); }
   WH_LAUNCH_CHECK("love_train_kernel");
   return 0;
 }
@@ -512,9 +514,9 @@ int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x,
                 int wlen, int k_spec, double* out, double* coarse) {
   const size_t lds = sizeof(double) * (2 * N + 2 * (N / 2 + 8) + 32 + 8);
   if (int rc = wh::allow_lds(&d4c_kernel<N, FUSED>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL((d4c_kernel<N, FUSED>), dim3((unsigned)b->total_frames), dim3(ft_of(N)), lds, st, x, b->d_x_off,
+  { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL((d4c_kernel<N, FUSED>), dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_of(N)), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, gate, thr, fs, nap, interval, win, wlen, ctx->d_twiddle, k_spec, out,
-                     coarse); }
+                     coarse, (long long)b->total_frames); }
   WH_LAUNCH_CHECK("d4c_kernel");
   return 0;
 }

@@ -32,6 +32,26 @@ __device__ __forceinline__ void sync() {
   }
 }
 
+// Workgroups are dealt to the 8 XCDs of the MI355X round-robin by linear id, and every XCD has its own L2.  The
+// per-frame / per-pulse kernels read overlapping neighbourhoods (a 5 ms hop against 20-40 ms analysis windows; the
+// two spectrogram rows a pulse interpolates are its neighbour's too), so unit u = consecutive ids would put every
+// neighbourhood into all eight L2s.  This mapping gives XCD x the contiguous range [x*ceil(n/8), (x+1)*ceil(n/8)).
+// Returns n (out of range) for the padding ids of the last rows.
+#ifndef WH_XCD_REMAP
+#define WH_XCD_REMAP 1
+#endif
+__device__ __forceinline__ long long xcd_unit(long long id, long long n) {
+#if WH_XCD_REMAP
+  constexpr int kXcds = 8;
+  const long long per = (n + kXcds - 1) / kXcds;
+  const long long u = (id % kXcds) * per + id / kXcds;
+  return (id / kXcds < per && u < n) ? u : n;
+#else
+  return id < n ? id : n;
+#endif
+}
+__host__ __device__ __forceinline__ long long xcd_grid(long long n) { return ((n + 7) / 8) * 8; }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = WH_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WH_WAVE);

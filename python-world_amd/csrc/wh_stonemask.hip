@@ -59,11 +59,13 @@ __device__ __forceinline__ double weighted_if(const double2* X, const double2* D
 __global__ __launch_bounds__(64) void stonemask_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, const double* __restrict__ f0_in, double* __restrict__ f0_out, double fs,
-    const double* __restrict__ qtime, int kmax, const double2* __restrict__ tw_base, int32_t* __restrict__ err) {
+    const double* __restrict__ qtime, int kmax, const double2* __restrict__ tw_base, int32_t* __restrict__ err,
+    long long n_frames) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* sm = reinterpret_cast<double*>(smem);  // x*main window
   double* sd = sm + (2 * kmax + 1);              // x*derivative window
-  const int64_t f = blockIdx.x;
+  const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
+  if (f >= n_frames) return;
   const double f0i = f0_in[f];
   const int lane = threadIdx.x;
   if (f0i == 0.0) {
@@ -174,8 +176,8 @@ extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   if (int rc = wh::const_table(ctx, key, qt, &d_qt)) return rc;
   int32_t* err = ctx->d_flags + WH_FLAG_STONEMASK_WINDOW;
   if (int rc = wh::allow_lds(&stonemask_kernel, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "stonemask_kernel"); hipLaunchKernelGGL(stonemask_kernel, dim3((unsigned)b->total_frames), dim3(64), lds, st, x, b->d_x_off,
-                     b->d_frame_utt, tp, f0, refined_f0, fs, d_qt, kmax, ctx->d_twiddle, err); }
+  { wh::KernelTimer _kt(ctx, st, "stonemask_kernel"); hipLaunchKernelGGL(stonemask_kernel, dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(64), lds, st, x, b->d_x_off,
+                     b->d_frame_utt, tp, f0, refined_f0, fs, d_qt, kmax, ctx->d_twiddle, err, (long long)b->total_frames); }
   WH_LAUNCH_CHECK("stonemask_kernel");
   return 0;
 }

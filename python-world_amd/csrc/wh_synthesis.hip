@@ -24,7 +24,10 @@ namespace {
 #ifndef WH_FT_SYNTH
 #define WH_FT_SYNTH 256
 #endif
-constexpr int FT = WH_FT_SYNTH;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
+// Threads cooperating on one pulse / frame: 256 up to N = 1024, 512 from N = 2048 (44.1 / 48 kHz), where the 54 KB
+// of LDS per pulse leave two workgroups per CU and the thread count is the occupancy (measured 58.6 -> 50.5 ms on
+// config 5).
+constexpr int ft_syn(int n) { return n >= 2048 ? 2 * WH_FT_SYNTH : WH_FT_SYNTH; }
 
 struct SynUtt {
   int64_t f_off, nf;      // frames
@@ -473,6 +476,7 @@ __device__ __forceinline__ double normal_at(uint64_t seed, uint64_t q) {
 // independent chains on different buffers run side by side through the same barrier phases.
 template <int N, int GT>
 __device__ __forceinline__ void min_phase_half(double* amp, double2* zb, const double2* tw_base) {
+  constexpr int FT = ft_syn(N);
   double* zr = reinterpret_cast<double*>(zb);
   const int gt = threadIdx.x & (GT - 1);
 #pragma unroll 1
@@ -549,6 +553,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   const double* __restrict__ dc_base = A.dc_base;
   const double2* __restrict__ tw_base = A.tw_base;
   double* __restrict__ y = A.y;
+  constexpr int FT = ft_syn(N);
   constexpr int K = N / 2 + 1;
   constexpr int NZ = 256;
   constexpr int R = N / FT;  // consecutive output samples per thread
@@ -753,7 +758,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
 }
 
 template <int N>
-__global__ __launch_bounds__(FT) void response_kernel(RespArgs A) {
+__global__ __launch_bounds__(ft_syn(N)) void response_kernel(RespArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // (No XCD-contiguous mapping here, unlike the per-frame kernels: neighbouring pulses overlap-add into the same
   // samples, and with all of them in flight on one XCD the FP64 atomics pile onto a few memory channels —
@@ -785,7 +790,7 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
   const int64_t grid = pcap_max * B;  // one workgroup per pulse slot; slots past the real count exit at once
   { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_time, p_idx, p_shift, p_noff, p_frames, p_weight, p_count, p_base, B, vuv_s, noise, seed, d_dc, ctx->d_twiddle, y};
-  hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(FT), lds, st, ra); }
+  hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(ft_syn(N)), lds, st, ra); }
   WH_LAUNCH_CHECK("response_kernel");
   return 0;
 }
@@ -891,11 +896,12 @@ __global__ __launch_bounds__(256) void req_pulse_kernel(const SynUtt* __restrict
 }
 
 template <int N>
-__global__ __launch_bounds__(FT) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
+__global__ __launch_bounds__(ft_syn(N)) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
                                                         const double* __restrict__ spectrogram,
                                                         const double* __restrict__ exc,
                                                         const double2* __restrict__ tw_base, double* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int FT = ft_syn(N);
   constexpr int K = N / 2 + 1;
   double2* zb = reinterpret_cast<double2*>(smem);        // minimum-phase half spectrum (N/2+1 complex)
   double2* sb = zb + (N / 2 + 1);                         // windowed excitation frame / its half spectrum
@@ -944,7 +950,7 @@ int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, const 
   const size_t lds = sizeof(double2) * 2 * (N / 2 + 1) + sizeof(double) * (N / 2 + 8);
   if (int rc = wh::allow_lds(&req_filter_kernel<N>, lds)) return rc;
   if (max_nf < 4) return 0;
-  { wh::KernelTimer _kt(ctx, st, "req_filter_kernel"); hipLaunchKernelGGL(req_filter_kernel<N>, dim3((unsigned)(max_nf - 3), B), dim3(FT), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, y); }
+  { wh::KernelTimer _kt(ctx, st, "req_filter_kernel"); hipLaunchKernelGGL(req_filter_kernel<N>, dim3((unsigned)(max_nf - 3), B), dim3(ft_syn(N)), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, y); }
   WH_LAUNCH_CHECK("req_filter_kernel");
   return 0;
 }

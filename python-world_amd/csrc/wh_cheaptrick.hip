@@ -1,4 +1,4 @@
-// CheapTrick spectral envelope — one 128-thread workgroup per frame, everything between the
+// CheapTrick spectral envelope — one 128-thread workgroup per frame (256 from N = 2048), everything between the
 // waveform gather and the final envelope stays in LDS (~13*N bytes): window → real FFT → power →
 // low-band replica → block-scan smoothing → log → real FFT → lifter → inverse real FFT → exp.
 // All three transforms run as N/2-point complex FFTs on sample pairs (wh_device.h: rfft_lds / irfft_lds).
@@ -11,14 +11,16 @@ namespace {
 #ifndef WH_FT_CHEAPTRICK
 #define WH_FT_CHEAPTRICK 128
 #endif
-constexpr int FT = WH_FT_CHEAPTRICK;  // threads cooperating on one frame / pulse (64 = one wave, no s_barrier)
+// Threads cooperating on one frame: 128 up to N = 1024, 256 from N = 2048 (measured on configs 2 and 5).
+constexpr int ft_ct(int n) { return n >= 2048 ? 2 * WH_FT_CHEAPTRICK : WH_FT_CHEAPTRICK; }
 
 template <int N>
-__global__ __launch_bounds__(FT) void cheaptrick_kernel(
+__global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv, double fs, double q1,
     double f0_low_limit, const double2* __restrict__ tw_base, double* __restrict__ spec_out,
     double2* __restrict__ ps_out, long long n_frames) {
+  constexpr int FT = ft_ct(N);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = N / 2 + 1;
   double2* zb = reinterpret_cast<double2*>(smem);   // N/2+1 complex = the N-sample real buffer (+1 bin)
@@ -136,7 +138,7 @@ int launch(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, cons
   const size_t lds = sizeof(double) * ((N + N / 8 + 2) + (N / 2 + 2) + 32);
   const double low = fs * 3.0 / (N - 3.0);
   if (int rc = wh::allow_lds(&cheaptrick_kernel<N>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "cheaptrick_kernel"); hipLaunchKernelGGL(cheaptrick_kernel<N>, dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(FT), lds, st, x, b->d_x_off,
+  { wh::KernelTimer _kt(ctx, st, "cheaptrick_kernel"); hipLaunchKernelGGL(cheaptrick_kernel<N>, dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_ct(N)), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, fs, q1, low, ctx->d_twiddle, spec,
                      reinterpret_cast<double2*>(ps), (long long)b->total_frames); }
   WH_LAUNCH_CHECK("cheaptrick_kernel");

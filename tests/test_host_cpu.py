@@ -115,3 +115,28 @@ def test_shard_ranges_properties():
         if n >= w:
             assert all(e > s for s, e in r)
     assert shard_ranges([160000] * 1024, 8) == [(128 * i, 128 * (i + 1)) for i in range(8)]
+
+
+def test_lane_split_and_bench_bytes():
+    """WorldBatchLanes deals utterances by the rank-sharding rule; bench.py's algorithmic bytes per frame are the
+    SURVEY 8(d) figures (17 744 B/frame for the whole path at 16 kHz / fft 1024)."""
+    import bench
+    from world.batch import WorldBatchLanes
+
+    assert WorldBatchLanes.split([160000] * 64, 2) == [(0, 32), (32, 64)]
+    parts = WorldBatchLanes.split([1000, 50000, 2000, 30000, 700], 3)
+    assert parts[0][0] == 0 and parts[-1][1] == 5 and all(a[1] == b[0] for a, b in zip(parts[:-1], parts[1:]))
+    per_kernel, path = bench.algo_bytes_per_frame(16000, 1024)
+    assert path == 17744 and per_kernel["d4c_kernel"] == 640 + 24 + 4104
+    per48, path48 = bench.algo_bytes_per_frame(48000, 2048, 2.0)
+    assert per48["d4c_kernel"] == 1920 + 24 + 8200 and path48 == 1920 + 3840 + 48 + 4 * 8200
+
+
+def test_arange_length_memo_is_numpy():
+    """time_axis_params memoises len(np.arange(...)) — the float-arange quirk (Q9) must survive the cache."""
+    from world.synthesis import _arange_len
+
+    for start, stop, step in ((0.0, 10.0 + 1 / 48000, 1 / 48000), (0.0, 2.0 + 1 / 16000, 1 / 16000),
+                              (0.005, 1.2 + 1 / 22050, 1 / 22050)):
+        for _ in range(2):
+            assert _arange_len(start, stop, step) == len(np.arange(start, stop, step))

@@ -44,20 +44,24 @@ __global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
   const int hwl = (int)(1.5 * fs / f0 + 0.5);
   const int L = 2 * hwl + 1;
   const long long centre = wh::frame_centre(pos, fs);
+  // per-frame constants are inverted once and multiplied in (an FP64 divide is ~12 dependent instructions; the
+  // results move by an ulp)
+  const double inv_span = 1.0 / fs / 1.5;
   double s_w2 = 0.0;
   for (int j = threadIdx.x; j < L; j += FT) {
-    const double t = (double)(j - hwl) / fs / 1.5;
+    const double t = (double)(j - hwl) * inv_span;
     const double w = 0.5 * cospi(t * f0) + 0.5;  // cos(pi*t*f0)
     s_w2 += w * w;
     if (j < N) zr[j] = w;
   }
   const double norm = sqrt(wh::block_sum<FT>(s_w2, scratch));
+  const double inv_norm = 1.0 / norm;
   double s_sw = 0.0, s_w = 0.0;
   for (int j = threadIdx.x; j < L; j += FT) {
     const double seg = wh::sample_clamped(xu, xn, centre + (j - hwl));
     // np.fft crops rows longer than N, the means still see them (Q7)
-    double w = j < N ? zr[j] : 0.5 * cospi(((double)(j - hwl) / fs / 1.5) * f0) + 0.5;
-    w = w / norm;
+    double w = j < N ? zr[j] : 0.5 * cospi(((double)(j - hwl) * inv_span) * f0) + 0.5;
+    w = w * inv_norm;
     s_sw += seg * w;
     s_w += w;
     if (j < N) zr[j] = w;
@@ -65,11 +69,12 @@ __global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
   wh::block_sum2<FT>(s_sw, s_w, scratch);
   const double mean_sw = s_sw / (double)L;
   const double mean_w = s_w / (double)L;
+  const double dc = mean_sw / mean_w;
   for (int j = threadIdx.x; j < N; j += FT) {
     double v = 0.0;
     if (j < L) {
       const double w = zr[j];
-      v = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w - w * mean_sw / mean_w;
+      v = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w - w * dc;
     }
     zr[j] = v;
   }
@@ -96,10 +101,11 @@ __global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
   wh::BandLookup lk;
   lk.init(zr, N, fs);
   lk.set_half_width(f0 / 3);
+  const double scale_f0 = 1.5 / f0;
   for (int k = threadIdx.x; k < K; k += FT) {
     // the reference adds rand()*eps here "to avoid log(0)" (cheaptrick.py:117, unseeded, Q10); its mean eps/2 keeps
     // that guarantee (digital silence) deterministically
-    aux[k] = log(lk.band(k) * 1.5 / f0 + 0.5 * 2.220446049250313e-16);
+    aux[k] = log(lk.band(k) * scale_f0 + 0.5 * 2.220446049250313e-16);
   }
   wh::sync<FT>();
 
@@ -108,8 +114,9 @@ __global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
   // distinct bins only and both transforms are real (forward of a real sequence, inverse to a real one).
   for (int n = threadIdx.x; n < N; n += FT) zr[n] = aux[n <= N / 2 ? n : N - n];
   wh::sync<FT>();
+  const double inv_fs = 1.0 / fs;
   for (int m = threadIdx.x; m < K; m += FT) {
-    const double q = (double)m / fs;
+    const double q = (double)m * inv_fs;
     double sl = 1.0, sn = 0.0;
     if (m > 0) {
       sn = sinpi(f0 * q);  // sin(pi*f0*q)
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
   wh::sync<FT>();
   wh::irfft_lds<N, FT>(zb, tw_base);
   double* o = spec_out + f * (int64_t)K;
-  for (int k = threadIdx.x; k < K; k += FT) o[k] = exp(zr[k] / N);
+  for (int k = threadIdx.x; k < K; k += FT) o[k] = exp(zr[k] * (1.0 / N));  // N is a power of two: exact
 }
 
 template <int N>

@@ -51,8 +51,11 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
   const int L = 2 * hwl + 1;
   const long long centre = wh::frame_centre(pos, fs);
   const double phase = (pos * fs - (double)(long long)(pos * fs + 0.5)) / fs;
+  // per-frame constants are inverted once and multiplied in: an FP64 divide is ~12 instructions with a long
+  // dependency chain, and the per-sample ones were a fifth of this kernel's instruction count (results move by an ulp)
+  const double inv_span = 1.0 / fs / half_length;
   auto win = [&](int j) -> double {
-    const double c1 = cospi(((double)(j - hwl) / fs / half_length + phase) * cf);  // cos(pi*t*f0)
+    const double c1 = cospi(((double)(j - hwl) * inv_span + phase) * cf);  // cos(pi*t*f0)
     return BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);  // cos(2a) = 2cos^2(a)-1
   };
   // samples j = tid + q*FT of the window stay in this thread's registers from the gather to the DC removal
@@ -80,13 +83,14 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
   wh::block_sum2<FT>(s_sw, s_w, scratch);
   const double mean_sw = s_sw / (double)L;
   const double mean_w = s_w / (double)L;
+  const double dc = mean_sw / mean_w;
   double e = 0.0;
 #pragma unroll
   for (int q = 0; q < N / FT; ++q) {
     const int j = threadIdx.x + q * FT;
     double val = 0.0;
     if (j < L) {
-      val = swq[q] - wq[q] * mean_sw / mean_w;
+      val = swq[q] - wq[q] * dc;
       e += val * val;
     }
     v[q] = val;
@@ -94,7 +98,7 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
   if (!ENERGY) return 0.0;  // callers that do not normalise skip the second reduction (two barriers)
   for (int j = N + threadIdx.x; j < L; j += FT) {  // cropped tail still counts in the energy
     const double w = win(j);
-    const double val = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w - w * mean_sw / mean_w;
+    const double val = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w - w * dc;
     e += val * val;
   }
   return wh::block_sum<FT>(e, scratch);
@@ -250,11 +254,12 @@ __device__ __forceinline__ void add_centroid(const double* xu, long long xn, dou
   double v[N / FT];
   const double energy = d4c_window<true, N>(xu, xn, fs, cf, pos, 2.0, reinterpret_cast<double*>(buf), v, scratch);
   const double nrm = sqrt(energy);
+  const double inv_nrm = 1.0 / nrm;
   double2 zin[N / FT];
 #pragma unroll
   for (int q = 0; q < N / FT; ++q) {
     const int j = threadIdx.x + q * FT;
-    const double val = v[q] / nrm;
+    const double val = v[q] * inv_nrm;
     zin[q] = make_double2(val, val * (double)(j + 1));  // n is 1-based
   }
   if constexpr (N >= WH_D4C_MAXR * FT && WH_D4C_REGFFT) {
@@ -394,13 +399,14 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     wh::sync<FT>();
   }
   double* cum = zr;  // the FFT buffer is idle during the smoothing steps
+  const double inv_cf = 1.0 / cf;
   wh::low_band_replica<FT>(pw, cum, N, fs, cf, 1.2 * cf);
   wh::scan_mirrored<FT, N>(pw, cum, fs, scratch);
   wh::BandLookup lk;
   lk.init(cum, N, fs);
   lk.set_half_width(cf / 2);
   for (int k = threadIdx.x; k < K; k += FT) {
-    const double sm = lk.band(k) / cf;
+    const double sm = lk.band(k) * inv_cf;
     cent[k] = cent[k] / sm;  // T_g = centroid / smoothed power (d4c.py:169; no zero guard, Q14)
   }
   wh::sync<FT>();
@@ -410,13 +416,14 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   {
     const double w2 = cf / 2;
     lk.set_half_width(w2 / 2);
-    for (int k = threadIdx.x; k < K; k += FT) pw[k] = lk.band(k) / w2;  // T_gs
+    const double inv_w2 = 1.0 / w2;
+    for (int k = threadIdx.x; k < K; k += FT) pw[k] = lk.band(k) * inv_w2;  // T_gs
   }
   wh::sync<FT>();
   wh::scan_mirrored<FT, N>(pw, cum, fs, scratch);
   lk.init(cum, N, fs);
   lk.set_half_width(cf / 2);
-  for (int k = threadIdx.x; k < K; k += FT) cent[k] = pw[k] - lk.band(k) / cf;  // T_D = T_gs - T_gb
+  for (int k = threadIdx.x; k < K; k += FT) cent[k] = pw[k] - lk.band(k) * inv_cf;  // T_D = T_gs - T_gb
   wh::sync<FT>();
 
 #if WH_D4C_ABLATE == 3

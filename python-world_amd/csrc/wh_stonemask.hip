@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
   const int hwl = (int)hwl_d;
   const int L = 2 * hwl + 1;
   const double wlit = (2 * hwl_d + 1) / fs;
+  const double inv_fs = 1.0 / fs, two_over_wlit = 2.0 / wlit;  // per-frame reciprocals instead of per-sample divides
   int nfft = 1;
   {
     int e = 0;
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
     const double bt = qtime[(j - hwl) + kmax];
     const double v = (t0 + bt) * fs;
     const double idx_raw = v > 0 ? v + 0.5 : v - 0.5;
-    const double wt = (idx_raw - 1) / fs - t0;
-    const double c = cospi(2 * wt / wlit);           // cos(2*pi*wt/wlit) without the generic range reduction
+    const double wt = (idx_raw - 1) * inv_fs - t0;
+    const double c = cospi(wt * two_over_wlit);           // cos(2*pi*wt/wlit) without the generic range reduction
     return 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1);  // cos(4a) = 2cos^2(2a) - 1
   };
   double prev_last = 0.0;

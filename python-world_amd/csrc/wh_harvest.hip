@@ -252,8 +252,9 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   int bins[6];
 #pragma unroll
   for (int h = 0; h < 6; ++h) bins[h] = (int)(f0c * nfft / fs * (double)(h + 1) + 0.5);
+  const double inv_fs = 1.0 / fs;  // the sample index below is floor(integer + 0.501 +- 1e-12): an ulp cannot move it
   auto idx_raw_at = [&](int j) -> double {
-    const double v = (t0 + (double)(j - hwl) / fs) * fs + 0.001;  // "first-aid treatment", harvest.py:178
+    const double v = (t0 + (double)(j - hwl) * inv_fs) * fs + 0.001;  // "first-aid treatment", harvest.py:178
     return v > 0 ? v + 0.5 : v - 0.5;                               // round_matlab does not truncate (Q1)
   };
   // window phase: 2*common = pi*xw, xw advances by dx per unit step of idx_raw (steps are 1, or 2 where the

@@ -107,6 +107,10 @@ __device__ __forceinline__ void interp_four_trains(const double* __restrict__ ed
     return;
   }
   double v[4];
+  // interval locations (e[i]+e[i+1])/2/fs are formed with one multiply by 0.5/fs: the divide would sit in every step
+  // of the binary searches (~40 FP64 divides per call); the interpolant is continuous across its nodes, so the last
+  // bit of a location cannot change the result by more than its own rounding
+  const double half_inv_fs = 0.5 / fs;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const double* e = edges + (int64_t)k * cap;
@@ -114,13 +118,13 @@ __device__ __forceinline__ void interp_four_trains(const double* __restrict__ ed
     int lo = 0, hi = ni;        // lower_bound: count of locations < t
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      const double loc = (e[mid] + e[mid + 1]) / 2 / fs;
+      const double loc = (e[mid] + e[mid + 1]) * half_inv_fs;
       if (loc < t) lo = mid + 1; else hi = mid;
     }
     int ih = lo < 1 ? 1 : (lo > ni - 1 ? ni - 1 : lo);
     const int il = ih - 1;
-    const double x_lo = (e[il] + e[il + 1]) / 2 / fs;
-    const double x_hi = (e[ih] + e[ih + 1]) / 2 / fs;
+    const double x_lo = (e[il] + e[il + 1]) * half_inv_fs;
+    const double x_hi = (e[ih] + e[ih + 1]) * half_inv_fs;
     const double y_lo = fs / (e[il + 1] - e[il]);
     const double y_hi = fs / (e[ih + 1] - e[ih]);
     const double slope = (y_hi - y_lo) / (x_hi - x_lo);

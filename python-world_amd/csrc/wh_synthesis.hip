@@ -37,14 +37,17 @@ struct SynUtt {
   double t0, dt;          // time axis t_i = t0 + i*dt  (NumPy arange semantics, host-computed)
 };
 
-__device__ __forceinline__ double lerp_tp(const double* __restrict__ tp, const double* __restrict__ v, int64_t nf, double t) {
-  // searchsorted-left, hi clipped to [1, nf-1]; slope*(t-x_lo)+y_lo  (SciPy interp1d linear + extrapolate)
+// searchsorted-left, hi clipped to [1, nf-1]: the segment SciPy's interp1d(linear, extrapolate) evaluates t on
+__device__ __forceinline__ int64_t lerp_segment(const double* __restrict__ tp, int64_t nf, double t) {
   int64_t lo = 0, hi = nf;
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
     if (tp[mid] < t) lo = mid + 1; else hi = mid;
   }
-  int64_t ih = lo < 1 ? 1 : (lo > nf - 1 ? nf - 1 : lo);
+  return lo < 1 ? 1 : (lo > nf - 1 ? nf - 1 : lo);
+}
+// slope*(t-x_lo)+y_lo on that segment
+__device__ __forceinline__ double lerp_on(const double* __restrict__ tp, const double* __restrict__ v, int64_t ih, double t) {
   const int64_t il = ih - 1;
   const double slope = (v[ih] - v[il]) / (tp[ih] - tp[il]);
   return slope * (t - tp[il]) + v[il];
@@ -58,8 +61,9 @@ __global__ __launch_bounds__(256) void prep_kernel(const SynUtt* __restrict__ me
   if (i >= m.ny) return;
   const double t = m.t0 + (double)i * m.dt;
   const double* tpu = tp + m.f_off;
-  const double f_raw = lerp_tp(tpu, f0 + m.f_off, m.nf, t);
-  const bool v = lerp_tp(tpu, vuv + m.f_off, m.nf, t) > 0.5;
+  const int64_t ih = lerp_segment(tpu, m.nf, t);  // one search serves both interpolants
+  const double f_raw = lerp_on(tpu, f0 + m.f_off, ih, t);
+  const bool v = lerp_on(tpu, vuv + m.f_off, ih, t) > 0.5;
   double fi = f_raw * (v ? 1.0 : 0.0);
   if (fi == 0.0) fi = fi + 500.0;  // default_f0, synthesis.py:126
   phase[m.y_off + i] = 2 * M_PI * fi / fs;

@@ -438,14 +438,13 @@ __global__ __launch_bounds__(128) void hv_prune_kernel(const HvUtt* __restrict__
   double v = rf0[o + e], s = rsc[o + e];
   if (inner && v != 0.0) {
     double e1 = 1.0, e2 = 1.0;  // SelectBestF0 with allowed_range = 1 (a zero candidate gives exactly 1)
-    for (int k = 0; k < n_next; ++k) {
-      const double a = fabs(v - nb_next[k]) / v;
-      if (!(a > e1)) e1 = a;
-    }
-    for (int k = 0; k < n_prev; ++k) {
-      const double b = fabs(v - nb_prev[k]) / v;
-      if (!(b > e2)) e2 = b;
-    }
+    // min_k |v - nb_k| / v == (min_k |v - nb_k|) / v bit for bit (division by v > 0 is monotone): one divide per
+    // neighbour frame instead of one per neighbour candidate
+    double d1 = INFINITY, d2 = INFINITY;
+    for (int k = 0; k < n_next; ++k) d1 = fmin(d1, fabs(v - nb_next[k]));
+    for (int k = 0; k < n_prev; ++k) d2 = fmin(d2, fabs(v - nb_prev[k]));
+    if (n_next > 0) e1 = fmin(e1, d1 / v);
+    if (n_prev > 0) e2 = fmin(e2, d2 / v);
     if (fmin(e1, e2) > 0.05) {
       v = 0.0;
       s = 0.0;

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void band_events_kernel(const BandJob* __restr
       constexpr int R = kBandR;
       const int i0 = threadIdx.x * R;
       double acc[R], r[R];
-      const int top = i0 + (lb - 1);  // input index of output i0 for tap 0 (even)
+      // input index of output i0 for tap 0: top = i0 + (lb - 1), even
       const double2* zt2 = reinterpret_cast<const double2*>(zt);
       const int pl2 = pl >> 1;
       const int full = (lb - 1) >> 1;  // steps with two real taps; one last tap follows (lb is odd)

@@ -540,11 +540,9 @@ struct RespArgs {
 template <int N>
 __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, char* smem) {
   const SynUtt* __restrict__ meta = A.meta;
-  const double* __restrict__ tp = A.tp;
   const double* __restrict__ spectrogram = A.spectrogram;
   const double* __restrict__ aperiodicity = A.aperiodicity;
   const double fs = A.fs;
-  const double* __restrict__ p_time = A.p_time;
   const int64_t* __restrict__ p_idx = A.p_idx;
   const double* __restrict__ p_shift = A.p_shift;
   const int64_t* __restrict__ p_noff = A.p_noff;

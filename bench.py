@@ -30,6 +30,7 @@ FS = 16000
 SECONDS = 10.0
 UTT_PER_GPU = 64
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # FP64 vector FMA: 256 CUs x 4 SIMDs x 16 lanes/clk x 2 flop x 2.4 GHz (the SIMD-16 ceiling)
 
 # Algorithmic (compulsory) HBM bytes per 5 ms frame of each dominant-kernel candidate, float64 API dtypes —
 # SURVEY.md §8(d) components: x hop (640 B at 16 kHz), f0+vuv+tp 24 B, spectrogram and aperiodicity
@@ -89,6 +90,20 @@ def pmc_traffic(kernel, lanes):
             parts = line.split()
             if parts and parts[0] == kernel:
                 return float(parts[3]) * 1e6 / lanes, os.path.relpath(path, ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
+def pmc_fp64_flops(kernel, lanes):
+    """FP64 floating-point operations per launch of `kernel` (2*FMA + ADD + MUL + TRANS instructions x 64 lanes) from the
+    committed rocprofv3 SQ-counter digest of this workload (profiles/sq_counters_cfg2_latest.txt).  None if unavailable."""
+    path = os.path.join(ROOT, "profiles", "sq_counters_cfg2_latest.txt")
+    try:
+        for line in open(path):
+            parts = line.split()
+            if parts and parts[0] == kernel:
+                return float(parts[1]) * 1e-6 * float(parts[-1]) * 1e12 / lanes, os.path.relpath(path, ROOT)
     except Exception:
         pass
     return None, None
@@ -232,6 +247,13 @@ def main():
                         "frames_per_launch": frames_per_launch,
                         "avg_launch_ms": kernel_ms[dominant],
                         "path_algorithmic_GBps": PATH_BYTES_PER_FRAME * frames_per_step * args.steps / elapsed / 1e9}
+            # second view of the same kernel: the path is FP64-compute/latency-bound, not HBM-bound
+            flops, flops_src = (pmc_fp64_flops(dominant, len(rts)) if args.config == 2 and args.utts == UTT_PER_GPU
+                                else (None, None))
+            if flops:
+                roofline["fp64_vector"] = {"achieved": flops / avg_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": flops / avg_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                           "flops_per_launch": flops, "flops_source": flops_src}
         out = {
             "metric": "analysis+synthesis frames/sec (and xRT), %d kHz / 5 ms hop" % (FS // 1000),
             "value": value,

@@ -1,11 +1,12 @@
 // Device-side building blocks shared by every WORLD kernel (gfx950 / CDNA4, wave64).
 //
-//  * block_sum / block_scan : 256-thread workgroup reductions and prefix sums built from
-//    64-lane wave shuffles plus one LDS hop across the 4 waves.
-//  * fft_lds<N>             : in-place complex FP64 Stockham FFT on an LDS-resident buffer.
-//    Every pass pulls its radix-4 (or final radix-2) operands into registers, barriers, and
-//    writes the auto-sorted outputs back into the same buffer, so no ping-pong copy is needed
-//    and a 4096-point transform fits 64 KiB of the CU's 160 KiB LDS.
+//  * block_sum*            : workgroup reductions built from 64-lane wave shuffles plus one LDS hop across
+//    the waves; xcd_unit: workgroup id -> unit mapping that keeps neighbouring units on one XCD (one L2).
+//  * fft_lds<N>            : in-place complex FP64 Stockham FFT on an LDS-resident buffer.  Every pass pulls
+//    its radix-8 / 4 / 2 operands into registers, barriers, and writes the auto-sorted outputs back into the
+//    same buffer, so no ping-pong copy is needed and a 4096-point transform fits 64 KiB of the CU's 160 KiB
+//    LDS; intermediate layouts are XOR-swizzled against store bank conflicts; fft_lds_from_regs feeds the
+//    first pass from registers; rfft_lds / irfft_lds do real transforms through half-size complex ones.
 //
 // All arithmetic is FP64: the reference is float64 end to end and the F0 stages take discrete
 // decisions on it.

@@ -1,15 +1,16 @@
 // DIO F0 estimator, batched over utterances.  Replaces dio() of the reference (world/dio.py:10-55).
 //
 // The reference filters by whole-utterance FFT products; here every filter is a short direct FIR
-// (161-tap low-cut, <=80-tap Nuttall low-pass per band) evaluated from LDS tiles, with the same
+// (161-tap low-cut staged per 256 outputs, <=80-tap Nuttall low-pass per band) evaluated from LDS tiles, with the same
 // circular-convolution indexing the reference's zero-padded FFT implies, so no utterance-length
 // FFT is needed and the work is tile-parallel:
 //   iir_fwd / iir_bwd : zero-phase 3-pole decimation low-pass (dio.py:359-476).  The serial
 //                       recurrence is cut into chunks; each lane warms its state up over W samples
 //                       before its chunk (|pole|^W < 1e-20), so chunks run in parallel.
 //   lowcut_kernel     : Hann-derived low-cut FIR (dio.py:74-88)
-//   band_kernel       : per (utterance, band): low-pass FIR from LDS, four zero-crossing trains,
-//                       ordered stream compaction by packed block scans (dio.py:128-140,190-204)
+//   band_events_kernel: per (utterance, band, segment): low-pass FIR from LDS, four zero-crossing trains,
+//                       ordered stream compaction by packed block scans into segment-private lists
+//                       (dio.py:128-140,190-204); band_concat_kernel joins the segments
 //   cand_kernel       : per (frame, band): binary search + linear inter/extrapolation of the four
 //                       interval-F0 trains, mean / sample-std, range masks, stability (dio.py:92-185)
 //   sort_kernel       : per frame insertion sort by stability (dio.py:113-124)

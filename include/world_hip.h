@@ -162,6 +162,11 @@ int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, const double
                       const double* vuv, double fs, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
                       int64_t pulse_cap, int32_t* h_pulse_count, int64_t* h_noise_total);
 
+/* decode()'s peak normalisation (world/main.py:209-212): per utterance u, y[h_y_off[u] .. h_y_off[u+1]) is divided
+ * by max|y| when that exceeds 1.  In place, on the stream; the workspace of ctx is used (call it after wh_synthesis*
+ * has finished enqueueing, as the Python mirror does). */
+int wh_peak_normalise(wh_ctx* ctx, void* stream, double* y, const int64_t* h_y_off, int n_utt);
+
 /* The phase accumulator of synthesis() is np.cumsum over the per-sample phase increments (world/synthesis.py:128):
  * a sequential float64 sum whose rounding decides the pulse positions.  This entry exposes the routine that
  * reproduces it bit for bit (in place, n_seg independent segments of NON-NEGATIVE doubles, h_off[n_seg + 1] element

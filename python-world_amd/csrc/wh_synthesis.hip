@@ -1037,6 +1037,59 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   return 0;
 }
 
+// ---- peak normalisation of decode(): y /= max|y| where it exceeds 1 (world/main.py:209-212), per utterance ----
+// Non-negative doubles order like their bit patterns, so the maximum is an integer atomicMax.
+__global__ __launch_bounds__(256) void peak_max_kernel(const double* __restrict__ y, const int64_t* __restrict__ off,
+                                                       unsigned long long* __restrict__ peak_bits) {
+  __shared__ unsigned long long wmax[4];
+  const int u = blockIdx.y;
+  const int64_t s = off[u], n = off[u + 1] - s;
+  unsigned long long m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(y[s + i]));
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long v = (unsigned long long)__shfl_xor((long long)m, o, 64);
+    m = v > m ? v : m;
+  }
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) m = wmax[w] > m ? wmax[w] : m;
+    atomicMax(peak_bits + u, m);
+  }
+}
+__global__ __launch_bounds__(256) void peak_scale_kernel(double* __restrict__ y, const int64_t* __restrict__ off,
+                                                         const unsigned long long* __restrict__ peak_bits) {
+  const int u = blockIdx.y;
+  const double peak = __longlong_as_double((long long)peak_bits[u]);
+  if (!(peak > 1.0)) return;  // world/main.py:210: only when the maximum exceeds 1 (a NaN peak leaves y alone)
+  const int64_t s = off[u], n = off[u + 1] - s;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[s + i] = y[s + i] / peak;
+}
+
+extern "C" int wh_peak_normalise(wh_ctx* ctx, void* stream, double* y, const int64_t* h_y_off, int n_utt) {
+  if (!ctx || !y || !h_y_off || n_utt < 0) return wh::fail_msg("wh_peak_normalise", "bad argument");
+  if (n_utt == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<int64_t> off(h_y_off, h_y_off + n_utt + 1);
+  int64_t* d_off = nullptr;
+  if (int rc = wh::persistent_upload(ctx, "peak.off", off, &d_off)) return rc;
+  int64_t max_n = 0;
+  for (int u = 0; u < n_utt; ++u) max_n = std::max(max_n, off[u + 1] - off[u]);
+  if (int rc = wh::ws_reserve(ctx, sizeof(unsigned long long) * (size_t)n_utt)) return rc;
+  unsigned long long* d_peak = reinterpret_cast<unsigned long long*>(ctx->ws);
+  WH_CHECK(hipMemsetAsync(d_peak, 0, sizeof(unsigned long long) * (size_t)n_utt, st));
+  const unsigned gx = (unsigned)std::min<int64_t>(64, (max_n + 4 * 256 - 1) / (4 * 256) + 1);
+  { wh::KernelTimer _kt(ctx, st, "peak_max_kernel"); hipLaunchKernelGGL(peak_max_kernel, dim3(gx, n_utt), dim3(256), 0, st, y, d_off, d_peak); }
+  WH_LAUNCH_CHECK("peak_max_kernel");
+  { wh::KernelTimer _kt(ctx, st, "peak_scale_kernel"); hipLaunchKernelGGL(peak_scale_kernel, dim3(gx, n_utt), dim3(256), 0, st, y, d_off, d_peak); }
+  WH_LAUNCH_CHECK("peak_scale_kernel");
+  return 0;
+}
+
 // In-place exact sequential cumulative sum of n_seg independent segments of NON-NEGATIVE doubles
 // (h_off[n_seg + 1] element offsets into d_data) — the routine behind the phase accumulator, exposed so that its
 // bit-for-bit agreement with np.cumsum can be tested directly.

@@ -48,6 +48,7 @@ SIGNATURES = {
     "wh_synthesis": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp,
                             ctypes.c_uint64, _vp, _vp]),
     "wh_cumsum_exact": (_int, [_vp, _vp, _vp, _vp, _int]),
+    "wh_peak_normalise": (_int, [_vp, _vp, _vp, _vp, _int]),
     "wh_synthesis_plan": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
     "wh_synthesis_requiem": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp, _vp, ctypes.c_int64,
                                     _vp, _int, _vp, ctypes.c_int64, _int, _vp, _vp]),

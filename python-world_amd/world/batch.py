@@ -146,19 +146,12 @@ class WorldBatch:
 
     def _peak_normalise(self, y, y_off):
         """y /= max|y| where it exceeds 1 (world/main.py:209-212), per utterance, on the device."""
-        torch = self.rt.torch
-        n = len(y_off) - 1
-        lens = np.diff(y_off)
-        if n > 0 and np.all(lens == lens[0]):
-            v = y.view(n, int(lens[0]))
-            m = v.abs().amax(dim=1, keepdim=True)
-            v /= torch.where(m > 1.0, m, torch.ones_like(m))
-        else:
-            for u in range(n):
-                seg = y[int(y_off[u]):int(y_off[u + 1])]
-                m = seg.abs().max()
-                if float(m) > 1.0:
-                    seg /= m
+        import ctypes
+
+        rt = self.rt
+        off = np.ascontiguousarray(y_off, dtype=np.int64)
+        _hip.check(rt.lib.wh_peak_normalise(rt.ctx, rt.stream(), rt.ptr(y), off.ctypes.data_as(ctypes.c_void_p),
+                                            len(off) - 1))
 
 
 class WorldBatchLanes:

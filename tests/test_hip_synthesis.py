@@ -79,3 +79,30 @@ def test_synthesis_device_rng_statistics(golden):
     assert not np.array_equal(ys[0], ys[1])
     assert 0.75 < np.mean(dev) / np.mean(ref) < 1.33
     assert rt.take_flags() == [0] * 16
+
+
+def test_peak_normalisation_branches():
+    """decode() divides by max|y| only where it exceeds 1 (world/main.py:209-212): a loud and a quiet utterance in
+    one batch, against the same pair scaled on the host."""
+    from world import _hip
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+    import ctypes
+
+    fs = 16000
+    xs = [4.0 * synth_utterance(81, fs, 0.7), 0.2 * synth_utterance(82, fs, 0.6)]
+    wb = WorldBatch()
+    enc = wb.encode(xs, fs, f0_method="dio")
+    rng = np.random.RandomState(2)
+    noise = [rng.randn(2 * len(x)) for x in xs]
+    y, y_off = wb.decode_device(enc, noise=noise)
+    y = y.cpu().numpy()
+    loud, quiet = y[y_off[0]:y_off[1]], y[y_off[1]:y_off[2]]
+    assert np.max(np.abs(loud)) == 1.0          # divided by its own maximum
+    assert 0.0 < np.max(np.abs(quiet)) < 1.0    # left alone
+    # the entry point itself on known data: [3, -6, 1.5] -> /6 ; [0.25, -0.5] untouched ; empty segment tolerated
+    rt = wb.rt
+    d = rt.to_device(np.array([3.0, -6.0, 1.5, 0.25, -0.5]))
+    off = np.array([0, 3, 3, 5], dtype=np.int64)
+    _hip.check(rt.lib.wh_peak_normalise(rt.ctx, rt.stream(), rt.ptr(d), off.ctypes.data_as(ctypes.c_void_p), 3))
+    assert np.array_equal(d.cpu().numpy(), np.array([0.5, -1.0, 0.25, 0.25, -0.5]))

@@ -97,15 +97,21 @@ __global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
   wh::low_band_replica<FT>(aux, zr, N, fs, f0, f0 + fs / N);
 
   // ---- step 2: rectangular smoothing, width 2*f0/3 (cheaptrick.py:103-131) -------------------
-  wh::scan_mirrored<FT, N>(aux, zr, fs, scratch);
-  wh::BandLookup lk;
-  lk.init(zr, N, fs);
-  lk.set_half_width(f0 / 3);
-  const double scale_f0 = 1.5 / f0;
-  for (int k = threadIdx.x; k < K; k += FT) {
+  // (a sliding windowed sum per thread-owned run of bins, wh_spectral.h: BandWindow)
+  wh::fill_mirrored<FT, N>(aux, zr, fs);
+  {
+    constexpr int KR = (K + FT - 1) / FT;
+    const int k0 = threadIdx.x * KR;
+    double bandv[KR];
+    wh::BandWindow bw;
+    bw.init(zr, N, fs, f0 / 3);
+    bw.run<KR>(k0, K, bandv);
+    const double scale_f0 = 1.5 / f0;
     // the reference adds rand()*eps here "to avoid log(0)" (cheaptrick.py:117, unseeded, Q10); its mean eps/2 keeps
     // that guarantee (digital silence) deterministically
-    aux[k] = log(lk.band(k) * scale_f0 + 0.5 * 2.220446049250313e-16);
+#pragma unroll
+    for (int r = 0; r < KR; ++r)
+      if (k0 + r < K) aux[k0 + r] = log(bandv[r] * scale_f0 + 0.5 * 2.220446049250313e-16);
   }
   wh::sync<FT>();
 

@@ -398,32 +398,40 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     }
     wh::sync<FT>();
   }
-  double* cum = zr;  // the FFT buffer is idle during the smoothing steps
+  double* cum = zr;  // the FFT buffer is idle during the smoothing steps (low-band scratch, then the mirrored spectra)
   const double inv_cf = 1.0 / cf;
   wh::low_band_replica<FT>(pw, cum, N, fs, cf, 1.2 * cf);
-  wh::scan_mirrored<FT, N>(pw, cum, fs, scratch);
-  wh::BandLookup lk;
-  lk.init(cum, N, fs);
-  lk.set_half_width(cf / 2);
-  for (int k = threadIdx.x; k < K; k += FT) {
-    const double sm = lk.band(k) * inv_cf;
-    cent[k] = cent[k] / sm;  // T_g = centroid / smoothed power (d4c.py:169; no zero guard, Q14)
-  }
+  // the three rectangular smoothings as sliding windowed sums (wh_spectral.h: BandWindow); thread t owns the bins
+  // [t*KR, (t+1)*KR) throughout, so only the mirrored-spectrum fills need barriers
+  constexpr int KR = (K + FT - 1) / FT;
+  const int k0 = threadIdx.x * KR;
+  double bandv[KR];
+  wh::BandWindow bw;
+  wh::fill_mirrored<FT, N>(pw, cum, fs);
+  bw.init(cum, N, fs, cf / 2);
+  bw.run<KR>(k0, K, bandv);
+#pragma unroll
+  for (int r = 0; r < KR; ++r)
+    if (k0 + r < K) cent[k0 + r] = cent[k0 + r] / (bandv[r] * inv_cf);  // T_g = centroid / smoothed power (d4c.py:169; no zero guard, Q14)
   wh::sync<FT>();
   // ---- group-delay shaping (d4c.py:165-174) --------------------------------------------------
-  wh::scan_mirrored<FT, N>(cent, cum, fs, scratch);
-  lk.init(cum, N, fs);
+  wh::fill_mirrored<FT, N>(cent, cum, fs);
   {
     const double w2 = cf / 2;
-    lk.set_half_width(w2 / 2);
     const double inv_w2 = 1.0 / w2;
-    for (int k = threadIdx.x; k < K; k += FT) pw[k] = lk.band(k) * inv_w2;  // T_gs
+    bw.init(cum, N, fs, w2 / 2);
+    bw.run<KR>(k0, K, bandv);
+#pragma unroll
+    for (int r = 0; r < KR; ++r)
+      if (k0 + r < K) pw[k0 + r] = bandv[r] * inv_w2;  // T_gs
   }
   wh::sync<FT>();
-  wh::scan_mirrored<FT, N>(pw, cum, fs, scratch);
-  lk.init(cum, N, fs);
-  lk.set_half_width(cf / 2);
-  for (int k = threadIdx.x; k < K; k += FT) cent[k] = pw[k] - lk.band(k) * inv_cf;  // T_D = T_gs - T_gb
+  wh::fill_mirrored<FT, N>(pw, cum, fs);
+  bw.init(cum, N, fs, cf / 2);
+  bw.run<KR>(k0, K, bandv);
+#pragma unroll
+  for (int r = 0; r < KR; ++r)
+    if (k0 + r < K) cent[k0 + r] = pw[k0 + r] - bandv[r] * inv_cf;  // T_D = T_gs - T_gb
   wh::sync<FT>();
 
 #if WH_D4C_ABLATE == 3

@@ -60,37 +60,34 @@ __device__ __forceinline__ void low_band_replica(double* p, double* tmp, int N, 
   sync<NT>();
 }
 
-// The prefix-sum array is stored with one double of padding after every 8 (element i at i + i/8, N + N/8 doubles):
-// the scan gives each thread a contiguous run, and with an unpadded layout the lanes of a wave would walk LDS at a
-// stride of 8 doubles, 8 of them on every bank.
-__device__ __forceinline__ int scan_pad(int i) { return i + (i >> 3); }
+// Rectangular smoothing on the doubled frequency axis (cheaptrick.py:103-131 / d4c.py:178-233).
+// The reference takes the cumulative sum c of the Hermitian-symmetric spectrum s (times fs/N), interpolates it
+// linearly and differences it at centre +- half.  With q = the real-valued bin index of a look-up position,
+// interp(c)(q) = c[floor q] + frac(q) * s[floor q + 1], so
+//     band(k) = sum_{i = k+b_lo+1}^{k+b_hi} s[i]  +  f_hi * s[k+b_hi+1]  -  f_lo * s[k+b_lo+1]
+// (indices modulo N on the mirrored spectrum; b_*, f_* are the integer and fractional parts of the two look-up
+// offsets, constant per frame): a plain windowed sum.  Each thread owns a run of consecutive bins and slides the
+// window along it (two LDS reads per further bin), so the smoothing needs the mirrored spectrum in LDS and ONE
+// barrier — not a 2048-element block prefix sum (four barriers and a shuffle scan) plus four interpolated
+// look-ups per bin; and it is free of the cancellation of differencing two large cumulative values.
+template <int NT, int N>
+__device__ __forceinline__ void fill_mirrored(const double* p_half, double* v, double fs) {
+  const double df = fs / N;
+  for (int i = threadIdx.x; i < N; i += NT) v[i] = p_half[i <= N / 2 ? i : N - i] * df;
+  sync<NT>();
+}
 
-// Doubled-spectrum cumulative lookup (cheaptrick.py:103-131 / d4c.py:178-233).
-// cum[scan_pad(i)], i<N: inclusive prefix sum of the Hermitian-symmetric spectrum times fs/N.
-struct BandLookup {
-  const double* cum;
-  int N;
-  double x0, dx, inv_dx, xlast, total;
-  __device__ __forceinline__ void init(const double* c, int n, double fs) {
-    cum = c;
-    N = n;
-    const double half = fs / n / 2;
-    x0 = (0.0 / n * fs - fs) + half;
-    const double x1 = (1.0 / n * fs - fs) + half;
-    dx = x1 - x0;
-    inv_dx = 1.0 / dx;  // the interpolant is continuous across bins, so a last-bit change of q is harmless
-    xlast = ((double)(2 * n - 1) / n * fs - fs) + half;
-    total = c[scan_pad(n - 1)];
-  }
-  __device__ __forceinline__ double seg(int i) const { return i < N ? cum[scan_pad(i)] : total + cum[scan_pad(i - N)]; }
-  // Band mean around every bin centre: the look-up positions centre_k +- half sit at a CONSTANT fractional
-  // offset from bin k (q_k = k + const), so base index and fraction are found once per frame instead of by a
-  // divide/floor per bin.  (Differs from evaluating q_k per bin only by rounding of q; the interpolant is
-  // continuous, so the value is unaffected.)  Requires centre +- half inside the doubled axis (always true for
-  // k <= N/2 and half < fs/2 - fs/N).
-  int b_lo, b_hi;
+struct BandWindow {
+  const double* v;
+  int mask, b_lo, b_hi;
   double f_lo, f_hi;
-  __device__ __forceinline__ void set_half_width(double half) {
+  __device__ __forceinline__ void init(const double* vv, int n, double fs, double half) {
+    v = vv;
+    mask = n - 1;
+    const double half_bin = fs / n / 2;
+    const double x0 = (0.0 / n * fs - fs) + half_bin;
+    const double x1 = (1.0 / n * fs - fs) + half_bin;
+    const double inv_dx = 1.0 / (x1 - x0);
     const double q_lo = ((0.0 - half) - x0) * inv_dx, q_hi = ((0.0 + half) - x0) * inv_dx;
     const double fl = floor(q_lo), fh = floor(q_hi);
     b_lo = (int)fl;
@@ -98,58 +95,23 @@ struct BandLookup {
     f_lo = q_lo - fl;
     f_hi = q_hi - fh;
   }
-  __device__ __forceinline__ double band(int k) const {  // at(c_k + half) - at(c_k - half)
-    const double l0 = seg(k + b_lo), h0 = seg(k + b_hi);
-    const double lo = l0 + (seg(k + b_lo + 1) - l0) * f_lo;
-    const double hi = h0 + (seg(k + b_hi + 1) - h0) * f_hi;
-    return hi - lo;
-  }
-  __device__ __forceinline__ double at(double xi) const {
-    xi = fmax(x0, fmin(xlast, xi));
-    const double q = (xi - x0) * inv_dx;
-    const double b = floor(q);
-    const double fr = q - b;
-    const int bi = (int)b;
-    const double y0 = seg(bi);
-    const double dy = (bi < 2 * N - 1) ? seg(bi + 1) - y0 : 0.0;
-    return y0 + dy * fr;
+  // out[r] = band(k0 + r), r < R (bins at or beyond k_end are skipped)
+  template <int R>
+  __device__ __forceinline__ void run(int k0, int k_end, double (&out)[R]) const {
+    int lo = k0 + b_lo, hi = k0 + b_hi;
+    double s = 0.0;
+    if (k0 < k_end)
+      for (int i = lo + 1; i <= hi; ++i) s += v[i & mask];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (k0 + r < k_end) {
+        out[r] = (s + f_hi * v[(hi + 1) & mask]) - f_lo * v[(lo + 1) & mask];
+        ++lo;
+        ++hi;
+        s += v[hi & mask] - v[lo & mask];
+      }
+    }
   }
 };
-
-// p_half[0..N/2] (LDS) → cum (LDS, scan_pad layout, N + N/8 doubles) = inclusive scan of the mirrored full
-// spectrum × fs/N.  Fill with thread-strided ownership (neighbouring lanes on neighbouring addresses), scan with
-// thread-contiguous runs held in registers (read once, written once).  Contains barriers; p_half must be visible
-// on entry; cum visible on exit.  `scratch` >= NT/64 doubles.
-template <int NT, int N>
-__device__ __forceinline__ void scan_mirrored(const double* p_half, double* cum, double fs, double* scratch) {
-  static_assert(N % NT == 0, "scan_mirrored: N must be a multiple of the thread count");
-  constexpr int PER = N / NT;
-  const double df = fs / N;
-  for (int i = threadIdx.x; i < N; i += NT) {
-    const int k = i <= N / 2 ? i : N - i;
-    cum[scan_pad(i)] = p_half[k] * df;
-  }
-  sync<NT>();
-  const int base = threadIdx.x * PER;
-  double r[PER];
-  double run = 0.0;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    run += cum[scan_pad(base + i)];
-    r[i] = run;
-  }
-  const double incl = wave_scan_incl(run);
-  double off = incl - run;
-  if constexpr (NT > WH_WAVE) {
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 63) scratch[w] = incl;
-    __syncthreads();
-    for (int i = 0; i < w; ++i) off += scratch[i];
-  }
-#pragma unroll
-  for (int i = 0; i < PER; ++i) cum[scan_pad(base + i)] = r[i] + off;
-  sync<NT>();
-}
 
 }  // namespace wh

@@ -1,0 +1,31 @@
+"""Per-stage cycle counts inside d4c_kernel (build with WH_EXTRA_FLAGS=-DWH_D4C_STAGE_TIMER): workgroup-thread-0
+timestamps at the stage boundaries, summed over all voiced frames of config 2's batch."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "python-world_amd"))
+import torch
+from world._synthetic import synth_utterance
+from world.batch import WorldBatch
+
+wb = WorldBatch(0)
+xs = [synth_utterance(i, 16000, 10.0) for i in range(64)]
+batch, x_d, tp_d = wb.upload(xs, 16000)
+lib = wb.rt.lib
+buf = (ctypes.c_ulonglong * 8)()
+for it in range(3):
+    enc = wb.encode_device(batch, x_d, tp_d, 16000, f0_method="dio")
+    torch.cuda.synchronize()
+    lib.wh_debug_d4c_stages(buf, 1)
+v = np.array(list(buf), dtype=np.float64)
+names = ["stage1: 2 windows + fused FFT + gate", "centroid A (window + FFT + fold)", "centroid B", "low-band replica (cent)",
+         "stage3: power replica + 3 scans/lookups", "stage4: band window + rFFT + rank select", "outputs"]
+tot = v[:7].sum()
+voiced = float((enc.vuv.cpu().numpy() != 0).sum())
+for n, c in zip(names, v[:7]):
+    print("%-45s %6.1f %%   %8.0f cycles / voiced frame" % (n, 100 * c / tot, c / max(voiced, 1)))
+print("total %.0f cycles per voiced frame (workgroup latency)" % (tot / max(voiced, 1)))

@@ -26,6 +26,16 @@
 #ifndef WH_D4C_REGFFT
 #define WH_D4C_REGFFT 1
 #endif
+// -DWH_D4C_STAGE_TIMER: thread 0 of every workgroup adds the shader-clock cycles between stage boundaries to
+// g_d4c_stage[] (read with wh_debug_d4c_stages, tools/d4c_stage_timer.py) — the per-stage latencies quoted in DESIGN.md.
+#ifdef WH_D4C_STAGE_TIMER
+__device__ unsigned long long g_d4c_stage[16];
+#define STAGE_TIMER_BEGIN unsigned long long _t0 = __builtin_readcyclecounter();
+#define STAGE_MARK(i) { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long _t = __builtin_readcyclecounter(); atomicAdd(&g_d4c_stage[i], _t - _t0); _t0 = _t; } }
+#else
+#define STAGE_TIMER_BEGIN
+#define STAGE_MARK(i)
+#endif
 namespace {
 
 #ifndef WH_FT_D4C
@@ -303,6 +313,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   double* scratch = pw + (N / 2 + 8);                // 16
   double* band = scratch + 32;                       // nap (<= 8)
 
+  STAGE_TIMER_BEGIN
   const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
   if (f >= n_frames) return;
   const int u = frame_utt[f];
@@ -324,6 +335,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     double va[N / FT], vb[N / FT];
     d4c_window<true, N, false>(xu, xn, fs, fmax(f0v, 40.0), pos, 1.5, zr, va, scratch);
     d4c_window<false, N, false>(xu, xn, fs, cf, pos, 2.0, zr, vb, scratch);
+    STAGE_MARK(7)
     double2 zin[N / FT];
 #pragma unroll
     for (int q = 0; q < N / FT; ++q) zin[q] = make_double2(va[q], vb[q]);
@@ -335,6 +347,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
       wh::sync<FT>();
       wh::fft_lds<N, false, FT, FT, WH_D4C_MAXR>(buf, tw_base + N);
     }
+    STAGE_MARK(8)
     const int b0 = (int)(ceil(100.0 / (fs / N)) + 1);
     const int b1 = (int)(ceil(4000.0 / (fs / N)) + 1);
     const int b2 = (int)(ceil(7900.0 / (fs / N)) + 1);
@@ -374,10 +387,14 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = pw[threadIdx.x];
   return;
 #endif
+  STAGE_MARK(0)
   // ---- static centroid from two frames at +-T0/4 (d4c.py:132-142) + DC correction ----------
   add_centroid<N>(xu, xn, fs, cf, pos + 1 / cf / 4, buf, cent, true, tw_base, scratch);
+  STAGE_MARK(1)
   add_centroid<N>(xu, xn, fs, cf, pos - 1 / cf / 4, buf, cent, false, tw_base, scratch);
+  STAGE_MARK(2)
   wh::low_band_replica<FT>(cent, zr, N, fs, cf, 1.2 * cf);
+  STAGE_MARK(3)
 
 #if WH_D4C_ABLATE == 2
   if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = cent[threadIdx.x] + pw[3];
@@ -438,6 +455,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = cent[threadIdx.x] + pw[3];
   return;
 #endif
+  STAGE_MARK(4)
   // ---- band-wise aperiodicity (d4c.py:192-209) -----------------------------------------------
   const int boundary = (int)((double)N / wlen * 8 + 0.5);
   const int half = wlen / 2;
@@ -460,6 +478,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
       pw[k] = z.x * z.x + z.y * z.y;
     }
     wh::sync<FT>();
+    STAGE_MARK(9)
     double s_small, s_total;
     sum_smallest<K>(pw, N / 2 - boundary, buf, scratch, &s_small, &s_total);  // FFT buffer is free: selection scratch
     if (threadIdx.x == 0) band[b] = -10 * log10(s_small / s_total);
@@ -470,6 +489,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = band[0];
   return;
 #endif
+  STAGE_MARK(5)
   // ---- outputs (d4c.py:56-59 / d4cRequiem.py:40) ---------------------------------------------
   const double tilt = (cf - 100) * 2 / 100;
   if (k_spec > 0) {
@@ -498,6 +518,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     for (int b = threadIdx.x; b < nap + 2; b += FT)
       o[b] = b == 0 ? -60.0 : (b == nap + 1 ? -0.000000000001 : -fmax(0.0, band[b - 1] - tilt));
   }
+  STAGE_MARK(6)
 }
 
 int pow2_at_least(double v) { return (int)llround(pow(2.0, ceil(log2(v)))); }
@@ -579,6 +600,17 @@ int d4c_common(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, co
 }
 
 }  // namespace
+
+#ifdef WH_D4C_STAGE_TIMER
+extern "C" int wh_debug_d4c_stages(unsigned long long* out16, int reset) {
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_d4c_stage), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_d4c_stage), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 extern "C" int wh_d4c_bands(double fs, int requiem) {
   const int interval = (!requiem && fs < 16000) ? 2000 : 3000;

@@ -100,8 +100,20 @@ struct BandWindow {
   __device__ __forceinline__ void run(int k0, int k_end, double (&out)[R]) const {
     int lo = k0 + b_lo, hi = k0 + b_hi;
     double s = 0.0;
-    if (k0 < k_end)
-      for (int i = lo + 1; i <= hi; ++i) s += v[i & mask];
+    if (k0 < k_end) {
+      // four independent partial sums: the LDS reads of the first window pipeline instead of each waiting for the
+      // previous add
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int i = lo + 1;
+      for (; i + 3 <= hi; i += 4) {
+        s0 += v[i & mask];
+        s1 += v[(i + 1) & mask];
+        s2 += v[(i + 2) & mask];
+        s3 += v[(i + 3) & mask];
+      }
+      for (; i <= hi; ++i) s0 += v[i & mask];
+      s = (s0 + s1) + (s2 + s3);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (k0 + r < k_end) {

@@ -16,16 +16,18 @@ wb = WorldBatch(0)
 xs = [synth_utterance(i, 16000, 10.0) for i in range(64)]
 batch, x_d, tp_d = wb.upload(xs, 16000)
 lib = wb.rt.lib
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 for it in range(3):
     enc = wb.encode_device(batch, x_d, tp_d, 16000, f0_method="dio")
     torch.cuda.synchronize()
     lib.wh_debug_d4c_stages(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
-names = ["stage1: 2 windows + fused FFT + gate", "centroid A (window + FFT + fold)", "centroid B", "low-band replica (cent)",
-         "stage3: power replica + 3 scans/lookups", "stage4: band window + rFFT + rank select", "outputs"]
-tot = v[:7].sum()
+order = [(7, "start-up + the two stage-1 windows"), (8, "fused gate/power FFT"), (0, "gate reduction + power fold"),
+         (1, "centroid A (window + FFT + fold)"), (2, "centroid B"), (3, "low-band replica (cent)"),
+         (4, "smoothing: power replica + 3 sliding windows"), (9, "band window + real FFT + power"), (5, "rank select"),
+         (6, "outputs")]
+tot = v.sum()
 voiced = float((enc.vuv.cpu().numpy() != 0).sum())
-for n, c in zip(names, v[:7]):
-    print("%-45s %6.1f %%   %8.0f cycles / voiced frame" % (n, 100 * c / tot, c / max(voiced, 1)))
+for i, n in order:
+    print("%-48s %6.1f %%   %8.0f cycles / voiced frame" % (n, 100 * v[i] / tot, v[i] / max(voiced, 1)))
 print("total %.0f cycles per voiced frame (workgroup latency)" % (tot / max(voiced, 1)))

@@ -53,6 +53,21 @@ __device__ __forceinline__ long long xcd_unit(long long id, long long n) {
 }
 __host__ __device__ __forceinline__ long long xcd_grid(long long n) { return ((n + 7) / 8) * 8; }
 
+// Barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, so a global load
+// issued before it (the FFT passes fetch their twiddles ahead of the barrier) would have to land before any wave
+// may pass; with the fences restricted to the local address space the load stays in flight across the barrier.
+// Only valid where the threads hand each other LDS contents and nothing else.
+template <int NT>
+__device__ __forceinline__ void sync_lds() {
+  if constexpr (NT <= WH_WAVE) {
+    sync<NT>();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = WH_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WH_WAVE);
@@ -296,12 +311,12 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ s, const double2*
         v[p][r] = s[SWZ_IN ? (J % 64 == 0 ? fft_swz(j) + r * J : fft_swz(j + r * J)) : j + r * J];
     }
   }
-  sync<SNT>();
+  sync_lds<SNT>();
 #if !WH_FFT_TW_PREFETCH
   fft_pass_twiddles<N, NT, R, NS, INV>(tw, w);
 #endif
   fft_pass_finish<N, NT, R, NS, INV, SWZ_OUT>(s, v, w);
-  sync<SNT>();
+  sync_lds<SNT>();
 }
 
 template <int N, int NT, int NS, bool INV, int SNT = NT, int MAXR = 8>
@@ -336,9 +351,9 @@ __device__ __forceinline__ void fft_lds_from_regs(const double2 (&x)[N / NT], do
   for (int p = 0; p < PER; ++p)
 #pragma unroll
     for (int r = 0; r < R; ++r) v[p][r] = x[p + r * PER];
-  sync<NT>();
+  sync_lds<NT>();
   fft_pass_finish<N, NT, R, 1, INV, (R < N && MAXR >= 8)>(s, v, w);
-  sync<NT>();
+  sync_lds<NT>();
   fft_passes<N, NT, R, INV, NT, MAXR>(s, tw);
 }
 
@@ -372,7 +387,7 @@ __device__ __forceinline__ void rfft_lds(double2* z, const double2* __restrict__
       z[N / 2 - k] = make_double2(er - tr, ti - ei);  // conj(E - T)
     }
   }
-  sync<SNT>();
+  sync_lds<SNT>();
 }
 
 // Inverse.  in: z[k] = X[k], k = 0..N/2: the half spectrum; the result is Re(IDFT) of its Hermitian extension
@@ -395,7 +410,7 @@ __device__ __forceinline__ void irfft_lds(double2* z, const double2* __restrict_
     z[k] = make_double2(er - oi, ei + orr);                      // Z[k]     = 2E + i*2O
     if (k != 0) z[N / 2 - k] = make_double2(er + oi, orr - ei);  // Z[N/2-k] = conj(2E) + i*conj(2O)
   }
-  sync<SNT>();
+  sync_lds<SNT>();
   fft_lds<N / 2, true, NT, SNT, MAXR>(z, tw_base + N / 2);
 }
 

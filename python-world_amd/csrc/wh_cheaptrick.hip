@@ -1,6 +1,6 @@
 // CheapTrick spectral envelope — one 128-thread workgroup per frame (256 from N = 2048), everything between the
-// waveform gather and the final envelope stays in LDS (~13*N bytes): window → real FFT → power →
-// low-band replica → block-scan smoothing → log → real FFT → lifter → inverse real FFT → exp.
+// waveform gather and the final envelope stays in LDS (12*N bytes): window → real FFT → power →
+// low-band replica → sliding-window smoothing → log → real FFT → lifter → inverse real FFT → exp.
 // All three transforms run as N/2-point complex FFTs on sample pairs (wh_device.h: rfft_lds / irfft_lds).
 // Replaces cheaptrick()/estimate_one_slice() of the reference (world/cheaptrick.py:9-157).
 #include "wh_host.h"
@@ -24,8 +24,8 @@ __global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = N / 2 + 1;
   double2* zb = reinterpret_cast<double2*>(smem);   // N/2+1 complex = the N-sample real buffer (+1 bin)
-  double* zr = reinterpret_cast<double*>(smem);     // same memory viewed as reals; also the prefix-sum array
-  double* aux = zr + (N + N / 8 + 2);               // K+1 reals (zr doubles as the padded prefix-sum array)
+  double* zr = reinterpret_cast<double*>(smem);     // same memory viewed as reals; also the mirrored power spectrum
+  double* aux = zr + (N + 2);                       // K+1 reals
   double* scratch = aux + (K + 1);                  // 32 doubles
 
   const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
 template <int N>
 int launch(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
            const double* vuv, double fs, double q1, double* spec, double* ps) {
-  const size_t lds = sizeof(double) * ((N + N / 8 + 2) + (N / 2 + 2) + 32);
+  const size_t lds = sizeof(double) * ((N + 2) + (N / 2 + 2) + 32);
   const double low = fs * 3.0 / (N - 3.0);
   if (int rc = wh::allow_lds(&cheaptrick_kernel<N>, lds)) return rc;
   { wh::KernelTimer _kt(ctx, st, "cheaptrick_kernel"); hipLaunchKernelGGL(cheaptrick_kernel<N>, dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_ct(N)), lds, st, x, b->d_x_off,

@@ -2,7 +2,7 @@
 //   love_train_kernel : VUV gate, one workgroup per frame, one FFT          (world/d4c.py:68-88)
 //   d4c_kernel        : per gated frame, everything in LDS: two Blackman frames packed as
 //                       x + j*n*x into ONE complex FFT each (spectrum and time-weighted spectrum
-//                       are separated by Hermitian symmetry), Hann frame FFT, three block-scan
+//                       are separated by Hermitian symmetry), Hann frame FFT, three sliding-window
 //                       smoothings, then per 3 kHz band: Nuttall-windowed group delay → FFT →
 //                       rank-select of the smallest-energy bins → energy ratio      (world/d4c.py:114-209)
 // Replaces d4c() (world/d4c.py:10-64) and d4cRequiem() (world/d4cRequiem.py:9-44).
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = N / 2 + 1;
   double2* buf = reinterpret_cast<double2*>(smem);   // N complex (centroid FFT) / N/2+1 complex (real FFTs)
-  double* zr = reinterpret_cast<double*>(smem);      // the same 2N doubles: real buffers, prefix sums, scratch
+  double* zr = reinterpret_cast<double*>(smem);      // the same 2N doubles: real buffers, mirrored spectra, scratch
   double* cent = zr + 2 * N;                         // K (padded to N/2+8)
   double* pw = cent + (N / 2 + 8);                   // K
   double* scratch = pw + (N / 2 + 8);                // 16

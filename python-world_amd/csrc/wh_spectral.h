@@ -1,7 +1,7 @@
 // Device routines shared by the CheapTrick and D4C kernels: pitch-synchronous sample gather,
 // the "mirror the bins below f0" correction and the cumsum-based rectangular smoothing.
 // Formulas follow world/cheaptrick.py:64-131 and world/d4c.py:92-110,178-233 (reference);
-// the data movement (LDS staging, block scans) is this build's own.
+// the data movement (LDS staging, sliding windows) is this build's own.
 #pragma once
 #include "wh_device.h"
 

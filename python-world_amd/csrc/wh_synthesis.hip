@@ -16,6 +16,16 @@
 #include "wh_host.h"
 #include "wh_device.h"
 
+// -DWH_RESP_STAGE_TIMER: per-stage shader-clock cycles of response_kernel (thread 0 of every workgroup), read with
+// wh_debug_resp_stages (tools/resp_stage_timer.py).
+#ifdef WH_RESP_STAGE_TIMER
+__device__ unsigned long long g_resp_stage[8];
+#define RSTAGE_BEGIN unsigned long long _t0 = __builtin_readcyclecounter();
+#define RSTAGE_MARK(i) { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long _t = __builtin_readcyclecounter(); atomicAdd(&g_resp_stage[i], _t - _t0); _t0 = _t; } }
+#else
+#define RSTAGE_BEGIN
+#define RSTAGE_MARK(i)
+#endif
 namespace {
 
 #ifndef WH_RESP_ABLATE
@@ -397,10 +407,13 @@ __global__ void pulse_base_kernel(const int32_t* __restrict__ p_count, int n_utt
 __global__ __launch_bounds__(256) void pulse_frames_kernel(const SynUtt* __restrict__ meta, const double* __restrict__ tp,
                                                            const double* __restrict__ p_time,
                                                            const int32_t* __restrict__ p_count,
-                                                           int64_t* __restrict__ p_frames, double* __restrict__ p_weight) {
+                                                           const int64_t* __restrict__ p_base,
+                                                           int64_t* __restrict__ p_frames, double* __restrict__ p_weight,
+                                                           int32_t* __restrict__ p_utt) {
   const SynUtt m = meta[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= p_count[blockIdx.y]) return;
+  p_utt[p_base[blockIdx.y] + i] = blockIdx.y;  // flat pulse number -> utterance: one load in response_kernel instead of a search
   const double* tpu = tp + m.f_off;
   const double ptime = p_time[m.p_off + i];
   // temporal_position_index = interp(tp -> 1..F)(time), clipped to [1, F]
@@ -522,6 +535,7 @@ struct RespArgs {
   const int64_t* p_noff;
   const int64_t* p_frames;
   const double* p_weight;
+  const int32_t* p_utt;
   const int32_t* p_count;
   const int64_t* p_base;
   int n_utt;
@@ -548,7 +562,6 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   const int64_t* __restrict__ p_noff = A.p_noff;
   const int32_t* __restrict__ p_count = A.p_count;
   const int64_t* __restrict__ p_base = A.p_base;
-  const int n_utt = A.n_utt;
   const uint8_t* __restrict__ vuv_s = A.vuv_s;
   const double* __restrict__ noise = A.noise;
   const uint64_t seed = A.seed;
@@ -573,16 +586,9 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   double* scratch = nz + NZ;                                        // 16
   static_assert(2 * (K + 7) <= N + N / 16 + 2, "amplitude arrays must fit under the padded response");
 
+  RSTAGE_BEGIN
   wh::sync<FT>();
-  int u;
-  {
-    int lo = 0, hi = n_utt;  // largest u with p_base[u] <= gp
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (p_base[mid] <= gp) lo = mid; else hi = mid;
-    }
-    u = lo;
-  }
+  const int u = A.p_utt[gp];
   const SynUtt m = meta[u];
   const int i = (int)(gp - p_base[u]);
   const int count = p_count[u];
@@ -648,6 +654,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
     mean = wh::block_sum<FT>(part, scratch) / (double)nd;  // barriers: spec/asp/nz visible
   }
 
+  RSTAGE_MARK(0)
   // ---- minimum-phase responses (synthesis.py:86-116): aperiodic chain on thread group 0, periodic chain on
   //      group 1, advancing through the same barrier phases (with a single group: one after the other) --------
 #if WH_RESP_ABLATE == 2
@@ -668,6 +675,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
       }
     }
     wh::sync<FT>();
+    RSTAGE_MARK(1)
     wh::irfft_lds<N, GT, FT>(g == 0 ? zbA : zbP, tw_base);
   } else {
     min_phase_half<N, FT>(asp, zbA, tw_base);
@@ -684,6 +692,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
       wh::irfft_lds<N, FT, FT>(zbP, tw_base);
     }
   }
+  RSTAGE_MARK(2)
   // zrA[n] = N * aperiodic response, zrP[n] = N * periodic response (both before fftshift)
   for (int n = threadIdx.x; n < N; n += FT) rap[rap_index(n)] = zrA[(n + N / 2) & (N - 1)] / N;
   wh::sync<FT>();
@@ -732,6 +741,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
     }
   }
 
+  RSTAGE_MARK(3)
   // ---- DC removal of the periodic response (synthesis.py:72-73) ------------------------------------
   double dc_total = 0.0;
   const double gain = sqrt((double)(noise_size > 1 ? noise_size : 1));
@@ -757,6 +767,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
     else if (mm == N - 1) atomicAdd(&yu[m.ny - 1], v);  // last duplicate wins on the high side
 #endif
   }
+  RSTAGE_MARK(4)
 }
 
 template <int N>
@@ -776,8 +787,8 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
                 const double* spec, const double* ap, double fs, const double* p_time, const int64_t* p_idx,
                 const double* p_shift, const int64_t* p_noff, const int32_t* p_count, const int64_t* p_base,
                 const uint8_t* vuv_s, const double* noise, uint64_t seed, double* y, int64_t* p_frames,
-                double* p_weight) {
-  { wh::KernelTimer _kt(ctx, st, "pulse_frames_kernel"); hipLaunchKernelGGL(pulse_frames_kernel, dim3((unsigned)((pcap_max + 255) / 256), B), dim3(256), 0, st, d_meta, tp, p_time, p_count, p_frames, p_weight); }
+                double* p_weight, int32_t* p_utt) {
+  { wh::KernelTimer _kt(ctx, st, "pulse_frames_kernel"); hipLaunchKernelGGL(pulse_frames_kernel, dim3((unsigned)((pcap_max + 255) / 256), B), dim3(256), 0, st, d_meta, tp, p_time, p_count, p_base, p_frames, p_weight, p_utt); }
   WH_LAUNCH_CHECK("pulse_frames_kernel");
   std::vector<double> dc(N);
   double sum = 0.0;
@@ -791,7 +802,7 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   const size_t lds = sizeof(double) * (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32);
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
   const int64_t grid = pcap_max * B;  // one workgroup per pulse slot; slots past the real count exit at once
-  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_time, p_idx, p_shift, p_noff, p_frames, p_weight, p_count, p_base, B, vuv_s, noise, seed, d_dc, ctx->d_twiddle, y};
+  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_time, p_idx, p_shift, p_noff, p_frames, p_weight, p_utt, p_count, p_base, B, vuv_s, noise, seed, d_dc, ctx->d_twiddle, y};
   hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(ft_syn(N)), lds, st, ra); }
   WH_LAUNCH_CHECK("response_kernel");
   return 0;
@@ -1001,6 +1012,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   const size_t o_pb = off; off += al(sizeof(int64_t) * (B + 1));
   const size_t o_pf = off; off += al(sizeof(int64_t) * B * pulse_cap);
   const size_t o_pw = off; off += al(sizeof(double) * B * pulse_cap);
+  const size_t o_pu = off; off += al(sizeof(int32_t) * B * pulse_cap);
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
   SynUtt* d_meta = nullptr;
@@ -1013,6 +1025,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   int64_t* d_pn = reinterpret_cast<int64_t*>(ws + o_pn);
   int64_t* d_pf = reinterpret_cast<int64_t*>(ws + o_pf);
   double* d_pw = reinterpret_cast<double*>(ws + o_pw);
+  int32_t* d_pu = reinterpret_cast<int32_t*>(ws + o_pu);
   int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
   if (int rc = wh::persistent_upload(ctx, "syn.meta", meta, &d_meta)) return rc;
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
@@ -1026,10 +1039,10 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   WH_LAUNCH_CHECK("pulse_base_kernel");
   int rc;
   switch (fft_size) {
-    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw); break;
-    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw); break;
-    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw); break;
-    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw); break;
+    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
+    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
+    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
+    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
     default: return wh::fail_msg("wh_synthesis", "fft_size must be a power of two in [512, 4096]");
   }
   if (rc) return rc;
@@ -1089,6 +1102,17 @@ extern "C" int wh_peak_normalise(wh_ctx* ctx, void* stream, double* y, const int
   WH_LAUNCH_CHECK("peak_scale_kernel");
   return 0;
 }
+
+#ifdef WH_RESP_STAGE_TIMER
+extern "C" int wh_debug_resp_stages(unsigned long long* out8, int reset) {
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_resp_stage), sizeof(unsigned long long) * 8);
+  if (reset) {
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_resp_stage), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 // In-place exact sequential cumulative sum of n_seg independent segments of NON-NEGATIVE doubles
 // (h_off[n_seg + 1] element offsets into d_data) — the routine behind the phase accumulator, exposed so that its

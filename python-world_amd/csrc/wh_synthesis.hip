@@ -28,6 +28,9 @@ __device__ unsigned long long g_resp_stage[8];
 #endif
 namespace {
 
+#ifndef WH_RESP_TRANS_UNROLL
+#define WH_RESP_TRANS_UNROLL 1
+#endif
 #ifndef WH_RESP_ABLATE
 #define WH_RESP_ABLATE 0
 #endif
@@ -496,7 +499,7 @@ __device__ __forceinline__ void min_phase_half(double* amp, double2* zb, const d
   constexpr int FT = ft_syn(N);
   double* zr = reinterpret_cast<double*>(zb);
   const int gt = threadIdx.x & (GT - 1);
-#pragma unroll 1
+#pragma unroll WH_RESP_TRANS_UNROLL
   for (int k = gt; k <= N / 2; k += GT) amp[k] = log(fabs(amp[k])) / 2;
   wh::sync<FT>();
   for (int n = gt; n < N; n += GT) zr[n] = amp[n <= N / 2 ? n : N - n];
@@ -507,7 +510,7 @@ __device__ __forceinline__ void min_phase_half(double* amp, double2* zb, const d
   for (int n = gt; n < N; n += GT) zr[n] = n == 0 ? amp[0] : (n >= N / 2 ? 2 * amp[N - n] : 0.0);
   wh::sync<FT>();
   wh::rfft_lds<N, GT, FT>(zb, tw_base);
-#pragma unroll 1
+#pragma unroll WH_RESP_TRANS_UNROLL
   for (int k = gt; k <= N / 2; k += GT) {
     const double2 r = zb[k];  // sum c[n] e^{+i..} = conj(r)
     const double e = exp(r.x / N);
@@ -666,7 +669,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
     const int g = threadIdx.x / GT;
     min_phase_half<N, GT>(g == 0 ? asp : spec, g == 0 ? zbA : zbP, tw_base);
     if (g == 1) {
-#pragma unroll 1
+#pragma unroll WH_RESP_TRANS_UNROLL
       for (int k = threadIdx.x & (GT - 1); k <= N / 2; k += GT) {
         double sn, cs;
         sincospi(coef_pi * shift * (double)k, &sn, &cs);  // angle coef*shift*k expressed in units of pi

@@ -1,144 +1,143 @@
-"""`World` facade — same class, method names, arguments and result-dict keys as world/main.py:26-214
-of the reference; every stage it calls runs on the MI355X through libworld_hip.so.
+"""`World` facade: the class, method names, argument order / defaults and result-dict keys of the reference's
+world/main.py:26-214, with every stage running on the MI355X through libworld_hip.so.
 
-Only the analysis/synthesis path is provided: the reference's feature helpers
-(mel filterbank, MCEP, VAE glue, draw) are downstream of encode/decode and are not part of this build.
+Only the analysis/synthesis path is provided: the reference's feature helpers (mel filterbank,
+MCEP, VAE glue, draw) sit downstream of encode/decode and are not part of this build.
 """
 import logging
-from typing import Iterable
 
 import numpy as np
 
-from .cheaptrick import cheaptrick
-from .d4c import d4c
-from .d4cRequiem import d4cRequiem
-from .dio import dio
-from .get_seeds_signals import get_seeds_signals
-from .harvest import harvest
-from .stonemask import stonemask
-from .swipe import swipe
-from .synthesis import synthesis
-from .synthesisRequiem import synthesisRequiem
+from . import cheaptrick as _ct
+from . import d4c as _d4c
+from . import d4cRequiem as _d4cr
+from . import dio as _dio
+from . import get_seeds_signals as _seeds
+from . import harvest as _hv
+from . import stonemask as _sm
+from . import swipe as _swipe
+from . import synthesis as _syn
+from . import synthesisRequiem as _synr
+
+_SOURCE_KEYS = ('temporal_positions', 'vuv', 'f0')
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys}
+
+
+def _estimate_source(fs, x, method, floor, ceil, channels, target_fs, period, allowed_range):
+    """F0 stage shared by get_f0 / get_spectrum / encode (world/main.py:36-46, 62-72, 121-135).  allowed_range is None
+    for the two getters, which call dio() positionally without it."""
+    if method == 'dio':
+        extra = {} if allowed_range is None else {'allowed_range': allowed_range}
+        source = _dio.dio(x, fs, floor, ceil, channels, target_fs, period, **extra)
+        source['f0'] = _sm.stonemask(x, fs, source['temporal_positions'], source['f0'])
+        return source
+    if method == 'harvest':
+        return _hv.harvest(x, fs, f0_floor=floor, f0_ceil=ceil, frame_period=period)
+    if method == 'swipe':
+        return _swipe.swipe(fs, x, plim=[floor, ceil], sTHR=0.3)
+    raise Exception  # the reference raises a bare Exception for an unknown method
+
+
+def _aperiodicity(x, fs, source, fft_size, is_requiem):
+    if is_requiem:
+        return _d4cr.d4cRequiem(x, fs, source, fft_size=fft_size)
+    return _d4c.d4c(x, fs, source, fft_size_for_spectrum=fft_size)
 
 
 class World(object):
-    def get_f0(self, fs: int, x: np.ndarray, f0_method: str = 'harvest', f0_floor: int = 71, f0_ceil: int = 800,
-               channels_in_octave: int = 2, target_fs: int = 4000, frame_period: int = 5) -> tuple:
-        """world/main.py:27-49."""
-        source = self._f0(fs, x, f0_method, f0_floor, f0_ceil, channels_in_octave, target_fs, frame_period, None)
-        return source['temporal_positions'], source['f0'], source['vuv']
+    # ---- analysis -----------------------------------------------------------------------------------------
+    def get_f0(self, fs, x, f0_method='harvest', f0_floor=71, f0_ceil=800, channels_in_octave=2, target_fs=4000,
+               frame_period=5):
+        """(temporal_positions, f0, vuv) — world/main.py:27-49."""
+        s = _estimate_source(fs, x, f0_method, f0_floor, f0_ceil, channels_in_octave, target_fs, frame_period, None)
+        return tuple(s[k] for k in ('temporal_positions', 'f0', 'vuv'))
 
-    def get_spectrum(self, fs: int, x: np.ndarray, f0_method: str = 'harvest', f0_floor: int = 71,
-                     f0_ceil: int = 800, channels_in_octave: int = 2, target_fs: int = 4000, frame_period: int = 5,
-                     fft_size=None) -> dict:
+    def get_spectrum(self, fs, x, f0_method='harvest', f0_floor=71, f0_ceil=800, channels_in_octave=2,
+                     target_fs=4000, frame_period=5, fft_size=None):
         """world/main.py:51-79."""
-        source = self._f0(fs, x, f0_method, f0_floor, f0_ceil, channels_in_octave, target_fs, frame_period, None)
-        filt = cheaptrick(x, fs, source, fft_size=fft_size)
-        return {'f0': source['f0'],
-                'temporal_positions': source['temporal_positions'],
-                'fs': fs,
-                'ps spectrogram': filt['ps spectrogram'],
-                'spectrogram': filt['spectrogram']}
+        s = _estimate_source(fs, x, f0_method, f0_floor, f0_ceil, channels_in_octave, target_fs, frame_period, None)
+        env = _ct.cheaptrick(x, fs, s, fft_size=fft_size)
+        out = _pick(s, ('f0', 'temporal_positions'))
+        out['fs'] = fs
+        out.update(_pick(env, ('ps spectrogram', 'spectrogram')))
+        return out
 
-    def encode_w_gvn_f0(self, fs: int, x: np.ndarray, source: dict, fft_size=None, is_requiem: bool = False) -> dict:
-        """world/main.py:81-104 (including its quirks: fft_size=None raises TypeError at the assert and
-        is_requiem=True raises KeyError('coarse_ap'))."""
+    def encode_w_gvn_f0(self, fs, x, source, fft_size=None, is_requiem=False):
+        """world/main.py:81-104, quirks included: fft_size=None raises TypeError at the assert and is_requiem=True
+        raises KeyError('coarse_ap')."""
         assert np.all(source['f0'] >= 3 * fs / fft_size)
-        filt = cheaptrick(x, fs, source, fft_size=fft_size)
-        if is_requiem:
-            source = d4cRequiem(x, fs, source, fft_size=fft_size)
-        else:
-            source = d4c(x, fs, source, fft_size_for_spectrum=fft_size)
-        return {'temporal_positions': source['temporal_positions'],
-                'vuv': source['vuv'],
-                'f0': source['f0'],
-                'fs': fs,
-                'spectrogram': filt['spectrogram'],
-                'aperiodicity': source['aperiodicity'],
-                'coarse_ap': source['coarse_ap'],
-                'is_requiem': is_requiem}
+        env = _ct.cheaptrick(x, fs, source, fft_size=fft_size)
+        source = _aperiodicity(x, fs, source, fft_size, is_requiem)
+        out = _pick(source, _SOURCE_KEYS)
+        out['fs'] = fs
+        out['spectrogram'] = env['spectrogram']
+        out.update(_pick(source, ('aperiodicity', 'coarse_ap')))
+        out['is_requiem'] = is_requiem
+        return out
 
-    def encode(self, fs: int, x: np.ndarray, f0_method: str = 'harvest', f0_floor: int = 71, f0_ceil: int = 800,
-               channels_in_octave: int = 2, target_fs: int = 4000, frame_period: int = 5,
-               allowed_range: float = 0.1, fft_size=None, is_requiem: bool = False) -> dict:
+    def encode(self, fs, x, f0_method='harvest', f0_floor=71, f0_ceil=800, channels_in_octave=2, target_fs=4000,
+               frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False):
         """world/main.py:106-152."""
-        if fft_size != None:  # noqa: E711  (same test as the reference)
+        if fft_size != None:  # noqa: E711 — the reference's own test: 0 also counts as "given"
             f0_floor = 3.0 * fs / fft_size
-        source = self._f0(fs, x, f0_method, f0_floor, f0_ceil, channels_in_octave, target_fs, frame_period,
-                          allowed_range)
-        filt = cheaptrick(x, fs, source, fft_size=fft_size)
-        if is_requiem:
-            source = d4cRequiem(x, fs, source, fft_size=fft_size)
-        else:
-            source = d4c(x, fs, source, fft_size_for_spectrum=fft_size)
-        return {'temporal_positions': source['temporal_positions'],
-                'vuv': source['vuv'],
-                'fs': filt['fs'],
-                'f0': source['f0'],
-                'aperiodicity': source['aperiodicity'],
-                'ps spectrogram': filt['ps spectrogram'],
-                'spectrogram': filt['spectrogram'],
-                'is_requiem': is_requiem}
+        source = _estimate_source(fs, x, f0_method, f0_floor, f0_ceil, channels_in_octave, target_fs, frame_period,
+                                  allowed_range)
+        env = _ct.cheaptrick(x, fs, source, fft_size=fft_size)
+        source = _aperiodicity(x, fs, source, fft_size, is_requiem)
+        out = _pick(source, ('temporal_positions', 'vuv'))
+        out['fs'] = env['fs']
+        out.update(_pick(source, ('f0', 'aperiodicity')))
+        out.update(_pick(env, ('ps spectrogram', 'spectrogram')))
+        out['is_requiem'] = is_requiem
+        return out
 
-    @staticmethod
-    def _f0(fs, x, f0_method, f0_floor, f0_ceil, channels_in_octave, target_fs, frame_period, allowed_range):
-        if f0_method == 'dio':
-            if allowed_range is None:
-                source = dio(x, fs, f0_floor, f0_ceil, channels_in_octave, target_fs, frame_period)
-            else:
-                source = dio(x, fs, f0_floor=f0_floor, f0_ceil=f0_ceil, channels_in_octave=channels_in_octave,
-                             target_fs=target_fs, frame_period=frame_period, allowed_range=allowed_range)
-            source['f0'] = stonemask(x, fs, source['temporal_positions'], source['f0'])
-        elif f0_method == 'harvest':
-            source = harvest(x, fs, f0_floor=f0_floor, f0_ceil=f0_ceil, frame_period=frame_period)
-        elif f0_method == 'swipe':
-            source = swipe(fs, x, plim=[f0_floor, f0_ceil], sTHR=0.3)
-        else:
-            raise Exception
-        return source
-
-    def scale_pitch(self, dat: dict, factor: float) -> dict:
-        """In place, returns the same dict (world/main.py:154-162)."""
+    # ---- modification (all in place on the dict, like the reference) ------------------------------------------
+    def scale_pitch(self, dat, factor):
+        """world/main.py:154-162."""
         dat['f0'] *= factor
         return dat
 
-    def set_pitch(self, dat: dict, time: np.ndarray, value: np.ndarray) -> dict:
+    def set_pitch(self, dat, time, value):
         raise NotImplementedError  # world/main.py:164-165
 
-    def scale_duration(self, dat: dict, factor: float) -> dict:
-        """In place, returns the same dict (world/main.py:170-178)."""
+    def scale_duration(self, dat, factor):
+        """world/main.py:170-178."""
         dat['temporal_positions'] *= factor
         return dat
 
-    def modify_duration(self, dat: dict, from_time: Iterable, to_time: Iterable) -> dict:
-        """world/main.py:180-189 (returns None like the reference)."""
-        end = dat['temporal_positions'][-1]
-        assert np.all(np.diff(from_time)) > 0
-        assert np.all(np.diff(to_time)) > 0
-        assert from_time[0] > 0
-        assert from_time[-1] < end
-        from_time = np.r_[0, from_time, end]
+    def modify_duration(self, dat, from_time, to_time):
+        """Piecewise-linear time map anchored at 0 and at the last frame; returns None (world/main.py:180-189)."""
+        tp = dat['temporal_positions']
+        last = tp[-1]
+        # the reference's checks, written as it writes them (np.all(...) > 0, i.e. "not all steps are zero")
+        for axis in (from_time, to_time):
+            assert np.all(np.diff(axis)) > 0
+        assert from_time[0] > 0 and from_time[-1] < last
         if to_time[-1] == -1:
-            to_time[-1] = end
-        dat['temporal_positions'] = np.interp(dat['temporal_positions'], from_time, to_time)
+            to_time[-1] = last
+        dat['temporal_positions'] = np.interp(tp, np.r_[0, from_time, last], to_time)
 
-    def warp_spectrum(self, dat: dict, factor: float) -> dict:
-        """world/main.py:191-196."""
-        k = dat['spectrogram'].shape[0]
-        grid = np.arange(0, k) / k
-        dat['spectrogram'][:] = np.array([np.interp(grid ** factor, grid, s) for s in dat['spectrogram'].T]).T
+    def warp_spectrum(self, dat, factor):
+        """Frequency warping of every frame by f -> f**factor on the normalised axis (world/main.py:191-196)."""
+        spec = dat['spectrogram']
+        axis = np.arange(spec.shape[0]) / spec.shape[0]
+        warped = np.stack([np.interp(axis ** factor, axis, column) for column in spec.T], axis=1)
+        spec[:] = warped
         return dat
 
-    def decode(self, dat: dict) -> dict:
-        """world/main.py:198-214."""
+    # ---- synthesis ----------------------------------------------------------------------------------------------
+    def decode(self, dat):
+        """world/main.py:198-214: pulse-wise or Requiem synthesis, then peak normalisation above 1."""
         if dat['is_requiem']:
-            seeds_signals = get_seeds_signals(dat['fs'])
-            y = synthesisRequiem(dat, dat, seeds_signals)
+            y = _synr.synthesisRequiem(dat, dat, _seeds.get_seeds_signals(dat['fs']))
         else:
-            y = synthesis(dat, dat)
-        m = np.max(np.abs(y))
-        if m > 1.0:
+            y = _syn.synthesis(dat, dat)
+        peak = np.max(np.abs(y))
+        if peak > 1.0:
             logging.info('rescaling waveform')
-            y /= m
+            y /= peak
         dat['out'] = y
         return dat

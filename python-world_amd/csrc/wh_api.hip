@@ -140,6 +140,7 @@ int wh_ctx_destroy(wh_ctx* ctx) {
 
 int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16) {
   if (!ctx || !h_flags16) return wh::fail_msg("wh_take_flags", "null argument");
+  WH_ENTER(ctx);
   hipStream_t st = (hipStream_t)stream;
   WH_CHECK(hipMemcpyAsync(h_flags16, ctx->d_flags, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   WH_CHECK(hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int32_t), st));
@@ -156,6 +157,7 @@ int wh_profile_enable(wh_ctx* ctx, int on) {
 
 int wh_profile_collect(wh_ctx* ctx, char* names, size_t names_bytes, float* ms, int max_records, int* n_records) {
   if (!ctx || !names || !ms || !n_records) return wh::fail_msg("wh_profile_collect", "null argument");
+  WH_ENTER(ctx);
   WH_CHECK(hipDeviceSynchronize());
   const int n = (int)ctx->prof_names.size();
   std::string joined;

@@ -164,6 +164,7 @@ extern "C" int wh_cheaptrick(wh_ctx* ctx, void* stream, const wh_batch* b, const
                              double* f0, const double* vuv, double fs, int fft_size, double q1, double* spectrogram,
                              double* ps_spectrogram) {
   if (!ctx || !b || !x || !tp || !f0 || !vuv || !spectrogram) return wh::fail_msg("wh_cheaptrick", "null argument");
+  WH_ENTER(ctx);
   if (b->total_frames == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   switch (fft_size) {

@@ -621,6 +621,7 @@ extern "C" int wh_d4c(wh_ctx* ctx, void* stream, const wh_batch* b, const double
                       const double* vuv, double fs, double threshold, int fft_size_for_spectrum, double* aperiodicity,
                       double* coarse_ap) {
   if (!ctx || !b || !x || !tp || !f0 || !vuv || !aperiodicity) return wh::fail_msg("wh_d4c", "null argument");
+  WH_ENTER(ctx);
   if (fft_size_for_spectrum < 2) return wh::fail_msg("wh_d4c", "fft_size_for_spectrum must be >= 2");
   const int nfft = pow2_at_least(4 * fs / 47.0 + 1);
   const int interval = fs < 16000 ? 2000 : 3000;
@@ -632,6 +633,7 @@ extern "C" int wh_d4c_requiem(wh_ctx* ctx, void* stream, const wh_batch* b, cons
                               double* f0, const double* vuv, double fs, double threshold, int fft_size,
                               double* band_aperiodicity) {
   if (!ctx || !b || !x || !tp || !f0 || !vuv || !band_aperiodicity) return wh::fail_msg("wh_d4c_requiem", "null argument");
+  WH_ENTER(ctx);
   const int nfft = fft_size > 0 ? fft_size : pow2_at_least(3 * fs / 47.0 + 1);
   return d4c_common(ctx, stream, b, x, tp, f0, vuv, fs, threshold, nfft, 3000, 0, band_aperiodicity, nullptr);
 }

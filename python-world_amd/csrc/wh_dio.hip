@@ -401,6 +401,7 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   if (!ctx || !b || !x || !tp || !h_band_f0 || !h_band_bias || !h_band_len || !h_band_taps || !h_lowcut || !f0_out ||
       !vuv_out)
     return wh::fail_msg("wh_dio", "null argument");
+  WH_ENTER(ctx);
   if (n_bands < 1 || n_bands > kMaxBands) return wh::fail_msg("wh_dio", "n_bands must be in [1, 32]");
   hipStream_t st = (hipStream_t)stream;
   const int B = b->n_utt;

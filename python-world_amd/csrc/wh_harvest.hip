@@ -491,6 +491,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
                           double* dbg_y, double* dbg_raw, double* dbg_f0_1ms) {
   if (!ctx || !b || !x || !tp || !h_band_f0 || !h_band_half || !h_band_taps || !f0_out || !vuv_out)
     return wh::fail_msg("wh_harvest", "null argument");
+  WH_ENTER(ctx);
   if (decimation_ratio > 1 && (!h_ba || !h_zi)) return wh::fail_msg("wh_harvest", "decimation filter missing");
   if (n_bands < 3 || n_bands > 1024) return wh::fail_msg("wh_harvest", "n_bands out of range");
   hipStream_t st = (hipStream_t)stream;

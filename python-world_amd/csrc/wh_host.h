@@ -99,6 +99,10 @@ struct KernelTimer {
     if (_e != hipSuccess) return wh::fail(#expr, _e);    \
   } while (0)
 
+// First statement of every C-ABI entry that allocates or launches: make the context's device current on the calling
+// thread (a process may hold contexts for several GPUs; allocations and launches follow the current device).
+#define WH_ENTER(ctx) WH_CHECK(hipSetDevice((ctx)->device))
+
 #define WH_LAUNCH_CHECK(name)                            \
   do {                                                   \
     hipError_t _e = hipGetLastError();                   \

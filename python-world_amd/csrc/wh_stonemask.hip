@@ -163,6 +163,7 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
 extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp,
                             const double* f0, double fs, const double* h_qtime, int kmax, double* refined_f0) {
   if (!ctx || !b || !x || !tp || !f0 || !h_qtime || !refined_f0) return wh::fail_msg("wh_stonemask", "null argument");
+  WH_ENTER(ctx);
   if (b->total_frames == 0) return 0;
   if (kmax < 1) return wh::fail_msg("wh_stonemask", "kmax must be >= 1");
   const size_t lds = sizeof(double) * 2 * (2 * (size_t)kmax + 1);

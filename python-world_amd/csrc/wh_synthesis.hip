@@ -980,6 +980,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
                             int32_t* pulse_count_out) {
   if (!ctx || !b || !tp || !f0 || !vuv || !spectrogram || !aperiodicity || !h_y_off || !h_t0 || !h_dt || !y)
     return wh::fail_msg("wh_synthesis", "null argument");
+  WH_ENTER(ctx);
   if (noise && !h_noise_off) return wh::fail_msg("wh_synthesis", "noise given without h_noise_off");
   if (pulse_cap < 1) return wh::fail_msg("wh_synthesis", "pulse_cap must be >= 1");
   hipStream_t st = (hipStream_t)stream;
@@ -1088,6 +1089,7 @@ __global__ __launch_bounds__(256) void peak_scale_kernel(double* __restrict__ y,
 
 extern "C" int wh_peak_normalise(wh_ctx* ctx, void* stream, double* y, const int64_t* h_y_off, int n_utt) {
   if (!ctx || !y || !h_y_off || n_utt < 0) return wh::fail_msg("wh_peak_normalise", "bad argument");
+  WH_ENTER(ctx);
   if (n_utt == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   std::vector<int64_t> off(h_y_off, h_y_off + n_utt + 1);
@@ -1122,6 +1124,7 @@ extern "C" int wh_debug_resp_stages(unsigned long long* out8, int reset) {
 // bit-for-bit agreement with np.cumsum can be tested directly.
 extern "C" int wh_cumsum_exact(wh_ctx* ctx, void* stream, double* d_data, const int64_t* h_off, int n_seg) {
   if (!ctx || !d_data || !h_off || n_seg < 0) return wh::fail_msg("wh_cumsum_exact", "bad argument");
+  WH_ENTER(ctx);
   if (n_seg == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   std::vector<int64_t> off(h_off, h_off + n_seg + 1);
@@ -1140,6 +1143,7 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
                                  int64_t* h_noise_total) {
   if (!ctx || !b || !tp || !f0 || !vuv || !h_y_off || !h_t0 || !h_dt || !h_pulse_count || !h_noise_total)
     return wh::fail_msg("wh_synthesis_plan", "null argument");
+  WH_ENTER(ctx);
   hipStream_t st = (hipStream_t)stream;
   const int B = b->n_utt;
   std::vector<SynUtt> meta(B);
@@ -1212,6 +1216,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   if (!ctx || !b || !tp || !f0 || !vuv || !spectrogram || !band_aperiodicity || !h_y_off || !h_t0 || !h_dt || !h_hop ||
       !pulse_seed || !noise_seed || !h_cursor || !y)
     return wh::fail_msg("wh_synthesis_requiem", "null argument");
+  WH_ENTER(ctx);
   if (n_bands < 1 || n_bands > 8) return wh::fail_msg("wh_synthesis_requiem", "n_bands must be in [1, 8]");
   if (pulse_cap < 1 || noise_len < 1) return wh::fail_msg("wh_synthesis_requiem", "bad pulse_cap / noise_len");
   hipStream_t st = (hipStream_t)stream;

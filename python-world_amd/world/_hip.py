@@ -65,6 +65,18 @@ class WorldHipError(RuntimeError):
     pass
 
 
+# WH_FLAG_* of include/world_hip.h: sticky conditions raised by kernels instead of failing silently
+FLAG_STONEMASK_WINDOW, FLAG_EVENT_OVERFLOW, FLAG_NOISE_SHORT, FLAG_NO_PULSE, FLAG_PULSE_OVERFLOW = range(5)
+FLAG_MESSAGES = {
+    FLAG_STONEMASK_WINDOW: "StoneMask: a frame's f0 needs a longer analysis window than the one sized from min_f0 "
+                           "(frame left unrefined)",
+    FLAG_EVENT_OVERFLOW: "a zero-crossing event list exceeded its capacity (pathological input)",
+    FLAG_NOISE_SHORT: "synthesis ran out of host-supplied noise samples",
+    FLAG_NO_PULSE: "an utterance produced no pulse (the reference asserts, world/synthesis.py:131)",
+    FLAG_PULSE_OVERFLOW: "more pulses than pulse_cap: trailing pulses were dropped",
+}
+
+
 def load_library():
     """dlopen libworld_hip.so and attach the prototypes.  Raises if it has not been built."""
     global _lib
@@ -175,6 +187,15 @@ class Runtime:
         buf = (ctypes.c_int32 * 16)()
         check(self.lib.wh_take_flags(self.ctx, self.stream(), buf))
         return list(buf)
+
+    def check_flags(self, where, allow=()):
+        """take_flags() and raise WorldHipError for every condition that is set and not in ``allow``.  Returns the
+        flag list (so that a caller can react to an allowed one, e.g. retry with a larger pulse capacity)."""
+        flags = self.take_flags()
+        bad = [FLAG_MESSAGES.get(i, "device flag %d" % i) for i, v in enumerate(flags) if v and i not in allow]
+        if bad:
+            raise WorldHipError("%s: %s" % (where, "; ".join(bad)))
+        return flags
 
     # ---- batch descriptor -----------------------------------------------------------------
     def make_batch(self, x_off, frame_off):

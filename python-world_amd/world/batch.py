@@ -13,17 +13,43 @@ from .d4c import d4c_device
 from .d4cRequiem import d4c_requiem_device
 from .dio import dio_device
 from .stonemask import stonemask_device
-from .synthesis import synthesis_device, time_axis_params
+from .synthesis import safe_pulse_cap, synthesis_device, time_axis_params
 
 
 class BatchEncoding:
+    """Result of WorldBatch.encode_device: the reference's encode() dict (world/main.py:144-152) for a whole batch,
+    resident in HBM.  ``temporal_positions`` / ``f0`` / ``vuv`` are flat per-frame tensors (batch frame layout),
+    ``spectrogram`` / ``aperiodicity`` are frame-major [F][K] (aperiodicity [F][nap+2] dB when ``is_requiem``).
+
+    decode_device derives the output geometry (sample counts, time axis, Requiem hop) on the HOST from the frame
+    times with NumPy's own float-arange semantics; the host copy those need is cached in
+    ``tp_host`` and kept in step by the modifiers below.  Assigning a new tensor to ``temporal_positions`` drops
+    the cache (the next decode downloads the frame times); editing the tensor in place behind the object's back
+    is not supported — use scale_duration / modify_duration."""
+
     def __init__(self, rt, batch, fs, tp, f0, vuv, spectrogram, aperiodicity, fft_size, is_requiem, frame_period,
                  tp_host=None):
         self.rt, self.batch, self.fs = rt, batch, fs
-        self.tp_host = tp_host  # host copy of the frame times (kept in step with scale_duration): no D2H in decode
-        self.temporal_positions, self.f0, self.vuv = tp, f0, vuv
+        self._tp = tp
+        self.tp_host = tp_host  # host copy of the frame times: no D2H in decode
+        self.f0, self.vuv = f0, vuv
         self.spectrogram, self.aperiodicity = spectrogram, aperiodicity
         self.fft_size, self.is_requiem, self.frame_period = fft_size, is_requiem, frame_period
+
+    @property
+    def temporal_positions(self):
+        return self._tp
+
+    @temporal_positions.setter
+    def temporal_positions(self, value):
+        self._tp = value
+        self.tp_host = None  # whoever replaces the tensor owns its content: refreshed from the device on demand
+
+    def host_times(self):
+        """Frame times on the host (downloaded once if the cache was invalidated)."""
+        if self.tp_host is None:
+            self.tp_host = self._tp.cpu().numpy()
+        return self.tp_host
 
     @property
     def n_utt(self):
@@ -36,7 +62,7 @@ class BatchEncoding:
 
     def scale_duration(self, factor):
         """world/main.py:170-178, on the device."""
-        self.temporal_positions *= factor
+        self._tp *= factor
         if self.tp_host is not None:
             self.tp_host = self.tp_host * factor
         return self
@@ -82,15 +108,18 @@ class WorldBatch:
         x_d = rt.to_device(np.concatenate(xs))
         tp_h = np.concatenate([_tables.frame_times(n, frame_period) for n in nfs])
         tp_d = rt.to_device(tp_h)
-        self._tp_host = {tp_d.data_ptr(): tp_h}
+        batch.tp_d, batch.tp_host = tp_d, tp_h  # the frame grid belongs to the batch descriptor (no pointer-keyed lookup)
         return batch, x_d, tp_d
 
     @_on_lane_stream
     def encode_device(self, batch, x_d, tp_d, fs, f0_method='dio', f0_floor=71, f0_ceil=800, channels_in_octave=2,
                       target_fs=4000, frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False,
-                      f0_done=None):
+                      f0_done=None, check=True):
         """world/main.py:106-152 for a resident batch.  tp_d is not modified (a copy is kept in the result).
-        ``f0_done``: optional callable invoked once the F0 stage has been enqueued (used to stagger lanes)."""
+        ``f0_done``: optional callable invoked once the F0 stage has been enqueued (used to stagger lanes).
+        ``check``: read the sticky device flags afterwards (synchronises this lane's stream) and raise WorldHipError
+        if a kernel reported a condition; pass False to keep the call asynchronous and check later
+        (``WorldBatch.check()``)."""
         rt = self.rt
         if fft_size is not None:
             f0_floor = 3.0 * fs / fft_size
@@ -111,37 +140,63 @@ class WorldBatch:
             ap_d = d4c_requiem_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, fft_size)
         else:
             ap_d, _ = d4c_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, ct_fft)
-        tp_host = getattr(self, "_tp_host", {}).get(tp_d.data_ptr())
+        tp_host = batch.tp_host if getattr(batch, "tp_d", None) is tp_d else None
+        if check:
+            rt.check_flags("encode_device")
         return BatchEncoding(rt, batch, fs, tp_d.clone(), f0_d, vuv_d, spec_d, ap_d, ct_fft, is_requiem, frame_period,
                              tp_host=None if tp_host is None else tp_host.copy())
+
+    def check(self, where="WorldBatch"):
+        """Read-and-clear the device condition flags of this lane; raises WorldHipError if any is set."""
+        with self.rt.on_stream():
+            return self.rt.check_flags(where)
 
     def encode(self, xs, fs, **kw):
         batch, x_d, tp_d = self.upload(xs, fs, kw.get('frame_period', 5))
         return self.encode_device(batch, x_d, tp_d, fs, **kw)
 
     @_on_lane_stream
-    def decode_device(self, enc, noise=None, seed=0, pulse_cap=None, seeds=None):
+    def decode_device(self, enc, noise=None, seed=0, pulse_cap=None, seeds=None, cursor=None, check=True):
         """world/main.py:198-214 for a resident encoding.  Returns (y tensor, y_off) — concatenated
         waveforms, peak-normalised per utterance where max|y| > 1.  ``noise``: optional list of per-utterance
-        standard-normal arrays (reference-parity mode); default = on-device Philox stream ``seed``."""
+        standard-normal arrays (reference-parity mode); default = on-device Philox stream ``seed``.
+        Requiem encodings: ``seeds`` = get_seeds_signals(fs) tables (built and cached per fs when omitted),
+        ``cursor`` = read position in the circular noise seed at which the first utterance starts (default 0 = a
+        fresh reference process); utterances consume the seed like consecutive reference calls.
+
+        Pulse capacity: ``pulse_cap`` slots per utterance; the default max(ny)//8+64 covers a mean f0 below fs/8.
+        With ``check`` (default) the sticky device flags are read afterwards (synchronises the stream): an overflow
+        of the DEFAULT capacity re-runs the decode with the safe bound ny//2+16 (f0 < fs/2), any other condition —
+        or an overflow of an explicit ``pulse_cap`` — raises WorldHipError.  ``check=False`` keeps the call
+        asynchronous; call ``WorldBatch.check()`` before trusting the audio."""
         rt = self.rt
         fo = enc.batch.frame_off
-        tp_h = enc.tp_host if enc.tp_host is not None else enc.temporal_positions.cpu().numpy()
+        tp_h = enc.host_times()
         geo = [time_axis_params(tp_h[int(fo[u]):int(fo[u + 1])], enc.fs) for u in range(enc.n_utt)]
         ny = [g[0] for g in geo]
-        if enc.is_requiem:
-            from .synthesisRequiem import synthesis_requiem_device
-            y, y_off = synthesis_requiem_device(rt, enc, ny, geo, seeds=seeds)
-        else:
-            noise_d = noise_off = None
-            if noise is not None:
-                noise_off = np.concatenate([[0], np.cumsum([len(n) for n in noise])])
-                noise_d = rt.to_device(np.concatenate(noise))
-            y, y_off = synthesis_device(rt, enc.batch, enc.temporal_positions, enc.f0, enc.vuv, enc.spectrogram,
-                                        enc.aperiodicity, enc.fs, enc.fft_size, ny, [g[1] for g in geo],
-                                        [g[2] for g in geo], noise_d=noise_d, noise_off=noise_off, seed=seed,
-                                        pulse_cap=pulse_cap)
-        self._peak_normalise(y, y_off)
+        noise_d = noise_off = None
+        if noise is not None and not enc.is_requiem:
+            noise_off = np.concatenate([[0], np.cumsum([len(n) for n in noise])])
+            noise_d = rt.to_device(np.concatenate(noise))
+
+        def run(cap):
+            if enc.is_requiem:
+                from .synthesisRequiem import synthesis_requiem_device
+                y, y_off = synthesis_requiem_device(rt, enc, ny, geo, seeds=seeds, cursor=cursor, pulse_cap=cap)
+            else:
+                y, y_off = synthesis_device(rt, enc.batch, enc.temporal_positions, enc.f0, enc.vuv, enc.spectrogram,
+                                            enc.aperiodicity, enc.fs, enc.fft_size, ny, [g[1] for g in geo],
+                                            [g[2] for g in geo], noise_d=noise_d, noise_off=noise_off, seed=seed,
+                                            pulse_cap=cap)
+            self._peak_normalise(y, y_off)
+            return y, y_off
+
+        y, y_off = run(pulse_cap)
+        if check:
+            flags = rt.check_flags("decode_device", allow=() if pulse_cap is not None else (_hip.FLAG_PULSE_OVERFLOW,))
+            if flags[_hip.FLAG_PULSE_OVERFLOW]:
+                y, y_off = run(safe_pulse_cap(ny))
+                rt.check_flags("decode_device")
         return y, y_off
 
     def _peak_normalise(self, y, y_off):
@@ -198,17 +253,23 @@ class WorldBatchLanes:
             if prev is not None and wb.rt.own_stream is not None:
                 wb.rt.own_stream.wait_event(prev)
             ev = torch.cuda.Event() if stagger and wb.rt.own_stream is not None else None
+            kw.setdefault("check", False)  # lanes stay asynchronous: flags are read in synchronize()
             out.append(wb.encode_device(r[0], r[1], r[2], fs, f0_done=(ev.record if ev is not None else None), **kw))
             prev = ev
         return out
 
     def decode_device(self, encs, **kw):
-        """[(y, y_off) per lane]."""
+        """[(y, y_off) per lane]; asynchronous (``check=False`` unless asked otherwise): call synchronize()."""
+        kw.setdefault("check", False)
         return [wb.decode_device(e, **kw) if e is not None else None for wb, e in zip(self.lanes, encs)]
 
-    def synchronize(self):
+    def synchronize(self, check=True):
+        """Wait for every lane; with ``check`` raise WorldHipError if a kernel of any lane reported a condition."""
         for wb in self.lanes:
             if wb.rt.own_stream is not None:
                 wb.rt.own_stream.synchronize()
             else:
                 wb.rt.torch.cuda.current_stream(wb.rt.device).synchronize()
+        if check:
+            for wb in self.lanes:
+                wb.check("WorldBatchLanes")

@@ -4,6 +4,12 @@ import numpy as np
 
 from . import _hip
 
+# The reference dithers every smoothed spectrum with np.random.rand(K)*eps from NumPy's GLOBAL stream
+# (world/cheaptrick.py:117); this build adds the dither's mean eps/2 instead and leaves the generator alone, so a
+# seeded reference encode()+decode() and a seeded encode()+decode() here enter synthesis with different generator
+# states.  Set this flag to draw (and discard) the same F*K uniforms per call and keep the two generators in step.
+CONSUME_REFERENCE_RNG = False
+
 
 def default_fft_size(fs, f0_low_limit=71):
     return int(2 ** np.ceil(np.log2(3 * fs / f0_low_limit + 1)))
@@ -39,6 +45,8 @@ def cheaptrick(x, fs, source_object, q1=-0.15, fft_size=None):
     vuv_d = rt.to_device(source_object['vuv'])
     spec, ps = cheaptrick_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, fft_size, q1, want_ps=True)
     f0[...] = f0_d.cpu().numpy()  # the reference mutates the caller's array
+    if CONSUME_REFERENCE_RNG:
+        np.random.rand(nf * (fft_size // 2 + 1))  # one rand(K) per frame in the reference: same stream position
     return {'temporal_positions': tp,
             'spectrogram': np.ascontiguousarray(spec.cpu().numpy().T),
             'fs': fs,

@@ -42,6 +42,7 @@ def dio(x, fs, f0_floor=71, f0_ceil=800, channels_in_octave=2, target_fs=4000, f
     f0, vuv, cand, raw = dio_device(rt, batch, rt.to_device(x), rt.to_device(tp), fs, f0_floor, f0_ceil,
                                     channels_in_octave, target_fs, frame_period, allowed_range, want_candidates=True,
                                     index_bias=_index_bias)
+    rt.check_flags("dio")
     nb = cand.numel() // nf
     return {'f0': f0.cpu().numpy(),
             'f0_candidates': cand.cpu().numpy().reshape(nb, nf),

@@ -43,7 +43,5 @@ def harvest(x, fs, f0_floor=71, f0_ceil=800, frame_period=5):
     tp = _tables.frame_times(nf, frame_period)
     batch = rt.make_batch([0, len(x)], [0, nf])
     f0, vuv = harvest_device(rt, batch, rt.to_device(x), rt.to_device(tp), fs, f0_floor, f0_ceil, frame_period)
-    flags = rt.take_flags()
-    if flags[1]:
-        raise _hip.WorldHipError("Harvest zero-crossing list overflow (pathological input)")
+    rt.check_flags("harvest")
     return {'temporal_positions': tp, 'f0': f0.cpu().numpy(), 'vuv': vuv.cpu().numpy()}

@@ -30,4 +30,5 @@ def stonemask(x, fs, temporal_positions, f0):
     batch = rt.make_batch([0, len(x)], [0, len(f0)])
     out = stonemask_device(rt, batch, rt.to_device(x), rt.to_device(temporal_positions), rt.to_device(f0), fs,
                            float(pos.min()))
+    rt.check_flags("stonemask")
     return out.cpu().numpy()

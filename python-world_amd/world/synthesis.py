@@ -24,6 +24,16 @@ def time_axis_params(temporal_positions, fs):
     return ny, tp0, dt
 
 
+def default_pulse_cap(ny_list):
+    """Pulse slots per utterance the batched decode allocates by default: enough for a mean f0 below fs/8."""
+    return int(max(ny_list)) // 8 + 64
+
+
+def safe_pulse_cap(ny_list):
+    """Upper bound for any f0 below fs/2 (a pulse needs a phase wrap, i.e. at least two samples)."""
+    return int(max(ny_list)) // 2 + 16
+
+
 def synthesis_device(rt, batch, tp_d, f0_d, vuv_d, spec_d, ap_d, fs, fft_size, ny_list, t0_list, dt_list,
                      noise_d=None, noise_off=None, seed=0, pulse_cap=None):
     """Device-resident core.  spec_d/ap_d are frame-major [F][K].  Returns the concatenated waveform tensor."""
@@ -31,7 +41,7 @@ def synthesis_device(rt, batch, tp_d, f0_d, vuv_d, spec_d, ap_d, fs, fft_size, n
     t0 = np.ascontiguousarray(t0_list, dtype=np.float64)
     dt = np.ascontiguousarray(dt_list, dtype=np.float64)
     if pulse_cap is None:
-        pulse_cap = int(max(ny_list)) // 8 + 64
+        pulse_cap = default_pulse_cap(ny_list)  # callers read WH_FLAG_PULSE_OVERFLOW and retry with safe_pulse_cap
     y = rt.empty((int(y_off[-1]),))
     vp = ctypes.c_void_p
     noff = None
@@ -63,7 +73,10 @@ def synthesis_plan(rt, batch, tp_d, f0_d, vuv_d, fs, ny_list, t0_list, dt_list, 
 def synthesis(source_object, filter_object):
     """Same contract as the reference.  Randomness: exactly as many np.random.randn samples are drawn
     from NumPy's global stream as the reference draws (one randn(max(3, noise_size)) per pulse), so a
-    seeded call reproduces the reference's noise and leaves the generator in the same state."""
+    call that starts from the same generator state reproduces the reference's noise and leaves the generator in
+    the same state.  Note that the reference's cheaptrick() also consumes the global stream (one rand(K) per frame,
+    world/cheaptrick.py:117) and this build's cheaptrick() does not unless ``world.cheaptrick.CONSUME_REFERENCE_RNG``
+    is set: to compare seeded encode→decode runs sample for sample, reseed right before decode (or set that flag)."""
     rt = _hip.Runtime.get()
     vuv = np.asarray(source_object['vuv'], dtype=np.float64)
     f0 = np.asarray(source_object['f0'], dtype=np.float64)
@@ -78,10 +91,11 @@ def synthesis(source_object, filter_object):
     tp_d, f0_d, vuv_d = rt.to_device(tp), rt.to_device(f0), rt.to_device(vuv)
     spec_d = rt.to_device(np.ascontiguousarray(spectrogram.T))
     ap_d = rt.to_device(np.ascontiguousarray(aperiodicity.T))
-    cap = ny // 2 + 16
+    cap = safe_pulse_cap([ny])
     counts, draws = synthesis_plan(rt, batch, tp_d, f0_d, vuv_d, fs, [ny], [t0], [dt], cap)
     assert counts[0] > 0  # world/synthesis.py:131
     noise = np.random.randn(int(draws[0]))
     y, _ = synthesis_device(rt, batch, tp_d, f0_d, vuv_d, spec_d, ap_d, fs, fft_size, [ny], [t0], [dt],
                             noise_d=rt.to_device(noise), noise_off=[0, len(noise)], pulse_cap=cap)
+    rt.check_flags("synthesis")
     return y.cpu().numpy()

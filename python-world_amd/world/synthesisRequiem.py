@@ -1,11 +1,33 @@
 """Requiem synthesis — drop-in for world/synthesisRequiem.py:12 of the reference, executed by the HIP
 kernels behind wh_synthesis_requiem (include/world_hip.h)."""
 import ctypes
+import weakref
 
 import numpy as np
 
 from . import _hip
-from .synthesis import time_axis_params
+from .synthesis import default_pulse_cap, safe_pulse_cap, time_axis_params
+
+_seed_cache = {}  # (id(pulse), id(noise), device) -> (weakref(noise), pulse_d, noise_d)
+
+
+def seeds_on_device(rt, seeds):
+    """Device copies of the seed tables, uploaded once per (tables, device): a decode loop that passes the same
+    ``seeds`` dict does not re-upload 0.5-2 MB per call.  The cache entry dies with the host arrays."""
+    if 'pulse_d' in seeds and 'noise_d' in seeds:  # already resident (world.get_seeds_signals.get_seeds_signals_device)
+        return seeds['pulse_d'], seeds['noise_d'], seeds['pulse_d'].shape, seeds['noise_d'].shape
+    pulse, noise = seeds['pulse'], seeds['noise']
+    key = (id(pulse), id(noise), rt.index)
+    hit = _seed_cache.get(key)
+    if hit is not None and hit[0]() is noise:
+        return hit[1], hit[2], pulse.shape, noise.shape
+    pulse_d = rt.to_device(np.ascontiguousarray(pulse, dtype=np.float64))
+    noise_d = rt.to_device(np.ascontiguousarray(noise, dtype=np.float64))
+    try:
+        _seed_cache[key] = (weakref.ref(noise, lambda _r, k=key: _seed_cache.pop(k, None)), pulse_d, noise_d)
+    except TypeError:
+        pass
+    return pulse_d, noise_d, pulse.shape, noise.shape
 
 
 def generate_noise(N, noise_seed, frequency_band):
@@ -38,34 +60,39 @@ def synthesis_requiem_core(rt, batch, tp_d, f0_d, vuv_d, spec_d, band_d, fs, fft
     dt = np.ascontiguousarray([g[2] for g in geo], dtype=np.float64)
     hop = np.ascontiguousarray(hops, dtype=np.int64)
     cur = np.ascontiguousarray(cursors, dtype=np.int64)
-    pulse = np.ascontiguousarray(seeds['pulse'], dtype=np.float64)
-    noise = np.ascontiguousarray(seeds['noise'], dtype=np.float64)
-    nb = pulse.shape[1]
+    pulse_d, noise_d, pshape, nshape = seeds_on_device(rt, seeds)
+    nb = int(pshape[1])
     if pulse_cap is None:
-        pulse_cap = int(max(ny)) // 8 + 64
+        pulse_cap = default_pulse_cap(ny)  # callers read WH_FLAG_PULSE_OVERFLOW and retry with safe_pulse_cap
     y = rt.empty((int(y_off[-1]),))
     vp = ctypes.c_void_p
-    pulse_d, noise_d = rt.to_device(pulse), rt.to_device(noise)
     _hip.check(rt.lib.wh_synthesis_requiem(
         rt.ctx, rt.stream(), batch.handle, rt.ptr(tp_d), rt.ptr(f0_d), rt.ptr(vuv_d), rt.ptr(spec_d), rt.ptr(band_d),
         float(fs), int(fft_size), y_off.ctypes.data_as(vp), t0.ctypes.data_as(vp), dt.ctypes.data_as(vp),
-        hop.ctypes.data_as(vp), int(pulse_cap), rt.ptr(pulse_d), int(pulse.shape[0]), rt.ptr(noise_d),
-        int(noise.shape[0]), int(nb), cur.ctypes.data_as(vp), rt.ptr(y)))
+        hop.ctypes.data_as(vp), int(pulse_cap), rt.ptr(pulse_d), int(pshape[0]), rt.ptr(noise_d),
+        int(nshape[0]), int(nb), cur.ctypes.data_as(vp), rt.ptr(y)))
     return y, y_off
 
 
-def synthesis_requiem_device(rt, enc, ny, geo, seeds=None, cursor=None):
+_default_seeds = {}  # fs -> seeds dict built once (the batched path's default when the caller passes none)
+
+
+def synthesis_requiem_device(rt, enc, ny, geo, seeds=None, cursor=None, pulse_cap=None):
     """Batch decode of a BatchEncoding (is_requiem=True).  Utterances consume the noise seed one after the
-    other exactly like consecutive reference calls sharing the persistent cursor."""
+    other exactly like consecutive reference calls sharing the persistent cursor (world/synthesisRequiem.py:131-141,
+    world/main.py:205-206); ``cursor`` (nb,) is the position the first utterance starts at (default zeros)."""
     from .get_seeds_signals import get_seeds_signals
 
     if seeds is None:
-        seeds = get_seeds_signals(enc.fs)
-    nb = seeds['pulse'].shape[1]
-    nlen = seeds['noise'].shape[0]
+        seeds = _default_seeds.get(enc.fs)
+        if seeds is None:
+            seeds = _default_seeds[enc.fs] = get_seeds_signals(enc.fs)
+    _, _, pshape, nshape = seeds_on_device(rt, seeds)
+    nb = int(pshape[1])
+    nlen = int(nshape[0])
     cur = np.zeros(nb) if cursor is None else np.array(cursor, dtype=np.float64)
     fo = enc.batch.frame_off
-    tp_h = enc.tp_host if enc.tp_host is not None else enc.temporal_positions.cpu().numpy()
+    tp_h = enc.host_times()
     hops, cursors = [], []
     for u in range(enc.n_utt):
         t = tp_h[int(fo[u]):int(fo[u + 1])]
@@ -73,7 +100,9 @@ def synthesis_requiem_device(rt, enc, ny, geo, seeds=None, cursor=None):
         cursors.append(cur.copy())
         cur = _advance(cur, ny[u], nlen)
     y, y_off = synthesis_requiem_core(rt, enc.batch, enc.temporal_positions, enc.f0, enc.vuv, enc.spectrogram,
-                                      enc.aperiodicity, enc.fs, enc.fft_size, geo, hops, seeds, np.array(cursors))
+                                      enc.aperiodicity, enc.fs, enc.fft_size, geo, hops, seeds, np.array(cursors),
+                                      pulse_cap=pulse_cap)
+    enc.requiem_cursor = cur  # where the next batch would continue (the reference's generate_noise.current_index)
     return y, y_off
 
 
@@ -98,6 +127,7 @@ def synthesisRequiem(source_object, filter_object, seeds_signals):
                                   rt.to_device(np.ascontiguousarray(spectrogram.T)),
                                   rt.to_device(np.ascontiguousarray(band.T)), fs, fft_size, geo,
                                   [int((tp[1] - tp[0]) * fs)], seeds_signals,
-                                  np.array([generate_noise.current_index]), pulse_cap=geo[0][0] // 2 + 16)
+                                  np.array([generate_noise.current_index]), pulse_cap=safe_pulse_cap([geo[0][0]]))
+    rt.check_flags("synthesisRequiem")
     generate_noise.current_index = _advance(np.asarray(generate_noise.current_index, dtype=np.float64), geo[0][0], nlen)
     return y.cpu().numpy()

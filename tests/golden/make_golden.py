@@ -173,8 +173,58 @@ def tables_fixture():
     print("tables written", {k: int(v) for k, v in out.items()})
 
 
+def getters_fixture():
+    """A-3: World.get_f0 / get_spectrum / encode_w_gvn_f0 (world/main.py:27-104) on the 16 kHz synthetic utterance:
+    shapes, leading values and column/row sums of what the reference returns."""
+    fs = 16000
+    x = _syn.synth_utterance(0, fs, 1.2)
+    W = R.main.World()
+    out = {"fs": fs, "seconds": 1.2, "utt": 0}
+    for method in ("harvest", "dio"):
+        tp, f0, vuv = W.get_f0(fs, x.copy(), f0_method=method)
+        out["getf0_%s_tp" % method] = tp.copy()
+        out["getf0_%s_f0" % method] = f0.copy()
+        out["getf0_%s_vuv" % method] = vuv.copy()
+    g = W.get_spectrum(fs, x.copy(), f0_method="dio")
+    out["getspec_keys"] = np.array(sorted(g.keys()))
+    out["getspec_f0"] = g["f0"].copy()  # CheapTrick's 500 Hz substitutions are visible here (Q6)
+    out["getspec_shape"] = np.array(g["spectrogram"].shape)
+    out["getspec_ps_shape"] = np.array(g["ps spectrogram"].shape)
+    out["getspec_head"] = g["spectrogram"][:16, :16].copy()
+    out["getspec_colsum"] = g["spectrogram"].sum(axis=0)
+    out["getspec_rowsum"] = g["spectrogram"].sum(axis=1)
+    cols = np.unique(np.linspace(0, g["spectrogram"].shape[1] - 1, 5).astype(int))
+    out["getspec_ps_cols"] = cols
+    out["getspec_ps"] = g["ps spectrogram"][:, cols].copy()
+    # encode_w_gvn_f0: the caller's source must satisfy f0 >= 3*fs/fft_size on EVERY frame (world/main.py:92)
+    fft_size = 1024
+    d = R.dio.dio(x.copy(), fs)
+    f0 = R.stonemask.stonemask(x, fs, d["temporal_positions"], d["f0"])
+    f0 = np.maximum(f0, 3 * fs / fft_size)
+    src = {"f0": f0.copy(), "vuv": d["vuv"].copy(), "temporal_positions": d["temporal_positions"].copy()}
+    out["gvn_src_f0"] = f0.copy()
+    out["gvn_src_vuv"] = d["vuv"].copy()
+    out["gvn_src_tp"] = d["temporal_positions"].copy()
+    e = W.encode_w_gvn_f0(fs, x.copy(), src, fft_size=fft_size, is_requiem=False)
+    out["gvn_keys"] = np.array(sorted(e.keys()))
+    out["gvn_f0"] = e["f0"].copy()
+    out["gvn_spec_head"] = e["spectrogram"][:16, :16].copy()
+    out["gvn_spec_colsum"] = e["spectrogram"].sum(axis=0)
+    out["gvn_ap_head"] = e["aperiodicity"][:16, :16].copy()
+    out["gvn_ap_colsum"] = e["aperiodicity"].sum(axis=0)
+    out["gvn_coarse"] = e["coarse_ap"].copy()
+    out["gvn_fft_size"] = fft_size
+    np.savez_compressed(os.path.join(HERE, "golden_getters.npz"), **out)
+    print("getters written", {k: getattr(v, "shape", v) for k, v in out.items() if k.endswith("shape") or k.endswith("keys")})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # regenerate selected fixtures only: python make_golden.py getters heads ...
+        for name in sys.argv[1:]:
+            globals()[name + "_fixture"]()
+        sys.exit(0)
     stage_fixture(_syn.synth_utterance(0, 16000, 1.2), 16000, "syn16k")
     stage_fixture(_syn.synth_utterance(5, 48000, 0.5), 48000, "syn48k")
     tables_fixture()
     mwm_fixture()
+    getters_fixture()

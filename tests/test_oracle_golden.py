@@ -133,3 +133,28 @@ def test_config1_mwm_end_to_end(golden):
     assert np.allclose(y[:4096], g["out_head_std"], rtol=0, atol=1e-7)
     assert np.allclose(y[-4096:], g["out_tail_std"], rtol=0, atol=1e-7)
     assert np.allclose(np.add.reduceat(y, np.arange(0, len(y), 256)), g["out_blocksum_std"], rtol=0, atol=1e-6)
+
+
+def test_getters_fixture_pins_oracle(golden):
+    """A-3 fixture (World.get_f0 / get_spectrum / encode_w_gvn_f0 of the reference) against the oracle stages."""
+    from world._synthetic import synth_utterance
+
+    g = golden("getters")
+    fs = int(g["fs"])
+    x = synth_utterance(int(g["utt"]), fs, float(g["seconds"]))
+    h = pitch_harvest.harvest_np(x, fs)
+    assert np.array_equal(h["vuv"], g["getf0_harvest_vuv"]) and np.array_equal(h["f0"], g["getf0_harvest_f0"])
+    d = pitch_dio.dio_np(x, fs)
+    f0 = pitch_dio.stonemask_np(x, fs, d["temporal_positions"], d["f0"])
+    assert np.array_equal(d["vuv"], g["getf0_dio_vuv"])
+    assert np.allclose(f0, g["getf0_dio_f0"], rtol=1e-12, atol=0)
+    sp, ps, f0u = envelope.cheaptrick_np(x, fs, f0, d["vuv"], d["temporal_positions"])
+    assert np.allclose(f0u, g["getspec_f0"], rtol=1e-12, atol=0)
+    assert rel_rms(sp.sum(axis=0), g["getspec_colsum"]) < 1e-10
+    assert rel_rms(sp[:16, :16], g["getspec_head"]) < 1e-10
+    sp2, _, f0u2 = envelope.cheaptrick_np(x, fs, g["gvn_src_f0"], g["gvn_src_vuv"], g["gvn_src_tp"], fft_size=1024)
+    ap, coarse, f0o = aperiodicity.d4c_np(x, fs, f0u2, g["gvn_src_vuv"], g["gvn_src_tp"], fft_size_for_spectrum=1024)
+    assert np.allclose(f0o, g["gvn_f0"], rtol=1e-12, atol=0)
+    assert rel_rms(sp2.sum(axis=0), g["gvn_spec_colsum"]) < 1e-10
+    assert rel_rms(ap.sum(axis=0), g["gvn_ap_colsum"]) < 1e-9
+    assert np.max(np.abs(coarse - g["gvn_coarse"])) < 1e-8

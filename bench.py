@@ -2,17 +2,27 @@
 """Benchmark of the MI355X WORLD hot path (BASELINE.json metric: analysis+synthesis frames/s and xRT,
 16 kHz / 5 ms hop).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload at every N (weak scaling): BASELINE config 2 per GPU — 64 x 10 s synthetic 16 kHz utterances,
-encode (DIO + StoneMask + CheapTrick + D4C) + decode (pulse-wise synthesis), inputs resident in HBM before
-the timed region, outputs left in HBM.  A "step" is one full encode+decode pass over the rank's batch.
-Utterances are independent: ranks shard them with NO collective on the data path; the only communication
-is the barrier / max-reduce of the timing.
+Workload at every N (weak scaling, the default): BASELINE config 2 per GPU — 64 x 10 s synthetic 16 kHz utterances,
+encode (DIO + StoneMask + CheapTrick + D4C) + decode (pulse-wise synthesis), inputs resident in HBM before the timed
+region, outputs left in HBM.  A "step" is one full encode+decode pass over the rank's batch.  Utterances are
+independent: ranks shard them with NO collective on the data path; the only communication is the barrier /
+max-reduce of the timing.  `--scaling strong` fixes the TOTAL batch (`--utts` utterances) and shards it over the
+ranks with world.distributed.shard_ranges (the product's sharding rule).
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md §Measurement for the field definitions).
+The timed region replays the step from a captured hipGraph when capture succeeds (`graph: true` in the JSON; the
+same launches, no per-launch host work); the per-kernel HIP-event durations that feed `roofline` come from an
+un-captured pass of the same K steps right after it (events cannot be read back from inside a graph).
+
+Rank 0 prints ONE JSON line.  On a single GPU it also carries (each timed by this process):
+  cpu_baseline   : the NumPy oracle on the host cores (1 core and all cores, median of 3), bounded sample;
+  with_transfers : config 2 once more with the H2D of x and the D2H of f0/vuv/spectrogram/aperiodicity/out through
+                   pinned buffers inside the timed region (what a host-buffer caller sees; never `value`);
+  north_star     : BASELINE.json's target workload on ONE GPU — 1024 x 10 s, Harvest + CheapTrick + D4C-Requiem
+                   encode + Requiem decode (>= 500 xRT asked).
 """
 import argparse
 import json
@@ -31,6 +41,7 @@ SECONDS = 10.0
 UTT_PER_GPU = 64
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # FP64 vector FMA: 256 CUs x 4 SIMDs x 16 lanes/clk x 2 flop x 2.4 GHz (the SIMD-16 ceiling)
+
 
 # Algorithmic (compulsory) HBM bytes per 5 ms frame of each dominant-kernel candidate, float64 API dtypes —
 # SURVEY.md §8(d) components: x hop (640 B at 16 kHz), f0+vuv+tp 24 B, spectrogram and aperiodicity
@@ -55,23 +66,25 @@ def algo_bytes_per_frame(fs, fft_size, out_hop_scale=1.0):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=None,
-                    help="utterances per GPU (default: 64 = BASELINE config 2; 16 for config 5)")
+                    help="utterances per GPU (weak) or in total (strong); default 64 = BASELINE config 2, 16 for config 5")
     ap.add_argument("--seconds", type=float, default=None, help="utterance length (default 10 s; 60 s for config 5)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-utts", type=int, default=12, help="utterances of the batch timed through the CPU oracle")
+    ap.add_argument("--cpu-utts", type=int, default=4, help="utterances per repeat of the 1-core CPU oracle leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the with_transfers and north_star blocks")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--north-star-utts", type=int, default=1024)
     ap.add_argument("--lanes", type=int, default=1,
                     help="independent sub-batches in flight per GPU, each on its own HIP stream (world.batch."
-                         "WorldBatchLanes).  2 staggered lanes measure ~6%% faster on config 2, but the per-kernel "
-                         "HIP-event durations then include the other lane's overlap, so the default keeps one lane and "
-                         "clean per-kernel attribution")
+                         "WorldBatchLanes).  The default keeps one lane and clean per-kernel attribution")
     ap.add_argument("--no-stagger", action="store_true", help="start all lanes together (ablation)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config: 2 = DIO path encode+decode (the metric's config, default); "
                          "3 = Harvest F0 only; 4 = Harvest + CheapTrick + D4C-Requiem encode + Requiem decode; "
-                         "5 = 48 kHz long-form: encode, scale_pitch(1.5), scale_duration(2.0), decode")
+                         "5 = 48 kHz long-form: Harvest encode, scale_pitch(1.5), scale_duration(2.0), decode")
     args = ap.parse_args()
     if args.utts is None:
         args.utts = 16 if args.config == 5 else UTT_PER_GPU
@@ -80,52 +93,127 @@ def parse():
     return args
 
 
-def pmc_traffic(kernel, lanes):
-    """HBM bytes per launch of `kernel` measured with rocprofv3 PMC passes on this workload (committed under
-    profiles/; bench.py itself cannot run the profiler around its own timed region).  The file holds bytes per
-    pass over the whole 64-utterance batch; one launch covers 1/lanes of it.  None if unavailable."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic_cfg2_latest.txt")
+# ---- synthetic input ------------------------------------------------------------------------------------------
+def _synth_one(job):
+    from world._synthetic import synth_utterance
+    u, fs, seconds = job
+    return synth_utterance(u, fs, seconds)
+
+
+def make_inputs(first, count, fs, seconds):
+    """`count` distinct synthetic utterances (SURVEY §8(d) generator), generated on all host cores and cached in
+    $WH_SYNTH_CACHE (default /tmp/wh_synth) so that repeated runs on one box do not pay for them again."""
+    cache = os.environ.get("WH_SYNTH_CACHE", "/tmp/wh_synth")
+    path = os.path.join(cache, "u%d_n%d_fs%d_s%g.npy" % (first, count, fs, seconds))
     try:
-        for line in open(path):
-            parts = line.split()
-            if parts and parts[0] == kernel:
-                return float(parts[3]) * 1e6 / lanes, os.path.relpath(path, ROOT)
+        arr = np.load(path)
+        return [arr[i] for i in range(count)]
     except Exception:
         pass
-    return None, None
-
-
-def pmc_fp64_flops(kernel, lanes):
-    """FP64 floating-point operations per launch of `kernel` (2*FMA + ADD + MUL + TRANS instructions x 64 lanes) from the
-    committed rocprofv3 SQ-counter digest of this workload (profiles/sq_counters_cfg2_latest.txt).  None if unavailable."""
-    path = os.path.join(ROOT, "profiles", "sq_counters_cfg2_latest.txt")
+    jobs = [(first + i, fs, seconds) for i in range(count)]
+    procs = min(len(jobs), os.cpu_count() or 1, 32)
+    if procs > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(procs) as pool:
+            xs = pool.map(_synth_one, jobs)
+    else:
+        xs = [_synth_one(j) for j in jobs]
     try:
-        for line in open(path):
-            parts = line.split()
-            if parts and parts[0] == kernel:
-                return float(parts[1]) * 1e-6 * float(parts[-1]) * 1e12 / lanes, os.path.relpath(path, ROOT)
+        os.makedirs(cache, exist_ok=True)
+        np.save(path, np.stack(xs))
     except Exception:
         pass
-    return None, None
+    return xs
 
 
-def cpu_baseline(xs, n_utts):
-    """The NumPy oracle (a 'port' of the reference path) on a bounded sample of the same workload."""
+# ---- CPU baseline (runs BEFORE the GPU is initialised: the all-cores leg forks) -------------------------------------
+def _cpu_one(job):
     from oracle import api as oapi
-
-    n_utts = min(n_utts, len(xs))
-    frames = 0
-    t0 = time.perf_counter()
-    for u in range(n_utts):
-        dat = oapi.encode_np(FS, xs[u], f0_method="dio")
-        np.random.seed(u)
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except Exception:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    x, fs, seed = job
+    with ctx:
+        dat = oapi.encode_np(fs, x, f0_method="dio")
+        np.random.seed(seed)
         oapi.decode_np(dat)
-        frames += len(dat["f0"])
-    dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d of the %d utterances (%.0f s each), encode(dio)+decode through oracle/ (NumPy), %.1f s wall"
-                      % (n_utts, len(xs), len(xs[0]) / FS, dt),
-            "x_realtime": n_utts * len(xs[0]) / FS / dt}
+    return len(dat["f0"])
+
+
+def cpu_baseline(xs, fs, n_utts, repeats=3):
+    """The NumPy oracle (a 'port' of the reference path) on a bounded sample of the same workload:
+    (i) 1 core, per-utterance loop — the reference's execution model; (ii) all host cores, a process pool over
+    utterances.  One warm-up utterance, then `repeats` timed repeats each; medians reported."""
+    import multiprocessing as mp
+
+    n_utts = max(1, min(n_utts, len(xs)))
+    cores = os.cpu_count() or 1
+    _cpu_one((xs[0], fs, 0))  # warm-up (imports, FFT plans)
+    one = []
+    for r in range(repeats):
+        t0 = time.perf_counter()
+        frames = sum(_cpu_one((xs[u], fs, u)) for u in range(n_utts))
+        one.append(frames / (time.perf_counter() - t0))
+    pool_n = min(cores, 64)
+    jobs = [(xs[u % len(xs)], fs, u) for u in range(pool_n)]
+    allc = []
+    t_pool = time.perf_counter()
+    with mp.get_context("fork").Pool(pool_n) as pool:
+        pool.map(_cpu_one, jobs[:pool_n])  # warm-up inside the workers
+        for r in range(repeats):
+            t0 = time.perf_counter()
+            frames = sum(pool.map(_cpu_one, jobs, chunksize=1))
+            allc.append(frames / (time.perf_counter() - t0))
+    t_pool = time.perf_counter() - t_pool
+    v1, vn = float(np.median(one)), float(np.median(allc))
+    sec = len(xs[0]) / fs
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d of the %d utterances (%.0f s each) per repeat, encode(dio)+decode through oracle/ (NumPy), "
+                      "1 warm-up + median of %d repeats" % (n_utts, len(xs), sec, repeats),
+            "x_realtime": v1 * 0.005,
+            "all_cores": {"value": vn, "unit": "frames/s", "cores": pool_n, "host_cpus": cores, "x_realtime": vn * 0.005,
+                          "sample": "%d utterances per repeat over a %d-process pool, median of %d repeats"
+                                    % (pool_n, pool_n, repeats)},
+            "cpu_model": model, "repeats_1core": [round(v, 1) for v in one], "repeats_all_cores": [round(v, 1) for v in allc]}
+
+
+def pmc_table(name):
+    """rows of a committed rocprofv3 PMC digest under profiles/ (bench.py cannot run the profiler around itself)."""
+    path = os.path.join(ROOT, "profiles", name)
+    rows = {}
+    try:
+        for line in open(path):
+            parts = line.split()
+            if parts and not line.startswith("#") and parts[0].endswith("_kernel"):
+                rows[parts[0]] = parts
+    except Exception:
+        pass
+    return rows, os.path.relpath(path, ROOT)
+
+
+def pmc_traffic(kernel, lanes, config):
+    rows, src = pmc_table("hbm_traffic_cfg%d_latest.txt" % config)
+    if kernel in rows:
+        return float(rows[kernel][3]) * 1e6 / lanes, src
+    return None, None
+
+
+def pmc_fp64_flops(kernel, lanes, config):
+    rows, src = pmc_table("sq_counters_cfg%d_latest.txt" % config)
+    if kernel in rows:
+        return float(rows[kernel][1]) * 1e-6 * float(rows[kernel][-1]) * 1e12 / lanes, src
+    return None, None
 
 
 def main():
@@ -133,62 +221,44 @@ def main():
     args = parse()
     if args.config == 5:
         FS = 48000
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+
+    # ---- inputs (host) and the CPU baseline, before any GPU state exists in this process --------------------------
+    if args.scaling == "strong":
+        from world.distributed import shard_ranges
+        lo, hi = shard_ranges([int(FS * args.seconds)] * args.utts, world)[rank]
+        first, count = lo, hi - lo
+    else:
+        first, count = rank * args.utts, args.utts
+    distinct = min(count, 64 if args.config != 5 else 16)  # a larger batch repeats its first 64 (16) utterances
+    xs_distinct = make_inputs(first, distinct, FS, args.seconds)
+    xs = [xs_distinct[i % distinct] for i in range(count)]
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.config == 2:
+        cpu = cpu_baseline(xs_distinct, FS, args.cpu_utts)
+
+    import torch
+    import torch.distributed as dist
+
     torch.cuda.set_device(local_rank)
     if world > 1 or "RANK" in os.environ:  # under torch.distributed.run the RCCL path is exercised even for 1 rank
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from world._synthetic import synth_utterance
     from world.batch import WorldBatchLanes
 
     # args.lanes independent sub-batches per GPU, each on its own HIP stream and library context; one "step" is
     # still one pass of the hot path over the whole per-GPU batch
-    wl = WorldBatchLanes(local_rank, lanes=max(1, min(args.lanes, args.utts)))
+    wl = WorldBatchLanes(local_rank, lanes=max(1, min(args.lanes, max(count, 1))))
     rts = [wb.rt for wb in wl.lanes]
-    first = rank * args.utts
-    xs = [synth_utterance(first + i, FS, args.seconds) for i in range(args.utts)]
     wl.upload(xs, FS)  # inputs resident in HBM before the timed region
     frames_per_step = wl.total_frames
 
-    if args.config == 2:
-        def step(seed):
-            encs = wl.encode_device(FS, stagger=not args.no_stagger, f0_method="dio")
-            return wl.decode_device(encs, seed=seed)
-    elif args.config == 3:
-        from world.harvest import harvest_device
-
-        def step(seed):
-            out = []
-            for wb, r in zip(wl.lanes, wl.resident):
-                with wb.rt.on_stream():
-                    out.append(harvest_device(wb.rt, r[0], r[1], r[2], FS))
-            return out
-    elif args.config == 5:
-        def step(seed):
-            encs = wl.encode_device(FS, stagger=not args.no_stagger, f0_method="dio")
-            for e in encs:
-                with e.rt.on_stream():
-                    e.scale_pitch(1.5).scale_duration(2.0)
-            return wl.decode_device(encs, seed=seed)
-    else:
-        from world.get_seeds_signals import get_seeds_signals
-        import random
-        random.seed(0)
-        np.random.seed(0)
-        seeds = get_seeds_signals(FS)
-
-        def step(seed):
-            encs = wl.encode_device(FS, stagger=not args.no_stagger, f0_method="harvest", is_requiem=True)
-            return wl.decode_device(encs, seeds=seeds)
+    step = make_step(args, wl, FS)
 
     def fence():
         if dist.is_initialized():
@@ -198,14 +268,34 @@ def main():
     for w in range(args.warmup):
         step(w)
     fence()
-    for rt in rts:
-        rt.profile(True)
+    for wb in wl.lanes:
+        wb.check("bench warm-up")
+
+    # ---- hipGraph capture of one step (single lane; falls back to eager launches if anything refuses) --------------
+    graph = None
+    if not args.no_graph and len(rts) == 1:
+        graph = try_capture(torch, lambda: step(1000))
+    fence()
+
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(1000 + k)
+    if graph is not None:
+        for k in range(args.steps):
+            graph.replay()
+    else:
+        for k in range(args.steps):
+            step(1000 + k)
     host_enqueue = time.perf_counter() - t0  # the launches are asynchronous: host time to enqueue all K steps
     fence()
     elapsed = time.perf_counter() - t0
+
+    # ---- un-captured pass of the same K steps with a HIP-event pair around every kernel launch ------------------
+    for rt in rts:
+        rt.profile(True)
+    tp0 = time.perf_counter()
+    for k in range(args.steps):
+        step(1000 + k)
+    fence()
+    eager_elapsed = time.perf_counter() - tp0
     records, flags = [], [0] * 16
     for rt in rts:
         records += rt.profile_collect()
@@ -216,12 +306,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        tot = torch.tensor([frames_per_step, count], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        frames_all, utts_all = float(tot[0].item()), float(tot[1].item())
+    else:
+        frames_all, utts_all = float(frames_per_step), float(count)
 
     if rank == 0:
-        total_frames = frames_per_step * world * args.steps
-        audio_s = args.utts * args.seconds * world * args.steps
+        total_frames = frames_all * args.steps
+        audio_s = utts_all * args.seconds * args.steps
         value = total_frames / elapsed
-        # per-kernel launch durations from the HIP-event records of the timed region (rank 0, each lane's stream)
+        # per-kernel launch durations from the HIP-event records of the profiled pass (rank 0, each lane's stream)
         agg = {}
         for name, ms in records:
             a = agg.setdefault(name, [0.0, 0])
@@ -232,28 +327,36 @@ def main():
         roofline = None
         if dominant:
             from world.cheaptrick import default_fft_size
-            ALGO_BYTES_PER_FRAME, PATH_BYTES_PER_FRAME = algo_bytes_per_frame(FS, default_fft_size(FS),
-                                                                              2.0 if args.config == 5 else 1.0)
-            per_frame = ALGO_BYTES_PER_FRAME.get(dominant, PATH_BYTES_PER_FRAME)
+            per_k, path_b = algo_bytes_per_frame(FS, default_fft_size(FS), 2.0 if args.config == 5 else 1.0)
+            per_frame = per_k.get(dominant, path_b)
             avg_s = kernel_ms[dominant] / 1e3
             # every lane launches the kernel once per step on its share of the frames
             frames_per_launch = frames_per_step * args.steps / agg[dominant][1]
             achieved = per_frame * frames_per_launch / avg_s / 1e9
-            traffic, traffic_src = (pmc_traffic(dominant, len(rts)) if args.config == 2 and args.utts == UTT_PER_GPU
-                                    else (None, None))
+            std = args.utts == UTT_PER_GPU and args.scaling == "weak" and args.config in (2, 3, 4)
+            traffic, traffic_src = pmc_traffic(dominant, len(rts), args.config) if std else (None, None)
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": per_frame * frames_per_launch,
                         "frames_per_launch": frames_per_launch,
                         "avg_launch_ms": kernel_ms[dominant],
-                        "path_algorithmic_GBps": PATH_BYTES_PER_FRAME * frames_per_step * args.steps / elapsed / 1e9}
-            # second view of the same kernel: the path is FP64-compute/latency-bound, not HBM-bound (DESIGN.md section 4)
-            flops, flops_src = (pmc_fp64_flops(dominant, len(rts)) if args.config == 2 and args.utts == UTT_PER_GPU
-                                else (None, None))
+                        "timing": "HIP events around every launch, un-captured pass of the same %d steps" % args.steps,
+                        "path_algorithmic_GBps": path_b * frames_per_step * args.steps / elapsed / 1e9}
+            # second view of the same kernel: the path is FP64-compute/latency-bound, not HBM-bound (DESIGN.md §4)
+            flops, flops_src = pmc_fp64_flops(dominant, len(rts), args.config) if std else (None, None)
             if flops:
-                roofline["fp64_vector"] = {"achieved": flops / avg_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": flops / avg_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                roofline["fp64_vector"] = {"achieved": flops / avg_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                                           "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                                            "flops_per_launch": flops, "flops_source": flops_src}
+        noise_note = "on-device Philox noise (not the reference-parity host-noise path)"
+        workloads = {
+            2: "BASELINE config 2 per GPU: %d x %.0f s synthetic 16 kHz utterances, DIO+StoneMask+CheapTrick+D4C encode + "
+               "pulse-wise synthesis decode with " + noise_note + ", HBM-resident",
+            3: "BASELINE config 3 per GPU: %d x %.0f s synthetic 16 kHz utterances, Harvest F0 only, HBM-resident",
+            4: "BASELINE config 4 per GPU: %d x %.0f s synthetic 16 kHz utterances, Harvest+CheapTrick+D4C-Requiem encode "
+               "+ Requiem decode, HBM-resident",
+            5: "BASELINE config 5 per GPU: %d x %.0f s synthetic 48 kHz utterances, Harvest+CheapTrick+D4C encode, "
+               "scale_pitch(1.5), scale_duration(2.0), pulse-wise decode with " + noise_note + ", HBM-resident"}
         out = {
             "metric": "analysis+synthesis frames/sec (and xRT), %d kHz / 5 ms hop" % (FS // 1000),
             "value": value,
@@ -263,33 +366,181 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "x_realtime": audio_s / elapsed,
+            "graph": graph is not None,
+            "eager_ms_per_step": eager_elapsed / args.steps * 1e3,
             "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
-            "config": {"workload": {2: "BASELINE config 2 per GPU: %d x %.0f s synthetic 16 kHz utterances, "
-                                       "DIO+StoneMask+CheapTrick+D4C encode + pulse-wise synthesis decode, HBM-resident",
-                                    3: "BASELINE config 3 per GPU: %d x %.0f s synthetic 16 kHz utterances, Harvest F0 only",
-                                    4: "BASELINE config 4 per GPU: %d x %.0f s synthetic 16 kHz utterances, Harvest+CheapTrick+"
-                                       "D4C-Requiem encode + Requiem decode",
-                                    5: "BASELINE config 5 per GPU: %d x %.0f s synthetic 48 kHz utterances, DIO+StoneMask+"
-                                       "CheapTrick+D4C encode, scale_pitch(1.5), scale_duration(2.0), pulse-wise decode"
-                                    }[args.config] % (args.utts, args.seconds),
-                       "utterances_per_gpu": args.utts, "fs": FS, "frame_period_ms": 5,
+            "config": {"workload": workloads[args.config] % (count, args.seconds),
+                       "utterances_per_gpu": count, "distinct_utterances": distinct, "fs": FS, "frame_period_ms": 5,
                        "frames_per_step_per_gpu": frames_per_step, "sharding": "utterances, no collective",
                        "lanes_per_gpu": len(rts)},
             "roofline": roofline,
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
             "device_flags": flags,
         }
-        if world == 1 and not args.no_cpu_baseline and args.config == 2:
-            out["cpu_baseline"] = cpu_baseline(xs, args.cpu_utts)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if world == 1 and not args.no_extras and args.config == 2 and args.scaling == "weak":
+            del graph
+            for key, fn in (("with_transfers", lambda: with_transfers_block(torch, wl, xs, FS)),
+                            ("north_star", lambda: north_star_block(torch, local_rank, xs_distinct, FS, args))):
+                try:
+                    out[key] = fn()
+                except Exception as e:  # an extra block must never cost the headline line
+                    out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def make_step(args, wl, fs):
+    if args.config == 2:
+        def step(seed):
+            encs = wl.encode_device(fs, stagger=not args.no_stagger, f0_method="dio")
+            return wl.decode_device(encs, seed=seed)
+    elif args.config == 3:
+        from world.harvest import harvest_device
+
+        def step(seed):
+            out = []
+            for wb, r in zip(wl.lanes, wl.resident):
+                with wb.rt.on_stream():
+                    out.append(harvest_device(wb.rt, r[0], r[1], r[2], fs))
+            return out
+    elif args.config == 5:
+        def step(seed):
+            encs = wl.encode_device(fs, stagger=not args.no_stagger, f0_method="harvest")
+            for e in encs:
+                with e.rt.on_stream():
+                    e.scale_pitch(1.5).scale_duration(2.0)
+            return wl.decode_device(encs, seed=seed)
+    else:
+        import random
+
+        from world.get_seeds_signals import get_seeds_signals
+        random.seed(0)
+        np.random.seed(0)
+        seeds = get_seeds_signals(fs)
+
+        def step(seed):
+            encs = wl.encode_device(fs, stagger=not args.no_stagger, f0_method="harvest", is_requiem=True)
+            return wl.decode_device(encs, seeds=seeds)
+    return step
+
+
+def try_capture(torch, fn):
+    """Capture one call of `fn` (kernel launches on torch's current stream, allocations from torch's graph pool) into
+    a hipGraph.  None if capture is refused (a synchronous call inside the step, an unsupported node...)."""
+    try:
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                keep = fn()
+        g._keep = keep  # outputs live in the graph's private pool
+        torch.cuda.current_stream().wait_stream(s)
+        g.replay()
+        torch.cuda.synchronize()
+        return g
+    except Exception as e:
+        sys.stderr.write("hipGraph capture failed, timing eager launches: %s: %s\n" % (type(e).__name__, e))
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        return None
+
+
+def with_transfers_block(torch, wl, xs, fs, steps=5):
+    """Config 2 as a host-buffer caller sees it: per step H2D of the waveforms from pinned memory, encode + decode,
+    D2H of f0 / vuv / spectrogram / aperiodicity / out into pinned buffers, one stream, nothing overlapped."""
+    wb = wl.lanes[0]
+    rt = wb.rt
+    batch, x_d, tp_d = wl.resident[0]
+    x_pin = torch.from_numpy(np.concatenate(xs)).pin_memory()
+    enc = wb.encode_device(batch, x_d, tp_d, fs, f0_method="dio", check=False)
+    y, _ = wb.decode_device(enc, seed=1, check=False)
+    outs = [enc.f0, enc.vuv, enc.spectrogram, enc.aperiodicity, y]
+    pins = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in outs]
+    nbytes_d2h = sum(t.numel() * t.element_size() for t in outs)
+
+    def one(seed):
+        x_d.copy_(x_pin, non_blocking=True)
+        e = wb.encode_device(batch, x_d, tp_d, fs, f0_method="dio", check=False)
+        yy, _ = wb.decode_device(e, seed=seed, check=False)
+        for p, t in zip(pins, (e.f0, e.vuv, e.spectrogram, e.aperiodicity, yy)):
+            p.copy_(t, non_blocking=True)
+
+    one(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one(10 + k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    wb.check("with_transfers")
+    frames = batch.total_frames
+    return {"ms_per_step": dt * 1e3, "value": frames / dt, "unit": "frames/s",
+            "x_realtime": len(xs) * len(xs[0]) / fs / dt, "steps": steps,
+            "h2d_MB_per_step": x_pin.numel() * 8 / 1e6, "d2h_MB_per_step": nbytes_d2h / 1e6,
+            "note": "config 2 step incl. H2D of x and D2H of f0/vuv/spectrogram/aperiodicity/out via pinned host "
+                    "buffers on one stream (no overlap); 'ps spectrogram' is not materialised"}
+
+
+def north_star_block(torch, device_index, xs_distinct, fs, args, steps=3):
+    """BASELINE.json north_star on ONE GPU: 1024 x 10 s at 16 kHz, encode(harvest, is_requiem=True) + Requiem decode."""
+    import random
+
+    from world.batch import WorldBatch
+    from world.get_seeds_signals import get_seeds_signals
+
+    n = args.north_star_utts
+    xs = [xs_distinct[i % len(xs_distinct)] for i in range(n)]
+    wb = WorldBatch(device_index)
+    batch, x_d, tp_d = wb.upload(xs, fs)
+    random.seed(0)
+    np.random.seed(0)
+    seeds = get_seeds_signals(fs)
+
+    def one():
+        enc = wb.encode_device(batch, x_d, tp_d, fs, f0_method="harvest", is_requiem=True, check=False)
+        return wb.decode_device(enc, seeds=seeds, check=False)
+
+    one()
+    torch.cuda.synchronize()
+    wb.rt.profile(True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    agg = {}
+    for name, ms in wb.rt.profile_collect():
+        a = agg.setdefault(name, [0.0, 0])
+        a[0] += ms
+        a[1] += 1
+    wb.rt.profile(False)
+    wb.check("north_star")
+    frames = batch.total_frames
+    dom = max(agg.items(), key=lambda kv: kv[1][0])[0]
+    per_k, path_b = algo_bytes_per_frame(fs, 1024)
+    dom_ms = agg[dom][0] / agg[dom][1]
+    # Requiem path: 9584 B/frame encode+decode (SURVEY §8(d)); Harvest kernels are priced on the F0-only 664 B/frame
+    achieved = per_k.get(dom, 664) * frames / (dom_ms / 1e3) / 1e9
+    return {"workload": "%d x %.0f s synthetic 16 kHz utterances (the %d distinct ones repeated) on 1 GPU: Harvest+CheapTrick+"
+                        "D4C-Requiem encode + Requiem decode, HBM-resident" % (n, len(xs[0]) / fs, len(xs_distinct)),
+            "ms_per_step": dt * 1e3, "value": frames / dt, "unit": "frames/s", "x_realtime": n * len(xs[0]) / fs / dt,
+            "target_x_realtime": 500, "steps": steps, "frames_per_step": frames,
+            "dominant_kernel": dom, "dominant_kernel_ms": dom_ms,
+            "dominant_kernel_hbm_frac": achieved / HBM_PEAK_GBS,
+            "path_algorithmic_GBps": 9584 * frames / dt / 1e9,
+            "kernel_ms": {k: round(v[0] / v[1], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]}}
 
 
 if __name__ == "__main__":

@@ -57,7 +57,7 @@ int const_table(wh_ctx* ctx, const std::string& key, const std::vector<double>& 
   *out = d;
   return 0;
 }
-int persistent_upload(wh_ctx* ctx, const std::string& slot, const void* host, size_t bytes, void** dptr) {
+int persistent_upload(wh_ctx* ctx, hipStream_t st, const std::string& slot, const void* host, size_t bytes, void** dptr) {
   wh_ctx::Persist& e = ctx->persist[slot];
   if (e.d && e.host.size() == bytes && (bytes == 0 || memcmp(e.host.data(), host, bytes) == 0)) {
     *dptr = e.d;
@@ -65,17 +65,30 @@ int persistent_upload(wh_ctx* ctx, const std::string& slot, const void* host, si
   }
   if (e.cap < bytes || !e.d) {
     if (e.d) {
-      WH_CHECK(hipDeviceSynchronize());
+      WH_CHECK(hipDeviceSynchronize());  // kernels of earlier calls may still read the buffer that is about to go
       WH_CHECK(hipFree(e.d));
       e.d = nullptr;
     }
     const size_t want = bytes < 256 ? 256 : bytes + bytes / 4;
     WH_CHECK(hipMalloc(&e.d, want));
     e.cap = want;
-  } else {
-    WH_CHECK(hipDeviceSynchronize());  // a kernel of an earlier call may still be reading the old content
   }
-  if (bytes) WH_CHECK(hipMemcpy(e.d, host, bytes, hipMemcpyHostToDevice));
+  if (bytes) {
+    const int k = e.next_stage;
+    e.next_stage = (k + 1) % wh_ctx::Persist::kStages;
+    if (e.stage_done[k]) WH_CHECK(hipEventSynchronize(e.stage_done[k]));  // the copy that last used this staging buffer
+    if (e.stage_cap[k] < bytes) {
+      if (e.stage[k]) WH_CHECK(hipHostFree(e.stage[k]));
+      e.stage[k] = nullptr;
+      const size_t want = bytes < 256 ? 256 : bytes + bytes / 4;
+      WH_CHECK(hipHostMalloc(&e.stage[k], want, hipHostMallocDefault));
+      e.stage_cap[k] = want;
+    }
+    if (!e.stage_done[k]) WH_CHECK(hipEventCreateWithFlags(&e.stage_done[k], hipEventDisableTiming));
+    memcpy(e.stage[k], host, bytes);
+    WH_CHECK(hipMemcpyAsync(e.d, e.stage[k], bytes, hipMemcpyHostToDevice, st));
+    WH_CHECK(hipEventRecord(e.stage_done[k], st));
+  }
   e.host.assign(reinterpret_cast<const char*>(host), reinterpret_cast<const char*>(host) + bytes);
   *dptr = e.d;
   return 0;
@@ -133,7 +146,13 @@ int wh_ctx_destroy(wh_ctx* ctx) {
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   for (auto& kv : ctx->tables) (void)hipFree(kv.second);
   for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
-  for (auto& kv : ctx->persist) if (kv.second.d) (void)hipFree(kv.second.d);
+  for (auto& kv : ctx->persist) {
+    if (kv.second.d) (void)hipFree(kv.second.d);
+    for (int k = 0; k < wh_ctx::Persist::kStages; ++k) {
+      if (kv.second.stage[k]) (void)hipHostFree(kv.second.stage[k]);
+      if (kv.second.stage_done[k]) (void)hipEventDestroy(kv.second.stage_done[k]);
+    }
+  }
   delete ctx;
   return 0;
 }

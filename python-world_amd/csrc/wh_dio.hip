@@ -504,11 +504,11 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   {
     std::vector<double> taps(h_band_taps, h_band_taps + taps_total), lc(h_lowcut, h_lowcut + 2 * lowcut_half + 1),
         bf(h_band_f0, h_band_f0 + n_bands);
-    if (int rc = wh::persistent_upload(ctx, "dio.meta", meta, &d_meta)) return rc;
-    if (int rc = wh::persistent_upload(ctx, "dio.taps", taps, &d_taps)) return rc;
-    if (int rc = wh::persistent_upload(ctx, "dio.lowcut", lc, &d_lc)) return rc;
-    if (int rc = wh::persistent_upload(ctx, "dio.band_f0", bf, &d_bf)) return rc;
-    if (int rc = wh::persistent_upload(ctx, "dio.tapinfo", ti, &d_ti)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "dio.meta", meta, &d_meta)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "dio.taps", taps, &d_taps)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "dio.lowcut", lc, &d_lc)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "dio.band_f0", bf, &d_bf)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "dio.tapinfo", ti, &d_ti)) return rc;
   }
 
   // ---- decimation ---------------------------------------------------------------------------------
@@ -541,7 +541,7 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
         j.seg_counts = d_scnt + ((int64_t)u * n_bands + i) * kBandSegs * 4;
         j.seg_cap = seg_cap[u];
       }
-    if (int rc = wh::persistent_upload(ctx, "dio.jobs", jobs, &d_jobs)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "dio.jobs", jobs, &d_jobs)) return rc;
   }
   if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands, d_ti + 2 * n_bands,
                                       max_lb, false, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW, kBandSegs))

@@ -605,11 +605,11 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     }
   {
     std::vector<double> taps(h_band_taps, h_band_taps + taps_total), bf(h_band_f0, h_band_f0 + n_bands);
-    if (int rc = wh::persistent_upload(ctx, "hv.meta", meta, &d_meta)) return rc;
-    if (int rc = wh::persistent_upload(ctx, "hv.jobs", jobs, &d_jobs)) return rc;
-    if (int rc = wh::persistent_upload(ctx, "hv.taps", taps, &d_taps)) return rc;
-    if (int rc = wh::persistent_upload(ctx, "hv.band_f0", bf, &d_bf)) return rc;
-    if (int rc = wh::persistent_upload(ctx, "hv.tapinfo", ti, &d_ti)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "hv.meta", meta, &d_meta)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "hv.jobs", jobs, &d_jobs)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "hv.taps", taps, &d_taps)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "hv.band_f0", bf, &d_bf)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "hv.tapinfo", ti, &d_ti)) return rc;
   }
 
   // ---- decimation -----------------------------------------------------------------------------------

@@ -492,7 +492,7 @@ inline int harvest_contour(wh_ctx* ctx, hipStream_t st, int B, const HvUtt* d_me
   HcSec* d_secs = reinterpret_cast<HcSec*>(d_ws + o_secs);
   int32_t* d_ns = reinterpret_cast<int32_t*>(d_ws + o_ns);
   double* d_ch = reinterpret_cast<double*>(d_ws + o_ch);
-  if (int rc = wh::persistent_upload(ctx, "hv.contour", hc, &d_hc)) return rc;
+  if (int rc = wh::persistent_upload(ctx, st, "hv.contour", hc, &d_hc)) return rc;
   const dim3 gf((unsigned)((max_nf1 + 255) / 256), B);
   { wh::KernelTimer _kt(ctx, st, "hc_base_kernel"); hipLaunchKernelGGL(hc_base_kernel, gf, dim3(256), 0, st, d_meta, d_hc, d_pf0, d_psc, d_rows); }
   WH_LAUNCH_CHECK("hc_base_kernel");

@@ -23,6 +23,13 @@ struct wh_ctx {
     void* d = nullptr;
     size_t cap = 0;
     std::vector<char> host;
+    // changed content is staged in pinned host memory and copied with hipMemcpyAsync on the call's stream: the copy is
+    // ordered behind every kernel of earlier calls (which may still read the old content) without a device sync
+    static constexpr int kStages = 4;
+    void* stage[kStages] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_cap[kStages] = {0, 0, 0, 0};
+    hipEvent_t stage_done[kStages] = {nullptr, nullptr, nullptr, nullptr};
+    int next_stage = 0;
   };
   std::map<std::string, Persist> persist;
   // optional per-kernel timing (HIP events on the launch stream), see wh_profile_*
@@ -53,12 +60,14 @@ inline const double2* twiddle(const wh_ctx* ctx, int n) { return ctx->d_twiddle 
 // Upload-once constant table keyed by name (synchronous on first use, cached afterwards).
 int const_table(wh_ctx* ctx, const std::string& key, const std::vector<double>& host, const double** out);
 // Upload `bytes` from host memory into the persistent device buffer named `slot` unless it already holds
-// exactly these bytes.  Synchronous (and possibly reallocating) only when the content changed.
-int persistent_upload(wh_ctx* ctx, const std::string& slot, const void* host, size_t bytes, void** dptr);
+// exactly these bytes.  Changed content goes through a ring of pinned staging buffers and hipMemcpyAsync on `st`
+// (no device synchronisation; a context is driven from one stream at a time, so stream order protects readers of
+// the old content).  Only growing the buffer synchronises (hipFree).
+int persistent_upload(wh_ctx* ctx, hipStream_t st, const std::string& slot, const void* host, size_t bytes, void** dptr);
 template <typename T>
-inline int persistent_upload(wh_ctx* ctx, const std::string& slot, const std::vector<T>& v, T** dptr) {
+inline int persistent_upload(wh_ctx* ctx, hipStream_t st, const std::string& slot, const std::vector<T>& v, T** dptr) {
   void* p = nullptr;
-  const int rc = persistent_upload(ctx, slot, v.data(), v.size() * sizeof(T), &p);
+  const int rc = persistent_upload(ctx, st, slot, v.data(), v.size() * sizeof(T), &p);
   *dptr = reinterpret_cast<T*>(p);
   return rc;
 }

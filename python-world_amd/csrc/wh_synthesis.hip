@@ -1031,7 +1031,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   double* d_pw = reinterpret_cast<double*>(ws + o_pw);
   int32_t* d_pu = reinterpret_cast<int32_t*>(ws + o_pu);
   int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
-  if (int rc = wh::persistent_upload(ctx, "syn.meta", meta, &d_meta)) return rc;
+  if (int rc = wh::persistent_upload(ctx, st, "syn.meta", meta, &d_meta)) return rc;
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
                      d_phase, d_vuv); }
@@ -1094,7 +1094,7 @@ extern "C" int wh_peak_normalise(wh_ctx* ctx, void* stream, double* y, const int
   hipStream_t st = (hipStream_t)stream;
   std::vector<int64_t> off(h_y_off, h_y_off + n_utt + 1);
   int64_t* d_off = nullptr;
-  if (int rc = wh::persistent_upload(ctx, "peak.off", off, &d_off)) return rc;
+  if (int rc = wh::persistent_upload(ctx, st, "peak.off", off, &d_off)) return rc;
   int64_t max_n = 0;
   for (int u = 0; u < n_utt; ++u) max_n = std::max(max_n, off[u + 1] - off[u]);
   if (int rc = wh::ws_reserve(ctx, sizeof(unsigned long long) * (size_t)n_utt)) return rc;
@@ -1129,7 +1129,7 @@ extern "C" int wh_cumsum_exact(wh_ctx* ctx, void* stream, double* d_data, const 
   hipStream_t st = (hipStream_t)stream;
   std::vector<int64_t> off(h_off, h_off + n_seg + 1);
   int64_t* d_off = nullptr;
-  if (int rc = wh::persistent_upload(ctx, "cumsum.off", off, &d_off)) return rc;
+  if (int rc = wh::persistent_upload(ctx, st, "cumsum.off", off, &d_off)) return rc;
   { wh::KernelTimer _kt(ctx, st, "exact_cumsum_kernel"); hipLaunchKernelGGL(exact_cumsum_kernel, dim3(n_seg), dim3(kXThreads), 0, st, d_data, d_off); }
   WH_LAUNCH_CHECK("exact_cumsum_kernel");
   return 0;
@@ -1182,7 +1182,7 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
   int64_t* d_pi = reinterpret_cast<int64_t*>(ws + o_pi);
   int64_t* d_pn = reinterpret_cast<int64_t*>(ws + o_pn);
   int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
-  if (int rc = wh::persistent_upload(ctx, "syn.meta", meta, &d_meta)) return rc;
+  if (int rc = wh::persistent_upload(ctx, st, "syn.meta", meta, &d_meta)) return rc;
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
                      d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
@@ -1272,8 +1272,8 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   int64_t* d_pb = reinterpret_cast<int64_t*>(ws + o_pb);
   double* d_lin = reinterpret_cast<double*>(ws + o_lin);
   double* d_exc = reinterpret_cast<double*>(ws + o_exc);
-  if (int rc = wh::persistent_upload(ctx, "syn.meta", meta, &d_meta)) return rc;
-  if (int rc = wh::persistent_upload(ctx, "syn.req", rq, &d_rq)) return rc;
+  if (int rc = wh::persistent_upload(ctx, st, "syn.meta", meta, &d_meta)) return rc;
+  if (int rc = wh::persistent_upload(ctx, st, "syn.req", rq, &d_rq)) return rc;
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs, d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");

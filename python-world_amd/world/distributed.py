@@ -62,3 +62,75 @@ def max_over_ranks(value, device=None, group=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+class ShardedWorldBatch:
+    """One 1024-utterance (or any) batch over the GPUs of a node: rank r encodes / decodes the contiguous utterance
+    range shard_ranges gives it on its own GPU, with no collective on the data path; the dense
+    outputs stay on the rank that produced them, the small per-utterance results (f0, vuv, Requiem band
+    aperiodicity, output lengths) can be gathered to one rank.  One process per GPU; works un-initialised
+    (world_size 1) as a plain single-GPU batch.
+
+    ``backend``: object with ``encode(xs, fs, **kw) -> enc`` and ``decode_device(enc, **kw) -> (y, y_off)``; default
+    ``world.batch.WorldBatch`` on ``device_index`` (LOCAL_RANK).  The CPU (gloo) test passes a stub here."""
+
+    def __init__(self, device_index=None, backend=None, group=None):
+        import os
+
+        self.group = group
+        self.world, self.rank = 1, 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        except ImportError:
+            pass
+        if backend is None:
+            from .batch import WorldBatch
+            if device_index is None:
+                device_index = int(os.environ.get("LOCAL_RANK", "0"))
+            backend = WorldBatch(device_index)
+        self.backend = backend
+        self.range = (0, 0)
+        self.lengths = None
+
+    def shard(self, lengths):
+        """[start, end) of this rank for a batch with the given utterance lengths (samples)."""
+        self.lengths = [int(n) for n in lengths]
+        self.range = my_range(self.lengths, self.world, self.rank)
+        return self.range
+
+    def encode(self, utterances, fs, lengths=None, **kw):
+        """``utterances``: the whole batch as a list of 1-D arrays — every rank passes the same list and takes its
+        slice — or a callable ``u -> waveform`` together with ``lengths`` so that a rank only ever materialises its own
+        utterances.  Returns this rank's encoding (None for an empty shard)."""
+        if callable(utterances):
+            lo, hi = self.shard(lengths)
+            mine = [utterances(u) for u in range(lo, hi)]
+        else:
+            lo, hi = self.shard([len(x) for x in utterances])
+            mine = list(utterances[lo:hi])
+        self.enc = self.backend.encode(mine, fs, **kw) if mine else None
+        return self.enc
+
+    def decode(self, enc=None, **kw):
+        """This rank's (y, y_off), or None for an empty shard."""
+        enc = self.enc if enc is None else enc
+        return self.backend.decode_device(enc, **kw) if enc is not None else None
+
+    def gather_small(self, per_utterance, dst=0):
+        """Gather a list with one small NumPy array per LOCAL utterance to ``dst`` in global utterance order."""
+        if self.world == 1:
+            return list(per_utterance)
+        return gather_small(list(per_utterance), group=self.group, dst=dst)
+
+    def gather_f0(self, enc=None, dst=0):
+        """[(f0, vuv)] per utterance of the whole batch on ``dst`` (None elsewhere): <= 16 B per frame over xGMI."""
+        enc = self.enc if enc is None else enc
+        local = []
+        if enc is not None:
+            fo = enc.batch.frame_off
+            f0, vuv = enc.f0.cpu().numpy(), enc.vuv.cpu().numpy()
+            local = [(f0[int(fo[u]):int(fo[u + 1])].copy(), vuv[int(fo[u]):int(fo[u + 1])].copy())
+                     for u in range(enc.n_utt)]
+        return self.gather_small(local, dst=dst)

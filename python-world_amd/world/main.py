@@ -94,6 +94,44 @@ class World(object):
         out['is_requiem'] = is_requiem
         return out
 
+    # ---- batched convenience (not in the reference; SURVEY.md §8(b): "World.encode_batch/decode_batch") ----------
+    def encode_batch(self, fs, xs, **kw):
+        """encode() for a list of utterances in one pass per kernel.  Under an initialised torch.distributed process
+        group (one process per GPU) the batch is sharded by utterance over the ranks and the list holds only this
+        rank's utterances; use ``world.distributed.ShardedWorldBatch`` directly to keep results on the device."""
+        from .distributed import ShardedWorldBatch
+
+        sb = ShardedWorldBatch()
+        enc = sb.encode(xs, fs, **kw)
+        dats = enc.to_dicts() if enc is not None else []
+        for d in dats:
+            d['_batch_range'] = sb.range
+        return dats
+
+    def decode_batch(self, dats, **kw):
+        """decode() for a list of encode()/encode_batch() dicts that share fs / is_requiem / fft size: one batched
+        synthesis; adds 'out' to every dict (peak-normalised like decode()) and returns the list."""
+        from .batch import BatchEncoding, WorldBatch
+
+        if not dats:
+            return dats
+        wb = WorldBatch()
+        rt = wb.rt
+        nfs = [len(d['f0']) for d in dats]
+        frame_off = np.concatenate([[0], np.cumsum(nfs)])
+        batch = rt.make_batch(np.zeros(len(dats) + 1, dtype=np.int64), frame_off)
+        cat = lambda key: rt.to_device(np.concatenate([np.asarray(d[key], dtype=np.float64) for d in dats]))  # noqa: E731
+        rows = lambda key: rt.to_device(np.concatenate([np.asarray(d[key], dtype=np.float64).T for d in dats]))  # noqa: E731
+        tp_h = np.concatenate([np.asarray(d['temporal_positions'], dtype=np.float64) for d in dats])
+        fft_size = (dats[0]['spectrogram'].shape[0] - 1) * 2
+        enc = BatchEncoding(rt, batch, dats[0]['fs'], rt.to_device(tp_h), cat('f0'), cat('vuv'), rows('spectrogram'),
+                            rows('aperiodicity'), fft_size, bool(dats[0]['is_requiem']), None, tp_host=tp_h)
+        y, y_off = wb.decode_device(enc, **kw)
+        y = y.cpu().numpy()
+        for u, d in enumerate(dats):
+            d['out'] = y[int(y_off[u]):int(y_off[u + 1])].copy()
+        return dats
+
     # ---- modification (all in place on the dict, like the reference) ------------------------------------------
     def scale_pitch(self, dat, factor):
         """world/main.py:154-162."""

@@ -48,3 +48,84 @@ def test_two_rank_shard_gather_and_timing():
     mp.spawn(_worker, args=(2, port, lengths, ret), nprocs=2, join=True)
     assert ret["n"] == len(lengths) and ret["order_ok"] and ret["frames_ok"]
     assert ret["t0"] == ret["t1"] == 1.25
+
+
+class _StubEncoding:
+    """What ShardedWorldBatch needs from an encoding, on the CPU: per-utterance frame offsets and flat f0 / vuv."""
+
+    def __init__(self, xs, fs, first_marker):
+        import torch
+
+        nfs = [int(1000 * len(x) / fs / 5 + 1) for x in xs]
+        self.n_utt = len(xs)
+        self.batch = type("B", (), {"frame_off": np.concatenate([[0], np.cumsum(nfs)])})()
+        # the stub "analysis": f0 of utterance = its first sample (a marker the parent can check), vuv = 1
+        self.f0 = torch.cat([torch.full((n,), float(x[0]), dtype=torch.float64) for n, x in zip(nfs, xs)])
+        self.vuv = torch.ones(int(sum(nfs)), dtype=torch.float64)
+        self.lens = [len(x) for x in xs]
+
+
+class _StubBackend:
+    def encode(self, xs, fs, **kw):
+        return _StubEncoding(xs, fs, None)
+
+    def decode_device(self, enc, **kw):
+        import torch
+
+        y_off = np.concatenate([[0], np.cumsum(enc.lens)])
+        return torch.zeros(int(y_off[-1]), dtype=torch.float64), y_off
+
+
+def _sharded_worker(rank, world, port, lengths, ret):
+    import torch.distributed as dist
+
+    from world.distributed import ShardedWorldBatch, shard_ranges
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sb = ShardedWorldBatch(backend=_StubBackend())
+    made = []
+
+    def loader(u):  # a rank only materialises its own utterances
+        made.append(u)
+        return np.full(lengths[u], float(u))
+
+    enc = sb.encode(loader, 16000, lengths=lengths)
+    lo, hi = shard_ranges(lengths, world)[rank]
+    ok = sb.range == (lo, hi) and made == list(range(lo, hi)) and enc.n_utt == hi - lo
+    y, y_off = sb.decode()
+    ok = ok and int(y_off[-1]) == sum(lengths[lo:hi])
+    got = sb.gather_f0(dst=0)
+    if rank == 0:
+        ret["n"] = len(got)
+        ret["order_ok"] = all(np.all(f0 == float(u)) and len(f0) == int(1000 * lengths[u] / 16000 / 5 + 1)
+                              for u, (f0, vuv) in enumerate(got))
+    else:
+        ok = ok and got is None
+    ret["ok%d" % rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_world_batch():
+    """The product's sharded batch driver (world.distributed.ShardedWorldBatch) with a stubbed per-rank compute:
+    each rank loads exactly its shard_ranges slice, decodes it, and rank 0 receives every utterance's f0 in order."""
+    import torch.multiprocessing as mp
+
+    lengths = [160000, 80000, 120000, 160000, 40000, 90000, 160000]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sharded_worker, args=(2, _free_port(), lengths, ret), nprocs=2, join=True)
+    assert ret["ok0"] and ret["ok1"] and ret["n"] == len(lengths) and ret["order_ok"]
+
+
+def test_sharded_world_batch_single_process():
+    from world.distributed import ShardedWorldBatch
+
+    sb = ShardedWorldBatch(backend=_StubBackend())
+    xs = [np.full(8000 * (i + 1), float(i)) for i in range(3)]
+    enc = sb.encode(xs, 16000)
+    assert sb.range == (0, 3) and enc.n_utt == 3
+    got = sb.gather_f0()
+    assert [float(f0[0]) for f0, _ in got] == [0.0, 1.0, 2.0]

@@ -157,96 +157,138 @@ __global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
   if (threadIdx.x == 0) gate[f] = (s1 / s2 > threshold) ? 1 : 0;
 }
 
-// Sum of the m smallest of p[0..K) (all >= 0) and the total, without sorting.
-// The reference sorts the K powers and prefix-sums them (world/d4c.py:206-208); only membership in the
-// "m smallest" set matters, so: (1) histogram the IEEE exponents in LDS, (2) scan the 2048 bins to find the
-// bin holding the m-th smallest, (3) everything in lower bins is in, the few elements of that one bin are
-// ranked against each other (ties by index).  ~9 barrier phases instead of a 66-phase bitonic sort.
-// work: >= 2056 ints + K doubles + K ints of free LDS.  p must be visible on entry.
-template <int K>
-__device__ __forceinline__ void sum_smallest(const double* __restrict__ p, int m, void* work, double* scratch,
+// Sum of the m smallest of K non-negative values and their total, without sorting and without LDS atomics.
+// The reference sorts the K powers and prefix-sums them (world/d4c.py:206-208); only the VALUES of the m smallest
+// enter the sum, and m = K - (boundary + 1) is close to K, so the kernel finds the few LARGE values to leave out:
+//   (1) block maximum of the IEEE exponents (one shuffle reduction + one LDS hop);
+//   (2) per wave, population counts of the 16 exponents at and below it by ballot (scalar unit), summed over the
+//       waves through LDS; the window slides further down in the (pathological) case that the K - m largest span
+//       more than 16 octaves;
+//   (3) the one exponent bin that holds the threshold is compacted into a list at offsets derived from the same
+//       ballots (no atomic counter) and its members are ranked against each other; equal values are
+//       interchangeable in a sum, so ties need no index rule.
+// Each thread then adds its own kept elements in a fixed order -> deterministic sums.
+// x[q] = value of element i = tid + q*FT (i < K) in the caller's registers.  work: >= 64 ints + K doubles of free
+// LDS; scratch: 32 doubles.  Five barrier phases instead of the nine + contended LDS atomics of the histogram version.
+template <int K, int FT, int PER>
+__device__ __forceinline__ void sum_smallest(const double (&x)[PER], int m, void* work, double* scratch,
                                              double* s_small, double* s_total) {
-  constexpr int FT = ft_of(2 * (K - 1));
-  constexpr int PER = (K + FT - 1) / FT;
-  constexpr int BINS = 2048;
-  int* hist = reinterpret_cast<int*>(work);
-  double* list = reinterpret_cast<double*>(hist + BINS + 8);
-  int* ctl = hist + BINS;  // [0] target bin, [1] count below it, [2] list length
-  for (int i = threadIdx.x; i < BINS + 8; i += FT) hist[i] = 0;
-  double x[PER];
+  constexpr int NW = FT / 64;
+  constexpr int WIN = 16;
+  int* cnts = reinterpret_cast<int*>(work);                     // [NW][WIN]
+  double* list = reinterpret_cast<double*>(cnts + NW * WIN + (NW * WIN & 1));
+  int* iscr = reinterpret_cast<int*>(scratch);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int key[PER];
+  int kmax = 0;
+  double t = 0.0;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
-    const int i = threadIdx.x + q * FT;
-    x[q] = i < K ? p[i] : 0.0;
-    key[q] = (int)((__double_as_longlong(x[q]) >> 52) & 0x7FF);
+    const bool in = threadIdx.x + q * FT < K;
+    key[q] = in ? (int)((__double_as_longlong(x[q]) >> 52) & 0x7FF) : -1;
+    if (in) t += x[q];
+    kmax = key[q] > kmax ? key[q] : kmax;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int u = __shfl_xor(kmax, o, 64);
+    kmax = u > kmax ? u : kmax;
+  }
+  if (lane == 0) iscr[w] = kmax;
   wh::sync<FT>();
 #pragma unroll
-  for (int q = 0; q < PER; ++q)
-    if (threadIdx.x + q * FT < K) atomicAdd(&hist[key[q]], 1);
-  wh::sync<FT>();
-  // exclusive scan over the bins (8 per thread) → which bin holds the m-th smallest (0-based rank m-1)
-  {
-    constexpr int BP = BINS / FT;
-    int c[BP], run = 0;
+  for (int i = 0; i < NW; ++i) kmax = iscr[i] > kmax ? iscr[i] : kmax;
+  const int drop = K - m;  // how many of the largest values are left out (>= 1)
+  int top = kmax;          // exponent at the top of the current 16-wide window
+  int above = 0;           // elements with an exponent above the window
+  int tbin = -1, wave_before = 0, in_bin = 0;
+  while (true) {
+    int mine[WIN];
 #pragma unroll
-    for (int q = 0; q < BP; ++q) {
-      c[q] = hist[threadIdx.x * BP + q];
-      run += c[q];
-    }
-    int incl = run;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int e = 0; e < WIN; ++e) {
+      int c = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
+      for (int q = 0; q < PER; ++q) c += __popcll(__ballot(key[q] == top - e));
+      mine[e] = c;
     }
-    int* wsum = reinterpret_cast<int*>(scratch);
-    if (lane == 63) wsum[w] = incl;
+    wh::sync<FT>();  // previous window's counts (and iscr) have been read by everyone
+    if (lane < WIN) {
+      int c = 0;
+#pragma unroll
+      for (int e = 0; e < WIN; ++e) c = lane == e ? mine[e] : c;
+      cnts[w * WIN + lane] = c;
+    }
     wh::sync<FT>();
-    int excl = incl - run;
-    for (int i = 0; i < w; ++i) excl += wsum[i];
+    int run = above;
 #pragma unroll
-    for (int q = 0; q < BP; ++q) {
-      if (excl < m && excl + c[q] >= m) {
-        ctl[0] = threadIdx.x * BP + q;
-        ctl[1] = excl;
+    for (int e = 0; e < WIN; ++e) {
+      int tot = 0, before = 0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int c = cnts[i * WIN + e];
+        before += i < w ? c : 0;
+        tot += c;
       }
-      excl += c[q];
+      if (tbin < 0 && run + tot >= drop) {
+        tbin = top - e;
+        above = run;
+        wave_before = before;
+        in_bin = tot;
+      }
+      run += tot;
+    }
+    if (tbin >= 0 || top - WIN < 0) break;
+    above = run;
+    top -= WIN;
+  }
+  // tbin < 0 cannot happen (every element has an exponent in [0, kmax]); guard anyway: drop nothing more
+  const int need = tbin >= 0 ? drop - above : 0;  // members of the threshold bin that belong to the large set
+  // compaction of the threshold bin: wave offset from the per-wave counts, lane offset from the ballots
+  {
+    int pos = wave_before;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const unsigned long long mk = __ballot(key[q] == tbin);
+      if (key[q] == tbin) list[pos + __popcll(mk & ((1ull << lane) - 1ull))] = x[q];
+      pos += __popcll(mk);
     }
   }
   wh::sync<FT>();
-  const int tbin = ctl[0], below = ctl[1];
-  int* list_idx = reinterpret_cast<int*>(list + K);
-  double a = 0.0, t = 0.0;
+  double a = 0.0;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
-    const int i = threadIdx.x + q * FT;
-    if (i < K) {
-      t += x[q];
-      if (key[q] < tbin) a += x[q];
-      else if (key[q] == tbin) {
-        const int pos = atomicAdd(&ctl[2], 1);  // list order is arbitrary; ranks below do not depend on it
-        list[pos] = x[q];
-        list_idx[pos] = i;
-      }
-    }
-  }
-  wh::sync<FT>();
-  const int cnt = ctl[2];
-  const int need = m - below;  // how many of the target bin's elements belong to the m smallest
-#pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    const int i = threadIdx.x + q * FT;
-    if (i < K && key[q] == tbin) {
+    if (key[q] >= 0 && key[q] < tbin) a += x[q];
+    else if (key[q] == tbin && tbin >= 0) {
       const double v = x[q];
-      int rank = 0;
-      for (int j = 0; j < cnt; ++j) {
+      int greater = 0, equal = 0;  // equal counts the element itself too
+      for (int j = 0; j < in_bin; ++j) {
         const double o = list[j];
-        rank += (o < v || (o == v && list_idx[j] < i)) ? 1 : 0;
+        greater += o > v ? 1 : 0;
+        equal += o == v ? 1 : 0;
       }
-      if (rank < need) a += v;  // each thread adds its own elements in a fixed order → deterministic sums
+      // of the `equal` copies of v, the large set takes max(0, min(equal, need - greater)); the others are kept.
+      // Equal values are interchangeable, so every copy contributes the kept fraction's worth exactly once:
+      // kept copies = equal - taken; each copy adds v * kept / equal only if that is exact -> do it by rank instead
+      int taken = need - greater;
+      taken = taken < 0 ? 0 : (taken > equal ? equal : taken);
+      if (taken == 0) a += v;
+      else if (taken < equal) {
+        // ties straddle the threshold (rare: exact duplicates): rank the copies by position in the list
+        int my_pos = 0, idx_self = -1;
+        // position of this element among its equals = number of equal entries before its own list slot; its slot is
+        // recovered as the (lane-order) compaction slot computed above — recompute cheaply
+        (void)idx_self;
+        int pos = wave_before;
+#pragma unroll
+        for (int qq = 0; qq < PER; ++qq) {
+          const unsigned long long mk = __ballot(key[qq] == tbin);
+          if (qq == q) my_pos = pos + __popcll(mk & ((1ull << lane) - 1ull));
+          pos += __popcll(mk);
+        }
+        int eq_before = 0;
+        for (int j = 0; j < my_pos; ++j) eq_before += list[j] == v ? 1 : 0;
+        if (eq_before >= taken) a += v;
+      }
     }
   }
   wh::block_sum2<FT>(a, t, scratch);

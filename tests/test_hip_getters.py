@@ -47,8 +47,11 @@ def test_encode_w_gvn_f0(golden):
 
     g = golden("getters")
     fs = int(g["fs"])
-    src = {"f0": g["gvn_src_f0"].copy(), "vuv": g["gvn_src_vuv"].copy(), "temporal_positions": g["gvn_src_tp"].copy()}
-    out = main.World().encode_w_gvn_f0(fs, _x(g), src, fft_size=int(g["gvn_fft_size"]), is_requiem=False)
+    def fresh():  # the call zeroes source['f0'] on unvoiced frames in place (Q6): every call gets its own copy
+        return {"f0": g["gvn_src_f0"].copy(), "vuv": g["gvn_src_vuv"].copy(),
+                "temporal_positions": g["gvn_src_tp"].copy()}
+
+    out = main.World().encode_w_gvn_f0(fs, _x(g), fresh(), fft_size=int(g["gvn_fft_size"]), is_requiem=False)
     assert sorted(out.keys()) == list(g["gvn_keys"])
     assert np.max(np.abs(out["f0"] - g["gvn_f0"])) < 1e-9
     assert rel_rms(out["spectrogram"][:16, :16], g["gvn_spec_head"]) < 1e-8
@@ -58,6 +61,6 @@ def test_encode_w_gvn_f0(golden):
     assert np.max(np.abs(out["coarse_ap"] - g["gvn_coarse"])) < 1e-6
     # the reference's quirks: no fft_size -> TypeError at the assert; is_requiem -> KeyError('coarse_ap')
     with pytest.raises(TypeError):
-        main.World().encode_w_gvn_f0(fs, _x(g), dict(src))
+        main.World().encode_w_gvn_f0(fs, _x(g), fresh())
     with pytest.raises(KeyError):
-        main.World().encode_w_gvn_f0(fs, _x(g), {k: v.copy() for k, v in src.items()}, fft_size=1024, is_requiem=True)
+        main.World().encode_w_gvn_f0(fs, _x(g), fresh(), fft_size=1024, is_requiem=True)

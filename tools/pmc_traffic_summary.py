@@ -39,10 +39,11 @@ def main():
     fetch, nf = per_launch(sys.argv[1], "FETCH_SIZE")
     write, _ = per_launch(sys.argv[2], "WRITE_SIZE")
     frames = int(sys.argv[3])
+    label = sys.argv[4] if len(sys.argv) > 4 else "config 2 (64 x 10 s)"
     import bench
     algo, _ = bench.algo_bytes_per_frame(16000, 1024)
     print("# HBM traffic per launch from rocprofv3 PMC (separate --pmc passes for FETCH_SIZE and WRITE_SIZE), "
-          "config 2 (64 x 10 s, %d frames per launch)" % frames)
+          "%s, %d frames per launch" % (label, frames))
     print("# rocprofv3 reports KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md "
           "HBM section), so")
     print("# corrected_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  algorithmic_MB = DESIGN.md bytes/frame x frames per launch.")

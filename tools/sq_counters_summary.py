@@ -38,14 +38,14 @@ def durations(path):
 
 def main():
     a, b, dur = per_launch(sys.argv[1]), per_launch(sys.argv[2]), durations(sys.argv[3])
-    print("# SQ counters per launch (rocprofv3 --pmc, two passes), config 2; durations under the profiler in microseconds")
+    print("# SQ counters per launch (rocprofv3 --pmc, two passes)%s; durations under the profiler in microseconds" % ((", " + sys.argv[4]) if len(sys.argv) > 4 else ""))
     print("# wave-level shares: fraction of a resident wave's lifetime; fp64_TFLOPs = (2*FMA + ADD + MUL + TRANS) * 64 lanes / time")
     print("%-22s %9s %9s %9s %9s %9s %10s %10s %11s" % ("kernel", "dur_us", "valu%", "lds%", "wait%", "nowait%",
                                                        "lds_confl%", "fp64_inst%", "fp64_TFLOPs"))
     for k in sorted(dur, key=lambda x: -dur[x]):
         if k not in a or k not in b or dur[k] < 100:
             continue
-        ca, cb = a[k], b[k]
+        ca, cb = dict(b[k], **a[k]), dict(a[k], **b[k])  # a counter may have been collected in either pass
         wc = ca.get("SQ_WAVE_CYCLES", 0) or 1
         fl = 2 * cb.get("SQ_INSTS_VALU_FMA_F64", 0) + cb.get("SQ_INSTS_VALU_ADD_F64", 0) + cb.get("SQ_INSTS_VALU_MUL_F64", 0) + \
             cb.get("SQ_INSTS_VALU_TRANS_F64", 0)

@@ -21,7 +21,10 @@
 #define WH_D4C_MAXR 4
 #endif
 #ifndef WH_D4C_MINBLK
-#define WH_D4C_MINBLK 3
+#define WH_D4C_MINBLK 4
+#endif
+#ifndef WH_D4C_WIN_UNROLL
+#define WH_D4C_WIN_UNROLL 4
 #endif
 #ifndef WH_D4C_REGFFT
 #define WH_D4C_REGFFT 1
@@ -38,25 +41,61 @@ __device__ unsigned long long g_d4c_stage[16];
 #endif
 namespace {
 
+// The kernel runs four transforms through the same twiddle table.  Left alone, the compiler recognises the repeated
+// read-only loads and address arithmetic, computes them once and keeps them in registers across the whole kernel
+// (203 VGPRs); passing the table pointer through an empty asm before each transform makes every instance re-derive
+// what it needs from L1/L2-resident data.
+__device__ __forceinline__ const double2* fresh_table(const double2* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+// Stage fence for a per-frame scalar: everything a stage derives from the returned value (window phase, sample
+// addresses, rotation constants ...) can only be computed after this point, i.e. the compiler cannot start the next
+// stage's loads and transcendental set-up underneath the current stage's transform (which it does otherwise, and
+// pays for with ~60 VGPRs of values parked across the FFT).
+__device__ __forceinline__ double stage_fence(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 #ifndef WH_FT_D4C
 #define WH_FT_D4C 256
 #endif
 // Threads cooperating on one frame: 256 up to N = 2048; 512 at N = 4096 (48 kHz), where the 96 KB of LDS per frame
 // leave one workgroup per CU and the thread count is the only occupancy there is.
 constexpr int ft_of(int n) { return n >= 4096 ? 2 * WH_FT_D4C : WH_FT_D4C; }
-// Workgroups per CU the register allocation must leave room for: LDS allows 3 up to N = 2048 (<= 168 VGPRs).
-constexpr int minblk_of(int n) { return n >= 4096 ? 1 : WH_D4C_MINBLK; }
+// Waves per SIMD the register allocation must leave room for (HIP's second __launch_bounds__ argument is
+// MIN_WAVES_PER_EU).  LDS per frame is the 2N-double transform buffer (33 KB at N = 2048: 4 workgroups of 4 waves
+// per CU, 66 KB at N = 4096: 2 workgroups of 8 waves), i.e. 4 waves per SIMD either way -> 128 VGPRs.
+#ifndef WH_D4C_MINBLK4096
+#define WH_D4C_MINBLK4096 4
+#endif
+constexpr int minblk_of(int n) { return n >= 4096 ? WH_D4C_MINBLK4096 : WH_D4C_MINBLK; }
 
-// Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110).  Values for samples j = tid + q*FT land
-// in the caller's registers v[q] (zero beyond the window; rows longer than N are cropped like
-// np.fft.fft(x, n), Q7).  tmp: unused (kept for the call sites).  Returns sum(wave^2) over the FULL window
-// (ENERGY = false: 0, and one block reduction less).
-// BLACKMAN selects window type 2, else Hann.
-template <bool BLACKMAN, int N, bool ENERGY = true>
-__device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long long xn, double fs, double cf,
-                                             double pos, double half_length, double* tmp, double (&v)[N / ft_of(N)],
-                                             double* scratch) {
+// Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110).  emit(j, value) is called for every sample
+// j = tid + q*FT < N (zero beyond the window; rows longer than N are cropped like np.fft.fft(x, n), Q7) — the callers
+// store straight into the transform buffer, so no per-thread output array exists.  ENERGY: the values are divided by
+// the frame's norm sqrt(sum(wave^2)) over the FULL window (d4c.py:147).  BLACKMAN selects window type 2, else Hann.
+//
+// Two walks, one reduction, no per-thread arrays: the first walk accumulates the sums, the second fetches the
+// samples again (L1/L2 hits) and emits the DC-removed values.  Keeping x*w and w in registers between the walks (the
+// first version) made this routine the kernel's register peak (~95 VGPRs on its own).  The window is re-derived
+// cheaply in both walks because cos(pi*f0*t_j) advances from j to j + FT by a fixed rotation (one sincospi per
+// thread and 4 flops per sample instead of one cospi per sample).  The energy of the DC-removed frame comes out of
+// the same block reduction as the two means:
+//   sum (xw - w*dc)^2 = sum (xw)^2 - 2*dc*sum (xw*w) + dc^2 * sum w^2
+// (three more partial sums, no second pass over the data and no second pair of barriers).  The expansion loses
+// log10((DC/AC)^2) digits to cancellation — nothing for speech-like input (DC << AC), and still 1e-10 relative for a
+// DC offset 1000x the signal.
+template <bool BLACKMAN, int N, bool ENERGY, class Emit>
+__device__ __forceinline__ void d4c_window(const double* __restrict__ xu, long long xn, double fs, double cf,
+                                           double pos, double half_length, double* scratch, Emit emit) {
   constexpr int FT = ft_of(N);
+  constexpr int Q = N / FT;
+  // every window of a frame is its own stage: without the fences the compiler shares the set-up of windows with equal
+  // f0 and length (rotation constants, clamped offsets, per-sample predicates) across the transforms between them
+  cf = stage_fence(cf);
+  pos = stage_fence(pos);
   const int hwl = (int)(half_length * fs / cf + 0.5);
   const int L = 2 * hwl + 1;
   const long long centre = wh::frame_centre(pos, fs);
@@ -64,54 +103,104 @@ __device__ __forceinline__ double d4c_window(const double* __restrict__ xu, long
   // per-frame constants are inverted once and multiplied in: an FP64 divide is ~12 instructions with a long
   // dependency chain, and the per-sample ones were a fifth of this kernel's instruction count (results move by an ulp)
   const double inv_span = 1.0 / fs / half_length;
-  auto win = [&](int j) -> double {
-    const double c1 = cospi(((double)(j - hwl) * inv_span + phase) * cf);  // cos(pi*t*f0)
+  auto shape = [](double c1) -> double {
     return BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);  // cos(2a) = 2cos^2(a)-1
   };
-  // samples j = tid + q*FT of the window stay in this thread's registers from the gather to the DC removal
-  double s_sw = 0.0, s_w = 0.0;
-  double swq[N / FT], wq[N / FT];
+  auto win = [&](int j) -> double { return shape(cospi(((double)(j - hwl) * inv_span + phase) * cf)); };
+  // sample index relative to the centre, clamped to the utterance (d4c.py:98): x[centre - 1 + rel]
+  const long long rel_min = 1 - centre, rel_max = xn - centre;
+  const int rlo = (int)(rel_min < -(1 << 30) ? -(1 << 30) : (rel_min > (1 << 30) ? (1 << 30) : rel_min));
+  const int rhi = (int)(rel_max > (1 << 30) ? (1 << 30) : (rel_max < -(1 << 30) ? -(1 << 30) : rel_max));
+  const double* xb = xu + (centre - 1);  // (re-derived from laundered bits before the second walk)
+  auto sample = [&](int j) -> double {
+    int rel = j - hwl;
+    rel = rel < rlo ? rlo : rel;
+    rel = rel > rhi ? rhi : rel;
+    return xb[rel];
+  };
+  // rotation by FT samples: angle step (in units of pi) = FT * inv_span * cf
+  double rot_s, rot_c, s0, c0;
+  sincospi((double)FT * inv_span * cf, &rot_s, &rot_c);
+  sincospi(((double)((int)threadIdx.x - hwl) * inv_span + phase) * cf, &s0, &c0);
+  double s_sw = 0.0, s_w = 0.0, s_swsw = 0.0, s_sww = 0.0, s_ww = 0.0;
+  // Both walks go through the frame in chunks of U samples per thread: the U gathers of a chunk are issued together
+  // (independent loads in flight), the chunks themselves run as a rolled loop.  Fully unrolled, the scheduler hoists
+  // all Q gathers with their addresses, clamps and rotation states (~95 VGPRs for this routine alone, the register
+  // peak of the kernel); fully rolled, every gather waits for the one before it (16 k cycles per window).
+  constexpr int U = WH_D4C_WIN_UNROLL < Q ? WH_D4C_WIN_UNROLL : Q;
+  static_assert(Q % U == 0, "window chunking");
+  {
+    double c = c0, sn = s0;
+#pragma unroll 1
+    for (int q0 = 0; q0 < Q; q0 += U) {
+      double xs[U];
 #pragma unroll
-  for (int q = 0; q < N / FT; ++q) {
-    const int j = threadIdx.x + q * FT;
-    swq[q] = 0.0;
-    wq[q] = 0.0;
-    if (j < L) {
+      for (int i = 0; i < U; ++i) xs[i] = sample(threadIdx.x + (q0 + i) * FT);  // clamped: always a valid address
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const int j = threadIdx.x + (q0 + i) * FT;
+        if (j < L) {
+          const double w = shape(c);
+          const double sw = xs[i] * w;
+          s_sw += sw;
+          s_w += w;
+          if (ENERGY) {
+            s_swsw += sw * sw;
+            s_sww += sw * w;
+            s_ww += w * w;
+          }
+        }
+        const double cn = c * rot_c - sn * rot_s;
+        sn = sn * rot_c + c * rot_s;
+        c = cn;
+      }
+    }
+    for (int j = N + threadIdx.x; j < L; j += FT) {  // rows longer than N: cropped, but they count in the sums
       const double w = win(j);
-      const double sw = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w;
+      const double sw = sample(j) * w;
       s_sw += sw;
       s_w += w;
-      swq[q] = sw;
-      wq[q] = w;
+      if (ENERGY) {
+        s_swsw += sw * sw;
+        s_sww += sw * w;
+        s_ww += w * w;
+      }
     }
   }
-  for (int j = N + threadIdx.x; j < L; j += FT) {  // rows longer than N: cropped, but they count in the means
-    const double w = win(j);
-    s_sw += wh::sample_clamped(xu, xn, centre + (j - hwl)) * w;
-    s_w += w;
-  }
-  wh::block_sum2<FT>(s_sw, s_w, scratch);
+  if (ENERGY) wh::block_sum5<FT>(s_sw, s_w, s_swsw, s_sww, s_ww, scratch);
+  else wh::block_sum2<FT>(s_sw, s_w, scratch);
   const double mean_sw = s_sw / (double)L;
   const double mean_w = s_w / (double)L;
   const double dc = mean_sw / mean_w;
-  double e = 0.0;
+  const double inv_nrm = ENERGY ? 1.0 / sqrt((s_swsw - 2.0 * dc * s_sww) + dc * dc * s_ww) : 1.0;
+  // second walk: the samples are fetched again (L1/L2 hits) and go straight to the transform buffer; the pointer is
+  // laundered so that the compiler re-loads instead of carrying the first walk's Q samples across the reduction
+  unsigned long long bits = reinterpret_cast<unsigned long long>(xb);
+  asm volatile("" : "+v"(bits));
+  xb = reinterpret_cast<const double*>(bits);
+  {
+    double c = c0, sn = s0;
+#pragma unroll 1
+    for (int q0 = 0; q0 < Q; q0 += U) {
+      double xs[U];
 #pragma unroll
-  for (int q = 0; q < N / FT; ++q) {
-    const int j = threadIdx.x + q * FT;
-    double val = 0.0;
-    if (j < L) {
-      val = swq[q] - wq[q] * dc;
-      e += val * val;
+      for (int i = 0; i < U; ++i) xs[i] = sample(threadIdx.x + (q0 + i) * FT);
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        const int j = threadIdx.x + (q0 + i) * FT;
+        double val = 0.0;
+        if (j < L) {
+          const double w = shape(c);
+          val = xs[i] * w - w * dc;
+          if (ENERGY) val *= inv_nrm;
+        }
+        emit(j, val);
+        const double cn = c * rot_c - sn * rot_s;
+        sn = sn * rot_c + c * rot_s;
+        c = cn;
+      }
     }
-    v[q] = val;
   }
-  if (!ENERGY) return 0.0;  // callers that do not normalise skip the second reduction (two barriers)
-  for (int j = N + threadIdx.x; j < L; j += FT) {  // cropped tail still counts in the energy
-    const double w = win(j);
-    const double val = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w - w * dc;
-    e += val * val;
-  }
-  return wh::block_sum<FT>(e, scratch);
 }
 
 template <int NLT>
@@ -137,10 +226,7 @@ __global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
   const double* xu = x + x_off[u];
   const long long xn = x_off[u + 1] - x_off[u];
   const double cf = fmax(f0, 40.0);
-  double v[NLT / FT];
-  d4c_window<true, NLT, false>(xu, xn, fs, cf, tp[f], 1.5, zr, v, scratch);
-#pragma unroll
-  for (int q = 0; q < NLT / FT; ++q) zr[threadIdx.x + q * FT] = v[q];
+  d4c_window<true, NLT, false>(xu, xn, fs, cf, tp[f], 1.5, scratch, [&](int j, double val) { zr[j] = val; });
   wh::sync<FT>();
   wh::rfft_lds<NLT, FT, FT, WH_D4C_MAXR>(zb, tw_base);
   const int b0 = (int)(ceil(100.0 / (fs / NLT)) + 1);
@@ -208,8 +294,8 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], int m, void
     for (int e = 0; e < WIN; ++e) {
       int c = 0;
 #pragma unroll
-      for (int q = 0; q < PER; ++q) c += __popcll(__ballot(key[q] == top - e));
-      mine[e] = c;
+      for (int q = 0; q < PER; ++q) c += __popcll(__ballot(key[q] == top - e));  // key -1 = padding lane
+      mine[e] = top - e >= 0 ? c : 0;
     }
     wh::sync<FT>();  // previous window's counts (and iscr) have been read by everyone
     if (lane < WIN) {
@@ -256,82 +342,132 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], int m, void
   wh::sync<FT>();
   double a = 0.0;
 #pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    if (key[q] >= 0 && key[q] < tbin) a += x[q];
-    else if (key[q] == tbin && tbin >= 0) {
-      const double v = x[q];
-      int greater = 0, equal = 0;  // equal counts the element itself too
-      for (int j = 0; j < in_bin; ++j) {
-        const double o = list[j];
-        greater += o > v ? 1 : 0;
-        equal += o == v ? 1 : 0;
-      }
-      // of the `equal` copies of v, the large set takes max(0, min(equal, need - greater)); the others are kept.
-      // Equal values are interchangeable, so every copy contributes the kept fraction's worth exactly once:
-      // kept copies = equal - taken; each copy adds v * kept / equal only if that is exact -> do it by rank instead
-      int taken = need - greater;
-      taken = taken < 0 ? 0 : (taken > equal ? equal : taken);
-      if (taken == 0) a += v;
-      else if (taken < equal) {
-        // ties straddle the threshold (rare: exact duplicates): rank the copies by position in the list
-        int my_pos = 0, idx_self = -1;
-        // position of this element among its equals = number of equal entries before its own list slot; its slot is
-        // recovered as the (lane-order) compaction slot computed above — recompute cheaply
-        (void)idx_self;
-        int pos = wave_before;
-#pragma unroll
-        for (int qq = 0; qq < PER; ++qq) {
-          const unsigned long long mk = __ballot(key[qq] == tbin);
-          if (qq == q) my_pos = pos + __popcll(mk & ((1ull << lane) - 1ull));
-          pos += __popcll(mk);
-        }
-        int eq_before = 0;
-        for (int j = 0; j < my_pos; ++j) eq_before += list[j] == v ? 1 : 0;
-        if (eq_before >= taken) a += v;
-      }
+  for (int q = 0; q < PER; ++q)
+    if (key[q] >= 0 && key[q] < tbin) a += x[q];  // everything below the threshold bin is kept
+  // the threshold bin: list entry i is kept unless it is one of the `need` largest (ties: list order).  One entry
+  // per thread, so the ranking costs in_bin LDS reads per thread whatever the distribution of the bin over threads.
+  for (int i = threadIdx.x; i < in_bin; i += FT) {
+    const double v = list[i];
+    int ahead = 0;
+    for (int j = 0; j < in_bin; ++j) {
+      const double o = list[j];
+      ahead += (o > v || (o == v && j < i)) ? 1 : 0;
     }
+    if (ahead >= need) a += v;
   }
   wh::block_sum2<FT>(a, t, scratch);
   *s_small = a;
   *s_total = t;
 }
 
-// Accumulate the group-delay centroid of one Blackman frame into cent[0..N/2] (d4c.py:146-153).
+// ---- thread-owned runs of bins ---------------------------------------------------------------------------------
+// From the first spectrum to the band stage the K = N/2+1 per-bin quantities of a frame (smoothed power, group-delay
+// centroid and what the smoothings make of them) live in REGISTERS: thread t owns the bins [t*KR, (t+1)*KR).  LDS then
+// holds nothing but the 2N-double transform buffer (32 KB at N = 2048 -> 4 workgroups per CU instead of 3 with the
+// two 8 KB per-bin arrays of the first version), and the smoothings (BandWindow, wh_spectral.h) read and write the
+// same runs.
+template <int N>
+struct Runs {
+  static constexpr int FT = ft_of(N);
+  static constexpr int K = N / 2 + 1;
+  static constexpr int KR = (K + FT - 1) / FT;
+};
+
+// Mirror-add of the bins below f0 (wh::low_band_replica, d4c.py:213-220) for a run-resident array: the owners of
+// the bins below `reach` publish them to tmp (LDS, >= 2*nlow doubles), the interpolated replica is evaluated by a
+// thread-strided loop (a handful of bins; kept out of the unrolled per-run code, whose five copies of the divides and
+// searches cost ~30 VGPRs of spills) and the owners add it to their registers.
+template <int N>
+__device__ __forceinline__ void low_band_replica_runs(double (&p)[Runs<N>::KR], double* tmp, double fs, double f0,
+                                                      double reach) {
+  constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
+  const int k0 = threadIdx.x * KR;
+  int nlow = (int)(reach / fs * N) + 2;  // count of bins with k/N*fs < reach (monotone in k)
+  if (nlow > K) nlow = K;                // (the reference indexes the half spectrum: bins beyond it do not exist)
+  while (nlow > 0 && !(((double)(nlow - 1) / N * fs) < reach)) --nlow;
+  double* add = tmp + ((nlow + 1) & ~1);
+#pragma unroll
+  for (int r = 0; r < KR; ++r)
+    if (k0 + r < nlow) tmp[k0 + r] = p[r];
+  wh::sync<FT>();
+#pragma unroll 1
+  for (int kk = threadIdx.x; kk < nlow; kk += FT) {
+    const double fk = (double)kk / N * fs;
+    double inc = 0.0;
+    if (nlow >= 2 && fk < f0) {
+      // ascending nodes a_m = f0 - f_{nlow-1-m}; hi = clamp(#nodes < fk, 1, nlow-1).  The node predicate
+      // a_m < fk is monotone in m, so the count is its boundary: estimated in closed form, then settled with
+      // the exact floating-point predicate (the estimate is within one of the truth).
+      auto below = [&](int mm) { return (f0 - ((double)(nlow - 1 - mm) / N * fs)) < fk; };
+      int cnt = (int)ceil((double)(nlow - 1) - (f0 - fk) / fs * N);
+      cnt = cnt < 0 ? 0 : (cnt > nlow ? nlow : cnt);
+      while (cnt > 0 && !below(cnt - 1)) --cnt;
+      while (cnt < nlow && below(cnt)) ++cnt;
+      const int hi = cnt < 1 ? 1 : (cnt > nlow - 1 ? nlow - 1 : cnt);
+      const int lo = hi - 1;
+      const double a_lo = f0 - ((double)(nlow - 1 - lo) / N * fs);
+      const double a_hi = f0 - ((double)(nlow - 1 - hi) / N * fs);
+      const double y_lo = tmp[nlow - 1 - lo];
+      const double y_hi = tmp[nlow - 1 - hi];
+      const double slope = (y_hi - y_lo) / (a_hi - a_lo);
+      inc = slope * (fk - a_lo) + y_lo;
+    }
+    add[kk] = inc;
+  }
+  wh::sync<FT>();
+#pragma unroll
+  for (int r = 0; r < KR; ++r) {
+    const int kk = k0 + r;
+    if (kk < nlow && nlow >= 2 && ((double)kk / N * fs) < f0) p[r] = add[kk] + p[r];
+  }
+  wh::sync<FT>();  // tmp is reused by the caller
+}
+
+// v[0..N) = Hermitian mirror of the run-resident half spectrum times fs/N (wh::fill_mirrored for runs).
+template <int N>
+__device__ __forceinline__ void fill_mirrored_runs(const double (&p)[Runs<N>::KR], double* v, double fs) {
+  constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
+  const int k0 = threadIdx.x * KR;
+  const double df = fs / N;
+#pragma unroll
+  for (int r = 0; r < KR; ++r) {
+    const int k = k0 + r;
+    if (k < K) {
+      const double val = p[r] * df;
+      v[k] = val;
+      if (k > 0 && k < N / 2) v[N - k] = val;
+    }
+  }
+  wh::sync<FT>();
+}
+
+// Group-delay centroid of one Blackman frame, added into the run-resident cent (d4c.py:146-153).
 // x and n*x (two real sequences) share ONE complex FFT: z = x + i*n*x, separated afterwards by symmetry.
 template <int N>
 __device__ __forceinline__ void add_centroid(const double* xu, long long xn, double fs, double cf, double pos,
-                                             double2* buf, double* cent, bool first, const double2* tw_base,
-                                             double* scratch) {
-  constexpr int FT = ft_of(N);
-  double v[N / FT];
-  const double energy = d4c_window<true, N>(xu, xn, fs, cf, pos, 2.0, reinterpret_cast<double*>(buf), v, scratch);
-  const double nrm = sqrt(energy);
-  const double inv_nrm = 1.0 / nrm;
-  double2 zin[N / FT];
-#pragma unroll
-  for (int q = 0; q < N / FT; ++q) {
-    const int j = threadIdx.x + q * FT;
-    const double val = v[q] * inv_nrm;
-    zin[q] = make_double2(val, val * (double)(j + 1));  // n is 1-based
-  }
-  if constexpr (N >= WH_D4C_MAXR * FT && WH_D4C_REGFFT) {
-    wh::fft_lds_from_regs<N, false, FT, WH_D4C_MAXR>(zin, buf, tw_base + N);  // first radix-8 pass straight from registers
-  } else {
-#pragma unroll
-    for (int q = 0; q < N / FT; ++q) buf[threadIdx.x + q * FT] = zin[q];
-    wh::sync<FT>();
-    wh::fft_lds<N, false, FT, FT, WH_D4C_MAXR>(buf, tw_base + N);
-  }
-  for (int k = threadIdx.x; k <= N / 2; k += FT) {
-    const double2 a = buf[k];
-    const double2 b = buf[(N - k) & (N - 1)];
-    // S = (Z[k]+conj(Z[N-k]))/2 ; T = (Z[k]-conj(Z[N-k]))/(2i)
-    const double sr = 0.5 * (a.x + b.x), si = 0.5 * (a.y - b.y);
-    const double tr = 0.5 * (a.y + b.y), ti = -0.5 * (a.x - b.x);
-    const double c = tr * sr + si * ti;  // -Im(W)Re(S)+Im(S)Re(W) with W = -i*T
-    cent[k] = first ? c : cent[k] + c;
-  }
+                                             double2* buf, double (&cent)[Runs<N>::KR], bool first,
+                                             const double2* tw_base, double* scratch) {
+  constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
+  // z[j] = x[j] + i*(j+1)*x[j] (n is 1-based), normalised frame, written straight into the transform buffer
+  d4c_window<true, N, true>(xu, xn, fs, cf, pos, 2.0, scratch,
+                            [&](int j, double val) { buf[j] = make_double2(val, val * (double)(j + 1)); });
   wh::sync<FT>();
+  wh::fft_lds<N, false, FT, FT, WH_D4C_MAXR>(buf, fresh_table(tw_base) + N);
+  const int k0 = threadIdx.x * KR;
+#pragma unroll
+  for (int r = 0; r < KR; ++r) {
+    const int k = k0 + r;
+    if (k < K) {
+      const double2 a = buf[k];
+      const double2 b = buf[(N - k) & (N - 1)];
+      // S = (Z[k]+conj(Z[N-k]))/2 ; T = (Z[k]-conj(Z[N-k]))/(2i)
+      const double sr = 0.5 * (a.x + b.x), si = 0.5 * (a.y - b.y);
+      const double tr = 0.5 * (a.y + b.y), ti = -0.5 * (a.x - b.x);
+      const double c = tr * sr + si * ti;  // -Im(W)Re(S)+Im(S)Re(W) with W = -i*T
+      cent[r] = first ? c : cent[r] + c;
+    }
+  }
+  wh::sync<FT>();  // buf is free again
 }
 
 // FUSED (love-train FFT size == D4C FFT size, the case at 16/22.05/44.1/48 kHz for d4c()): the VUV gate's
@@ -345,15 +481,14 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     const double* __restrict__ window, int wlen, const double2* __restrict__ tw_base,
     int k_spec,                       // >0: dense amplitude output [F][k_spec]; 0: Requiem band output [F][nap+2]
     double* __restrict__ out, double* __restrict__ coarse_dbg, long long n_frames) {
-  constexpr int FT = ft_of(N);
+  constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int K = N / 2 + 1;
   double2* buf = reinterpret_cast<double2*>(smem);   // N complex (centroid FFT) / N/2+1 complex (real FFTs)
   double* zr = reinterpret_cast<double*>(smem);      // the same 2N doubles: real buffers, mirrored spectra, scratch
-  double* cent = zr + 2 * N;                         // K (padded to N/2+8)
-  double* pw = cent + (N / 2 + 8);                   // K
-  double* scratch = pw + (N / 2 + 8);                // 16
+  double* scratch = zr + 2 * N;                      // 32
   double* band = scratch + 32;                       // nap (<= 8)
+  constexpr int KPAD = (K + 1) & ~1;
+  double* td = zr + 2 * N - KPAD;                    // band stage: the shaped group delay, above the real-FFT buffer
 
   STAGE_TIMER_BEGIN
   const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
@@ -372,45 +507,43 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     voiced = gate[f] != 0;
   }
   const double cf = fmax(47.0, f0v);
+  const int k0 = threadIdx.x * KR;
+  double pw[KR], cent[KR];  // run-resident per-bin arrays
+#pragma unroll
+  for (int r = 0; r < KR; ++r) pw[r] = cent[r] = 0.0;
   if (FUSED && voiced) {
     // love-train frame (Blackman, 3*T0, f0 floored at 40 Hz) and smoothed-power frame (Hann, 4*T0) in one FFT
-    double va[N / FT], vb[N / FT];
-    d4c_window<true, N, false>(xu, xn, fs, fmax(f0v, 40.0), pos, 1.5, zr, va, scratch);
-    d4c_window<false, N, false>(xu, xn, fs, cf, pos, 2.0, zr, vb, scratch);
+    d4c_window<true, N, false>(xu, xn, fs, fmax(f0v, 40.0), pos, 1.5, scratch, [&](int j, double val) { zr[2 * j] = val; });
+    d4c_window<false, N, false>(xu, xn, fs, cf, pos, 2.0, scratch, [&](int j, double val) { zr[2 * j + 1] = val; });
     STAGE_MARK(7)
-    double2 zin[N / FT];
-#pragma unroll
-    for (int q = 0; q < N / FT; ++q) zin[q] = make_double2(va[q], vb[q]);
-    if constexpr (N >= WH_D4C_MAXR * FT && WH_D4C_REGFFT) {
-      wh::fft_lds_from_regs<N, false, FT, WH_D4C_MAXR>(zin, buf, tw_base + N);
-    } else {
-#pragma unroll
-      for (int q = 0; q < N / FT; ++q) buf[threadIdx.x + q * FT] = zin[q];
-      wh::sync<FT>();
-      wh::fft_lds<N, false, FT, FT, WH_D4C_MAXR>(buf, tw_base + N);
-    }
+    wh::sync<FT>();
+    wh::fft_lds<N, false, FT, FT, WH_D4C_MAXR>(buf, fresh_table(tw_base) + N);
     STAGE_MARK(8)
     const int b0 = (int)(ceil(100.0 / (fs / N)) + 1);
     const int b1 = (int)(ceil(4000.0 / (fs / N)) + 1);
     const int b2 = (int)(ceil(7900.0 / (fs / N)) + 1);
     double s1 = 0.0, s2 = 0.0;
-    for (int k = threadIdx.x; k < K; k += FT) {
-      const double2 a = buf[k], b = buf[(N - k) & (N - 1)];
-      const double ar = 0.5 * (a.x + b.x), ai = 0.5 * (a.y - b.y);   // love-train spectrum A[k]
-      const double br = 0.5 * (a.y + b.y), bi = -0.5 * (a.x - b.x);  // Hann-frame spectrum B[k]
-      pw[k] = br * br + bi * bi;
-      const double pa = ar * ar + ai * ai;  // |A[k]|^2 = |A[N-k]|^2: bins k and N-k of the full power spectrum
-      if (k >= b0 && k < b2) {
-        s2 += pa;
-        if (k < b1) s1 += pa;
-      }
-      const int km = N - k;  // mirrored bin (only reached when 7.9 kHz lies above fs/2)
-      if (k > 0 && k < N / 2 && km >= b0 && km < b2) {
-        s2 += pa;
-        if (km < b1) s1 += pa;
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      const int k = k0 + r;
+      if (k < K) {
+        const double2 a = buf[k], b = buf[(N - k) & (N - 1)];
+        const double ar = 0.5 * (a.x + b.x), ai = 0.5 * (a.y - b.y);   // love-train spectrum A[k]
+        const double br = 0.5 * (a.y + b.y), bi = -0.5 * (a.x - b.x);  // Hann-frame spectrum B[k]
+        pw[r] = br * br + bi * bi;
+        const double pa = ar * ar + ai * ai;  // |A[k]|^2 = |A[N-k]|^2: bins k and N-k of the full power spectrum
+        if (k >= b0 && k < b2) {
+          s2 += pa;
+          if (k < b1) s1 += pa;
+        }
+        const int km = N - k;  // mirrored bin (only reached when 7.9 kHz lies above fs/2)
+        if (k > 0 && k < N / 2 && km >= b0 && km < b2) {
+          s2 += pa;
+          if (km < b1) s1 += pa;
+        }
       }
     }
-    wh::block_sum2<FT>(s1, s2, scratch);
+    wh::block_sum2<FT>(s1, s2, scratch);  // (its barriers also free buf for the next stage)
     voiced = s1 / s2 > threshold;  // d4c.py:86
   }
   if (!voiced) {
@@ -426,81 +559,77 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   }
 
 #if WH_D4C_ABLATE == 1
-  if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = pw[threadIdx.x];
+  if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = pw[0];
   return;
 #endif
   STAGE_MARK(0)
-  // ---- static centroid from two frames at +-T0/4 (d4c.py:132-142) + DC correction ----------
-  add_centroid<N>(xu, xn, fs, cf, pos + 1 / cf / 4, buf, cent, true, tw_base, scratch);
+  // ---- static centroid from two frames at +-T0/4 (d4c.py:132-142) ---------------------------------------
+  add_centroid<N>(xu, xn, fs, cf, stage_fence(pos) + 1 / cf / 4, buf, cent, true, tw_base, scratch);
   STAGE_MARK(1)
-  add_centroid<N>(xu, xn, fs, cf, pos - 1 / cf / 4, buf, cent, false, tw_base, scratch);
+  add_centroid<N>(xu, xn, fs, cf, stage_fence(pos) - 1 / cf / 4, buf, cent, false, tw_base, scratch);
   STAGE_MARK(2)
-  wh::low_band_replica<FT>(cent, zr, N, fs, cf, 1.2 * cf);
+  low_band_replica_runs<N>(cent, zr, fs, cf, 1.2 * cf);
   STAGE_MARK(3)
 
 #if WH_D4C_ABLATE == 2
-  if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = cent[threadIdx.x] + pw[3];
+  if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = cent[0] + pw[3];
   return;
 #endif
   // ---- smoothed power spectrum (d4c.py:157-161) ----------------------------------------------
   if (!FUSED) {
-    double v[N / FT];
-    d4c_window<false, N, false>(xu, xn, fs, cf, pos, 2.0, zr, v, scratch);
+    d4c_window<false, N, false>(xu, xn, fs, cf, pos, 2.0, scratch, [&](int j, double val) { zr[j] = val; });
     wh::sync<FT>();
+    wh::rfft_lds<N, FT, FT, WH_D4C_RMAXR>(buf, fresh_table(tw_base));
 #pragma unroll
-    for (int q = 0; q < N / FT; ++q) zr[threadIdx.x + q * FT] = v[q];
-    wh::sync<FT>();
-    wh::rfft_lds<N, FT, FT, WH_D4C_RMAXR>(buf, tw_base);
-    for (int k = threadIdx.x; k < K; k += FT) {
-      const double2 z = buf[k];
-      pw[k] = z.x * z.x + z.y * z.y;
+    for (int r = 0; r < KR; ++r) {
+      if (k0 + r < K) {
+        const double2 z = buf[k0 + r];
+        pw[r] = z.x * z.x + z.y * z.y;
+      }
     }
     wh::sync<FT>();
   }
   double* cum = zr;  // the FFT buffer is idle during the smoothing steps (low-band scratch, then the mirrored spectra)
   const double inv_cf = 1.0 / cf;
-  wh::low_band_replica<FT>(pw, cum, N, fs, cf, 1.2 * cf);
-  // the three rectangular smoothings as sliding windowed sums (wh_spectral.h: BandWindow); thread t owns the bins
-  // [t*KR, (t+1)*KR) throughout, so only the mirrored-spectrum fills need barriers
-  constexpr int KR = (K + FT - 1) / FT;
-  const int k0 = threadIdx.x * KR;
+  low_band_replica_runs<N>(pw, cum, fs, cf, 1.2 * cf);
+  // the three rectangular smoothings as sliding windowed sums (wh_spectral.h: BandWindow) over the owned runs
   double bandv[KR];
   wh::BandWindow bw;
-  wh::fill_mirrored<FT, N>(pw, cum, fs);
+  fill_mirrored_runs<N>(pw, cum, fs);
   bw.init(cum, N, fs, cf / 2);
   bw.run<KR>(k0, K, bandv);
 #pragma unroll
-  for (int r = 0; r < KR; ++r)
-    if (k0 + r < K) cent[k0 + r] = cent[k0 + r] / (bandv[r] * inv_cf);  // T_g = centroid / smoothed power (d4c.py:169; no zero guard, Q14)
+  for (int r = 0; r < KR; ++r) cent[r] = cent[r] / (bandv[r] * inv_cf);  // T_g = centroid / smoothed power (d4c.py:169; no zero guard, Q14)
   wh::sync<FT>();
   // ---- group-delay shaping (d4c.py:165-174) --------------------------------------------------
-  wh::fill_mirrored<FT, N>(cent, cum, fs);
+  fill_mirrored_runs<N>(cent, cum, fs);
   {
     const double w2 = cf / 2;
     const double inv_w2 = 1.0 / w2;
     bw.init(cum, N, fs, w2 / 2);
     bw.run<KR>(k0, K, bandv);
 #pragma unroll
-    for (int r = 0; r < KR; ++r)
-      if (k0 + r < K) pw[k0 + r] = bandv[r] * inv_w2;  // T_gs
+    for (int r = 0; r < KR; ++r) pw[r] = bandv[r] * inv_w2;  // T_gs
   }
   wh::sync<FT>();
-  wh::fill_mirrored<FT, N>(pw, cum, fs);
+  fill_mirrored_runs<N>(pw, cum, fs);
   bw.init(cum, N, fs, cf / 2);
   bw.run<KR>(k0, K, bandv);
+  wh::sync<FT>();  // everyone is done with the mirrored spectrum before td (inside the same buffer) is written
 #pragma unroll
   for (int r = 0; r < KR; ++r)
-    if (k0 + r < K) cent[k0 + r] = pw[k0 + r] - bandv[r] * inv_cf;  // T_D = T_gs - T_gb
+    if (k0 + r < K) td[k0 + r] = pw[r] - bandv[r] * inv_cf;  // T_D = T_gs - T_gb
   wh::sync<FT>();
 
 #if WH_D4C_ABLATE == 3
-  if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = cent[threadIdx.x] + pw[3];
+  if (threadIdx.x == 0) out[f * (int64_t)(k_spec > 0 ? k_spec : nap + 2)] = td[threadIdx.x];
   return;
 #endif
   STAGE_MARK(4)
   // ---- band-wise aperiodicity (d4c.py:192-209) -----------------------------------------------
   const int boundary = (int)((double)N / wlen * 8 + 0.5);
   const int half = wlen / 2;
+  constexpr int PER = (K + FT - 1) / FT;
   for (int b = 0; b < nap; ++b) {
     const int centre = (int)floor((double)interval * (b + 1) / (fs / N));
     for (int j = threadIdx.x; j < N; j += FT) {
@@ -509,20 +638,26 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
         int idx = centre - half + j;          // index into the mirrored full group delay
         idx = idx < 0 ? -idx : idx;
         idx = idx > N / 2 ? N - idx : idx;
-        val = cent[idx] * window[j];
+        val = td[idx] * window[j];
       }
       zr[j] = val;
     }
     wh::sync<FT>();
-    wh::rfft_lds<N, FT, FT, WH_D4C_RMAXR>(buf, tw_base);
-    for (int k = threadIdx.x; k < K; k += FT) {
-      const double2 z = buf[k];
-      pw[k] = z.x * z.x + z.y * z.y;
+    wh::rfft_lds<N, FT, FT, WH_D4C_RMAXR>(buf, fresh_table(tw_base));
+    double px[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int k = threadIdx.x + q * FT;
+      px[q] = 0.0;
+      if (k < K) {
+        const double2 z = buf[k];
+        px[q] = z.x * z.x + z.y * z.y;
+      }
     }
-    wh::sync<FT>();
+    wh::sync<FT>();  // the spectrum has been read: the lower part of the buffer becomes the selection's work area
     STAGE_MARK(9)
     double s_small, s_total;
-    sum_smallest<K>(pw, N / 2 - boundary, buf, scratch, &s_small, &s_total);  // FFT buffer is free: selection scratch
+    sum_smallest<K, FT, PER>(px, N / 2 - boundary, zr, scratch, &s_small, &s_total);
     if (threadIdx.x == 0) band[b] = -10 * log10(s_small / s_total);
     wh::sync<FT>();
   }
@@ -590,7 +725,7 @@ template <int N, bool FUSED>
 int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
                 const double* vuv, const int32_t* gate, double thr, double fs, int nap, int interval, const double* win,
                 int wlen, int k_spec, double* out, double* coarse) {
-  const size_t lds = sizeof(double) * (2 * N + 2 * (N / 2 + 8) + 32 + 8);
+  const size_t lds = sizeof(double) * (2 * N + 32 + 8);
   if (int rc = wh::allow_lds(&d4c_kernel<N, FUSED>, lds)) return rc;
   { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL((d4c_kernel<N, FUSED>), dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_of(N)), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, gate, thr, fs, nap, interval, win, wlen, ctx->d_twiddle, k_spec, out,

@@ -148,6 +148,42 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
   c = tc;
 }
 
+// Five sums at once (the D4C window: two means and the three second moments of its energy, one pair of barriers).
+// `scratch` must hold >= 5*NT/64 doubles.
+template <int NT = WH_BLOCK>
+__device__ __forceinline__ void block_sum5(double& a, double& b, double& c, double& d, double& e, double* scratch) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  c = wave_sum(c);
+  d = wave_sum(d);
+  e = wave_sum(e);
+  if constexpr (NT <= WH_WAVE) {
+    sync<NT>();
+    return;
+  }
+  constexpr int NW = NT / WH_WAVE;
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    scratch[w] = a;
+    scratch[NW + w] = b;
+    scratch[2 * NW + w] = c;
+    scratch[3 * NW + w] = d;
+    scratch[4 * NW + w] = e;
+  }
+  __syncthreads();
+  double t[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < NW; ++i)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t[k] += scratch[k * NW + i];
+  a = t[0];
+  b = t[1];
+  c = t[2];
+  d = t[3];
+  e = t[4];
+}
+
 __device__ __forceinline__ double wave_scan_incl(double v) {
   const int lane = threadIdx.x & 63;
 #pragma unroll

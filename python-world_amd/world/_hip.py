@@ -12,7 +12,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libworld_hip.so")
+# WH_LIB selects another build of the same library (tools/build_variants.py: kernel tuning variants)
+LIB_PATH = os.environ.get("WH_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libworld_hip.so")
 
 _c_i64p = ctypes.POINTER(ctypes.c_int64)
 _vp = ctypes.c_void_p

@@ -218,6 +218,17 @@ def getters_fixture():
     print("getters written", {k: getattr(v, "shape", v) for k, v in out.items() if k.endswith("shape") or k.endswith("keys")})
 
 
+def longform_fixture():
+    """BASELINE config 5's long-form case: the reference's Harvest over one 60 s utterance at 48 kHz (12 001 frames,
+    60 001 1 ms frames) — f0 / vuv only (200 KB); the dense tensors of that length are checked through the oracle."""
+    fs = 48000
+    x = _syn.synth_utterance(75, fs, 60.0)
+    h = R.harvest.harvest(x, fs)
+    np.savez_compressed(os.path.join(HERE, "golden_longform48k.npz"), fs=fs, utt=75, seconds=60.0,
+                        harvest_f0=h["f0"], harvest_vuv=h["vuv"], tp=h["temporal_positions"])
+    print("longform written", h["f0"].shape, int(h["vuv"].sum()), "voiced")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected fixtures only: python make_golden.py getters heads ...
         for name in sys.argv[1:]:

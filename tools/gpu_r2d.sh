@@ -1,0 +1,23 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r2d; mkdir -p $O
+timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -4 $O/pytest.log
+B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
+$B > $O/bench_default.json 2> $O/bench_default.err
+for v in d4c_r8 d4c_r8c d4c_mb3; do
+  WH_LIB=python-world_amd/lib/variants/libworld_hip_$v.so $B > $O/bench_$v.json 2> $O/bench_$v.err
+done
+python bench.py --config 5 --steps 2 --warmup 1 > $O/bench_cfg5.json 2> $O/bench_cfg5.err
+WH_LIB=python-world_amd/lib/variants/libworld_hip_d4c_timer.so python tools/d4c_stage_timer.py > $O/stage_timer.txt 2>&1
+cat $O/stage_timer.txt
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r2d/bench_*.json')):
+    try:
+        d=json.load(open(f)); k=d['kernel_ms']
+        print(f.split('/')[-1], 'ms/step %.2f'%d['ms_per_step'], 'd4c %.3f'%k.get('d4c_kernel',0), 'resp %.3f'%k.get('response_kernel',0), 'ct %.3f'%k.get('cheaptrick_kernel',0))
+    except Exception as e:
+        print(f, 'ERR', e)
+PY
+timeout 600 tools/profile_suite.sh 2 r2d/prof_cfg2 > $O/prof2.log 2>&1

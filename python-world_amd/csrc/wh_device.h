@@ -16,6 +16,12 @@
 
 #define WH_BLOCK 256
 #define WH_WAVE 64
+// Thread index as the FFT / reduction helpers see it.  A translation unit whose kernel LOOPS over units may define
+// WH_TID as an opaque read of threadIdx.x (see wh_synthesis.hip): the helpers' per-thread addresses then stop being
+// loop invariants that the compiler hoists and keeps in registers across the whole loop body.
+#ifndef WH_TID
+#define WH_TID threadIdx.x
+#endif
 
 namespace wh {
 
@@ -83,9 +89,9 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
     sync<NT>();
     return v;
   }
-  const int w = threadIdx.x >> 6;
+  const int w = WH_TID >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) scratch[w] = v;
+  if ((WH_TID & 63) == 0) scratch[w] = v;
   __syncthreads();
   double t = 0.0;
 #pragma unroll
@@ -102,9 +108,9 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
     sync<NT>();
     return;
   }
-  const int w = threadIdx.x >> 6;
+  const int w = WH_TID >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
+  if ((WH_TID & 63) == 0) {
     scratch[w] = a;
     scratch[NT / WH_WAVE + w] = b;
   }
@@ -128,9 +134,9 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
     sync<NT>();
     return;
   }
-  const int w = threadIdx.x >> 6;
+  const int w = WH_TID >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
+  if ((WH_TID & 63) == 0) {
     scratch[w] = a;
     scratch[NT / WH_WAVE + w] = b;
     scratch[2 * (NT / WH_WAVE) + w] = c;
@@ -162,9 +168,9 @@ __device__ __forceinline__ void block_sum5(double& a, double& b, double& c, doub
     return;
   }
   constexpr int NW = NT / WH_WAVE;
-  const int w = threadIdx.x >> 6;
+  const int w = WH_TID >> 6;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
+  if ((WH_TID & 63) == 0) {
     scratch[w] = a;
     scratch[NW + w] = b;
     scratch[2 * NW + w] = c;
@@ -185,7 +191,7 @@ __device__ __forceinline__ void block_sum5(double& a, double& b, double& c, doub
 }
 
 __device__ __forceinline__ double wave_scan_incl(double v) {
-  const int lane = threadIdx.x & 63;
+  const int lane = WH_TID & 63;
 #pragma unroll
   for (int o = 1; o < WH_WAVE; o <<= 1) {
     double u = __shfl_up(v, o, WH_WAVE);
@@ -283,7 +289,7 @@ __device__ __forceinline__ void fft_pass_finish(double2* __restrict__ s, double2
                                                 const double2 (&w)[(N / R + NT - 1) / NT][R]) {
   constexpr int J = N / R;
   constexpr int PER = (J + NT - 1) / NT;
-  const int tid = threadIdx.x & (NT - 1);
+  const int tid = WH_TID & (NT - 1);
 #pragma unroll
   for (int p = 0; p < PER; ++p) {
     const int j = tid + p * NT;
@@ -310,7 +316,7 @@ template <int N, int NT, int R, int NS, bool INV>
 __device__ __forceinline__ void fft_pass_twiddles(const double2* __restrict__ tw, double2 (&w)[(N / R + NT - 1) / NT][R]) {
   constexpr int J = N / R;
   constexpr int PER = (J + NT - 1) / NT;
-  const int tid = threadIdx.x & (NT - 1);
+  const int tid = WH_TID & (NT - 1);
   if (NS > 1) {
     constexpr int STEP = N / (NS * R);
 #pragma unroll
@@ -334,7 +340,7 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ s, const double2*
   constexpr int J = N / R;
   constexpr int PER = (J + NT - 1) / NT;
   double2 v[PER][R], w[PER][R];
-  const int tid = threadIdx.x & (NT - 1);
+  const int tid = WH_TID & (NT - 1);
 #if WH_FFT_TW_PREFETCH
   fft_pass_twiddles<N, NT, R, NS, INV>(tw, w);
 #endif
@@ -407,7 +413,7 @@ template <int N, int NT = WH_BLOCK, int SNT = NT, int MAXR = 8>
 __device__ __forceinline__ void rfft_lds(double2* z, const double2* __restrict__ tw_base) {
   fft_lds<N / 2, false, NT, SNT, MAXR>(z, tw_base + N / 2);
   const double2* __restrict__ w = tw_base + N;
-  for (int k = threadIdx.x & (NT - 1); k <= N / 4; k += NT) {
+  for (int k = WH_TID & (NT - 1); k <= N / 4; k += NT) {
     if (k == 0) {
       const double2 a = z[0];
       z[0] = make_double2(a.x + a.y, 0.0);
@@ -432,7 +438,7 @@ __device__ __forceinline__ void rfft_lds(double2* z, const double2* __restrict__
 template <int N, int NT = WH_BLOCK, int SNT = NT, int MAXR = 8>
 __device__ __forceinline__ void irfft_lds(double2* z, const double2* __restrict__ tw_base) {
   const double2* __restrict__ w = tw_base + N;
-  for (int k = threadIdx.x & (NT - 1); k <= N / 4; k += NT) {
+  for (int k = WH_TID & (NT - 1); k <= N / 4; k += NT) {
     double2 a = z[k], b = z[N / 2 - k];
     if (k == 0) {  // DC and Nyquist bins: only their real parts reach a real output (Re of the inverse DFT)
       a.y = 0.0;

@@ -14,6 +14,16 @@
 //                     (direct convolution == the reference's truncated fftfilt), and scatter-add into
 //                     y with the reference's clipped-index semantics.
 #include "wh_host.h"
+// response_kernel walks a run of pulses in a loop.  With the plain thread index every per-thread LDS / twiddle address
+// of the ~15 transform passes in the loop body is a loop invariant: LLVM hoists them all in front of the loop and keeps
+// them alive across it (248 VGPRs, 2 waves per SIMD).  Reading the index through an empty volatile asm makes each use
+// its own value; the few integer instructions that are recomputed cost nothing next to 128 spare registers.
+__device__ __forceinline__ unsigned wh_opaque_tid() {
+  unsigned t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+#define WH_TID wh_opaque_tid()
 #include "wh_device.h"
 
 // -DWH_RESP_STAGE_TIMER: per-stage shader-clock cycles of response_kernel (thread 0 of every workgroup), read with
@@ -471,7 +481,7 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
   c0 = n0;
   c2 = n2;
 }
-__device__ __forceinline__ double normal_at(uint64_t seed, uint64_t q) {
+__device__ __attribute__((noinline)) double normal_at(uint64_t seed, uint64_t q) {  // a call: see log_call below
   uint32_t c0 = (uint32_t)(q >> 1), c1 = (uint32_t)((q >> 1) >> 32), c2 = 0x9E3779B9u, c3 = 0x243F6A88u;
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -488,6 +498,16 @@ __device__ __forceinline__ double normal_at(uint64_t seed, uint64_t q) {
   return (q & 1) ? rr * s : rr * c;
 }
 
+// Transcendentals of the per-pulse loop as real calls: inlined, their polynomial coefficients (64-bit literals live in
+// VGPR pairs) are loop invariants of response_kernel's pulse loop and get parked in registers across the whole body.
+__device__ __attribute__((noinline)) double log_call(double x) { return log(x); }
+__device__ __attribute__((noinline)) double exp_call(double x) { return exp(x); }
+__device__ __attribute__((noinline)) double2 sincospi_call(double x) {
+  double s, c;
+  sincospi(x, &s, &c);
+  return make_double2(s, c);
+}
+
 // Minimum-phase half spectrum (synthesis.py:103-111) from K = N/2+1 amplitude-like bins:
 // log|.|/2 (in place, amp is destroyed) → real FFT → fold the cepstrum onto its upper half (x2, bin 0 kept)
 // → inverse transform of that REAL sequence = conj of its real FFT → complex exp.  Both transforms are
@@ -498,9 +518,9 @@ template <int N, int GT>
 __device__ __forceinline__ void min_phase_half(double* amp, double2* zb, const double2* tw_base) {
   constexpr int FT = ft_syn(N);
   double* zr = reinterpret_cast<double*>(zb);
-  const int gt = threadIdx.x & (GT - 1);
+  const int gt = WH_TID & (GT - 1);
 #pragma unroll WH_RESP_TRANS_UNROLL
-  for (int k = gt; k <= N / 2; k += GT) amp[k] = log(fabs(amp[k])) / 2;
+  for (int k = gt; k <= N / 2; k += GT) amp[k] = log_call(fabs(amp[k])) / 2;
   wh::sync<FT>();
   for (int n = gt; n < N; n += GT) zr[n] = amp[n <= N / 2 ? n : N - n];
   wh::sync<FT>();
@@ -513,9 +533,9 @@ __device__ __forceinline__ void min_phase_half(double* amp, double2* zb, const d
 #pragma unroll WH_RESP_TRANS_UNROLL
   for (int k = gt; k <= N / 2; k += GT) {
     const double2 r = zb[k];  // sum c[n] e^{+i..} = conj(r)
-    const double e = exp(r.x / N);
-    double sn, cs;
-    sincospi(-r.y / N * M_1_PI, &sn, &cs);  // small angle in units of pi: cheap exact range reduction
+    const double e = exp_call(r.x / N);
+    const double2 sc = sincospi_call(-r.y / N * M_1_PI);  // small angle in units of pi: cheap exact range reduction
+    const double sn = sc.x, cs = sc.y;
     zb[k] = make_double2(e * cs, e * sn);
   }
   wh::sync<FT>();
@@ -550,12 +570,33 @@ struct RespArgs {
   double* y;
 };
 
-// One pulse per workgroup.  (A persistent grid-stride loop over pulses was measured first: the compiler then
-// hoists every loop-invariant LDS / twiddle address of the ~15 FFT passes out of the loop and keeps them live
-// across it — 219 VGPRs, 2 workgroups per CU.  Launching one workgroup per pulse slot and letting the surplus
-// ones exit costs < 0.2 ms and more than halves the register count.)
+// Overlap-add state of a workgroup's run of consecutive pulses: the run's contributions are accumulated in an
+// N-sample LDS ring that covers the window of the current pulse; when the window moves on, the samples that leave it
+// are final for this run and go to y with ONE atomic each (instead of one per pulse that touches them: a sample is
+// covered by N / pulse-spacing ~ 6-30 pulses).
+struct RunState {
+  int u;              // utterance of the pulses accumulated so far (-1: ring empty)
+  int64_t win_start;  // 1-based output index of the first sample of the ring's window
+};
+#ifndef WH_RESP_RUN
+#define WH_RESP_RUN 8
+#endif
+
+// Samples [a, b) (1-based, within the ring's current window) are final for this run: add them to y, clear the ring.
 template <int N>
-__device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, char* smem) {
+__device__ __forceinline__ void ring_flush(double* ring, int64_t a, int64_t b, double* __restrict__ yu, int64_t ny) {
+  constexpr int FT = ft_syn(N);
+  for (int64_t tgt = a + WH_TID; tgt < b; tgt += FT) {
+    const int slot = (int)(tgt & (N - 1));
+    const double v = ring[slot];
+    ring[slot] = 0.0;
+    if (v != 0.0 && tgt >= 1 && tgt < ny) atomicAdd(&yu[tgt - 1], v);
+  }
+}
+
+// One pulse of a run.
+template <int N>
+__device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, char* smem, double* ring, RunState& rs) {
   const SynUtt* __restrict__ meta = A.meta;
   const double* __restrict__ spectrogram = A.spectrogram;
   const double* __restrict__ aperiodicity = A.aperiodicity;
@@ -570,6 +611,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   const uint64_t seed = A.seed;
   const double* __restrict__ dc_base = A.dc_base;
   const double2* __restrict__ tw_base = A.tw_base;
+  asm volatile("" : "+s"(tw_base));  // per pulse: no twiddle address / value of one pulse survives into the next
   double* __restrict__ y = A.y;
   constexpr int FT = ft_syn(N);
   constexpr int K = N / 2 + 1;
@@ -622,7 +664,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   vi = vi < 0 ? 0 : (vi > m.ny - 1 ? m.ny - 1 : vi);
   const bool voiced = (vuv_s[m.y_off + vi] != 0) && (aper0 <= 0.999);
 
-  for (int k = threadIdx.x; k < K; k += FT) {
+  for (int k = WH_TID; k < K; k += FT) {
     const double sl = s_lo[k], sh = s_hi[k];
     const double al = a_lo[k] * a_lo[k], ah = a_hi[k] * a_hi[k];
     const double pl = fmax(0.001, 1 - al), ph = fmax(0.001, 1 - ah);
@@ -649,7 +691,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   double mean;
   {
     double part = 0.0;
-    for (int64_t j = threadIdx.x; j < nd; j += FT) {
+    for (int64_t j = WH_TID; j < nd; j += FT) {
       const double v = noise_at(j);
       part += v;
       if (j < NZ) nz[j] = v;  // the usual case nd <= NZ: generate / fetch each sample once
@@ -661,18 +703,18 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   // ---- minimum-phase responses (synthesis.py:86-116): aperiodic chain on thread group 0, periodic chain on
   //      group 1, advancing through the same barrier phases (with a single group: one after the other) --------
 #if WH_RESP_ABLATE == 2
-  if (threadIdx.x == 0) A.y[m.y_off] = spec[3] + asp[5] + mean;
+  if (WH_TID == 0) A.y[m.y_off] = spec[3] + asp[5] + mean;
   return;
 #endif
   const double coef_pi = 2.0 * fs / N;  // coefficient = 2*pi*fs/N (synthesis.py:59), kept in units of pi
-  if constexpr (NG == 2) {
-    const int g = threadIdx.x / GT;
+  if (NG == 2 && voiced) {
+    const int g = WH_TID / GT;
     min_phase_half<N, GT>(g == 0 ? asp : spec, g == 0 ? zbA : zbP, tw_base);
     if (g == 1) {
 #pragma unroll WH_RESP_TRANS_UNROLL
-      for (int k = threadIdx.x & (GT - 1); k <= N / 2; k += GT) {
-        double sn, cs;
-        sincospi(coef_pi * shift * (double)k, &sn, &cs);  // angle coef*shift*k expressed in units of pi
+      for (int k = WH_TID & (GT - 1); k <= N / 2; k += GT) {
+        const double2 sc = sincospi_call(coef_pi * shift * (double)k);  // angle coef*shift*k expressed in units of pi
+        const double sn = sc.x, cs = sc.y;
         const double2 z = zbP[k];
         zbP[k] = make_double2(z.x * cs + z.y * sn, z.y * cs - z.x * sn);  // z * exp(-i th): fractional delay
       }
@@ -681,13 +723,15 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
     RSTAGE_MARK(1)
     wh::irfft_lds<N, GT, FT>(g == 0 ? zbA : zbP, tw_base);
   } else {
+    // an unvoiced pulse has no periodic response (synthesis.py:69-75): one chain, on all the threads — 40 % of the
+    // pulses of speech-like input (the 500 Hz default rate of unvoiced stretches) do half the transform work
     min_phase_half<N, FT>(asp, zbA, tw_base);
     wh::irfft_lds<N, FT, FT>(zbA, tw_base);
     if (voiced) {
       min_phase_half<N, FT>(spec, zbP, tw_base);
-      for (int k = threadIdx.x; k <= N / 2; k += FT) {
-        double sn, cs;
-        sincospi(coef_pi * shift * (double)k, &sn, &cs);  // angle coef*shift*k expressed in units of pi
+      for (int k = WH_TID; k <= N / 2; k += FT) {
+        const double2 sc = sincospi_call(coef_pi * shift * (double)k);  // angle coef*shift*k expressed in units of pi
+        const double sn = sc.x, cs = sc.y;
         const double2 z = zbP[k];
         zbP[k] = make_double2(z.x * cs + z.y * sn, z.y * cs - z.x * sn);
       }
@@ -697,7 +741,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   }
   RSTAGE_MARK(2)
   // zrA[n] = N * aperiodic response, zrP[n] = N * periodic response (both before fftshift)
-  for (int n = threadIdx.x; n < N; n += FT) rap[rap_index(n)] = zrA[(n + N / 2) & (N - 1)] / N;
+  for (int n = WH_TID; n < N; n += FT) rap[rap_index(n)] = zrA[(n + N / 2) & (N - 1)] / N;
   wh::sync<FT>();
 
   // y[m] = sum_j nz[j] * ra[m-j], m < N: each thread owns R consecutive outputs and slides an R-wide
@@ -705,7 +749,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   double acc[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) acc[q] = 0.0;
-  const int m0 = threadIdx.x * R;
+  const int m0 = WH_TID * R;
 #if WH_RESP_ABLATE == 1
   for (int64_t j0 = 0; j0 < 0; j0 += NZ) {
 #else
@@ -713,7 +757,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
 #endif
     const int cnt = (int)(nd - j0 < NZ ? nd - j0 : NZ);
     wh::sync<FT>();
-    for (int j = threadIdx.x; j < NZ; j += FT) {
+    for (int j = WH_TID; j < NZ; j += FT) {
       double v = 0.0;
       if (j < cnt) v = (j0 == 0 ? nz[j] : noise_at(j0 + j)) - mean;
       nz[j] = v;  // zero padded to an even count
@@ -750,38 +794,62 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   const double gain = sqrt((double)(noise_size > 1 ? noise_size : 1));
   if (voiced) {
     double part = 0.0;
-    for (int n = threadIdx.x; n < N; n += FT) part += zrP[n] / N;
+    for (int n = WH_TID; n < N; n += FT) part += zrP[n] / N;
     dc_total = wh::block_sum<FT>(part, scratch);
   }
 
-  // ---- overlap-add with the reference's clipped fancy-index semantics (Q8) -----------------------
+  // ---- overlap-add with the reference's clipped fancy-index semantics (Q8), through the run's ring ----------
   double* yu = y + m.y_off;
+  const int64_t s1 = pidx - N / 2 + 1;  // 1-based index of this pulse's first tap
+  if (rs.u >= 0) {
+    if (rs.u != u || s1 < rs.win_start) {  // the run moved on to the next utterance: everything pending is final
+      const SynUtt mp = meta[rs.u];
+      ring_flush<N>(ring, rs.win_start, rs.win_start + N, y + mp.y_off, mp.ny);
+    } else {
+      const int64_t e = s1 < rs.win_start + N ? s1 : rs.win_start + N;
+      ring_flush<N>(ring, rs.win_start, e, yu, m.ny);
+    }
+    wh::sync<FT>();
+  }
+  rs.u = u;
+  rs.win_start = s1;
 #pragma unroll
   for (int q = 0; q < R; ++q) {
     const int mm = m0 + q;
-    const int64_t tgt = pidx - N / 2 + 1 + mm;  // 1-based
+    const int64_t tgt = s1 + mm;
     double v = acc[q];
     if (voiced) v += (zrP[(mm + N / 2) & (N - 1)] / N + dc_base[mm] * -dc_total) * gain;
     if (tgt < 1) continue;                    // clipped to 1 and overwritten by the in-range tap
-#ifdef WH_ABLATE_OLA
-    if (v == 1.2345e300) yu[0] = v;
-#else
-    if (tgt < m.ny) atomicAdd(&yu[tgt - 1], v);
+    if (tgt < m.ny) ring[(int)(tgt & (N - 1))] += v;    // this thread is the only writer of its R slots
     else if (mm == N - 1) atomicAdd(&yu[m.ny - 1], v);  // last duplicate wins on the high side
-#endif
   }
   RSTAGE_MARK(4)
 }
 
+// One workgroup per RUN of WH_RESP_RUN consecutive pulses (flat pulse numbering: utterance by utterance, in time
+// order).  The grid is sized from the host's pulse capacity; the runs that exist (device-side pulse count) are dealt
+// to the XCDs in contiguous ranges, so that the spectrogram / aperiodicity rows neighbouring pulses share are fetched
+// into one L2 — the surplus workgroups exit at once.
 template <int N>
-__global__ __launch_bounds__(ft_syn(N)) void response_kernel(RespArgs A) {
+__global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // (No XCD-contiguous mapping here, unlike the per-frame kernels: neighbouring pulses overlap-add into the same
-  // samples, and with all of them in flight on one XCD the FP64 atomics pile onto a few memory channels —
-  // measured 5.1 vs 4.7 ms.)
-  const int64_t gp = blockIdx.x;
-  if (gp >= A.p_base[A.n_utt]) return;  // pulse slots beyond the actual pulse count
-  response_pulse<N>(A, gp, smem);
+  constexpr int FT = ft_syn(N);
+  const int64_t total = A.p_base[A.n_utt];
+  const int64_t n_runs = (total + WH_RESP_RUN - 1) / WH_RESP_RUN;
+  const int64_t run = wh::xcd_unit(blockIdx.x, n_runs);
+  if (run >= n_runs) return;
+  double* ring = reinterpret_cast<double*>(smem) + (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32);
+  for (int i = threadIdx.x; i < N; i += FT) ring[i] = 0.0;
+  RunState rs{-1, 0};
+  const int64_t gp0 = run * WH_RESP_RUN;
+  const int64_t gp1 = gp0 + WH_RESP_RUN < total ? gp0 + WH_RESP_RUN : total;
+#pragma unroll 1
+  for (int64_t gp = gp0; gp < gp1; ++gp) response_pulse<N>(A, gp, smem, ring, rs);
+  wh::sync<FT>();
+  if (rs.u >= 0) {
+    const SynUtt mp = A.meta[rs.u];
+    ring_flush<N>(ring, rs.win_start, rs.win_start + N, A.y + mp.y_off, mp.ny);
+  }
 }
 
 
@@ -802,9 +870,10 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   for (int n = 0; n < N; ++n) dc[n] /= sum;
   const double* d_dc = nullptr;
   if (int rc = wh::const_table(ctx, "dc_base:" + std::to_string(N), dc, &d_dc)) return rc;
-  const size_t lds = sizeof(double) * (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32);
+  const size_t lds = sizeof(double) * (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32 + N);  // ... + the overlap-add ring
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
-  const int64_t grid = pcap_max * B;  // one workgroup per pulse slot; slots past the real count exit at once
+  // one workgroup per run of WH_RESP_RUN pulse slots; runs past the real pulse count exit at once
+  const int64_t grid = wh::xcd_grid((pcap_max * B + WH_RESP_RUN - 1) / WH_RESP_RUN);
   { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_time, p_idx, p_shift, p_noff, p_frames, p_weight, p_utt, p_count, p_base, B, vuv_s, noise, seed, d_dc, ctx->d_twiddle, y};
   hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(ft_syn(N)), lds, st, ra); }
   WH_LAUNCH_CHECK("response_kernel");

@@ -148,20 +148,111 @@ __global__ __launch_bounds__(256) void hv_pad_kernel(const HvUtt* __restrict__ m
   z[m.z_off + j] = v;
 }
 
+// One workgroup per (utterance, channel) walks the 1 ms frames in tiles of 256.  The four event trains are sorted
+// and the frames ascending, so the events a tile can need are a window that only moves forward: the workgroup keeps
+// a cursor per train, stages the next kRawChunk edges behind it in LDS with coalesced loads, and every frame searches
+// that window (9 LDS steps) — instead of every (frame, channel, train) walking a 13-deep chain of dependent global
+// loads over the whole list (the kernel was 82 % memory wait, 3 GB of traffic per launch).  A frame whose answer is
+// not inside the staged window (more than ~500 events in 256 ms: impossible for bands up to 880 Hz, but guarded)
+// falls back to the global search.  Same arithmetic as wh::interp_four_trains.
+constexpr int kRawChunk = 512;
+
 __global__ __launch_bounds__(256) void hv_raw_kernel(const HvUtt* __restrict__ meta, const wh::BandJob* __restrict__ jobs,
                                                      const double* __restrict__ band_f0, int nb, double fs_d,
                                                      double f0_floor, double f0_ceil, double* __restrict__ raw) {
-  const HvUtt m = meta[blockIdx.z];
-  const int b = blockIdx.y;
-  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (f >= m.nf1) return;
-  const double t = (double)f * 1 / 1000;  // basic_temporal_positions (harvest.py:21)
-  const wh::BandJob job = jobs[(int64_t)blockIdx.z * nb + b];
-  double cand, dev;
-  wh::interp_four_trains(job.edges, job.cap, job.counts, fs_d, t, false, &cand, &dev);
+  __shared__ double ch[4][kRawChunk];
+  __shared__ int s_next[4];
+  const HvUtt m = meta[blockIdx.y];
+  const int b = blockIdx.x;
+  const wh::BandJob job = jobs[(int64_t)blockIdx.y * nb + b];
+  double* out = raw + m.f1_off * nb + (int64_t)b * m.nf1;
+  int cnt[4];
+  bool usable = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    cnt[k] = job.counts[k];
+    usable = usable && (cnt[k] - 1 >= 3);
+  }
+  if (!usable) {  // fewer than 3 intervals in a train: no candidate anywhere (dio.py:159-162)
+    for (int64_t f = threadIdx.x; f < m.nf1; f += 256) out[f] = 0.0;
+    return;
+  }
   const double bf = band_f0[b];
-  if (cand > bf * 1.1 || cand < bf * 0.9 || cand > f0_ceil || cand < f0_floor) cand = 0.0;  // harvest.py:273-276
-  raw[m.f1_off * nb + (int64_t)b * m.nf1 + f] = cand;
+  const double half_inv_fs = 0.5 / fs_d;
+  int pos[4] = {0, 0, 0, 0};  // per train: number of interval locations before the current tile's first frame
+  for (int64_t f0 = 0; f0 < m.nf1; f0 += 256) {
+    int start[4], have[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      start[k] = pos[k] - 2 > 0 ? pos[k] - 2 : 0;
+      have[k] = cnt[k] - start[k] < kRawChunk ? cnt[k] - start[k] : kRawChunk;  // edges staged
+      const double* e = job.edges + (int64_t)k * job.cap + start[k];
+      for (int i = threadIdx.x; i < have[k]; i += 256) ch[k][i] = e[i];
+    }
+    __syncthreads();
+    const int64_t f = f0 + threadIdx.x;
+    int lo_g[4] = {0, 0, 0, 0};
+    if (f < m.nf1) {
+      const double t = (double)f * 1 / 1000;  // basic_temporal_positions (harvest.py:21)
+      double v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ni = cnt[k] - 1;       // intervals of the whole train; location i = (e[i]+e[i+1])/2/fs
+        const int nloc = have[k] - 1;    // locations inside the staged window
+        int lo = 0, hi = nloc;           // lower_bound inside the window
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          const double loc = (ch[k][mid] + ch[k][mid + 1]) * half_inv_fs;
+          if (loc < t) lo = mid + 1; else hi = mid;
+        }
+        const bool inside = lo < nloc || start[k] + have[k] == cnt[k];
+        const double* e = job.edges + (int64_t)k * job.cap;
+        int g = start[k] + lo;  // count of locations < t over the whole train
+        if (!inside) {          // the window ended before t: global search (never taken for speech bands)
+          int l2 = g, h2 = ni;
+          while (l2 < h2) {
+            const int mid = (l2 + h2) >> 1;
+            const double loc = (e[mid] + e[mid + 1]) * half_inv_fs;
+            if (loc < t) l2 = mid + 1; else h2 = mid;
+          }
+          g = l2;
+        }
+        lo_g[k] = g;
+        const int ih = g < 1 ? 1 : (g > ni - 1 ? ni - 1 : g);
+        const int il = ih - 1;
+        double e0, e1, e2, e3;  // e[il], e[il+1], e[ih], e[ih+1]
+        if (inside && il >= start[k] && ih + 1 < start[k] + have[k]) {
+          e0 = ch[k][il - start[k]];
+          e1 = ch[k][il + 1 - start[k]];
+          e2 = ch[k][ih - start[k]];
+          e3 = ch[k][ih + 1 - start[k]];
+        } else {
+          e0 = e[il];
+          e1 = e[il + 1];
+          e2 = e[ih];
+          e3 = e[ih + 1];
+        }
+        const double x_lo = (e0 + e1) * half_inv_fs;
+        const double x_hi = (e2 + e3) * half_inv_fs;
+        const double y_lo = fs_d / (e1 - e0);
+        const double y_hi = fs_d / (e3 - e2);
+        const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+        v[k] = slope * (t - x_lo) + y_lo;
+      }
+      double cand = (((v[0] + v[1]) + v[2]) + v[3]) / 4;
+      if (cand > bf * 1.1 || cand < bf * 0.9 || cand > f0_ceil || cand < f0_floor) cand = 0.0;  // harvest.py:273-276
+      out[f] = cand;
+    }
+    // the last frame of the tile hands its counts to the next tile as the new cursors
+    const int64_t last = f0 + 255 < m.nf1 - 1 ? f0 + 255 : m.nf1 - 1;
+    if (f == last) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s_next[k] = lo_g[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pos[k] = s_next[k];
+  }
 }
 
 // NumPy's pairwise summation for n <= 128 (what np.mean does on the run of channel values)
@@ -300,17 +391,65 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
     // Every index of the frame is positive (all frames but the first few of an utterance): idx_raw, and with it the
     // window phase xw, is linear in j, so this lane's samples j = l16 + 16 i are a fixed rotation of 16*pi*dx apart —
     // one sincospi to start, a 4-flop rotation per sample after that (<= 43 steps: error growth ~1e-15).
+    // The derivative window needs the Blackman values of samples j-1 and j+1: those are what the neighbouring lanes
+    // of the row hold in the same iteration (lane 0's left neighbour is lane 15's value of the previous iteration,
+    // lane 15's right neighbour lane 0's value of the next one, which is therefore computed one iteration ahead), so
+    // they are fetched with two DPP row rotates each instead of being recomputed (2 x (rotation + Blackman) = 16
+    // FP64 operations per sample in a kernel that is VALU-bound).  All 16 lanes of a row run the same number of
+    // iterations (validity is a predicate), which keeps every source lane of the rotates alive.  The twiddle index
+    // (bin*j) mod nfft advances by a constant per iteration: an add and a mask instead of a 32-bit multiply.
     double s16, c16, s2, c2;
     sincospi(16 * dx, &s16, &c16);
     {
       const double ir0 = idx_raw_at(l16);
       sincospi(2 * ((ir0 - 1) / fs - t0) / wlit, &s2, &c2);
     }
-    for (int j = l16; j < L; j += 16) {
-      sample(j, idx_raw_at(j), s2, c2, false, false);
-      const double cn = c2 * c16 - s2 * s16;
+    auto blackman = [](double c) { return 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1); };  // cos(4c) = 2cos^2(2c) - 1
+    // twiddle look-ups as element offsets into the table in use, already scaled by its subsampling shift: the
+    // offset of harmonic h advances by (16*bin_h mod nfft) << shift per iteration.  All six harmonics are accumulated
+    // whatever nh is (the surplus ones, for candidates above fs/12, are simply not read afterwards): no per-harmonic
+    // predication inside the loop.
+    int tix[6], tstep[6];
+    const int tmask = ((nfft - 1) << tw_sh);
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      tix[h] = ((bins[h] * l16) & (nfft - 1)) << tw_sh;
+      tstep[h] = ((bins[h] * 16) & (nfft - 1)) << tw_sh;
+    }
+    double m_prev = 0.0, m_cur = blackman(c2);
+    const int n_it = (L + 15) >> 4;
+    int j = l16;
+    for (int it = 0; it < n_it; ++it, j += 16) {
+      const double cn = c2 * c16 - s2 * s16;  // phase of sample j + 16
       s2 = s2 * c16 + c2 * s16;
       c2 = cn;
+      const double m_next = blackman(c2);
+      const double right = dpp_f64<0x12F>(m_cur), right_wrap = dpp_f64<0x12F>(m_next);  // lane l <- lane l+1 (15 <- 0)
+      const double left = dpp_f64<0x121>(m_cur), left_wrap = dpp_f64<0x121>(m_prev);     // lane l <- lane l-1 (0 <- 15)
+      const double mn = j + 1 < L ? (l16 == 15 ? right_wrap : right) : 0.0;
+      const double mp = j > 0 ? (l16 == 0 ? left_wrap : left) : 0.0;
+      const double mj = m_cur;
+      double dw;
+      if (j == 0) dw = -mn / 2;
+      else if (j == L - 1) dw = mp / 2;
+      else dw = -((mn - mj) + (mj - mp)) / 2;
+      double smp = 0.0;
+      if (j < L) {
+        const double irc = fmax(1.0, fmin((double)ylen, idx_raw_at(j))) - 1;
+        smp = yl[(int64_t)irc - ybase];
+      }
+      const double a = smp * mj, d = smp * dw;
+#pragma unroll
+      for (int h = 0; h < 6; ++h) {
+        const double2 w = tw[tix[h]];
+        xr[h] = fma(a, w.x, xr[h]);
+        xi[h] = fma(a, w.y, xi[h]);
+        dr[h] = fma(d, w.x, dr[h]);
+        di[h] = fma(d, w.y, di[h]);
+        tix[h] = (tix[h] + tstep[h]) & tmask;
+      }
+      m_prev = m_cur;
+      m_cur = m_next;
     }
   } else {
     for (int j = l16; j < L; j += 16) {
@@ -397,15 +536,44 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict_
   }
   __syncthreads();
   const int n_items = cl_n;
-  const int grp = threadIdx.x >> 4;  // 16 rows of 16 lanes
-  for (int it = grp; it < n_items; it += 16) {
-    const int q = cl_meta[it];
-    const int64_t f = f_first + q / kRows;
-    double r0, r1;
-    hv_refine_row(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[it], f0_floor, f0_ceil, tw_base, twl, tw_n, &r0, &r1);
-    if ((threadIdx.x & 15) == 0) {
-      rf0[(m.f1_off + f) * kRows + q % kRows] = r0;
-      rsc[(m.f1_off + f) * kRows + q % kRows] = r1;
+  // A wave refines four candidates at once, one per 16-lane row, and runs as long as its longest one: the window
+  // length goes with 1/f0 (31 ... 340 samples at 8 kHz), and a frame's candidates are typically an f0 with its
+  // octave neighbours.  Counting sort of the work list by iteration count, so that the rows of a wave (consecutive
+  // entries) carry windows of the same length class.
+  {
+    __shared__ int bucket[32], order[kFramesPerBlock * kRows];
+    if (threadIdx.x < 32) bucket[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_items; i += 256) {
+      const int len = 2 * (int)ceil(3 * fs / cl_val[i] / 2) + 1;
+      int key = (len + 15) >> 4;
+      key = key > 31 ? 31 : key;
+      atomicAdd(&bucket[key], 1);
+      cl_meta[i] |= key << 16;  // q < 420 fits 16 bits
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // exclusive scan of 32 counts, longest first (the long items start the block's schedule)
+      int run = 0;
+      for (int k = 31; k >= 0; --k) {
+        const int c = bucket[k];
+        bucket[k] = run;
+        run += c;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_items; i += 256) order[atomicAdd(&bucket[cl_meta[i] >> 16], 1)] = i;
+    __syncthreads();
+    const int grp_ = threadIdx.x >> 4;
+    for (int it = grp_; it < n_items; it += 16) {
+      const int src = order[it];
+      const int q = cl_meta[src] & 0xffff;
+      const int64_t f = f_first + q / kRows;
+      double r0, r1;
+      hv_refine_row(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, twl, tw_n, &r0, &r1);
+      if ((threadIdx.x & 15) == 0) {
+        rf0[(m.f1_off + f) * kRows + q % kRows] = r0;
+        rsc[(m.f1_off + f) * kRows + q % kRows] = r1;
+      }
     }
   }
 }
@@ -644,7 +812,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands, d_ti + 2 * n_bands,
                                       max_lb, true, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW))
     return rc;
-  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3((unsigned)((max_nf1 + 255) / 256), n_bands, B), dim3(256), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw); }
+  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B), dim3(256), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw); }
   WH_LAUNCH_CHECK("hv_raw_kernel");
   if (dbg_raw) WH_CHECK(hipMemcpyAsync(dbg_raw, d_raw, sizeof(double) * f1_tot * n_bands, hipMemcpyDeviceToDevice, st));
   { wh::KernelTimer _kt(ctx, st, "hv_detect_kernel"); hipLaunchKernelGGL(hv_detect_kernel, dim3((unsigned)((max_nf1 + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw, d_dc, d_dn); }

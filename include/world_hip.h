@@ -188,6 +188,40 @@ int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b, const dou
                          int64_t pulse_cap, const double* pulse_seed, int pulse_fft, const double* noise_seed,
                          int64_t noise_len, int n_bands, const int64_t* h_cursor, double* y);
 
+/* ---- Spectral feature heads: replace World.encode_lfbank / encode_mcep / decode_mcep  (world/main.py:305-358) ---- */
+/* One dense product per frame with an elementwise prologue and epilogue, on the FP64 matrix cores:
+ *     out[f][n] = epi( sum_{k<ka} pro(a[f*lda + k], k) * h_w[k*nw + n] ),   f < n_rows, n < nw;  out row stride ldo
+ *   prologue 0: pro(v) = v;  1: pro(v, k) = pscale * (v * h_p[k])^2  (encode_lfbank: pre-emphasis |H(k)| and
+ *   1/nfft power, main.py:313-316);  2: pro(v) = log(v)  (encode_mcep, main.py:333)
+ *   epilogue 0: none;  1: log with 0 -> DBL_EPSILON (main.py:321-322);  2: exp (decode_mcep, main.py:358)
+ * a / out: DEVICE, frame-major (wh_cheaptrick's spectrogram layout).  h_w[ka][nw] and h_p[ka] are HOST tables: the mel
+ * filterbank transposed (get_filterbanks, main.py:275-303), or the cosine rows of the inverse / forward real FFT with
+ * the mel warp of main.py:335-337 / 351-356 folded in — built by the host with the reference's own expressions. */
+int wh_feature_matmul(wh_ctx* ctx, void* stream, const double* a, int64_t n_rows, int ka, int64_t lda, int prologue,
+                      const double* h_p, double pscale, const double* h_w, int nw, int epilogue, double* out, int64_t ldo);
+/* get_context (main.py:360-365): out[i][j*d + c] = x[clamp(i + j - w, 0, n_rows-1)][c], j = 0..2w.  DEVICE pointers. */
+int wh_context_frames(wh_ctx* ctx, void* stream, const double* x, int64_t n_rows, int d, int w, double* out);
+
+/* ---- Modifiers on a resident encoding: replace World.warp_spectrum / modify_duration  (world/main.py:180-196) ---- */
+/* warp_spectrum: spectrogram[n_frames][k_bins] (DEVICE, in place): frame <- np.interp((k/K)^factor, k/K, frame).  The
+ * query points are the same for every frame, so the host runs NumPy's search once per bin and passes (HOST tables)
+ * h_src[k] = interval index j, h_dx[k] = x_k - xp[j], h_den[k] = xp[j+1] - xp[j], with h_den[k] = 0 where np.interp
+ * returns fp[j] itself (exact knot / last knot / beyond it); the kernel applies NumPy's
+ * (fp[j+1]-fp[j]) / den * dx + fp[j]. */
+int wh_warp_spectrum(wh_ctx* ctx, void* stream, double* spectrogram, int64_t n_frames, int k_bins, const int32_t* h_src,
+                     const double* h_dx, const double* h_den);
+/* modify_duration: tp_out[f] = np.interp(tp_in[f], xp_u, fp_u) for the utterance u of frame f; h_xp / h_fp
+ * [n_utt][n_anchor] (HOST): xp_u = [0, from_time..., last frame time of u], fp_u = to_time with a trailing -1 replaced
+ * by that last frame time (main.py:186-189).  tp_out must not alias tp_in (the reference installs a new array). */
+int wh_modify_duration(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp_in, double* tp_out,
+                       const double* h_xp, const double* h_fp, int n_anchor);
+
+/* ---- 16-bit PCM at the batch boundary (the reference's WAV usage: example/prosody.py:12-13,57) ---------------------- */
+/* x[i] = pcm[i] / (2^15 - 1); pcm[i] = int16(trunc(y[i] * 2^15)) (low 16 bits, like NumPy's astype on the reference's
+ * platform).  DEVICE pointers: the 2-byte samples cross PCIe instead of the 8-byte ones. */
+int wh_pcm16_to_f64(wh_ctx* ctx, void* stream, const int16_t* pcm, int64_t n, double* x);
+int wh_f64_to_pcm16(wh_ctx* ctx, void* stream, const double* y, int64_t n, int16_t* pcm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,167 @@
+// Spectral feature heads downstream of encode(): log mel filterbank energies, mel-cepstrum and its inverse, context
+// stacking.  Replaces World.encode_lfbank / encode_mcep / decode_mcep / get_context (world/main.py:305-365).
+//
+// All three heads are one dense product per frame — the only dense contractions in the reference
+// (`np.dot(pspec, fb.T)`, world/main.py:320; the irfft / rfft of encode_mcep / decode_mcep keep 12 coefficients, i.e.
+// a 513 x 12 cosine matrix with the mel warp folded in) — with an elementwise prologue and epilogue:
+//     out[f][n] = epi( sum_k pro(A[f][k], k) * W[k][n] )
+//   encode_lfbank : pro = (a * |H(k)|)^2 / nfft (pre-emphasis, power), W = fb^T,           epi = log (0 -> eps)
+//   encode_mcep   : pro = log a,                                     W = warp + irfft rows, epi = none
+//   decode_mcep   : pro = none,                                      W = rfft rows + warp,  epi = exp
+// feature_matmul_kernel runs it on the FP64 matrix cores (v_mfma_f64_16x16x4_f64): a workgroup of four waves takes
+// 64 frames, each wave a 16-frame strip; the A strip of a 32-wide k chunk is staged in LDS through coalesced loads
+// with the prologue applied on the way in, W (k-major, zero-padded to multiples of 32 x 16) is read straight from L2.
+// The products are HBM-bound (4104 B in per 32 x 8 B out for the filterbank), the matrix cores just keep the
+// arithmetic off the critical path.
+//
+// MFMA operand layout (measured, tools/ubench/mfma_check.hip): A[i][k] in lane 16k+i, B[k][j] in lane 16k+j,
+// D[4r + l/16][l%16] in register r of lane l.
+#include <math.h>
+
+#include "wh_device.h"
+#include "wh_host.h"
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kFeatKC = 32;   // k chunk staged in LDS
+constexpr int kFeatNT = 4;    // 16-column tiles per workgroup (accumulators: 4 x 4 doubles per lane)
+constexpr int kFeatRows = 64;
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void feature_matmul_kernel(const double* __restrict__ A, long long n_rows, int ka,
+                                                             long long lda, const double* __restrict__ P, double pscale,
+                                                             const double* __restrict__ W, int kpad, int npad, int nw,
+                                                             double* __restrict__ out, long long ldo) {
+  __shared__ double As[kFeatRows][kFeatKC + 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long f0 = (long long)blockIdx.x * kFeatRows;
+  const int nt0 = blockIdx.y * kFeatNT;
+  const int ntiles = npad / 16;
+  double4_t acc[kFeatNT];
+#pragma unroll
+  for (int t = 0; t < kFeatNT; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+  for (int kc = 0; kc < kpad; kc += kFeatKC) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < kFeatRows * kFeatKC; idx += 256) {
+      const int r = idx / kFeatKC, c = idx % kFeatKC;
+      const long long f = f0 + r;
+      const int k = kc + c;
+      double v = 0.0;
+      if (f < n_rows && k < ka) {
+        v = A[f * lda + k];
+        if (PRO == 1) {
+          v = v * P[k];
+          v = pscale * (v * v);  // 1 / nfft * np.square(spec * |h|)  (main.py:314-316)
+        } else if (PRO == 2) {
+          v = log(v);
+        }
+      }
+      As[r][c] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < kFeatKC / 4; ++kk) {
+      const double a = As[16 * w + (lane & 15)][4 * kk + (lane >> 4)];
+      const double* wrow = W + (long long)(kc + 4 * kk + (lane >> 4)) * npad + (lane & 15);
+#pragma unroll
+      for (int t = 0; t < kFeatNT; ++t) {
+        if (nt0 + t < ntiles) {
+          const double b = wrow[16 * (nt0 + t)];
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kFeatNT; ++t) {
+    const int n = 16 * (nt0 + t) + (lane & 15);
+    if (nt0 + t < ntiles && n < nw) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long f = f0 + 16 * w + 4 * r + (lane >> 4);
+        if (f < n_rows) {
+          double v = acc[t][r];
+          if (EPI == 1) v = log(v == 0.0 ? 2.220446049250313e-16 : v);  // np.where(feat == 0, eps, feat); np.log
+          else if (EPI == 2) v = exp(v);
+          out[f * ldo + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// get_context (main.py:360-365): out[i] = rows i-w .. i+w of X side by side, the first / last row repeated at the ends
+__global__ __launch_bounds__(256) void context_kernel(const double* __restrict__ X, long long n, int d, int w,
+                                                      double* __restrict__ out) {
+  const long long width = (long long)(2 * w + 1) * d;
+  const long long i = blockIdx.x;
+  for (long long c = threadIdx.x; c < width; c += 256) {
+    long long src = i + c / d - w;
+    src = src < 0 ? 0 : (src > n - 1 ? n - 1 : src);
+    out[i * width + c] = X[src * d + c % d];
+  }
+}
+
+template <int PRO>
+int launch_epi(int epi, dim3 grid, hipStream_t st, const double* A, long long n_rows, int ka, long long lda, const double* P,
+               double pscale, const double* W, int kpad, int npad, int nw, double* out, long long ldo) {
+  switch (epi) {
+    case 0: hipLaunchKernelGGL((feature_matmul_kernel<PRO, 0>), grid, dim3(256), 0, st, A, n_rows, ka, lda, P, pscale, W, kpad, npad, nw, out, ldo); break;
+    case 1: hipLaunchKernelGGL((feature_matmul_kernel<PRO, 1>), grid, dim3(256), 0, st, A, n_rows, ka, lda, P, pscale, W, kpad, npad, nw, out, ldo); break;
+    case 2: hipLaunchKernelGGL((feature_matmul_kernel<PRO, 2>), grid, dim3(256), 0, st, A, n_rows, ka, lda, P, pscale, W, kpad, npad, nw, out, ldo); break;
+    default: return wh::fail_msg("wh_feature_matmul", "epilogue must be 0 (none), 1 (log) or 2 (exp)");
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int wh_feature_matmul(wh_ctx* ctx, void* stream, const double* a, int64_t n_rows, int ka, int64_t lda,
+                                 int prologue, const double* h_p, double pscale, const double* h_w, int nw, int epilogue,
+                                 double* out, int64_t ldo) {
+  if (!ctx || !a || !h_w || !out) return wh::fail_msg("wh_feature_matmul", "null argument");
+  WH_ENTER(ctx);
+  if (n_rows <= 0) return 0;
+  if (ka < 1 || nw < 1 || lda < ka || ldo < nw) return wh::fail_msg("wh_feature_matmul", "bad shape");
+  if (prologue == 1 && !h_p) return wh::fail_msg("wh_feature_matmul", "prologue 1 needs the per-column table");
+  hipStream_t st = (hipStream_t)stream;
+  const int kpad = ((ka + kFeatKC - 1) / kFeatKC) * kFeatKC;
+  const int npad = ((nw + 15) / 16) * 16;
+  std::vector<double> wp((size_t)kpad * npad, 0.0);  // zero padding: the surplus k rows / n columns contribute nothing
+  for (int k = 0; k < ka; ++k)
+    for (int n = 0; n < nw; ++n) wp[(size_t)k * npad + n] = h_w[(size_t)k * nw + n];
+  double* d_w = nullptr;
+  double* d_p = nullptr;
+  if (int rc = wh::persistent_upload(ctx, st, "feat.w." + std::to_string(prologue) + std::to_string(epilogue), wp, &d_w)) return rc;
+  if (prologue == 1) {
+    std::vector<double> pv(h_p, h_p + ka);
+    if (int rc = wh::persistent_upload(ctx, st, "feat.p", pv, &d_p)) return rc;
+  }
+  const dim3 grid((unsigned)((n_rows + kFeatRows - 1) / kFeatRows), (unsigned)((npad / 16 + kFeatNT - 1) / kFeatNT));
+  int rc;
+  {
+    wh::KernelTimer _kt(ctx, st, "feature_matmul_kernel");
+    switch (prologue) {
+      case 0: rc = launch_epi<0>(epilogue, grid, st, a, n_rows, ka, lda, d_p, pscale, d_w, kpad, npad, nw, out, ldo); break;
+      case 1: rc = launch_epi<1>(epilogue, grid, st, a, n_rows, ka, lda, d_p, pscale, d_w, kpad, npad, nw, out, ldo); break;
+      case 2: rc = launch_epi<2>(epilogue, grid, st, a, n_rows, ka, lda, d_p, pscale, d_w, kpad, npad, nw, out, ldo); break;
+      default: return wh::fail_msg("wh_feature_matmul", "prologue must be 0 (none), 1 (pre-emphasised power) or 2 (log)");
+    }
+  }
+  if (rc) return rc;
+  WH_LAUNCH_CHECK("feature_matmul_kernel");
+  return 0;
+}
+
+extern "C" int wh_context_frames(wh_ctx* ctx, void* stream, const double* x, int64_t n_rows, int d, int w, double* out) {
+  if (!ctx || !x || !out) return wh::fail_msg("wh_context_frames", "null argument");
+  WH_ENTER(ctx);
+  if (n_rows <= 0) return 0;
+  if (d < 1 || w < 0) return wh::fail_msg("wh_context_frames", "bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  { wh::KernelTimer _kt(ctx, st, "context_kernel"); hipLaunchKernelGGL(context_kernel, dim3((unsigned)n_rows), dim3(256), 0, st, x, (long long)n_rows, d, w, out); }
+  WH_LAUNCH_CHECK("context_kernel");
+  return 0;
+}

@@ -56,6 +56,13 @@ SIGNATURES = {
     "wh_d4c": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int, _vp, _vp]),
     "wh_d4c_bands": (_int, [_dbl, _int]),
     "wh_d4c_requiem": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int, _vp]),
+    "wh_feature_matmul": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, ctypes.c_int64, _int, _vp, _dbl, _vp, _int, _int, _vp,
+                                 ctypes.c_int64]),
+    "wh_context_frames": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _int, _vp]),
+    "wh_warp_spectrum": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _vp, _vp, _vp]),
+    "wh_modify_duration": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
+    "wh_pcm16_to_f64": (_int, [_vp, _vp, _vp, ctypes.c_int64, _vp]),
+    "wh_f64_to_pcm16": (_int, [_vp, _vp, _vp, ctypes.c_int64, _vp]),
 }
 
 _lib = None

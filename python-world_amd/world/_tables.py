@@ -6,6 +6,8 @@ evaluated here with the same NumPy expressions and uploaded (SURVEY.md §7.3 Q2,
 """
 import math
 
+import functools
+
 import numpy as np
 from scipy.signal.windows import hann
 
@@ -105,3 +107,21 @@ def harvest_tables(fs, f0_floor, f0_ceil):
          "band_taps": np.ascontiguousarray(np.concatenate(taps), dtype=np.float64)}
     _HV_CACHE[key] = t
     return t
+
+
+@functools.lru_cache(maxsize=16)
+def warp_tables(k_bins, factor):
+    """NumPy's search for World.warp_spectrum (world/main.py:191-196), done once per (K, factor): for query points
+    x_k = (k/K)**factor on the knots xp_k = k/K, the interval index j with xp[j] <= x < xp[j+1], x - xp[j] and
+    xp[j+1] - xp[j]; a zero denominator marks the cases in which np.interp returns fp[j] itself (exact knot, last
+    knot, or x beyond it)."""
+    xp = np.arange(0, k_bins) / k_bins
+    x = xp ** factor
+    j = np.searchsorted(xp, x, side="right") - 1
+    j = np.clip(j, 0, k_bins - 1)
+    copy = (j >= k_bins - 1) | (xp[j] == x) | (x > xp[-1])
+    jn = np.minimum(j + 1, k_bins - 1)
+    den = np.where(copy, 0.0, xp[jn] - xp[j])
+    dx = np.where(copy, 0.0, x - xp[j])
+    return (np.ascontiguousarray(j, dtype=np.int32), np.ascontiguousarray(dx, dtype=np.float64),
+            np.ascontiguousarray(den, dtype=np.float64))

@@ -36,6 +36,20 @@ class BatchEncoding:
         self.spectrogram, self.aperiodicity = spectrogram, aperiodicity
         self.fft_size, self.is_requiem, self.frame_period = fft_size, is_requiem, frame_period
 
+    @classmethod
+    def from_dicts(cls, rt, dats):
+        """Upload a list of encode() dicts (reference layout: (bins, frames) arrays) that share fs / is_requiem / FFT
+        size as one resident batch."""
+        nfs = [len(d['f0']) for d in dats]
+        frame_off = np.concatenate([[0], np.cumsum(nfs)])
+        batch = rt.make_batch(np.zeros(len(dats) + 1, dtype=np.int64), frame_off)
+        flat = lambda key: rt.to_device(np.concatenate([np.asarray(d[key], dtype=np.float64) for d in dats]))  # noqa: E731
+        rows = lambda key: rt.to_device(np.concatenate([np.asarray(d[key], dtype=np.float64).T for d in dats]))  # noqa: E731
+        tp_h = np.concatenate([np.asarray(d['temporal_positions'], dtype=np.float64) for d in dats])
+        fft_size = (dats[0]['spectrogram'].shape[0] - 1) * 2
+        return cls(rt, batch, dats[0]['fs'], rt.to_device(tp_h), flat('f0'), flat('vuv'), rows('spectrogram'),
+                   rows('aperiodicity'), fft_size, bool(dats[0]['is_requiem']), None, tp_host=tp_h)
+
     @property
     def temporal_positions(self):
         return self._tp
@@ -66,6 +80,61 @@ class BatchEncoding:
         if self.tp_host is not None:
             self.tp_host = self.tp_host * factor
         return self
+
+    def warp_spectrum(self, factor):
+        """world/main.py:191-196 on the device, in place: every frame becomes np.interp((k/K)**factor, k/K, frame)."""
+        import ctypes
+
+        k = self.spectrogram.shape[1]
+        src, dx, den = _tables.warp_tables(int(k), float(factor))
+        vp = ctypes.c_void_p
+        _hip.check(self.rt.lib.wh_warp_spectrum(self.rt.ctx, self.rt.stream(), self.rt.ptr(self.spectrogram),
+                                                int(self.spectrogram.shape[0]), int(k), src.ctypes.data_as(vp),
+                                                dx.ctypes.data_as(vp), den.ctypes.data_as(vp)))
+        return self
+
+    def modify_duration(self, from_time, to_time):
+        """world/main.py:180-189 for every utterance of the batch (each with its own last frame time as the final
+        anchor): temporal_positions <- np.interp(tp, [0, *from_time, end], to_time), a trailing -1 in to_time meaning
+        `end`.  Evaluated by a kernel on the resident frame times; like the reference it installs a NEW array."""
+        import ctypes
+
+        from_time = np.asarray(from_time, dtype=np.float64)
+        to_time = np.array(to_time, dtype=np.float64)
+        assert np.all(np.diff(from_time)) > 0 and np.all(np.diff(to_time)) > 0  # the reference's checks, as written
+        assert from_time[0] > 0
+        assert len(to_time) == len(from_time) + 2
+        tp_h = self.host_times()
+        fo = self.batch.frame_off
+        xp, fp = [], []
+        for u in range(self.n_utt):
+            end = float(tp_h[int(fo[u + 1]) - 1])
+            assert from_time[-1] < end
+            xp.append(np.r_[0, from_time, end])
+            t = to_time.copy()
+            if t[-1] == -1:
+                t[-1] = end
+            fp.append(t)
+        xp = np.ascontiguousarray(xp, dtype=np.float64)
+        fp = np.ascontiguousarray(fp, dtype=np.float64)
+        out = self.rt.empty((self.batch.total_frames,))
+        vp = ctypes.c_void_p
+        _hip.check(self.rt.lib.wh_modify_duration(self.rt.ctx, self.rt.stream(), self.batch.handle, self.rt.ptr(self._tp),
+                                                  self.rt.ptr(out), xp.ctypes.data_as(vp), fp.ctypes.data_as(vp),
+                                                  int(xp.shape[1])))
+        self.temporal_positions = out  # (drops the host cache: decode downloads the new frame times once)
+        return self
+
+    # ---- spectral feature heads on the resident spectrogram (world/main.py:305-341; world/features.py) ----------
+    def lfbank(self, prefac=0.97, nfilt=32, lowfreq=0, highfreq=None):
+        """encode_lfbank of every frame of the batch: device tensor [F][nfilt]."""
+        from .features import lfbank_device
+        return lfbank_device(self.rt, self.spectrogram, prefac, self.fs, nfilt, lowfreq, highfreq)
+
+    def mcep(self, n0=12, lowhz=0, highhz=8000):
+        """encode_mcep of every frame of the batch: device tensor [F][n0]."""
+        from .features import mcep_device
+        return mcep_device(self.rt, self.spectrogram, n0, self.fs, lowhz, highhz)
 
     def to_dicts(self):
         """List of per-utterance dicts with the reference's keys and (bins, frames) layouts."""
@@ -154,6 +223,34 @@ class WorldBatch:
     def encode(self, xs, fs, **kw):
         batch, x_d, tp_d = self.upload(xs, fs, kw.get('frame_period', 5))
         return self.encode_device(batch, x_d, tp_d, fs, **kw)
+
+    @_on_lane_stream
+    def upload_pcm16(self, pcm_list, fs, frame_period=5):
+        """upload() for 16-bit PCM (what scipy.io.wavfile.read returns): the int16 samples cross PCIe (a quarter of
+        the float64 bytes) and are scaled on the device like the reference's callers do, x = pcm / (2**15 - 1)
+        (example/prosody.py:13).  Returns (batch, x_d, tp_d)."""
+        rt = self.rt
+        pcm_list = [np.ascontiguousarray(p, dtype=np.int16) for p in pcm_list]
+        lens = [len(p) for p in pcm_list]
+        nfs = [_tables.frame_count(n, fs, frame_period) for n in lens]
+        batch = rt.make_batch(np.concatenate([[0], np.cumsum(lens)]), np.concatenate([[0], np.cumsum(nfs)]))
+        pcm_d = rt.torch.from_numpy(np.concatenate(pcm_list)).to(rt.device)
+        x_d = rt.empty((int(sum(lens)),))
+        _hip.check(rt.lib.wh_pcm16_to_f64(rt.ctx, rt.stream(), rt.ptr(pcm_d), int(sum(lens)), rt.ptr(x_d)))
+        tp_h = np.concatenate([_tables.frame_times(n, frame_period) for n in nfs])
+        tp_d = rt.to_device(tp_h)
+        batch.tp_d, batch.tp_host = tp_d, tp_h
+        return batch, x_d, tp_d
+
+    @_on_lane_stream
+    def to_pcm16(self, y, y_off):
+        """List of per-utterance int16 arrays from decode_device's output, (y * 2**15).astype(int16) evaluated on the
+        device (example/prosody.py:57): a quarter of the float64 bytes come back over PCIe."""
+        rt = self.rt
+        pcm_d = rt.empty((int(y.shape[0]),), dtype=rt.torch.int16)
+        _hip.check(rt.lib.wh_f64_to_pcm16(rt.ctx, rt.stream(), rt.ptr(y), int(y.shape[0]), rt.ptr(pcm_d)))
+        pcm = pcm_d.cpu().numpy()
+        return [pcm[int(y_off[u]):int(y_off[u + 1])].copy() for u in range(len(y_off) - 1)]
 
     @_on_lane_stream
     def decode_device(self, enc, noise=None, seed=0, pulse_cap=None, seeds=None, cursor=None, check=True):

@@ -1,8 +1,9 @@
 """`World` facade: the class, method names, argument order / defaults and result-dict keys of the reference's
 world/main.py:26-214, with every stage running on the MI355X through libworld_hip.so.
 
-Only the analysis/synthesis path is provided: the reference's feature helpers (mel filterbank,
-MCEP, VAE glue, draw) sit downstream of encode/decode and are not part of this build.
+The analysis/synthesis path and the spectral feature heads that follow encode() (mel filterbank energies, mel-cepstrum
+and its inverse, context stacking: world/features.py) are provided; the reference's plotting and Keras/VAE glue
+(draw, encode_vae) are not part of this build.
 """
 import logging
 
@@ -11,6 +12,7 @@ import numpy as np
 from . import cheaptrick as _ct
 from . import d4c as _d4c
 from . import d4cRequiem as _d4cr
+from . import features as _feat
 from . import dio as _dio
 from . import get_seeds_signals as _seeds
 from . import harvest as _hv
@@ -116,16 +118,7 @@ class World(object):
         if not dats:
             return dats
         wb = WorldBatch()
-        rt = wb.rt
-        nfs = [len(d['f0']) for d in dats]
-        frame_off = np.concatenate([[0], np.cumsum(nfs)])
-        batch = rt.make_batch(np.zeros(len(dats) + 1, dtype=np.int64), frame_off)
-        cat = lambda key: rt.to_device(np.concatenate([np.asarray(d[key], dtype=np.float64) for d in dats]))  # noqa: E731
-        rows = lambda key: rt.to_device(np.concatenate([np.asarray(d[key], dtype=np.float64).T for d in dats]))  # noqa: E731
-        tp_h = np.concatenate([np.asarray(d['temporal_positions'], dtype=np.float64) for d in dats])
-        fft_size = (dats[0]['spectrogram'].shape[0] - 1) * 2
-        enc = BatchEncoding(rt, batch, dats[0]['fs'], rt.to_device(tp_h), cat('f0'), cat('vuv'), rows('spectrogram'),
-                            rows('aperiodicity'), fft_size, bool(dats[0]['is_requiem']), None, tp_host=tp_h)
+        enc = BatchEncoding.from_dicts(wb.rt, dats)
         y, y_off = wb.decode_device(enc, **kw)
         y = y.cpu().numpy()
         for u, d in enumerate(dats):
@@ -165,6 +158,28 @@ class World(object):
         warped = np.stack([np.interp(axis ** factor, axis, column) for column in spec.T], axis=1)
         spec[:] = warped
         return dat
+
+    # ---- spectral feature heads (world/main.py:257-365; world/features.py) ----------------------------------------
+    def hz2mel(self, hz):
+        return _feat.hz2mel(hz)
+
+    def mel2hz(self, mel):
+        return _feat.mel2hz(mel)
+
+    def get_filterbanks(self, nfilt=20, nfft=512, samplerate=16000, lowfreq=0, highfreq=None):
+        return _feat.get_filterbanks(nfilt, nfft, samplerate, lowfreq, highfreq)
+
+    def encode_lfbank(self, spec, prefac=0.97, fs=16000, nfilt=32, lowfreq=0, highfreq=None):
+        return _feat.encode_lfbank(spec, prefac, fs, nfilt, lowfreq, highfreq)
+
+    def encode_mcep(self, spec, n0=12, fs=16000, lowhz=0, highhz=8000):
+        return _feat.encode_mcep(spec, n0, fs, lowhz, highhz)
+
+    def decode_mcep(self, cepstrum, fft_size):
+        return _feat.decode_mcep(cepstrum, fft_size)
+
+    def get_context(self, X, w=5):
+        return _feat.get_context(X, w)
 
     # ---- synthesis ----------------------------------------------------------------------------------------------
     def decode(self, dat):

@@ -218,6 +218,64 @@ def getters_fixture():
     print("getters written", {k: getattr(v, "shape", v) for k, v in out.items() if k.endswith("shape") or k.endswith("keys")})
 
 
+def modifiers_fixture():
+    """World.warp_spectrum / modify_duration (world/main.py:180-196) on the 16 kHz fixture's encode() tensors, then
+    the seeded pulse-wise decode of the result."""
+    g = np.load(os.path.join(HERE, "golden_syn16k.npz"))
+    fs = int(g["fs"])
+    W = R.main.World()
+    dat = {"f0": g["d4c_f0_after"].copy(), "vuv": g["dio_vuv"].copy(), "temporal_positions": g["tp"].copy(),
+           "spectrogram": g["ct_spectrogram"].copy(), "aperiodicity": g["d4c_aperiodicity"].copy(), "fs": fs,
+           "is_requiem": False}
+    out = {"fs": fs, "seed": SEED}
+    W.warp_spectrum(dat, 1.1)
+    out["warp_1p1_cols"] = dat["spectrogram"][:, ::30].copy()
+    out["warp_1p1_colsum"] = dat["spectrogram"].sum(axis=0)
+    out["warp_1p1_rowsum"] = dat["spectrogram"].sum(axis=1)
+    W.warp_spectrum(dat, 0.9)  # applied on top of the first warp, in place
+    out["warp_then_0p9_colsum"] = dat["spectrogram"].sum(axis=0)
+    from_time, to_time = [0.3, 0.7], [0.0, 0.4, 1.0, -1]
+    out["from_time"] = np.array(from_time)
+    out["to_time"] = np.array(to_time, dtype=np.float64)
+    assert W.modify_duration(dat, from_time, list(to_time)) is None
+    out["moddur_tp"] = dat["temporal_positions"].copy()
+    np.random.seed(SEED)
+    y = W.decode(dat)["out"]
+    out["y_len"] = len(y)
+    out["y_head"] = y[:4096].copy()
+    out["y_tail"] = y[-4096:].copy()
+    out["y_blocksum"] = np.add.reduceat(y, np.arange(0, len(y), 256))
+    np.savez_compressed(os.path.join(HERE, "golden_modifiers.npz"), **out)
+    print("modifiers written", len(y))
+
+
+def heads_fixture():
+    """Spectral feature heads of the reference (world/main.py:275-365) on the 16 kHz fixture's CheapTrick
+    spectrogram, used the way test/spectralFeatures.py:27-50 uses them (frames x bins)."""
+    g = np.load(os.path.join(HERE, "golden_syn16k.npz"))
+    spec = np.ascontiguousarray(g["ct_spectrogram"].T)
+    W = R.main.World()
+    out = {"fs": 16000}
+    out["fbank_20_512"] = W.get_filterbanks()
+    out["fbank_32_1024_rowsum"] = W.get_filterbanks(32, 1024, 16000).sum(axis=1)
+    lf = W.encode_lfbank(spec)
+    out["lfbank"] = lf
+    out["lfbank_24_hi6k"] = W.encode_lfbank(spec, prefac=0.9, nfilt=24, lowfreq=100, highfreq=6000)
+    mc = W.encode_mcep(spec)
+    out["mcep"] = mc
+    out["mcep_20"] = W.encode_mcep(spec, n0=20)
+    dec = W.decode_mcep(mc, 1024)
+    out["imcep_rows"] = dec[::40].copy()
+    out["imcep_colsum"] = dec.sum(axis=0)
+    out["imcep_rowsum"] = dec.sum(axis=1)
+    ctx = W.get_context(lf, w=5)
+    out["context_shape"] = np.array(ctx.shape)
+    out["context_rows"] = ctx[[0, 1, 4, 5, 120, 235, 236, 240]].copy()
+    out["context_w2_rowsum"] = W.get_context(mc, w=2).sum(axis=1)
+    np.savez_compressed(os.path.join(HERE, "golden_heads.npz"), **out)
+    print("heads written", lf.shape, mc.shape, dec.shape, ctx.shape)
+
+
 def longform_fixture():
     """BASELINE config 5's long-form case: the reference's Harvest over one 60 s utterance at 48 kHz (12 001 frames,
     60 001 1 ms frames) — f0 / vuv only (200 KB); the dense tensors of that length are checked through the oracle."""
@@ -239,3 +297,6 @@ if __name__ == "__main__":
     tables_fixture()
     mwm_fixture()
     getters_fixture()
+    heads_fixture()
+    modifiers_fixture()
+    longform_fixture()

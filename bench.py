@@ -420,16 +420,9 @@ def make_step(args, wl, fs):
                     e.scale_pitch(1.5).scale_duration(2.0)
             return wl.decode_device(encs, seed=seed)
     else:
-        import random
-
-        from world.get_seeds_signals import get_seeds_signals
-        random.seed(0)
-        np.random.seed(0)
-        seeds = get_seeds_signals(fs)
-
         def step(seed):
             encs = wl.encode_device(fs, stagger=not args.no_stagger, f0_method="harvest", is_requiem=True)
-            return wl.decode_device(encs, seeds=seeds)
+            return wl.decode_device(encs)  # seed tables: generated on the device once (wh_requiem_seeds), resident
     return step
 
 
@@ -495,22 +488,15 @@ def with_transfers_block(torch, wl, xs, fs, steps=5):
 
 def north_star_block(torch, device_index, xs_distinct, fs, args, steps=3):
     """BASELINE.json north_star on ONE GPU: 1024 x 10 s at 16 kHz, encode(harvest, is_requiem=True) + Requiem decode."""
-    import random
-
     from world.batch import WorldBatch
-    from world.get_seeds_signals import get_seeds_signals
 
     n = args.north_star_utts
     xs = [xs_distinct[i % len(xs_distinct)] for i in range(n)]
     wb = WorldBatch(device_index)
     batch, x_d, tp_d = wb.upload(xs, fs)
-    random.seed(0)
-    np.random.seed(0)
-    seeds = get_seeds_signals(fs)
-
     def one():
         enc = wb.encode_device(batch, x_d, tp_d, fs, f0_method="harvest", is_requiem=True, check=False)
-        return wb.decode_device(enc, seeds=seeds, check=False)
+        return wb.decode_device(enc, check=False)  # device-generated seed tables
 
     one()
     torch.cuda.synchronize()

@@ -202,6 +202,18 @@ int wh_feature_matmul(wh_ctx* ctx, void* stream, const double* a, int64_t n_rows
 /* get_context (main.py:360-365): out[i][j*d + c] = x[clamp(i + j - w, 0, n_rows-1)][c], j = 0..2w.  DEVICE pointers. */
 int wh_context_frames(wh_ctx* ctx, void* stream, const double* x, int64_t n_rows, int d, int w, double* out);
 
+/* ---- Requiem seed signals on the device: replaces get_seeds_signals()  (world/get_seeds_signals.py:8-73) --------- */
+/* pulse_seed[fft_size][n_bands] (DEVICE): the band pulses, deterministic, equal to the reference's up to rounding.
+ * noise_seed[noise_length][n_bands] (DEVICE): modified velvet noise (segments of the reference's three short periods
+ * chosen at random, one +-2 impulse per 4-sample cell at a random offset, signs balanced per segment in random
+ * order) circularly convolved with each band pulse.  The randomness comes from a Philox-4x32-10 stream keyed by
+ * `seed` instead of Python's `random` / NumPy's global generator: same construction and statistics, not the same
+ * samples.  velvet_out (optional, may be NULL): the velvet noise itself [noise_length].
+ * n_bands = wh_d4c_bands(fs, 1) + 2; fft_size / noise_length: the reference defaults are
+ * 1024 * 2^ceil(log2(fs/48000)) and 2^ceil(log2(fs/2)). */
+int wh_requiem_seeds(wh_ctx* ctx, void* stream, double fs, int fft_size, int64_t noise_length, int n_bands, uint64_t seed,
+                     double* pulse_seed, double* noise_seed, double* velvet_out);
+
 /* ---- Modifiers on a resident encoding: replace World.warp_spectrum / modify_duration  (world/main.py:180-196) ---- */
 /* warp_spectrum: spectrogram[n_frames][k_bins] (DEVICE, in place): frame <- np.interp((k/K)^factor, k/K, frame).  The
  * query points are the same for every frame, so the host runs NumPy's search once per bin and passes (HOST tables)

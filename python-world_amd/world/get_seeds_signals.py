@@ -71,3 +71,29 @@ def get_seeds_signals(fs: int, fft_size: int = None, noise_length: int = None):
     window = hann(fft_size + 2)[1:-1]
     pulse[:, 0] = pulse[:, 0] - np.mean(pulse[:, 0]) * window / np.mean(window)  # DC-free lowest band
     return {'pulse': pulse, 'noise': noise}
+
+
+def get_seeds_signals_device(fs, seed=0, fft_size=None, noise_length=None, device_index=None, want_velvet=False):
+    """The same tables generated ON the device (wh_requiem_seeds): {'pulse_d', 'noise_d'} torch tensors that
+    WorldBatch.decode_device(..., seeds=...) uses in place — no host RNG, no upload.  The pulses are the exact
+    deterministic ones; the velvet noise follows the reference's construction with a counter-based Philox stream
+    ``seed`` (statistically equivalent, not sample-identical: tests/test_hip_seeds.py)."""
+    import ctypes
+
+    from . import _hip
+
+    rt = _hip.Runtime.get(device_index)
+    if fft_size is None:
+        fft_size = int(1024 * (2 ** np.ceil(np.log2(fs / 48000))))
+    if noise_length is None:
+        noise_length = int(2 ** np.ceil(np.log2(fs / 2)))
+    nb = int(2 + np.floor(min(_UPPER, fs / 2 - _BAND_STEP) / _BAND_STEP))
+    pulse_d = rt.empty((int(fft_size), nb))
+    noise_d = rt.empty((int(noise_length), nb))
+    velvet_d = rt.empty((int(noise_length),)) if want_velvet else None
+    _hip.check(rt.lib.wh_requiem_seeds(rt.ctx, rt.stream(), float(fs), int(fft_size), int(noise_length), nb,
+                                       ctypes.c_uint64(int(seed)), rt.ptr(pulse_d), rt.ptr(noise_d), rt.ptr(velvet_d)))
+    out = {'pulse_d': pulse_d, 'noise_d': noise_d}
+    if want_velvet:
+        out['velvet_d'] = velvet_d
+    return out

@@ -74,19 +74,20 @@ def synthesis_requiem_core(rt, batch, tp_d, f0_d, vuv_d, spec_d, band_d, fs, fft
     return y, y_off
 
 
-_default_seeds = {}  # fs -> seeds dict built once (the batched path's default when the caller passes none)
+_default_seeds = {}  # (fs, device) -> device-resident seed tables (the batched path's default when the caller passes none)
 
 
 def synthesis_requiem_device(rt, enc, ny, geo, seeds=None, cursor=None, pulse_cap=None):
     """Batch decode of a BatchEncoding (is_requiem=True).  Utterances consume the noise seed one after the
     other exactly like consecutive reference calls sharing the persistent cursor (world/synthesisRequiem.py:131-141,
     world/main.py:205-206); ``cursor`` (nb,) is the position the first utterance starts at (default zeros)."""
-    from .get_seeds_signals import get_seeds_signals
+    from .get_seeds_signals import get_seeds_signals_device
 
-    if seeds is None:
-        seeds = _default_seeds.get(enc.fs)
+    if seeds is None:  # default of the batched path: tables generated on the device, once per (fs, device)
+        key = (enc.fs, rt.index)
+        seeds = _default_seeds.get(key)
         if seeds is None:
-            seeds = _default_seeds[enc.fs] = get_seeds_signals(enc.fs)
+            seeds = _default_seeds[key] = get_seeds_signals_device(enc.fs, seed=0, device_index=rt.index)
     _, _, pshape, nshape = seeds_on_device(rt, seeds)
     nb = int(pshape[1])
     nlen = int(nshape[0])

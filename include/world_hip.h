@@ -193,7 +193,8 @@ int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b, const dou
  *     out[f][n] = epi( sum_{k<ka} pro(a[f*lda + k], k) * h_w[k*nw + n] ),   f < n_rows, n < nw;  out row stride ldo
  *   prologue 0: pro(v) = v;  1: pro(v, k) = pscale * (v * h_p[k])^2  (encode_lfbank: pre-emphasis |H(k)| and
  *   1/nfft power, main.py:313-316);  2: pro(v) = log(v)  (encode_mcep, main.py:333)
- *   epilogue 0: none;  1: log with 0 -> DBL_EPSILON (main.py:321-322);  2: exp (decode_mcep, main.py:358)
+ *   epilogue 0: none;  1: log with 0 -> DBL_EPSILON (main.py:321-322);  2: exp (decode_mcep, main.py:358);
+ *   3: sqrt(max(0, v)) (SWIPE' loudness, swipe.py:42-44)
  * a / out: DEVICE, frame-major (wh_cheaptrick's spectrogram layout).  h_w[ka][nw] and h_p[ka] are HOST tables: the mel
  * filterbank transposed (get_filterbanks, main.py:275-303), or the cosine rows of the inverse / forward real FFT with
  * the mel warp of main.py:335-337 / 351-356 folded in — built by the host with the reference's own expressions. */
@@ -201,6 +202,26 @@ int wh_feature_matmul(wh_ctx* ctx, void* stream, const double* a, int64_t n_rows
                       const double* h_p, double pscale, const double* h_w, int nw, int epilogue, double* out, int64_t ldo);
 /* get_context (main.py:360-365): out[i][j*d + c] = x[clamp(i + j - w, 0, n_rows-1)][c], j = 0..2w.  DEVICE pointers. */
 int wh_context_frames(wh_ctx* ctx, void* stream, const double* x, int64_t n_rows, int d, int w, double* out);
+
+/* ---- SWIPE': replaces swipe()  (world/swipe.py:9-105; f0_method='swipe', world/main.py:45-46,134-135) ---------- */
+/* One entry of the window-size table (HOST): candidates [j0, j0+n_c) of the candidate set use window size ws with
+ * hop `hop` (= ws - noverlap of the reference's specgram call, swipe.py:35-38). */
+typedef struct wh_swipe_window {
+  int32_t ws, hop;          /* window length (power of two in [64, 4096]), hop in samples */
+  int32_t j0, n_c;
+  const double* h_window;   /* [ws]               np.hanning(ws + 2)[1:-1] */
+  const double* h_interp;   /* [ws/2+1][n_erb]    magnitude bins -> ERB grid: interp1d(kind='cubic') as a matrix, k-major */
+  const double* h_kernels;  /* [n_erb][n_c]       candidate kernels (pitchStrengthOneCandidate, swipe.py:127-146), k-major */
+  const double* h_mu;       /* [n_c]              window-size membership weights (swipe.py:62-66) */
+} wh_swipe_window;
+/* x: concatenated waveforms (DEVICE); the batch's frame grid is the output grid t = arange(nf) * dt with
+ * nf = int(1000*n/fs/(dt*1000) + 1).  HOST tables: h_pc[n_cand] candidate pitches, h_win[n_win], and for the parabolic
+ * refinement of a maximum at candidate j (swipe.py:83-100): h_ntc[j][3] = normalised periods of candidates j-1..j+1,
+ * h_fine[j][fine_stride] / h_n_fine[j] = the 1/768-octave evaluation grid (fine_stride must be 20).
+ * s_thr: pitch-strength threshold (frames below it are unvoiced, f0 = 0).  Outputs f0_out / vuv_out [total_frames]. */
+int wh_swipe(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, double fs, double dt, double s_thr, int n_cand,
+             const double* h_pc, int n_erb, int n_win, const wh_swipe_window* h_win, const double* h_ntc,
+             const double* h_fine, const int32_t* h_n_fine, int fine_stride, double* f0_out, double* vuv_out);
 
 /* ---- Requiem seed signals on the device: replaces get_seeds_signals()  (world/get_seeds_signals.py:8-73) --------- */
 /* pulse_seed[fft_size][n_bands] (DEVICE): the band pulses, deterministic, equal to the reference's up to rounding.

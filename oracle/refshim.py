@@ -41,6 +41,7 @@ def install(reference_root: str = REFERENCE_ROOT):
         nb.float64 = _Sig()
         nb.int64 = _Sig()
         sys.modules["numba"] = nb
+    import numpy.matlib  # noqa: F401 — world/swipe.py uses np.matlib without importing it
     if not hasattr(np, "int"):
         np.int = int  # removed alias used by the reference
     if not hasattr(scipy.signal, "hanning"):
@@ -62,6 +63,6 @@ def load():
 
     mods = {}
     for name in ("dio", "stonemask", "harvest", "cheaptrick", "d4c", "d4cRequiem", "synthesis",
-                 "synthesisRequiem", "get_seeds_signals", "main"):
+                 "synthesisRequiem", "get_seeds_signals", "swipe", "main"):
         mods[name] = importlib.import_module("world." + name)
     return types.SimpleNamespace(**mods)

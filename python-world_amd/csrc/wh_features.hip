@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void feature_matmul_kernel(const double* __res
           double v = acc[t][r];
           if (EPI == 1) v = log(v == 0.0 ? 2.220446049250313e-16 : v);  // np.where(feat == 0, eps, feat); np.log
           else if (EPI == 2) v = exp(v);
+          else if (EPI == 3) v = sqrt(fmax(0.0, v));  // SWIPE' loudness: np.sqrt(np.maximum(0, .)) (swipe.py:42-44)
           out[f * ldo + n] = v;
         }
       }
@@ -111,7 +112,8 @@ int launch_epi(int epi, dim3 grid, hipStream_t st, const double* A, long long n_
     case 0: hipLaunchKernelGGL((feature_matmul_kernel<PRO, 0>), grid, dim3(256), 0, st, A, n_rows, ka, lda, P, pscale, W, kpad, npad, nw, out, ldo); break;
     case 1: hipLaunchKernelGGL((feature_matmul_kernel<PRO, 1>), grid, dim3(256), 0, st, A, n_rows, ka, lda, P, pscale, W, kpad, npad, nw, out, ldo); break;
     case 2: hipLaunchKernelGGL((feature_matmul_kernel<PRO, 2>), grid, dim3(256), 0, st, A, n_rows, ka, lda, P, pscale, W, kpad, npad, nw, out, ldo); break;
-    default: return wh::fail_msg("wh_feature_matmul", "epilogue must be 0 (none), 1 (log) or 2 (exp)");
+    case 3: hipLaunchKernelGGL((feature_matmul_kernel<PRO, 3>), grid, dim3(256), 0, st, A, n_rows, ka, lda, P, pscale, W, kpad, npad, nw, out, ldo); break;
+    default: return wh::fail_msg("wh_feature_matmul", "epilogue must be 0 (none), 1 (log), 2 (exp) or 3 (sqrt of the positive part)");
   }
   return 0;
 }
@@ -134,7 +136,7 @@ extern "C" int wh_feature_matmul(wh_ctx* ctx, void* stream, const double* a, int
     for (int n = 0; n < nw; ++n) wp[(size_t)k * npad + n] = h_w[(size_t)k * nw + n];
   double* d_w = nullptr;
   double* d_p = nullptr;
-  if (int rc = wh::persistent_upload(ctx, st, "feat.w." + std::to_string(prologue) + std::to_string(epilogue), wp, &d_w)) return rc;
+  if (int rc = wh::persistent_upload(ctx, st, "feat.w." + std::to_string(prologue) + std::to_string(epilogue) + "." + std::to_string(ka) + "x" + std::to_string(nw), wp, &d_w)) return rc;
   if (prologue == 1) {
     std::vector<double> pv(h_p, h_p + ka);
     if (int rc = wh::persistent_upload(ctx, st, "feat.p", pv, &d_p)) return rc;

@@ -63,6 +63,7 @@ SIGNATURES = {
     "wh_modify_duration": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
     "wh_pcm16_to_f64": (_int, [_vp, _vp, _vp, ctypes.c_int64, _vp]),
     "wh_f64_to_pcm16": (_int, [_vp, _vp, _vp, ctypes.c_int64, _vp]),
+    "wh_swipe": (_int, [_vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _int, _vp, _int, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp]),
     "wh_requiem_seeds": (_int, [_vp, _vp, _dbl, _int, ctypes.c_int64, _int, ctypes.c_uint64, _vp, _vp, _vp]),
 }
 

@@ -199,6 +199,9 @@ class WorldBatch:
         elif f0_method == 'harvest':
             from .harvest import harvest_device
             f0_d, vuv_d = harvest_device(rt, batch, x_d, tp_d, fs, f0_floor, f0_ceil, frame_period)
+        elif f0_method == 'swipe':
+            from .swipe import swipe_device
+            f0_d, vuv_d = swipe_device(rt, batch, x_d, fs, (f0_floor, f0_ceil), frame_period / 1000, 0.3)  # main.py:134-135
         else:
             raise Exception
         if f0_done is not None:

@@ -249,6 +249,35 @@ def modifiers_fixture():
     print("modifiers written", len(y))
 
 
+def swipe_fixture():
+    """SWIPE' (world/swipe.py:9-105) as World.encode calls it (plim = [f0_floor, f0_ceil], sTHR = 0.3) on the synthetic
+    utterances and the reference's own test wav, plus one call without a threshold."""
+    from scipy.io import wavfile
+
+    out = {}
+    for tag, fs, u, sec in (("16k", 16000, 0, 1.2), ("48k", 48000, 5, 0.5), ("22k", 22050, 7, 0.8)):
+        x = _syn.synth_utterance(u, fs, sec)
+        r = R.swipe.swipe(fs, x, [71, 800], 0.005, 0.3)
+        out["f0_" + tag] = r["f0"]
+        out["vuv_" + tag] = r["vuv"]
+        out["tp_" + tag] = r["temporal_positions"]
+        out["args_" + tag] = np.array([fs, u, sec])
+    x = _syn.synth_utterance(0, 16000, 1.2)
+    out["f0_16k_nothr"] = R.swipe.swipe(16000, x, [71, 800], 0.005)["f0"]
+    fs, xi = wavfile.read(os.path.join(refshim.REFERENCE_ROOT, "test", "test-mwm.wav"))
+    r = R.swipe.swipe(fs, xi / (2 ** 15 - 1), [71, 800], 0.005, 0.3)
+    out["f0_mwm"] = r["f0"]
+    out["vuv_mwm"] = r["vuv"]
+    # through the facade: encode(f0_method='swipe') — f0 after CheapTrick / D4C, spectrogram column sums
+    dat = R.main.World().encode(16000, x, f0_method="swipe")
+    out["enc_f0"] = dat["f0"]
+    out["enc_vuv"] = dat["vuv"]
+    out["enc_spec_colsum"] = dat["spectrogram"].sum(axis=0)
+    out["enc_ap_colsum"] = dat["aperiodicity"].sum(axis=0)
+    np.savez_compressed(os.path.join(HERE, "golden_swipe.npz"), **out)
+    print("swipe written", {k: int(v.sum()) for k, v in out.items() if k.startswith("vuv")})
+
+
 def heads_fixture():
     """Spectral feature heads of the reference (world/main.py:275-365) on the 16 kHz fixture's CheapTrick
     spectrogram, used the way test/spectralFeatures.py:27-50 uses them (frames x bins)."""
@@ -298,5 +327,6 @@ if __name__ == "__main__":
     mwm_fixture()
     getters_fixture()
     heads_fixture()
+    swipe_fixture()
     modifiers_fixture()
     longform_fixture()

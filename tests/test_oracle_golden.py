@@ -158,3 +158,16 @@ def test_getters_fixture_pins_oracle(golden):
     assert rel_rms(sp2.sum(axis=0), g["gvn_spec_colsum"]) < 1e-10
     assert rel_rms(ap.sum(axis=0), g["gvn_ap_colsum"]) < 1e-9
     assert np.max(np.abs(coarse - g["gvn_coarse"])) < 1e-8
+
+
+@pytest.mark.parametrize("tag", ["16k", "48k", "22k"])
+def test_swipe_oracle_vs_reference(golden, tag):
+    """oracle/pitch_swipe.py against the reference's swipe() output (world/swipe.py:9-105)."""
+    from oracle import pitch_swipe
+    from world._synthetic import synth_utterance
+
+    g = golden("swipe")
+    fs, u, sec = g["args_" + tag]
+    r = pitch_swipe.swipe_np(int(fs), synth_utterance(int(u), int(fs), float(sec)), [71, 800], 0.005, 0.3)
+    assert np.array_equal(r["vuv"], g["vuv_" + tag])
+    assert np.array_equal(r["f0"], g["f0_" + tag])

@@ -206,4 +206,147 @@ inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Overlap-save form of the same filter bank (Harvest: 152 channels of 41-493 taps on every sample).
+//
+// The reference filters by FFT products over the whole utterance (world/harvest.py:262-266); the direct sums above
+// cost 26 750 FMAs per sample at 8 kHz.  Here the signal is cut into tiles of kOlsValid outputs; one forward real
+// FFT of kOlsN = 4096 samples per (utterance, tile) is shared by all channels (band_tile_fft_kernel, the block starts
+// H = max half-length before the tile so that one block serves every channel's delay), and per channel a tile costs a
+// spectrum product and one inverse real FFT (2048-point complex, four radix-8/4 passes in LDS): ~34 flops per output
+// and channel instead of 82-986.  A workgroup walks the tiles of kOlsBands channels of one utterance; the tile's
+// spectrum is fetched once into registers and reused for its channels.  The inverse transform is left unnormalised:
+// the crossing detector only looks at signs and ratios.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef WH_OLS_MINW
+#define WH_OLS_MINW 3  // waves per SIMD the channel walker's register allocation leaves room for
+#endif
+constexpr int kOlsN = 4096;
+constexpr int kOlsValid = 3072;  // three kBandTile sub-tiles per block (+2 look-ahead samples)
+constexpr int kOlsBands = 4;
+
+// T_b = rfft(taps_b zero-padded to kOlsN): [nb][kOlsN/2+1] complex
+static __global__ __launch_bounds__(256) void band_taps_fft_kernel(const double* __restrict__ taps_all,
+                                                                   const int32_t* __restrict__ tap_off,
+                                                                   const int32_t* __restrict__ tap_len,
+                                                                   const double2* __restrict__ tw_base,
+                                                                   double2* __restrict__ tspec) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* buf = reinterpret_cast<double*>(smem);
+  const int b = blockIdx.x;
+  const int lb = tap_len[b];
+  for (int i = threadIdx.x; i < kOlsN; i += 256) buf[i] = i < lb ? taps_all[tap_off[b] + i] : 0.0;
+  __syncthreads();
+  rfft_lds<kOlsN, 256>(reinterpret_cast<double2*>(buf), tw_base);
+  const double2* z = reinterpret_cast<const double2*>(buf);
+  for (int k = threadIdx.x; k <= kOlsN / 2; k += 256) tspec[(int64_t)b * (kOlsN / 2 + 1) + k] = z[k];
+}
+
+// Z_{u,tile} = rfft(z_u[t0 - H .. t0 - H + kOlsN)), t0 = tile * kOlsValid (samples outside the padded signal are 0)
+static __global__ __launch_bounds__(256) void band_tile_fft_kernel(const BandJob* __restrict__ jobs, int nb, int pad, int H,
+                                                                   const int64_t* __restrict__ tile_off,
+                                                                   const double2* __restrict__ tw_base,
+                                                                   double2* __restrict__ zspec) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* buf = reinterpret_cast<double*>(smem);
+  const int u = blockIdx.y;
+  const BandJob job = jobs[(int64_t)u * nb];  // z and M are the same for every band of the utterance
+  const int64_t tiles = (job.M + kOlsValid - 1) / kOlsValid;
+  if ((int64_t)blockIdx.x >= tiles) return;
+  const int64_t first = (int64_t)blockIdx.x * kOlsValid - H;
+  for (int i = threadIdx.x; i < kOlsN; i += 256) {
+    const int64_t j = first + i + pad;
+    buf[i] = (j >= 0 && j < job.M + 2 * pad) ? job.z[j] : 0.0;
+  }
+  __syncthreads();
+  rfft_lds<kOlsN, 256>(reinterpret_cast<double2*>(buf), tw_base);
+  const double2* z = reinterpret_cast<const double2*>(buf);
+  double2* out = zspec + (tile_off[u] + blockIdx.x) * (kOlsN / 2 + 1);
+  for (int k = threadIdx.x; k <= kOlsN / 2; k += 256) out[k] = z[k];
+}
+
+static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kernel(const BandJob* __restrict__ jobs, int nb, int H,
+                                                                     const int32_t* __restrict__ half,
+                                                                     const double2* __restrict__ tspec,
+                                                                     const double2* __restrict__ zspec,
+                                                                     const int64_t* __restrict__ tile_off,
+                                                                     const double2* __restrict__ tw_base,
+                                                                     int32_t* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = kOlsN / 2 + 1;           // 2049 spectrum bins
+  constexpr int PER = (KS + 255) / 256;       // 9 per thread
+  double2* ybuf = reinterpret_cast<double2*>(smem);
+  double* sig_all = reinterpret_cast<double*>(smem);
+  unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(ybuf + KS + 1);  // 8
+  const int u = blockIdx.y;
+  const int b0 = blockIdx.x * kOlsBands;
+  const BandJob job0 = jobs[(int64_t)u * nb + b0];
+  const int64_t M = job0.M;
+  const int64_t tiles = (M + kOlsValid - 1) / kOlsValid;
+  // running counts of the four crossing trains of each channel: kept in LDS between tiles so that the channel loop
+  // stays a real loop (unrolled, its four inlined inverse transforms and twelve crossing passes share one register
+  // allocation: 256 VGPRs + AGPRs)
+  __shared__ int s_cnt[kOlsBands][4];
+  if (threadIdx.x < kOlsBands * 4) s_cnt[threadIdx.x >> 2][threadIdx.x & 3] = 0;
+  __syncthreads();
+#pragma unroll 1
+  for (int64_t tile = 0; tile < tiles; ++tile) {
+    const int64_t t0 = tile * kOlsValid;
+    double2 zr[PER];
+    const double2* zs = zspec + (tile_off[u] + tile) * KS;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int k = threadIdx.x + q * 256;
+      zr[q] = k < KS ? zs[k] : make_double2(0.0, 0.0);
+    }
+#pragma unroll 1
+    for (int g = 0; g < kOlsBands; ++g) {
+      const int b = b0 + g;
+      if (b >= nb) break;
+      const BandJob job = jobs[(int64_t)u * nb + b];
+      const double2* ts = tspec + (int64_t)b * KS;
+      __syncthreads();  // the previous channel's crossings have been read out of the buffer
+      int base_cnt[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) base_cnt[t] = s_cnt[g][t];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int k = threadIdx.x + q * 256;
+        if (k < KS) ybuf[k] = cmul(zr[q], ts[k]);
+      }
+      __syncthreads();
+      irfft_lds<kOlsN, 256>(ybuf, tw_base);
+      // output i of the block is s[t0 + i - (H + h + 1)]: the tile's outputs start at index H + h + 1
+      const double* sig = sig_all + (H + half[b] + 1);
+#pragma unroll 1
+      for (int sub = 0; sub < kOlsValid / kBandTile; ++sub) {
+        const int64_t ts0 = t0 + (int64_t)sub * kBandTile;
+        if (ts0 >= M) break;
+        if (sub) __syncthreads();
+        emit_crossings(sig + sub * kBandTile, ts0, M, kBandTile, job.edges, job.cap, base_cnt, scan_scratch, flags);
+      }
+      __syncthreads();
+      if (threadIdx.x < 4) s_cnt[g][threadIdx.x] = base_cnt[threadIdx.x];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kOlsBands * 4 && b0 + (threadIdx.x >> 2) < nb)
+    jobs[(int64_t)u * nb + b0 + (threadIdx.x >> 2)].counts[threadIdx.x & 3] = s_cnt[threadIdx.x >> 2][threadIdx.x & 3];
+}
+
+// ws_spec: device scratch of (n_bands + total_tiles) * (kOlsN/2+1) complex; h_tile_off[n_utt+1] tile offsets (HOST).
+inline int launch_band_events_ols(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs, int nb, int n_utt, int pad, int H,
+                                  const double* d_taps, const int32_t* d_tap_off, const int32_t* d_tap_len,
+                                  const int32_t* d_half, const int64_t* d_tile_off, int64_t max_tiles, double2* d_tspec,
+                                  double2* d_zspec, int32_t* d_flag) {
+  const size_t lds_fft = sizeof(double) * (kOlsN + 2);
+  { KernelTimer _kt(ctx, st, "band_taps_fft_kernel"); hipLaunchKernelGGL(band_taps_fft_kernel, dim3(nb), dim3(256), lds_fft, st, d_taps, d_tap_off, d_tap_len, ctx->d_twiddle, d_tspec); }
+  { KernelTimer _kt(ctx, st, "band_tile_fft_kernel"); hipLaunchKernelGGL(band_tile_fft_kernel, dim3((unsigned)max_tiles, n_utt), dim3(256), lds_fft, st, d_jobs, nb, pad, H, d_tile_off, ctx->d_twiddle, d_zspec); }
+  const size_t lds = sizeof(double2) * (kOlsN / 2 + 2) + 64;
+  { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_ols_kernel, dim3((nb + kOlsBands - 1) / kOlsBands, n_utt), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag); }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail("band_events_ols_kernel", e);
+  return 0;
+}
+
 }  // namespace wh

@@ -351,9 +351,7 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   // window phase: 2*common = pi*xw, xw advances by dx per unit step of idx_raw (steps are 1, or 2 where the
   // +-0.5 offset flips sign at negative times)
   const double dx = 2.0 / (fs * wlit);
-  double sd1, cd1, sd2, cd2;
-  sincospi(dx, &sd1, &cd1);
-  sincospi(2 * dx, &sd2, &cd2);
+  double sd1 = 0.0, cd1 = 1.0, sd2 = 0.0, cd2 = 1.0;  // step rotations of the general path (set there)
   double xr[6], xi[6], dr[6], di[6];
 #pragma unroll
   for (int h = 0; h < 6; ++h) xr[h] = xi[h] = dr[h] = di[h] = 0.0;
@@ -452,6 +450,8 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       m_cur = m_next;
     }
   } else {
+    sincospi(dx, &sd1, &cd1);
+    sincospi(2 * dx, &sd2, &cd2);
     for (int j = l16; j < L; j += 16) {
       const double ir = idx_raw_at(j);
       const double xw = 2 * ((ir - 1) / fs - t0) / wlit;
@@ -740,6 +740,24 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t o_pf0 = off; off += al(sizeof(double) * f1_tot * kRows);
   const size_t o_psc = off; off += al(sizeof(double) * f1_tot * kRows);
   const size_t o_ct = off; off += al(contour_workspace_bytes(f1_tot, B));
+  // overlap-save band filters: tile spectra of every utterance + the channels' tap spectra
+  std::vector<int64_t> tile_off(B + 1, 0);
+  int64_t max_tiles = 0;
+  for (int u = 0; u < B; ++u) {
+    const int64_t t = (meta[u].ylen + wh::kOlsValid - 1) / wh::kOlsValid;
+    tile_off[u + 1] = tile_off[u] + t;
+    max_tiles = std::max(max_tiles, t);
+  }
+  int h_max = 0;
+  for (int i = 0; i < n_bands; ++i) h_max = std::max(h_max, (int)h_band_half[i]);
+#ifndef WH_HV_BAND_OLS
+#define WH_HV_BAND_OLS 1
+#endif
+  // the block of kOlsN inputs must cover H + h + 1 + kOlsValid + 2 outputs for every channel
+  const bool use_ols = WH_HV_BAND_OLS && (2 * h_max + 1 + wh::kOlsValid + 2 <= wh::kOlsN) && pad >= h_max + 1;
+  const size_t spec_bins = wh::kOlsN / 2 + 1;
+  const size_t o_tspec = off; off += use_ols ? al(sizeof(double2) * spec_bins * n_bands) : 0;
+  const size_t o_zspec = off; off += use_ols ? al(sizeof(double2) * spec_bins * (size_t)tile_off[B]) : 0;
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
   HvUtt* d_meta = nullptr;
@@ -809,9 +827,18 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   if (dbg_y) WH_CHECK(hipMemcpyAsync(dbg_y, d_y, sizeof(double) * y_tot, hipMemcpyDeviceToDevice, st));
 
   // ---- 152 channels: FIR + crossings, then per-frame raw candidates ------------------------------------
-  if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands, d_ti + 2 * n_bands,
-                                      max_lb, true, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW))
+  if (use_ols) {
+    int64_t* d_tile_off = nullptr;
+    if (int rc = wh::persistent_upload(ctx, st, "hv.tile_off", tile_off, &d_tile_off)) return rc;
+    if (int rc = wh::launch_band_events_ols(ctx, st, d_jobs, n_bands, B, pad, h_max, d_taps, d_ti, d_ti + n_bands,
+                                            d_ti + 2 * n_bands, d_tile_off, max_tiles,
+                                            reinterpret_cast<double2*>(ws + o_tspec), reinterpret_cast<double2*>(ws + o_zspec),
+                                            ctx->d_flags + WH_FLAG_EVENT_OVERFLOW))
+      return rc;
+  } else if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands,
+                                             d_ti + 2 * n_bands, max_lb, true, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW)) {
     return rc;
+  }
   { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B), dim3(256), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw); }
   WH_LAUNCH_CHECK("hv_raw_kernel");
   if (dbg_raw) WH_CHECK(hipMemcpyAsync(dbg_raw, d_raw, sizeof(double) * f1_tot * n_bands, hipMemcpyDeviceToDevice, st));

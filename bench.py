@@ -20,7 +20,8 @@ un-captured pass of the same K steps right after it (events cannot be read back 
 Rank 0 prints ONE JSON line.  On a single GPU it also carries (each timed by this process):
   cpu_baseline   : the NumPy oracle on the host cores (1 core and all cores, median of 3), bounded sample;
   with_transfers : config 2 once more with the H2D of x and the D2H of f0/vuv/spectrogram/aperiodicity/out through
-                   pinned buffers inside the timed region (what a host-buffer caller sees; never `value`);
+                   pinned buffers inside the timed region (what a host-buffer caller sees; never `value`), and
+                   with_transfers_overlapped: the same dealt to 4 lanes so that copies run under kernels;
   north_star     : BASELINE.json's target workload on ONE GPU — 1024 x 10 s, Harvest + CheapTrick + D4C-Requiem
                    encode + Requiem decode (>= 500 xRT asked).
 """
@@ -387,6 +388,7 @@ def main():
         if world == 1 and not args.no_extras and args.config == 2 and args.scaling == "weak":
             del graph
             for key, fn in (("with_transfers", lambda: with_transfers_block(torch, wl, xs, FS)),
+                            ("with_transfers_overlapped", lambda: with_transfers_lanes_block(torch, local_rank, xs, FS)),
                             ("north_star", lambda: north_star_block(torch, local_rank, xs_distinct, FS, args))):
                 try:
                     out[key] = fn()
@@ -484,6 +486,46 @@ def with_transfers_block(torch, wl, xs, fs, steps=5):
             "h2d_MB_per_step": x_pin.numel() * 8 / 1e6, "d2h_MB_per_step": nbytes_d2h / 1e6,
             "note": "config 2 step incl. H2D of x and D2H of f0/vuv/spectrogram/aperiodicity/out via pinned host "
                     "buffers on one stream (no overlap); 'ps spectrogram' is not materialised"}
+
+
+def with_transfers_lanes_block(torch, device_index, xs, fs, lanes=4, steps=5):
+    """The same host-buffer step with the batch dealt to `lanes` sub-batches on private HIP streams: the D2H of one
+    lane's results (PCIe is full duplex and has its own copy engines) runs under the kernels of the next."""
+    from world.batch import WorldBatchLanes
+
+    wl = WorldBatchLanes(device_index, lanes=lanes)
+    wl.upload(xs, fs)
+    parts = wl.split([len(x) for x in xs], lanes)
+    x_pins = [torch.from_numpy(np.concatenate(xs[a:b])).pin_memory() for a, b in parts]
+    pins = [None] * lanes
+
+    def one(seed):
+        for i, (wb, r) in enumerate(zip(wl.lanes, wl.resident)):
+            with wb.rt.on_stream():
+                batch, x_d, tp_d = r
+                x_d.copy_(x_pins[i], non_blocking=True)
+                e = wb.encode_device(batch, x_d, tp_d, fs, f0_method="dio", check=False)
+                yy, _ = wb.decode_device(e, seed=seed, check=False)
+                outs = (e.f0, e.vuv, e.spectrogram, e.aperiodicity, yy)
+                if pins[i] is None:
+                    pins[i] = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in outs]
+                for p, t in zip(pins[i], outs):
+                    p.copy_(t, non_blocking=True)
+
+    one(0)
+    wl.synchronize(check=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one(10 + k)
+    wl.synchronize(check=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    frames = wl.total_frames
+    return {"ms_per_step": dt * 1e3, "value": frames / dt, "unit": "frames/s",
+            "x_realtime": len(xs) * len(xs[0]) / fs / dt, "steps": steps, "lanes": lanes,
+            "note": "the with_transfers step dealt to %d lanes (private streams): one lane's D2H under the next "
+                    "lane's kernels" % lanes}
 
 
 def north_star_block(torch, device_index, xs_distinct, fs, args, steps=3):

@@ -218,6 +218,9 @@ inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs
 // spectrum is fetched once into registers and reused for its channels.  The inverse transform is left unnormalised:
 // the crossing detector only looks at signs and ratios.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef WH_OLS_PREFETCH
+#define WH_OLS_PREFETCH 0
+#endif
 #ifndef WH_OLS_MINW
 #define WH_OLS_MINW 3  // waves per SIMD the channel walker's register allocation leaves room for
 #endif
@@ -299,22 +302,49 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
       const int k = threadIdx.x + q * 256;
       zr[q] = k < KS ? zs[k] : make_double2(0.0, 0.0);
     }
+#if WH_OLS_PREFETCH
+    double2 tr[PER];  // tap spectrum of the channel about to be filtered, fetched under the previous channel's transform
+    {
+      const double2* ts = tspec + (int64_t)b0 * KS;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int k = threadIdx.x + q * 256;
+        tr[q] = k < KS ? ts[k] : make_double2(0.0, 0.0);
+      }
+    }
+#endif
 #pragma unroll 1
     for (int g = 0; g < kOlsBands; ++g) {
       const int b = b0 + g;
       if (b >= nb) break;
       const BandJob job = jobs[(int64_t)u * nb + b];
-      const double2* ts = tspec + (int64_t)b * KS;
       __syncthreads();  // the previous channel's crossings have been read out of the buffer
       int base_cnt[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) base_cnt[t] = s_cnt[g][t];
+#if WH_OLS_PREFETCH
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int k = threadIdx.x + q * 256;
+        if (k < KS) ybuf[k] = cmul(zr[q], tr[q]);
+      }
+      if (g + 1 < kOlsBands && b + 1 < nb) {
+        const double2* tn = tspec + (int64_t)(b + 1) * KS;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          const int k = threadIdx.x + q * 256;
+          tr[q] = k < KS ? tn[k] : make_double2(0.0, 0.0);
+        }
+      }
+#else
+      const double2* ts = tspec + (int64_t)b * KS;
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int k = threadIdx.x + q * 256;
         if (k < KS) ybuf[k] = cmul(zr[q], ts[k]);
       }
-      __syncthreads();
+#endif
+      sync_lds<256>();  // LDS-only: the prefetched tap spectrum may still be in flight
       irfft_lds<kOlsN, 256>(ybuf, tw_base);
       // output i of the block is s[t0 + i - (H + h + 1)]: the tile's outputs start at index H + h + 1
       const double* sig = sig_all + (H + half[b] + 1);
@@ -334,6 +364,89 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
     jobs[(int64_t)u * nb + b0 + (threadIdx.x >> 2)].counts[threadIdx.x & 3] = s_cnt[threadIdx.x >> 2][threadIdx.x & 3];
 }
 
+// Two channels per inverse transform.  The filtered tiles y_a, y_b of two channels are real, so the complex sequence
+// y_a + i*y_b is the inverse DFT of Y_a + i*Y_b (Hermitian extensions): ONE full-size complex inverse FFT (four
+// radix-8 passes, two butterflies per thread) instead of two half-size ones with their extra real-transform pass —
+// half the barrier phases per channel, and the split into the two channels is free (real and imaginary parts).  The
+// crossing detector then reads one component of the interleaved buffer (stride 2).
+static __global__ __launch_bounds__(256, 2) void band_events_ols2_kernel(const BandJob* __restrict__ jobs, int nb, int H,
+                                                                      const int32_t* __restrict__ half,
+                                                                      const double2* __restrict__ tspec,
+                                                                      const double2* __restrict__ zspec,
+                                                                      const int64_t* __restrict__ tile_off,
+                                                                      const double2* __restrict__ tw_base,
+                                                                      int32_t* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = kOlsN / 2 + 1;
+  constexpr int PER = (KS + 255) / 256;
+  double2* ybuf = reinterpret_cast<double2*>(smem);  // kOlsN complex
+  const double* comp = reinterpret_cast<const double*>(smem);
+  unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(ybuf + kOlsN);  // 8
+  const int u = blockIdx.y;
+  const int b0 = blockIdx.x * kOlsBands;
+  const int64_t M = jobs[(int64_t)u * nb + b0].M;
+  const int64_t tiles = (M + kOlsValid - 1) / kOlsValid;
+  __shared__ int s_cnt[kOlsBands][4];
+  if (threadIdx.x < kOlsBands * 4) s_cnt[threadIdx.x >> 2][threadIdx.x & 3] = 0;
+  __syncthreads();
+#pragma unroll 1
+  for (int64_t tile = 0; tile < tiles; ++tile) {
+    const int64_t t0 = tile * kOlsValid;
+    double2 zr[PER];
+    const double2* zs = zspec + (tile_off[u] + tile) * KS;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int k = threadIdx.x + q * 256;
+      zr[q] = k < KS ? zs[k] : make_double2(0.0, 0.0);
+    }
+#pragma unroll 1
+    for (int g = 0; g < kOlsBands; g += 2) {
+      const int ba = b0 + g;
+      if (ba >= nb) break;
+      const bool has_b = ba + 1 < nb;
+      const double2* ta = tspec + (int64_t)ba * KS;
+      const double2* tb = tspec + (int64_t)(has_b ? ba + 1 : ba) * KS;
+      __syncthreads();  // the previous pair's crossings have been read out of the buffer
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int k = threadIdx.x + q * 256;
+        if (k < KS) {
+          const double2 ya = cmul(zr[q], ta[k]);
+          double2 yb = cmul(zr[q], tb[k]);
+          if (!has_b) yb = make_double2(0.0, 0.0);
+          // Y[k] = Ya[k] + i*Yb[k];  Y[N-k] = conj(Ya[k]) + i*conj(Yb[k])
+          ybuf[k] = make_double2(ya.x - yb.y, ya.y + yb.x);
+          if (k > 0 && k < kOlsN / 2) ybuf[kOlsN - k] = make_double2(ya.x + yb.y, yb.x - ya.y);
+        }
+      }
+      __syncthreads();
+      fft_lds<kOlsN, true, 256>(ybuf, tw_base + kOlsN);
+      for (int c = 0; c < 2; ++c) {
+        const int b = ba + c;
+        if (b >= nb) break;
+        const BandJob job = jobs[(int64_t)u * nb + b];
+        int base_cnt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) base_cnt[t] = s_cnt[g + c][t];
+        // output i of the block is s[t0 + i - (H + h + 1)]; component c of complex sample i sits at comp[2 i + c]
+        const double* sig = comp + 2 * (H + half[b] + 1) + c;
+#pragma unroll 1
+        for (int sub = 0; sub < kOlsValid / kBandTile; ++sub) {
+          const int64_t ts0 = t0 + (int64_t)sub * kBandTile;
+          if (ts0 >= M) break;
+          __syncthreads();
+          emit_crossings<2>(sig + 2 * sub * kBandTile, ts0, M, kBandTile, job.edges, job.cap, base_cnt, scan_scratch, flags);
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) s_cnt[g + c][threadIdx.x] = base_cnt[threadIdx.x];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kOlsBands * 4 && b0 + (threadIdx.x >> 2) < nb)
+    jobs[(int64_t)u * nb + b0 + (threadIdx.x >> 2)].counts[threadIdx.x & 3] = s_cnt[threadIdx.x >> 2][threadIdx.x & 3];
+}
+
 // ws_spec: device scratch of (n_bands + total_tiles) * (kOlsN/2+1) complex; h_tile_off[n_utt+1] tile offsets (HOST).
 inline int launch_band_events_ols(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs, int nb, int n_utt, int pad, int H,
                                   const double* d_taps, const int32_t* d_tap_off, const int32_t* d_tap_len,
@@ -342,8 +455,17 @@ inline int launch_band_events_ols(wh_ctx* ctx, hipStream_t st, const BandJob* d_
   const size_t lds_fft = sizeof(double) * (kOlsN + 2);
   { KernelTimer _kt(ctx, st, "band_taps_fft_kernel"); hipLaunchKernelGGL(band_taps_fft_kernel, dim3(nb), dim3(256), lds_fft, st, d_taps, d_tap_off, d_tap_len, ctx->d_twiddle, d_tspec); }
   { KernelTimer _kt(ctx, st, "band_tile_fft_kernel"); hipLaunchKernelGGL(band_tile_fft_kernel, dim3((unsigned)max_tiles, n_utt), dim3(256), lds_fft, st, d_jobs, nb, pad, H, d_tile_off, ctx->d_twiddle, d_zspec); }
+#ifndef WH_OLS_PAIR
+#define WH_OLS_PAIR 0  // measured: 7.2 ms against 6.7 ms for the one-channel-per-transform walker at config 3
+#endif
+#if WH_OLS_PAIR
+  const size_t lds = sizeof(double2) * kOlsN + 64;
+  if (int rc = allow_lds(&band_events_ols2_kernel, lds)) return rc;
+  { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_ols2_kernel, dim3((nb + kOlsBands - 1) / kOlsBands, n_utt), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag); }
+#else
   const size_t lds = sizeof(double2) * (kOlsN / 2 + 2) + 64;
   { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_ols_kernel, dim3((nb + kOlsBands - 1) / kOlsBands, n_utt), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag); }
+#endif
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("band_events_ols_kernel", e);
   return 0;

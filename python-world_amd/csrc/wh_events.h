@@ -25,6 +25,8 @@ __device__ __forceinline__ unsigned long long wave_scan_incl_u64(unsigned long l
 //   edge value = (1-based sample position) - v[i]/(v[i+1]-v[i])   (dio.py:201)
 // edges: [4][cap]; base_cnt[4]: running counts (block-uniform registers, updated).
 // 256 threads, tile == 1024 (4 positions per thread).  Contains barriers.
+// STRIDE: distance in doubles between consecutive samples of sig (2: one component of an interleaved complex buffer).
+template <int STRIDE = 1>
 __device__ __forceinline__ void emit_crossings(const double* sig, int64_t t0, int64_t M, int tile, double* edges,
                                                int64_t cap, int* base_cnt, unsigned long long* scratch,
                                                int32_t* overflow_flag) {
@@ -38,7 +40,7 @@ __device__ __forceinline__ void emit_crossings(const double* sig, int64_t t0, in
     if (q >= per) break;
     const int i = tid * per + q;
     const int64_t g = t0 + i;
-    const double a = sig[i], b = sig[i + 1], c = sig[i + 2];
+    const double a = sig[i * STRIDE], b = sig[(i + 1) * STRIDE], c = sig[(i + 2) * STRIDE];
     if (g + 1 < M && a * b < 0) {  // crossing of s between g and g+1
       const double fe = (double)(g + 1) - a / (b - a);
       if (b < a) {

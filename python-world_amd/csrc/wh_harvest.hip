@@ -4,7 +4,8 @@
 //   hv_iir_fwd/bwd   : zero-phase Chebyshev-I decimation to ~8 kHz, SciPy filtfilt semantics (odd
 //                      extension by 9, steady-state initial conditions), chunk-parallel with state warm-up
 //                      (harvest.py:58-71,584-609)
-//   band_events      : 152 band-pass channels as direct FIR from LDS + zero-crossing compaction (wh_bands.h)
+//   band_events      : 152 band-pass channels + zero-crossing compaction (wh_bands.h): overlap-save FFT products
+//                      (one forward transform per 4096-sample tile shared by all channels), direct FIR as fallback
 //   hv_raw_kernel    : per (1 ms frame, channel) interpolation of the four interval-F0 trains (harvest.py:252-278)
 //   hv_detect_kernel : per frame: runs of >= 10 live channels -> candidate = mean (harvest.py:88-110)
 //   hv_refine_kernel : per frame: every overlapped candidate (+-3 frames, harvest.py:114-125) refined by
@@ -462,20 +463,33 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       sample(j, ir, s2, c2, two_next, two_prev);
     }
   }
-  double num = 0.0, den = 0.0, var = 0.0;
+  // The four sums of every harmonic go round the row; lane h then evaluates harmonic h alone — instantaneous
+  // frequency, amplitude, deviation: five FP64 divides and a square root, ~85 instructions that all sixteen lanes used
+  // to repeat for each of the six harmonics — and three more row sums collect the totals.
+  double sa = 0.0, sb = 0.0, sc_ = 0.0, sd = 0.0;
+  int my_bin = 0;
 #pragma unroll
   for (int h = 0; h < 6; ++h) {
-    if (h < nh) {
-      const double a = row16_sum(xr[h]), b = row16_sum(xi[h]), c = row16_sum(dr[h]), d = row16_sum(di[h]);
-      const double p = a * a + b * b;
-      const double nm = a * d - b * c;
-      const double inst = ((double)bins[h] / nfft + nm / p / 2 / M_PI) * fs;
-      const double amp = sqrt(p);
-      num += amp * inst;
-      den += amp * (double)(h + 1);
-      var += fabs((inst / (double)(h + 1) - f0c) / f0c);
+    const double a = row16_sum(xr[h]), b = row16_sum(xi[h]), c = row16_sum(dr[h]), d = row16_sum(di[h]);
+    if (l16 == h) {
+      sa = a;
+      sb = b;
+      sc_ = c;
+      sd = d;
+      my_bin = bins[h];
     }
   }
+  double t_num = 0.0, t_den = 0.0, t_var = 0.0;
+  if (l16 < nh) {
+    const double p = sa * sa + sb * sb;
+    const double nm = sa * sd - sb * sc_;
+    const double inst = ((double)my_bin / nfft + nm / p / 2 / M_PI) * fs;
+    const double amp = sqrt(p);
+    t_num = amp * inst;
+    t_den = amp * (double)(l16 + 1);
+    t_var = fabs((inst / (double)(l16 + 1) - f0c) / f0c);
+  }
+  const double num = row16_sum(t_num), den = row16_sum(t_den), var = row16_sum(t_var);
   double rf = num / den;
   double sc = 1 / (0.000000000001 + var / (double)nh);
   if (rf < f0_floor || rf > f0_ceil || sc < 2.5) {

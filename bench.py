@@ -20,8 +20,7 @@ un-captured pass of the same K steps right after it (events cannot be read back 
 Rank 0 prints ONE JSON line.  On a single GPU it also carries (each timed by this process):
   cpu_baseline   : the NumPy oracle on the host cores (1 core and all cores, median of 3), bounded sample;
   with_transfers : config 2 once more with the H2D of x and the D2H of f0/vuv/spectrogram/aperiodicity/out through
-                   pinned buffers inside the timed region (what a host-buffer caller sees; never `value`), and
-                   with_transfers_overlapped: the same dealt to 4 lanes so that copies run under kernels;
+                   pinned buffers inside the timed region (what a host-buffer caller sees; never `value`);
   north_star     : BASELINE.json's target workload on ONE GPU — 1024 x 10 s, Harvest + CheapTrick + D4C-Requiem
                    encode + Requiem decode (>= 500 xRT asked).
 """
@@ -78,6 +77,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the with_transfers and north_star blocks")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--north-star-utts", type=int, default=1024)
+    ap.add_argument("--transfer-lanes", type=int, default=0,
+                    help="also time the with_transfers step dealt to this many lanes (copies of one lane under the "
+                         "kernels of the next)")
     ap.add_argument("--lanes", type=int, default=1,
                     help="independent sub-batches in flight per GPU, each on its own HIP stream (world.batch."
                          "WorldBatchLanes).  The default keeps one lane and clean per-kernel attribution")
@@ -387,9 +389,11 @@ def main():
             out["cpu_baseline"] = cpu
         if world == 1 and not args.no_extras and args.config == 2 and args.scaling == "weak":
             del graph
-            for key, fn in (("with_transfers", lambda: with_transfers_block(torch, wl, xs, FS)),
-                            ("with_transfers_overlapped", lambda: with_transfers_lanes_block(torch, local_rank, xs, FS)),
-                            ("north_star", lambda: north_star_block(torch, local_rank, xs_distinct, FS, args))):
+            blocks = [("with_transfers", lambda: with_transfers_block(torch, wl, xs, FS))]
+            if args.transfer_lanes > 1:  # measured 41 ms with 4 lanes against 36.5 ms serial: off by default
+                blocks.append(("with_transfers_overlapped",
+                               lambda: with_transfers_lanes_block(torch, local_rank, xs, FS, args.transfer_lanes)))
+            for key, fn in blocks + [("north_star", lambda: north_star_block(torch, local_rank, xs_distinct, FS, args))]:
                 try:
                     out[key] = fn()
                 except Exception as e:  # an extra block must never cost the headline line

@@ -281,8 +281,11 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
   double2* ybuf = reinterpret_cast<double2*>(smem);
   double* sig_all = reinterpret_cast<double*>(smem);
   unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(ybuf + KS + 1);  // 8
-  const int u = blockIdx.y;
-  const int b0 = blockIdx.x * kOlsBands;
+  // utterance-fastest workgroup order: the workgroups in flight at any time share a few channel groups, so the
+  // 33 KB tap spectra they stream stay in every XCD's L2 (channel-fastest, each XCD cycled through all 5 MB of them
+  // and half of the 8.6 GB requested per launch came from HBM)
+  const int u = blockIdx.x;
+  const int b0 = blockIdx.y * kOlsBands;
   const BandJob job0 = jobs[(int64_t)u * nb + b0];
   const int64_t M = job0.M;
   const int64_t tiles = (M + kOlsValid - 1) / kOlsValid;
@@ -382,8 +385,11 @@ static __global__ __launch_bounds__(256, 2) void band_events_ols2_kernel(const B
   double2* ybuf = reinterpret_cast<double2*>(smem);  // kOlsN complex
   const double* comp = reinterpret_cast<const double*>(smem);
   unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(ybuf + kOlsN);  // 8
-  const int u = blockIdx.y;
-  const int b0 = blockIdx.x * kOlsBands;
+  // utterance-fastest workgroup order: the workgroups in flight at any time share a few channel groups, so the
+  // 33 KB tap spectra they stream stay in every XCD's L2 (channel-fastest, each XCD cycled through all 5 MB of them
+  // and half of the 8.6 GB requested per launch came from HBM)
+  const int u = blockIdx.x;
+  const int b0 = blockIdx.y * kOlsBands;
   const int64_t M = jobs[(int64_t)u * nb + b0].M;
   const int64_t tiles = (M + kOlsValid - 1) / kOlsValid;
   __shared__ int s_cnt[kOlsBands][4];
@@ -461,10 +467,10 @@ inline int launch_band_events_ols(wh_ctx* ctx, hipStream_t st, const BandJob* d_
 #if WH_OLS_PAIR
   const size_t lds = sizeof(double2) * kOlsN + 64;
   if (int rc = allow_lds(&band_events_ols2_kernel, lds)) return rc;
-  { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_ols2_kernel, dim3((nb + kOlsBands - 1) / kOlsBands, n_utt), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag); }
+  { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_ols2_kernel, dim3(n_utt, (nb + kOlsBands - 1) / kOlsBands), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag); }
 #else
   const size_t lds = sizeof(double2) * (kOlsN / 2 + 2) + 64;
-  { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_ols_kernel, dim3((nb + kOlsBands - 1) / kOlsBands, n_utt), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag); }
+  { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_ols_kernel, dim3(n_utt, (nb + kOlsBands - 1) / kOlsBands), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag); }
 #endif
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("band_events_ols_kernel", e);

@@ -33,8 +33,10 @@
 // g_d4c_stage[] (read with wh_debug_d4c_stages, tools/d4c_stage_timer.py) — the per-stage latencies quoted in DESIGN.md.
 #ifdef WH_D4C_STAGE_TIMER
 __device__ unsigned long long g_d4c_stage[16];
-#define STAGE_TIMER_BEGIN unsigned long long _t0 = __builtin_readcyclecounter();
-#define STAGE_MARK(i) { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long _t = __builtin_readcyclecounter(); atomicAdd(&g_d4c_stage[i], _t - _t0); _t0 = _t; } }
+// (the running time stamp of a workgroup lives in global memory so that device functions can mark stages too)
+__device__ unsigned long long g_d4c_t0[1 << 20];
+#define STAGE_TIMER_BEGIN { if (threadIdx.x == 0) g_d4c_t0[blockIdx.x & ((1 << 20) - 1)] = __builtin_readcyclecounter(); }
+#define STAGE_MARK(i) { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long _t = __builtin_readcyclecounter(); atomicAdd(&g_d4c_stage[i], _t - g_d4c_t0[blockIdx.x & ((1 << 20) - 1)]); g_d4c_t0[blockIdx.x & ((1 << 20) - 1)] = _t; } }
 #else
 #define STAGE_TIMER_BEGIN
 #define STAGE_MARK(i)
@@ -87,73 +89,126 @@ constexpr int minblk_of(int n) { return n >= 4096 ? WH_D4C_MINBLK4096 : WH_D4C_M
 // (three more partial sums, no second pass over the data and no second pair of barriers).  The expansion loses
 // log10((DC/AC)^2) digits to cancellation — nothing for speech-like input (DC << AC), and still 1e-10 relative for a
 // DC offset 1000x the signal.
-template <bool BLACKMAN, int N, bool ENERGY, class Emit>
-__device__ __forceinline__ void d4c_window(const double* __restrict__ xu, long long xn, double fs, double cf,
-                                           double pos, double half_length, double* scratch, Emit emit) {
-  constexpr int FT = ft_of(N);
-  constexpr int Q = N / FT;
-  // every window of a frame is its own stage: without the fences the compiler shares the set-up of windows with equal
-  // f0 and length (rotation constants, clamped offsets, per-sample predicates) across the transforms between them
-  cf = stage_fence(cf);
-  pos = stage_fence(pos);
+// Per-frame set-up of one analysis window, evaluated ONCE per workgroup by a single lane (win_setup) and read back by
+// every thread through LDS broadcasts: window length, clamped sample range, rotation constants and the start phase are
+// the same for all threads, yet as straight-line code each of the four waves spent ~280 instructions per window on
+// them (five FP64 divides, two sincospi, the 64-bit clamps) — a fifth of this kernel's instruction stream.
+// The per-thread start phase is base * E[tid]: E = exp(i*pi*delta*tid) costs one sincospi per thread and is shared by
+// the windows that have the same f0 and length (the Hann frame and the two centroid frames).
+constexpr int kWinTab = 16;  // doubles per window in the table
+struct WinSetup {
+  int hwl, L, rlo, rhi;
+  long long centre;
+  double rot_s, rot_c, base_s, base_c, delta, inv_span, phase, cf;
+};
+__device__ __forceinline__ void win_setup(double* tab, long long xn, double fs, double cf, double pos, double half_length,
+                                          int ft) {
   const int hwl = (int)(half_length * fs / cf + 0.5);
-  const int L = 2 * hwl + 1;
   const long long centre = wh::frame_centre(pos, fs);
   const double phase = (pos * fs - (double)(long long)(pos * fs + 0.5)) / fs;
   // per-frame constants are inverted once and multiplied in: an FP64 divide is ~12 instructions with a long
   // dependency chain, and the per-sample ones were a fifth of this kernel's instruction count (results move by an ulp)
   const double inv_span = 1.0 / fs / half_length;
-  auto shape = [](double c1) -> double {
-    return BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);  // cos(2a) = 2cos^2(a)-1
-  };
-  auto win = [&](int j) -> double { return shape(cospi(((double)(j - hwl) * inv_span + phase) * cf)); };
   // sample index relative to the centre, clamped to the utterance (d4c.py:98): x[centre - 1 + rel]
   const long long rel_min = 1 - centre, rel_max = xn - centre;
   const int rlo = (int)(rel_min < -(1 << 30) ? -(1 << 30) : (rel_min > (1 << 30) ? (1 << 30) : rel_min));
   const int rhi = (int)(rel_max > (1 << 30) ? (1 << 30) : (rel_max < -(1 << 30) ? -(1 << 30) : rel_max));
-  const double* xb = xu + (centre - 1);  // (re-derived from laundered bits before the second walk)
+  double rot_s, rot_c, base_s, base_c;
+  sincospi((double)ft * inv_span * cf, &rot_s, &rot_c);                 // rotation by FT samples
+  sincospi(((double)(0 - hwl) * inv_span + phase) * cf, &base_s, &base_c);  // phase of sample 0
+  tab[0] = (double)hwl;
+  tab[1] = (double)(2 * hwl + 1);
+  tab[2] = (double)rlo;
+  tab[3] = (double)rhi;
+  tab[4] = (double)centre;  // |centre| < 2^53
+  tab[5] = rot_s;
+  tab[6] = rot_c;
+  tab[7] = base_s;
+  tab[8] = base_c;
+  tab[9] = inv_span * cf;
+  tab[10] = inv_span;
+  tab[11] = phase;
+  tab[12] = cf;
+}
+__device__ __forceinline__ WinSetup win_load(const double* tab) {
+  WinSetup w;
+  w.hwl = (int)tab[0];
+  w.L = (int)tab[1];
+  w.rlo = (int)tab[2];
+  w.rhi = (int)tab[3];
+  w.centre = (long long)tab[4];
+  w.rot_s = tab[5];
+  w.rot_c = tab[6];
+  w.base_s = tab[7];
+  w.base_c = tab[8];
+  w.delta = tab[9];
+  w.inv_span = tab[10];
+  w.phase = tab[11];
+  w.cf = tab[12];
+  return w;
+}
+// E[tid] = exp(i*pi*delta*tid) as (sin, cos)
+__device__ __forceinline__ double2 win_thread_phase(double delta) {
+  double s, c;
+  sincospi(delta * (double)threadIdx.x, &s, &c);
+  return make_double2(s, c);
+}
+
+// slot / STRIDE: sample j is parked at slot[j * STRIDE] (LDS) between the gather and the second walk — the place emit()
+// overwrites with the final value, so the park costs no extra memory.
+template <bool BLACKMAN, int N, bool ENERGY, int STRIDE, class Emit>
+__device__ __forceinline__ void d4c_window(const double* __restrict__ xu, const double* tab, double2 e_tid,
+                                           double* scratch, double* slot, Emit emit) {
+  constexpr int FT = ft_of(N);
+  constexpr int Q = N / FT;
+  const WinSetup ws = win_load(tab);
+  const int hwl = ws.hwl, L = ws.L, rlo = ws.rlo, rhi = ws.rhi;
+  const double inv_span = ws.inv_span, phase = ws.phase, cf = ws.cf;
+  auto shape = [](double c1) -> double {
+    return BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);  // cos(2a) = 2cos^2(a)-1
+  };
+  auto win = [&](int j) -> double { return shape(cospi(((double)(j - hwl) * inv_span + phase) * cf)); };
+  const double* xb = xu + (ws.centre - 1);  // (re-derived from laundered bits before the second walk)
   auto sample = [&](int j) -> double {
     int rel = j - hwl;
     rel = rel < rlo ? rlo : rel;
     rel = rel > rhi ? rhi : rel;
     return xb[rel];
   };
-  // rotation by FT samples: angle step (in units of pi) = FT * inv_span * cf
-  double rot_s, rot_c, s0, c0;
-  sincospi((double)FT * inv_span * cf, &rot_s, &rot_c);
-  sincospi(((double)((int)threadIdx.x - hwl) * inv_span + phase) * cf, &s0, &c0);
+  const double rot_s = ws.rot_s, rot_c = ws.rot_c;
+  // phase of this thread's first sample: base * E[tid]
+  const double c0 = ws.base_c * e_tid.y - ws.base_s * e_tid.x;
+  const double s0 = ws.base_s * e_tid.y + ws.base_c * e_tid.x;
   double s_sw = 0.0, s_w = 0.0, s_swsw = 0.0, s_sww = 0.0, s_ww = 0.0;
-  // Both walks go through the frame in chunks of U samples per thread: the U gathers of a chunk are issued together
-  // (independent loads in flight), the chunks themselves run as a rolled loop.  Fully unrolled, the scheduler hoists
-  // all Q gathers with their addresses, clamps and rotation states (~95 VGPRs for this routine alone, the register
-  // peak of the kernel); fully rolled, every gather waits for the one before it (16 k cycles per window).
-  constexpr int U = WH_D4C_WIN_UNROLL < Q ? WH_D4C_WIN_UNROLL : Q;
-  static_assert(Q % U == 0, "window chunking");
+  // The gather is ONE round: all Q loads of the thread are issued together and parked in LDS as they arrive (each
+  // thread only ever touches its own slots, so no barrier is involved).  Both walks then read LDS.  Gathering inside
+  // the walks — in chunks of four, twice — put four dependent global-memory round trips (~3.5 k cycles each on the
+  // loaded chip) into every window: 15 k of a window's 20 k cycles; carrying the samples in registers across the
+  // reduction instead was the register peak of the kernel.
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int j = threadIdx.x + q * FT;
+    slot[j * STRIDE] = sample(j);  // clamped: always a valid address
+  }
   {
     double c = c0, sn = s0;
-#pragma unroll 1
-    for (int q0 = 0; q0 < Q; q0 += U) {
-      double xs[U];
-#pragma unroll
-      for (int i = 0; i < U; ++i) xs[i] = sample(threadIdx.x + (q0 + i) * FT);  // clamped: always a valid address
-#pragma unroll
-      for (int i = 0; i < U; ++i) {
-        const int j = threadIdx.x + (q0 + i) * FT;
-        if (j < L) {
-          const double w = shape(c);
-          const double sw = xs[i] * w;
-          s_sw += sw;
-          s_w += w;
-          if (ENERGY) {
-            s_swsw += sw * sw;
-            s_sww += sw * w;
-            s_ww += w * w;
-          }
+#pragma unroll 2
+    for (int q = 0; q < Q; ++q) {
+      const int j = threadIdx.x + q * FT;
+      if (j < L) {
+        const double w = shape(c);
+        const double sw = slot[j * STRIDE] * w;
+        s_sw += sw;
+        s_w += w;
+        if (ENERGY) {
+          s_swsw += sw * sw;
+          s_sww += sw * w;
+          s_ww += w * w;
         }
-        const double cn = c * rot_c - sn * rot_s;
-        sn = sn * rot_c + c * rot_s;
-        c = cn;
       }
+      const double cn = c * rot_c - sn * rot_s;
+      sn = sn * rot_c + c * rot_s;
+      c = cn;
     }
     for (int j = N + threadIdx.x; j < L; j += FT) {  // rows longer than N: cropped, but they count in the sums
       const double w = win(j);
@@ -167,38 +222,29 @@ __device__ __forceinline__ void d4c_window(const double* __restrict__ xu, long l
       }
     }
   }
+  STAGE_MARK(10)
   if (ENERGY) wh::block_sum5<FT>(s_sw, s_w, s_swsw, s_sww, s_ww, scratch);
   else wh::block_sum2<FT>(s_sw, s_w, scratch);
+  STAGE_MARK(11)
   const double mean_sw = s_sw / (double)L;
   const double mean_w = s_w / (double)L;
   const double dc = mean_sw / mean_w;
   const double inv_nrm = ENERGY ? 1.0 / sqrt((s_swsw - 2.0 * dc * s_sww) + dc * dc * s_ww) : 1.0;
-  // second walk: the samples are fetched again (L1/L2 hits) and go straight to the transform buffer; the pointer is
-  // laundered so that the compiler re-loads instead of carrying the first walk's Q samples across the reduction
-  unsigned long long bits = reinterpret_cast<unsigned long long>(xb);
-  asm volatile("" : "+v"(bits));
-  xb = reinterpret_cast<const double*>(bits);
   {
     double c = c0, sn = s0;
-#pragma unroll 1
-    for (int q0 = 0; q0 < Q; q0 += U) {
-      double xs[U];
-#pragma unroll
-      for (int i = 0; i < U; ++i) xs[i] = sample(threadIdx.x + (q0 + i) * FT);
-#pragma unroll
-      for (int i = 0; i < U; ++i) {
-        const int j = threadIdx.x + (q0 + i) * FT;
-        double val = 0.0;
-        if (j < L) {
-          const double w = shape(c);
-          val = xs[i] * w - w * dc;
-          if (ENERGY) val *= inv_nrm;
-        }
-        emit(j, val);
-        const double cn = c * rot_c - sn * rot_s;
-        sn = sn * rot_c + c * rot_s;
-        c = cn;
+#pragma unroll 2
+    for (int q = 0; q < Q; ++q) {
+      const int j = threadIdx.x + q * FT;
+      double val = 0.0;
+      if (j < L) {
+        const double w = shape(c);
+        val = slot[j * STRIDE] * w - w * dc;
+        if (ENERGY) val *= inv_nrm;
       }
+      emit(j, val);
+      const double cn = c * rot_c - sn * rot_s;
+      sn = sn * rot_c + c * rot_s;
+      c = cn;
     }
   }
 }
@@ -213,6 +259,7 @@ __global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
   double2* zb = reinterpret_cast<double2*>(smem);  // NLT/2+1 complex after the real FFT
   double* zr = reinterpret_cast<double*>(smem);    // 2*NLT doubles while windowing
   double* scratch = zr + 2 * NLT;
+  double* wtab = scratch + 48;  // window set-up table (kWinTab doubles)
   const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
   if (f >= n_frames) return;
   double f0 = f0_io[f];
@@ -226,7 +273,9 @@ __global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
   const double* xu = x + x_off[u];
   const long long xn = x_off[u + 1] - x_off[u];
   const double cf = fmax(f0, 40.0);
-  d4c_window<true, NLT, false>(xu, xn, fs, cf, tp[f], 1.5, scratch, [&](int j, double val) { zr[j] = val; });
+  if (threadIdx.x == 0) win_setup(wtab, xn, fs, cf, tp[f], 1.5, FT);
+  wh::sync<FT>();
+  d4c_window<true, NLT, false, 1>(xu, wtab, win_thread_phase(wtab[9]), scratch, zr, [&](int j, double val) { zr[j] = val; });
   wh::sync<FT>();
   wh::rfft_lds<NLT, FT, FT, WH_D4C_MAXR>(zb, tw_base);
   const int b0 = (int)(ceil(100.0 / (fs / NLT)) + 1);
@@ -444,13 +493,13 @@ __device__ __forceinline__ void fill_mirrored_runs(const double (&p)[Runs<N>::KR
 // Group-delay centroid of one Blackman frame, added into the run-resident cent (d4c.py:146-153).
 // x and n*x (two real sequences) share ONE complex FFT: z = x + i*n*x, separated afterwards by symmetry.
 template <int N>
-__device__ __forceinline__ void add_centroid(const double* xu, long long xn, double fs, double cf, double pos,
+__device__ __forceinline__ void add_centroid(const double* xu, const double* wtab, double2 e_tid,
                                              double2* buf, double (&cent)[Runs<N>::KR], bool first,
                                              const double2* tw_base, double* scratch) {
   constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
   // z[j] = x[j] + i*(j+1)*x[j] (n is 1-based), normalised frame, written straight into the transform buffer
-  d4c_window<true, N, true>(xu, xn, fs, cf, pos, 2.0, scratch,
-                            [&](int j, double val) { buf[j] = make_double2(val, val * (double)(j + 1)); });
+  d4c_window<true, N, true, 2>(xu, wtab, e_tid, scratch, reinterpret_cast<double*>(buf),
+                               [&](int j, double val) { buf[j] = make_double2(val, val * (double)(j + 1)); });
   wh::sync<FT>();
   wh::fft_lds<N, false, FT, FT, WH_D4C_MAXR>(buf, fresh_table(tw_base) + N);
   const int k0 = threadIdx.x * KR;
@@ -485,8 +534,9 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2* buf = reinterpret_cast<double2*>(smem);   // N complex (centroid FFT) / N/2+1 complex (real FFTs)
   double* zr = reinterpret_cast<double*>(smem);      // the same 2N doubles: real buffers, mirrored spectra, scratch
-  double* scratch = zr + 2 * N;                      // 32
-  double* band = scratch + 32;                       // nap (<= 8)
+  double* scratch = zr + 2 * N;                      // 40 (block_sum5 at 8 waves)
+  double* band = scratch + 40;                       // nap (<= 8)
+  double* wtab = band + 8;                           // 4 windows x kWinTab: gate, power, centroid +, centroid -
   constexpr int KPAD = (K + 1) & ~1;
   double* td = zr + 2 * N - KPAD;                    // band stage: the shaped group delay, above the real-FFT buffer
 
@@ -511,10 +561,21 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   double pw[KR], cent[KR];  // run-resident per-bin arrays
 #pragma unroll
   for (int r = 0; r < KR; ++r) pw[r] = cent[r] = 0.0;
+  // the four windows of the frame are set up by four lanes at once (win_setup); the three that share f0 and length
+  // also share the per-thread phase factor e_frame
+  if (voiced && threadIdx.x < 4) {
+    const int wdx = threadIdx.x;
+    const double wcf = wdx == 0 ? fmax(f0v, 40.0) : cf;
+    const double wpos = wdx == 2 ? pos + 1 / cf / 4 : (wdx == 3 ? pos - 1 / cf / 4 : pos);
+    win_setup(wtab + wdx * kWinTab, xn, fs, wcf, wpos, wdx == 0 ? 1.5 : 2.0, FT);
+  }
+  wh::sync<FT>();
+  double2 e_frame = make_double2(0.0, 1.0);
+  if (voiced) e_frame = win_thread_phase(wtab[kWinTab + 9]);
   if (FUSED && voiced) {
     // love-train frame (Blackman, 3*T0, f0 floored at 40 Hz) and smoothed-power frame (Hann, 4*T0) in one FFT
-    d4c_window<true, N, false>(xu, xn, fs, fmax(f0v, 40.0), pos, 1.5, scratch, [&](int j, double val) { zr[2 * j] = val; });
-    d4c_window<false, N, false>(xu, xn, fs, cf, pos, 2.0, scratch, [&](int j, double val) { zr[2 * j + 1] = val; });
+    d4c_window<true, N, false, 2>(xu, wtab, win_thread_phase(wtab[9]), scratch, zr, [&](int j, double val) { zr[2 * j] = val; });
+    d4c_window<false, N, false, 2>(xu, wtab + kWinTab, e_frame, scratch, zr + 1, [&](int j, double val) { zr[2 * j + 1] = val; });
     STAGE_MARK(7)
     wh::sync<FT>();
     wh::fft_lds<N, false, FT, FT, WH_D4C_MAXR>(buf, fresh_table(tw_base) + N);
@@ -564,9 +625,9 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
 #endif
   STAGE_MARK(0)
   // ---- static centroid from two frames at +-T0/4 (d4c.py:132-142) ---------------------------------------
-  add_centroid<N>(xu, xn, fs, cf, stage_fence(pos) + 1 / cf / 4, buf, cent, true, tw_base, scratch);
+  add_centroid<N>(xu, wtab + 2 * kWinTab, e_frame, buf, cent, true, tw_base, scratch);
   STAGE_MARK(1)
-  add_centroid<N>(xu, xn, fs, cf, stage_fence(pos) - 1 / cf / 4, buf, cent, false, tw_base, scratch);
+  add_centroid<N>(xu, wtab + 3 * kWinTab, e_frame, buf, cent, false, tw_base, scratch);
   STAGE_MARK(2)
   low_band_replica_runs<N>(cent, zr, fs, cf, 1.2 * cf);
   STAGE_MARK(3)
@@ -577,7 +638,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
 #endif
   // ---- smoothed power spectrum (d4c.py:157-161) ----------------------------------------------
   if (!FUSED) {
-    d4c_window<false, N, false>(xu, xn, fs, cf, pos, 2.0, scratch, [&](int j, double val) { zr[j] = val; });
+    d4c_window<false, N, false, 1>(xu, wtab + kWinTab, e_frame, scratch, zr, [&](int j, double val) { zr[j] = val; });
     wh::sync<FT>();
     wh::rfft_lds<N, FT, FT, WH_D4C_RMAXR>(buf, fresh_table(tw_base));
 #pragma unroll
@@ -713,7 +774,7 @@ std::vector<double> nuttall(int n) {
 template <int NLT>
 int launch_lt(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
               const double* vuv, double fs, double thr, int32_t* gate) {
-  const size_t lds = sizeof(double) * (2 * NLT + 32);
+  const size_t lds = sizeof(double) * (2 * NLT + 48 + kWinTab);
   if (int rc = wh::allow_lds(&love_train_kernel<NLT>, lds)) return rc;
   { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_of(NLT)), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, fs, thr, ctx->d_twiddle, gate, (long long)b->total_frames); }
@@ -725,7 +786,7 @@ template <int N, bool FUSED>
 int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
                 const double* vuv, const int32_t* gate, double thr, double fs, int nap, int interval, const double* win,
                 int wlen, int k_spec, double* out, double* coarse) {
-  const size_t lds = sizeof(double) * (2 * N + 32 + 8);
+  const size_t lds = sizeof(double) * (2 * N + 40 + 8 + 4 * kWinTab);
   if (int rc = wh::allow_lds(&d4c_kernel<N, FUSED>, lds)) return rc;
   { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL((d4c_kernel<N, FUSED>), dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_of(N)), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, gate, thr, fs, nap, interval, win, wlen, ctx->d_twiddle, k_spec, out,

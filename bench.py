@@ -393,6 +393,7 @@ def main():
             if args.transfer_lanes > 1:  # measured 41 ms with 4 lanes against 36.5 ms serial: off by default
                 blocks.append(("with_transfers_overlapped",
                                lambda: with_transfers_lanes_block(torch, local_rank, xs, FS, args.transfer_lanes)))
+            blocks.append(("varying_lengths", lambda: varying_lengths_block(torch, local_rank, xs, FS)))
             for key, fn in blocks + [("north_star", lambda: north_star_block(torch, local_rank, xs_distinct, FS, args))]:
                 try:
                     out[key] = fn()
@@ -530,6 +531,38 @@ def with_transfers_lanes_block(torch, device_index, xs, fs, lanes=4, steps=5):
             "x_realtime": len(xs) * len(xs[0]) / fs / dt, "steps": steps, "lanes": lanes,
             "note": "the with_transfers step dealt to %d lanes (private streams): one lane's D2H under the next "
                     "lane's kernels" % lanes}
+
+
+def varying_lengths_block(torch, device_index, xs, fs, steps=6):
+    """Config 2 with the utterance lengths changing from step to step (two resident batches with different, ragged
+    lengths, alternated): every step uploads new per-call metadata (offsets, job tables).  Those uploads are
+    stream-ordered copies from pinned staging buffers, so a changing batch costs no device synchronisation; compare
+    with `eager_ms_per_step` of the fixed batch."""
+    from world.batch import WorldBatch
+
+    wb = WorldBatch(device_index)
+    ragged = [x[:len(x) - 800 * (u % 9 + 1)] for u, x in enumerate(xs)]
+    res = [wb.upload(xs, fs), wb.upload(ragged, fs)]
+
+    def one(k):
+        batch, x_d, tp_d = res[k & 1]
+        enc = wb.encode_device(batch, x_d, tp_d, fs, f0_method="dio", check=False)
+        return wb.decode_device(enc, seed=k, check=False)
+
+    one(0), one(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one(k)
+    enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    wb.check("varying_lengths")
+    frames = (res[0][0].total_frames + res[1][0].total_frames) / 2
+    return {"ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": enq / steps * 1e3, "value": frames / dt,
+            "unit": "frames/s", "steps": steps,
+            "note": "two resident batches (64 x 10 s and a ragged 64 x 9.55-9.95 s) alternated: per-call tables change "
+                    "every step"}
 
 
 def north_star_block(torch, device_index, xs_distinct, fs, args, steps=3):

@@ -74,6 +74,36 @@ __device__ __forceinline__ void sync_lds() {
   }
 }
 
+// A lane-private serial recurrence over the samples [i0, i1) (the chunked IIR passes): the recurrence itself costs
+// ~40 cycles per sample, a dependent global load per sample ~1500, and the lanes of a wave sit a whole chunk apart so
+// nothing coalesces.  The samples are therefore fetched in blocks of B independent loads, one block ahead of the
+// block the recurrence is consuming.  interior(i) says that fast(i) .. fast(i + B - 1) are plain loads (no edge
+// extension); edge blocks go through slow().  body(i, v) runs in ascending i.
+template <int B, class Interior, class Fast, class Slow, class Body>
+__device__ __forceinline__ void serial_run(int64_t i0, int64_t i1, Interior interior, Fast fast, Slow slow, Body body) {
+  double cur[B], nxt[B];
+  auto fetch = [&](double (&v)[B], int64_t i) {
+    if (i + B > i1) return;
+    if (interior(i)) {
+#pragma unroll
+      for (int k = 0; k < B; ++k) v[k] = fast(i + k);
+    } else {
+#pragma unroll
+      for (int k = 0; k < B; ++k) v[k] = slow(i + k);
+    }
+  };
+  int64_t i = i0;
+  fetch(cur, i);
+  for (; i + B <= i1; i += B) {
+    fetch(nxt, i + B);
+#pragma unroll
+    for (int k = 0; k < B; ++k) body(i + k, cur[k]);
+#pragma unroll
+    for (int k = 0; k < B; ++k) cur[k] = nxt[k];
+  }
+  for (; i < i1; ++i) body(i, slow(i));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = WH_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WH_WAVE);

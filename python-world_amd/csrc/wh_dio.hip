@@ -76,6 +76,11 @@ __device__ __forceinline__ double padded(const double* __restrict__ x, int64_t n
     w0 = wt;                                                    \
   }
 
+#ifndef WH_IIR_BLOCK
+#define WH_IIR_BLOCK 16
+#endif
+constexpr int kIirBlock = WH_IIR_BLOCK;  // samples fetched together, a block ahead of the recurrence (wh::serial_run)
+
 __global__ __launch_bounds__(64) void iir_fwd_kernel(const double* __restrict__ x, const DioUtt* __restrict__ meta,
                                                      IirCoef c, int warm, double* __restrict__ tmp) {
   const DioUtt m = meta[blockIdx.y];
@@ -86,15 +91,21 @@ __global__ __launch_bounds__(64) void iir_fwd_kernel(const double* __restrict__ 
   const int64_t e = s + kChunk < len ? s + kChunk : len;
   const double* xu = x + m.x_off;
   double* out = tmp + m.tmp_off;
+  const int64_t n = m.n;
   double w0 = 0, w1 = 0, w2 = 0, yv = 0;
-  for (int64_t i = (s - warm > 0 ? s - warm : 0); i < s; ++i) IIR_STEP(padded(xu, m.n, i));
-  for (int64_t i = s; i < e; ++i) {
-    IIR_STEP(padded(xu, m.n, i));
-    out[i] = yv;
-  }
+  wh::serial_run<kIirBlock>(
+      s - warm > 0 ? s - warm : 0, e, [&](int64_t i) { return i >= kPad && i + kIirBlock <= kPad + n; },
+      [&](int64_t i) { return xu[i - kPad]; }, [&](int64_t i) { return padded(xu, n, i); },
+      [&](int64_t i, double v) {
+        IIR_STEP(v);
+        if (i >= s) out[i] = yv;
+      });
 }
 
-// Second pass over the time-reversed pass-1 output; only the decimated picks are stored (dio.py:465-476).
+// Second pass over the time-reversed pass-1 output; only the decimated picks are stored (dio.py:465-476):
+// y[k] = pass2[q + 8] for q = nbeg + k*r, q < n + 9, a negative q + 8 wrapping like a Python index.  The lane walks
+// natural indices j downwards, so (quotient, remainder) of j - 8 - nbeg by r are carried along instead of divided out
+// per sample; the wrapped picks (nbeg + 8 < 0: r > 8) are the same walk shifted by len.
 __global__ __launch_bounds__(64) void iir_bwd_kernel(const DioUtt* __restrict__ meta, IirCoef c, int warm, int r,
                                                      const double* __restrict__ tmp, double* __restrict__ y) {
   const DioUtt m = meta[blockIdx.y];
@@ -105,22 +116,34 @@ __global__ __launch_bounds__(64) void iir_bwd_kernel(const DioUtt* __restrict__ 
   const int64_t e = s + kChunk < len ? s + kChunk : len;
   const double* in = tmp + m.tmp_off;
   double* yo = y + m.y_off;
+  const int64_t ylen = m.ylen, qmax = m.n + kPad;
+  const bool wraps = m.nbeg + (kPad - 1) < 0;
+  auto floordiv = [](int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+  // walk state at i = s (j = len - 1 - s), for the plain and the wrapped pick
+  const int64_t d0 = (len - 1 - s) - (kPad - 1) - m.nbeg;
+  int64_t k0 = floordiv(d0, r), k1 = floordiv(d0 - len, r);
+  int r0 = (int)(d0 - k0 * r), r1 = (int)(d0 - len - k1 * r);
   double w0 = 0, w1 = 0, w2 = 0, yv = 0;
-  for (int64_t i = (s - warm > 0 ? s - warm : 0); i < s; ++i) IIR_STEP(in[len - 1 - i]);
-  for (int64_t i = s; i < e; ++i) {
-    IIR_STEP(in[len - 1 - i]);
-    const int64_t j = len - 1 - i;  // natural index of this output
-    // picks: tmp[q + 8] for q = nbeg + k*r, q < n + 9; a negative q+8 wraps like a Python index
-    int64_t q = j - (kPad - 1);
-    for (int pass = 0; pass < 2; ++pass) {
-      if (q >= m.nbeg && q < m.n + kPad && (pass == 0 || q + (kPad - 1) < 0)) {
-        const int64_t d = q - m.nbeg;
-        if (d % r == 0 && d / r < m.ylen) yo[d / r] = yv;
-      }
-      if (m.nbeg + (kPad - 1) >= 0) break;
-      q = j - len - (kPad - 1);
-    }
-  }
+  wh::serial_run<kIirBlock>(
+      s - warm > 0 ? s - warm : 0, e, [&](int64_t) { return true; }, [&](int64_t i) { return in[len - 1 - i]; },
+      [&](int64_t i) { return in[len - 1 - i]; },
+      [&](int64_t i, double v) {
+        IIR_STEP(v);
+        if (i >= s) {
+          if (r0 == 0 && k0 >= 0 && k0 < ylen && (len - 1 - i) - (kPad - 1) < qmax) yo[k0] = yv;
+          if (--r0 < 0) {
+            r0 = r - 1;
+            --k0;
+          }
+          if (wraps) {
+            if (r1 == 0 && k1 >= 0 && k1 < ylen) yo[k1] = yv;
+            if (--r1 < 0) {
+              r1 = r - 1;
+              --k1;
+            }
+          }
+        }
+      });
 }
 
 // z[m mod fft] = sum_k h[k] * yext[(m-k) mod fft], stored for m in [-pad, ylen+pad)   (dio.py:74-88)
@@ -243,10 +266,15 @@ __device__ __forceinline__ double select_best(double cur, double past, const dou
 // erosion, copies) run on all 256 threads, the change-point list is built by ordered ballot compaction,
 // and only the data-dependent forward/backward extensions (a few frames per voiced section) are walked
 // by one lane.
+// The walk is a chain of dependent reads (seven candidates and two contour values per frame stepped over): when the
+// utterance's candidate rows and the contour fit the CU's LDS (lds_cap doubles: 2001 frames x 7 bands = 128 KB) they are
+// staged there first and the walk runs at LDS latency instead of L2 latency (185 -> 60 us at 64 x 10 s).
 __global__ __launch_bounds__(256) void contour_kernel(const DioUtt* __restrict__ meta, int n_utt, int nb,
                                                       double frame_period, double f0_floor, double allowed,
                                                       double* __restrict__ cands_all, double* __restrict__ work,
-                                                      double* __restrict__ f0_out, double* __restrict__ vuv_out) {
+                                                      double* __restrict__ f0_out, double* __restrict__ vuv_out,
+                                                      int64_t lds_cap) {
+  extern __shared__ __attribute__((aligned(16))) double ct_sh[];  // [nb + 1][n] when it fits
   __shared__ int sh[8];
   __shared__ int sh_first;
   const int u = blockIdx.x;
@@ -334,6 +362,13 @@ __global__ __launch_bounds__(256) void contour_kernel(const DioUtt* __restrict__
   const int64_t nsec = (int64_t)floor((double)(nbl - (1 - first)) / 2);
   auto sec_start = [&](int64_t i) { return 1 + (int64_t)bl[(i - 1) * 2 + 1 + (1 - first) + 1]; };
   auto sec_end = [&](int64_t i) { return (int64_t)bl[i * 2 + (1 - first) + 1]; };
+  if ((int64_t)(nb + 1) * n <= lds_cap) {  // uniform: generic pointers into LDS from here on
+    for (int64_t i = tid; i < (int64_t)nb * n; i += 256) ct_sh[i] = cands[i];
+    for (int64_t i = tid; i < n; i += 256) ct_sh[(int64_t)nb * n + i] = s3[i];
+    cands = ct_sh;
+    s3 = ct_sh + (int64_t)nb * n;
+    __syncthreads();
+  }
   if (tid == 0) {
     // step 3 forward extension
     for (int64_t i = 0; i < nsec; ++i) {
@@ -409,13 +444,19 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   if (r < 1) return wh::fail_msg("wh_dio", "fs below target_fs");
   const IirCoef coef = (r >= 2 && r <= 12) ? kDecimate[r] : kDecimate[0];  // unknown ratio → all-zero filter (Q4)
   const double fs_d = target_fs;                                           // the true ratio is ignored (Q4)
+  // The band filters run on the register-tiled FIR of wh_bands.h, which wants odd tap counts (16-byte aligned input
+  // pairs): an even-length filter gets one trailing zero tap (a + 0*z == a, the sums are unchanged).
+#ifndef WH_DIO_BAND_TILED
+#define WH_DIO_BAND_TILED 1
+#endif
   int max_lb = 0, taps_total = 0;
-  std::vector<int32_t> tap_off(n_bands);
+  std::vector<int32_t> tap_off(n_bands), tap_len(n_bands);
   for (int i = 0; i < n_bands; ++i) {
-    tap_off[i] = taps_total;
-    taps_total += h_band_len[i];
-    if (h_band_len[i] > max_lb) max_lb = h_band_len[i];
     if (h_band_len[i] < 1) return wh::fail_msg("wh_dio", "empty band filter");
+    tap_len[i] = WH_DIO_BAND_TILED ? (h_band_len[i] | 1) : h_band_len[i];
+    tap_off[i] = taps_total;
+    taps_total += tap_len[i];
+    if (tap_len[i] > max_lb) max_lb = tap_len[i];
   }
   const int pad = max_lb + 2;
   const int hfl_pad = (int)(fs_d / f0_floor / 2 + 0.5) * 4;
@@ -497,13 +538,15 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   std::vector<int32_t> ti(n_bands * 3);
   for (int i = 0; i < n_bands; ++i) {
     ti[i] = tap_off[i];
-    ti[n_bands + i] = h_band_len[i];
+    ti[n_bands + i] = tap_len[i];
     ti[2 * n_bands + i] = h_band_bias[i];
   }
   // per-call tables live in persistent device buffers: re-uploaded (synchronously) only when they change
   {
-    std::vector<double> taps(h_band_taps, h_band_taps + taps_total), lc(h_lowcut, h_lowcut + 2 * lowcut_half + 1),
+    std::vector<double> taps(taps_total, 0.0), lc(h_lowcut, h_lowcut + 2 * lowcut_half + 1),
         bf(h_band_f0, h_band_f0 + n_bands);
+    for (int i = 0, src = 0; i < n_bands; src += h_band_len[i], ++i)
+      std::copy(h_band_taps + src, h_band_taps + src + h_band_len[i], taps.begin() + tap_off[i]);
     if (int rc = wh::persistent_upload(ctx, st, "dio.meta", meta, &d_meta)) return rc;
     if (int rc = wh::persistent_upload(ctx, st, "dio.taps", taps, &d_taps)) return rc;
     if (int rc = wh::persistent_upload(ctx, st, "dio.lowcut", lc, &d_lc)) return rc;
@@ -544,7 +587,7 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
     if (int rc = wh::persistent_upload(ctx, st, "dio.jobs", jobs, &d_jobs)) return rc;
   }
   if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands, d_ti + 2 * n_bands,
-                                      max_lb, false, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW, kBandSegs))
+                                      max_lb, WH_DIO_BAND_TILED != 0, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW, kBandSegs))
     return rc;
   // ---- candidates, sort, contour ------------------------------------------------------------------
   { wh::KernelTimer _kt(ctx, st, "cand_kernel"); hipLaunchKernelGGL(cand_kernel, dim3((unsigned)((max_nf + 255) / 256), n_bands, B), dim3(256), 0, st, d_meta, tp, d_e,
@@ -553,8 +596,15 @@ extern "C" int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double
   { wh::KernelTimer _kt(ctx, st, "sort_kernel"); hipLaunchKernelGGL(sort_kernel, dim3((unsigned)((max_nf + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw,
                      d_stab, d_sorted, cand_out); }
   WH_LAUNCH_CHECK("sort_kernel");
-  { wh::KernelTimer _kt(ctx, st, "contour_kernel"); hipLaunchKernelGGL(contour_kernel, dim3(B), dim3(256), 0, st, d_meta, B, n_bands, frame_period_ms, f0_floor,
-                     allowed_range, d_sorted, d_work, f0_out, vuv_out); }
+  {
+    // candidate rows + contour in LDS when the longest utterance fits (see contour_kernel)
+    const size_t want = sizeof(double) * (size_t)(n_bands + 1) * (size_t)max_nf;
+    const size_t lds = want <= 150 * 1024 ? want : 0;
+    if (int rc = wh::allow_lds(&contour_kernel, lds)) return rc;
+    wh::KernelTimer _kt(ctx, st, "contour_kernel");
+    hipLaunchKernelGGL(contour_kernel, dim3(B), dim3(256), lds, st, d_meta, B, n_bands, frame_period_ms, f0_floor,
+                       allowed_range, d_sorted, d_work, f0_out, vuv_out, (int64_t)(lds / sizeof(double)));
+  }
   WH_LAUNCH_CHECK("contour_kernel");
   return 0;
 }

@@ -65,6 +65,8 @@ __device__ __forceinline__ double hv_ext(const double* __restrict__ x, const HvU
     z2 = xin * c.b3 - yv * c.a3;          \
   }
 
+constexpr int kHBlock = 16;  // samples fetched together, a block ahead of the recurrence (wh::serial_run)
+
 __global__ __launch_bounds__(64) void hv_iir_fwd_kernel(const double* __restrict__ x, const HvUtt* __restrict__ meta,
                                                         Tdf2 c, int warm, double* __restrict__ tmp) {
   const HvUtt m = meta[blockIdx.y];
@@ -75,21 +77,25 @@ __global__ __launch_bounds__(64) void hv_iir_fwd_kernel(const double* __restrict
   const double* xu = x + m.x_off;
   double* out = tmp + m.t_off;
   double z0 = 0, z1 = 0, z2 = 0, yv = 0;
-  int64_t i = s - warm;
-  if (i <= 0) {  // the true start: steady-state initial conditions scaled by the first sample
-    i = 0;
+  int64_t i0 = s - warm;
+  if (i0 <= 0) {  // the true start: steady-state initial conditions scaled by the first sample
+    i0 = 0;
     const double x0 = hv_ext(xu, m, 0);
     z0 = c.zi0 * x0;
     z1 = c.zi1 * x0;
     z2 = c.zi2 * x0;
   }
-  for (; i < s; ++i) TDF2_STEP(hv_ext(xu, m, i));
-  for (i = s; i < e; ++i) {
-    TDF2_STEP(hv_ext(xu, m, i));
-    out[i] = yv;
-  }
+  const int64_t lo = kFPad + m.offset, hi = kFPad + m.offset + m.n;  // extended indices that are plain samples of x
+  wh::serial_run<kHBlock>(
+      i0, e, [&](int64_t i) { return i >= lo && i + kHBlock <= hi; }, [&](int64_t i) { return xu[i - lo]; },
+      [&](int64_t i) { return hv_ext(xu, m, i); },
+      [&](int64_t i, double v) {
+        TDF2_STEP(v);
+        if (i >= s) out[i] = yv;
+      });
 }
-
+// Second pass over the reversed pass-1 output; stores only the decimated picks p = pick0 + k*r of the filtfilt result
+// (quotient and remainder of p - pick0 by r are carried along the walk instead of divided out per sample).
 __global__ __launch_bounds__(64) void hv_iir_bwd_kernel(const HvUtt* __restrict__ meta, Tdf2 c, int warm, int r,
                                                         const double* __restrict__ tmp, double* __restrict__ y) {
   const HvUtt m = meta[blockIdx.y];
@@ -99,22 +105,32 @@ __global__ __launch_bounds__(64) void hv_iir_bwd_kernel(const HvUtt* __restrict_
   const int64_t e = s + kHChunk < len ? s + kHChunk : len;
   const double* in = tmp + m.t_off;
   double* yo = y + m.y_off;
+  const int64_t ylen = m.ylen;
   double z0 = 0, z1 = 0, z2 = 0, yv = 0;
-  int64_t i = s - warm;
-  if (i <= 0) {
-    i = 0;
+  int64_t i0 = s - warm;
+  if (i0 <= 0) {
+    i0 = 0;
     const double y0 = in[len - 1];
     z0 = c.zi0 * y0;
     z1 = c.zi1 * y0;
     z2 = c.zi2 * y0;
   }
-  for (; i < s; ++i) TDF2_STEP(in[len - 1 - i]);
-  for (i = s; i < e; ++i) {
-    TDF2_STEP(in[len - 1 - i]);
-    const int64_t p = (len - 1 - i) - kFPad;  // index into the filtfilt result
-    const int64_t d = p - m.pick0;
-    if (d >= 0 && d % r == 0 && d / r < m.ylen) yo[d / r] = yv;
-  }
+  const int64_t d0 = (len - 1 - s) - kFPad - m.pick0;  // p - pick0 at i = s; falls by one per step
+  int64_t k0 = d0 >= 0 ? d0 / r : -((-d0 + r - 1) / r);
+  int r0 = (int)(d0 - k0 * r);
+  wh::serial_run<kHBlock>(
+      i0, e, [&](int64_t) { return true; }, [&](int64_t i) { return in[len - 1 - i]; },
+      [&](int64_t i) { return in[len - 1 - i]; },
+      [&](int64_t i, double v) {
+        TDF2_STEP(v);
+        if (i >= s) {
+          if (r0 == 0 && k0 >= 0 && k0 < ylen) yo[k0] = yv;
+          if (--r0 < 0) {
+            r0 = r - 1;
+            --k0;
+          }
+        }
+      });
 }
 
 __global__ __launch_bounds__(256) void hv_copy_kernel(const double* __restrict__ x, const HvUtt* __restrict__ meta,
@@ -308,8 +324,9 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  // every control used here reads a live lane of the same row for every lane: no "old" value is needed
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // sum over the 16 lanes of a DPP row, result in every lane: xor-1, xor-2 quad permutes, then the two mirrors
@@ -321,9 +338,13 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
+// TWL: the twiddles come from the workgroup's LDS copy (tw_lds, at a compile-time offset of the dynamic LDS block, so
+// that a look-up is one ds_read_b128 whose address register is the running byte offset itself); else from the global
+// tables through tw_base.
+template <bool TWL>
 __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int64_t ybase, int64_t ylen, double fs,
                                               double t0, double f0c, double f0_floor, double f0_ceil,
-                                              const double2* __restrict__ tw_base, const double2* tw_lds, int tw_n,
+                                              const double2* __restrict__ tw_base, const char* tw_lds, int tw_n,
                                               double* out_f0, double* out_sc) {
   const int l16 = threadIdx.x & 15;
   const double hwl_d = ceil(3 * fs / f0c / 2);
@@ -339,8 +360,18 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   const int nh = (int)fmin(floor(fs / 2 / f0c), 6.0);
   // twiddles exp(-2*pi*i*k/nfft): from the workgroup's LDS copy of the largest table any of its candidates can
   // need (the smaller tables are its subsamples, bit for bit), else from the global table
-  const double2* tw = tw_lds ? tw_lds : tw_base + nfft;
-  const int tw_sh = tw_lds ? (__ffs(tw_n) - __ffs(nfft)) : 0;
+  const char* tw = TWL ? tw_lds : reinterpret_cast<const char*>(tw_base + nfft);
+  const int tw_sh = (TWL ? (__ffs(tw_n) - __ffs(nfft)) : 0) + 4;  // table subsampling, and elements -> bytes
+  auto twiddle = [&](int byte_off) -> double2 {
+    if constexpr (TWL) {  // the table sits at LDS address 0 (checked by the kernel): the offset IS the address
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      typedef const v2d __attribute__((address_space(3))) * lds_tw_t;
+      const v2d w = *(lds_tw_t)(size_t)(uint32_t)byte_off;
+      return make_double2(w.x, w.y);
+    } else {
+      return *reinterpret_cast<const double2*>(tw + byte_off);
+    }
+  };
   int bins[6];
 #pragma unroll
   for (int h = 0; h < 6; ++h) bins[h] = (int)(f0c * nfft / fs * (double)(h + 1) + 0.5);
@@ -378,7 +409,7 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
 #pragma unroll
     for (int h = 0; h < 6; ++h) {
       if (h < nh) {
-        const double2 w = tw[((bins[h] * j) & (nfft - 1)) << tw_sh];
+        const double2 w = twiddle(((bins[h] * j) & (nfft - 1)) << tw_sh);
         xr[h] = fma(a, w.x, xr[h]);
         xi[h] = fma(a, w.y, xi[h]);
         dr[h] = fma(d, w.x, dr[h]);
@@ -386,7 +417,13 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       }
     }
   };
-  if (idx_raw_at(0) > 1.0) {
+  // The sample index of j is floor(idx_raw_at(j)) = floor(A + j) with A = t0*fs - hwl + 0.501: it steps by exactly one
+  // per j as long as A's fraction stays clear of 0 and 1 by more than the rounding of the expression (~1e-9 at 60 s),
+  // which the 0.501 guarantees for every decimated rate that is a multiple of 50 Hz; checked here (row-uniform), and
+  // a frame that fails the check takes the general path below.
+  const double a0 = idx_raw_at(0);
+  const double a0_frac = a0 - floor(a0);
+  if (a0 > 1.0 && a0_frac > 1e-6 && a0_frac < 1.0 - 1e-6) {
     // Every index of the frame is positive (all frames but the first few of an utterance): idx_raw, and with it the
     // window phase xw, is linear in j, so this lane's samples j = l16 + 16 i are a fixed rotation of 16*pi*dx apart —
     // one sincospi to start, a 4-flop rotation per sample after that (<= 43 steps: error growth ~1e-15).
@@ -408,7 +445,7 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
     // offset of harmonic h advances by (16*bin_h mod nfft) << shift per iteration.  All six harmonics are accumulated
     // whatever nh is (the surplus ones, for candidates above fs/12, are simply not read afterwards): no per-harmonic
     // predication inside the loop.
-    int tix[6], tstep[6];
+    int tix[6], tstep[6];  // byte offsets
     const int tmask = ((nfft - 1) << tw_sh);
 #pragma unroll
     for (int h = 0; h < 6; ++h) {
@@ -418,6 +455,10 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
     double m_prev = 0.0, m_cur = blackman(c2);
     const int n_it = (L + 15) >> 4;
     int j = l16;
+    // staged-signal index of sample j: clamp(floor(A) + j, 1, ylen) - 1 - ybase, carried as an int
+    const int64_t i_first = (int64_t)a0;
+    const int i_lo = (int)(0 - ybase), i_hi = (int)(ylen - 1 - ybase);
+    int si = (int)(i_first - 1 - ybase) + l16;
     for (int it = 0; it < n_it; ++it, j += 16) {
       const double cn = c2 * c16 - s2 * s16;  // phase of sample j + 16
       s2 = s2 * c16 + c2 * s16;
@@ -433,14 +474,12 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       else if (j == L - 1) dw = mp / 2;
       else dw = -((mn - mj) + (mj - mp)) / 2;
       double smp = 0.0;
-      if (j < L) {
-        const double irc = fmax(1.0, fmin((double)ylen, idx_raw_at(j))) - 1;
-        smp = yl[(int64_t)irc - ybase];
-      }
+      if (j < L) smp = yl[si < i_lo ? i_lo : (si > i_hi ? i_hi : si)];
+      si += 16;
       const double a = smp * mj, d = smp * dw;
 #pragma unroll
       for (int h = 0; h < 6; ++h) {
-        const double2 w = tw[tix[h]];
+        const double2 w = twiddle(tix[h]);
         xr[h] = fma(a, w.x, xr[h]);
         xi[h] = fma(a, w.y, xi[h]);
         dr[h] = fma(d, w.x, dr[h]);
@@ -502,23 +541,32 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
 
 constexpr int kFramesPerBlock = 4;
 
+template <bool TWL>
 __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
                                                         const double* __restrict__ dc, const int32_t* __restrict__ dcount,
                                                         double fs, double f0_floor, double f0_ceil, int hmax, int seglen,
                                                         const double2* __restrict__ tw_base, int tw_n,
                                                         double* __restrict__ rf0, double* __restrict__ rsc) {
+  // All of the kernel's LDS is the dynamic block, so that it starts at LDS address 0 and the twiddle table's byte
+  // offsets are LDS addresses as they stand (hv_refine_lds_bytes mirrors this layout).
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double cl_val[kFramesPerBlock * kRows];
-  __shared__ int cl_meta[kFramesPerBlock * kRows];
-  __shared__ int cl_n;
   const HvUtt m = meta[blockIdx.y];
   const int64_t f_first = (int64_t)blockIdx.x * kFramesPerBlock;
   if (f_first >= m.nf1) return;
-  double* yl = reinterpret_cast<double*>(smem);  // staged signal around the block's frames
-  // ... followed by the twiddle table of the largest transform length (tw_n points; 0: read the global tables):
-  // every sample of every refinement gathers up to 6 twiddles at scattered indices — LDS serves those, the L1 does not
-  double2* twl = tw_n ? reinterpret_cast<double2*>(yl + ((seglen + 1) & ~1)) : nullptr;
-  for (int i = threadIdx.x; i < tw_n; i += 256) twl[i] = tw_base[tw_n + i];
+  // LDS: the twiddle table of the largest transform length first (tw_n points; TWL false: none, the global tables are
+  // read) — every sample of every refinement gathers 6 twiddles at scattered indices, LDS serves those, the L1 does
+  // not — then the staged signal around the block's frames.
+  double2* twl = reinterpret_cast<double2*>(smem);
+  if (TWL && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+  double* yl = reinterpret_cast<double*>(smem + (TWL ? sizeof(double2) * (size_t)tw_n : 0));
+  constexpr int kItems = kFramesPerBlock * kRows;
+  double* cl_val = yl + ((seglen + 1) & ~1);                 // kItems
+  int* cl_meta = reinterpret_cast<int*>(cl_val + kItems);    // kItems
+  int* order = cl_meta + kItems;                             // kItems
+  int* bucket = order + kItems;                              // 32
+  int& cl_n = bucket[32];
+  if (TWL)
+    for (int i = threadIdx.x; i < tw_n; i += 256) twl[i] = tw_base[tw_n + i];
   const int64_t centre0 = (int64_t)floor(((double)f_first * 1 / 1000) * fs + 0.5);
   int64_t ybase = centre0 - hmax - 3;
   if (ybase < 0) ybase = 0;
@@ -555,7 +603,6 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict_
   // octave neighbours.  Counting sort of the work list by iteration count, so that the rows of a wave (consecutive
   // entries) carry windows of the same length class.
   {
-    __shared__ int bucket[32], order[kFramesPerBlock * kRows];
     if (threadIdx.x < 32) bucket[threadIdx.x] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n_items; i += 256) {
@@ -583,7 +630,7 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict_
       const int q = cl_meta[src] & 0xffff;
       const int64_t f = f_first + q / kRows;
       double r0, r1;
-      hv_refine_row(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, twl, tw_n, &r0, &r1);
+      hv_refine_row<TWL>(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem, tw_n, &r0, &r1);
       if ((threadIdx.x & 15) == 0) {
         rf0[(m.f1_off + f) * kRows + q % kRows] = r0;
         rsc[(m.f1_off + f) * kRows + q % kRows] = r1;
@@ -865,9 +912,18 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     while (tw_n < 2 * hmax + 1) tw_n <<= 1;
     tw_n <<= 1;
     if (tw_n > 2048) tw_n = 0;  // 32 KB of LDS at most for the table; beyond that gather from the global tables
-    const size_t lds = sizeof(double) * (size_t)((seglen + 1) & ~1) + sizeof(double2) * (size_t)tw_n;
-    if (int rc = wh::allow_lds(&hv_refine_kernel, lds)) return rc;
-    { wh::KernelTimer _kt(ctx, st, "hv_refine_kernel"); hipLaunchKernelGGL(hv_refine_kernel, dim3((unsigned)((max_nf1 + kFramesPerBlock - 1) / kFramesPerBlock), B), dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rf0, d_rsc); }
+    const size_t lds = sizeof(double2) * (size_t)tw_n + sizeof(double) * (size_t)((seglen + 1) & ~1) +
+                       (sizeof(double) + 2 * sizeof(int)) * (size_t)(kFramesPerBlock * kRows) + sizeof(int) * 40;
+    const dim3 grid((unsigned)((max_nf1 + kFramesPerBlock - 1) / kFramesPerBlock), B);
+    if (tw_n) {
+      if (int rc = wh::allow_lds(&hv_refine_kernel<true>, lds)) return rc;
+      wh::KernelTimer _kt(ctx, st, "hv_refine_kernel");
+      hipLaunchKernelGGL(hv_refine_kernel<true>, grid, dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rf0, d_rsc);
+    } else {
+      if (int rc = wh::allow_lds(&hv_refine_kernel<false>, lds)) return rc;
+      wh::KernelTimer _kt(ctx, st, "hv_refine_kernel");
+      hipLaunchKernelGGL(hv_refine_kernel<false>, grid, dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rf0, d_rsc);
+    }
     WH_LAUNCH_CHECK("hv_refine_kernel");
   }
   { wh::KernelTimer _kt(ctx, st, "hv_prune_kernel"); hipLaunchKernelGGL(hv_prune_kernel, dim3((unsigned)max_nf1, B), dim3(128), 0, st, d_meta, d_rf0, d_rsc, d_pf0, d_psc); }

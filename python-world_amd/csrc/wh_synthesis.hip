@@ -60,9 +60,23 @@ struct SynUtt {
   double t0, dt;          // time axis t_i = t0 + i*dt  (NumPy arange semantics, host-computed)
 };
 
-// searchsorted-left, hi clipped to [1, nf-1]: the segment SciPy's interp1d(linear, extrapolate) evaluates t on
+// searchsorted-left, hi clipped to [1, nf-1]: the segment SciPy's interp1d(linear, extrapolate) evaluates t on.
+// The frame times are almost always an even grid (also after scale_duration), so the answer is first guessed from the
+// grid's mean step and checked against its definition (tp[lo-1] < t <= tp[lo]): two rounds of independent loads
+// instead of log2(nf) dependent ones; any other time axis falls through to the bisection.  Same result either way.
 __device__ __forceinline__ int64_t lerp_segment(const double* __restrict__ tp, int64_t nf, double t) {
   int64_t lo = 0, hi = nf;
+  if (nf >= 2) {
+    const double first = tp[0], last = tp[nf - 1];
+    const double g = ceil((t - first) * (double)(nf - 1) / (last - first));
+    if (g >= 1.0 && g <= (double)(nf - 1)) {
+      const int64_t gi = (int64_t)g;
+      const double a = tp[gi - 1], b = tp[gi], c = gi + 1 < nf ? tp[gi + 1] : b;
+      if (a < t && !(b < t)) return gi;                                    // already inside [1, nf-1]
+      if (b < t && !(c < t) && gi + 1 <= nf - 1) return gi + 1;
+      if (gi >= 2 && !(a < t) && tp[gi - 2] < t) return gi - 1;
+    }
+  }
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
     if (tp[mid] < t) lo = mid + 1; else hi = mid;
@@ -108,12 +122,16 @@ __global__ __launch_bounds__(256) void prep_kernel(const SynUtt* __restrict__ me
 //     takes one pass almost always.
 // 5 ns per sample for the sequential add chain (tools/ubench/chain.hip) becomes ~0.5 ns.
 #ifndef WH_XTILE
-#define WH_XTILE 2048
+#define WH_XTILE 4096
 #endif
 constexpr int kXTile = WH_XTILE;
-constexpr int kXThreads = 256;
+#ifndef WH_XTHREADS
+#define WH_XTHREADS 512
+#endif
+constexpr int kXThreads = WH_XTHREADS;
 constexpr int kXPer = kXTile / kXThreads;
-__device__ __forceinline__ int xpad(int i) { return i + (i >> 3); }  // thread-contiguous runs of 8: stride 9 doubles
+constexpr int kXLds = kXTile + kXTile / kXPer;  // padded tile (xpad)
+__device__ __forceinline__ int xpad(int i) { return i + i / kXPer; }  // thread-contiguous runs of kXPer: odd stride in doubles
 
 __device__ __forceinline__ int wave_min_int(int v) {
 #pragma unroll
@@ -124,7 +142,7 @@ __device__ __forceinline__ int wave_min_int(int v) {
   return v;
 }
 
-// p[0..n): in place.  xin / xout: kXTile + kXTile/8 doubles of LDS each; scr: 16 doubles.  One workgroup of 256.
+// p[0..n): in place.  xin / xout: kXLds doubles of LDS each; scr: 32 doubles.  One workgroup of kXThreads.
 // All integer quantities (r_j, their prefix sums, V_j < 2^53) are carried as integer-valued doubles: exact, and
 // the whole pass stays on the FP64 pipe.
 __device__ __forceinline__ void exact_cumsum_block(double* __restrict__ p, int64_t n, double* xin, double* xout,
@@ -197,7 +215,7 @@ __device__ __forceinline__ void exact_cumsum_block(double* __restrict__ p, int64
           if (idx >= s && idx < cnt && before + r[j] >= kTop && first_x == kXTile) first_x = idx;
         }
         const int mine = wave_min_int(first_tie < first_x ? first_tie : first_x);
-        int* iscr = reinterpret_cast<int*>(scr + 8);
+        int* iscr = reinterpret_cast<int*>(scr + 16);
         if (lane == 0) iscr[w] = mine;
         __syncthreads();
         jstop = iscr[0];
@@ -231,14 +249,14 @@ __device__ __forceinline__ void exact_cumsum_block(double* __restrict__ p, int64
 }
 
 __global__ __launch_bounds__(kXThreads) void phase_kernel(const SynUtt* __restrict__ meta, double* __restrict__ phase) {
-  __shared__ double xin[kXTile + kXTile / 8], xout[kXTile + kXTile / 8], scr[16];
+  __shared__ double xin[kXLds], xout[kXLds], scr[32];
   const SynUtt m = meta[blockIdx.x];
   exact_cumsum_block(phase + m.y_off, m.ny, xin, xout, scr);
 }
 
 // Test / utility entry: the same scan over independent segments off[i] .. off[i+1].
 __global__ __launch_bounds__(kXThreads) void exact_cumsum_kernel(double* __restrict__ data, const int64_t* __restrict__ off) {
-  __shared__ double xin[kXTile + kXTile / 8], xout[kXTile + kXTile / 8], scr[16];
+  __shared__ double xin[kXLds], xout[kXLds], scr[32];
   exact_cumsum_block(data + off[blockIdx.x], off[blockIdx.x + 1] - off[blockIdx.x], xin, xout, scr);
 }
 

@@ -225,7 +225,12 @@ inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs
 #define WH_OLS_MINW 3  // waves per SIMD the channel walker's register allocation leaves room for
 #endif
 constexpr int kOlsN = 4096;
-constexpr int kOlsValid = 3072;  // three kBandTile sub-tiles per block (+2 look-ahead samples)
+#ifndef WH_OLS_VALID
+#define WH_OLS_VALID 3584
+#endif
+constexpr int kOlsValid = WH_OLS_VALID;  // outputs kept per block: 256 x 14 positions (+2 look-ahead samples); the longest
+                                         // filter (493 taps) leaves 4096 - 495 = 3601
+constexpr int kOlsPer = kOlsValid / 256;
 constexpr int kOlsBands = 4;
 
 // T_b = rfft(taps_b zero-padded to kOlsN): [nb][kOlsN/2+1] complex
@@ -351,13 +356,7 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
       irfft_lds<kOlsN, 256>(ybuf, tw_base);
       // output i of the block is s[t0 + i - (H + h + 1)]: the tile's outputs start at index H + h + 1
       const double* sig = sig_all + (H + half[b] + 1);
-#pragma unroll 1
-      for (int sub = 0; sub < kOlsValid / kBandTile; ++sub) {
-        const int64_t ts0 = t0 + (int64_t)sub * kBandTile;
-        if (ts0 >= M) break;
-        if (sub) __syncthreads();
-        emit_crossings(sig + sub * kBandTile, ts0, M, kBandTile, job.edges, job.cap, base_cnt, scan_scratch, flags);
-      }
+      emit_crossings_block<1, kOlsPer>(sig, t0, M, job.edges, job.cap, base_cnt, scan_scratch, flags);
       __syncthreads();
       if (threadIdx.x < 4) s_cnt[g][threadIdx.x] = base_cnt[threadIdx.x];
     }
@@ -436,13 +435,8 @@ static __global__ __launch_bounds__(256, 2) void band_events_ols2_kernel(const B
         for (int t = 0; t < 4; ++t) base_cnt[t] = s_cnt[g + c][t];
         // output i of the block is s[t0 + i - (H + h + 1)]; component c of complex sample i sits at comp[2 i + c]
         const double* sig = comp + 2 * (H + half[b] + 1) + c;
-#pragma unroll 1
-        for (int sub = 0; sub < kOlsValid / kBandTile; ++sub) {
-          const int64_t ts0 = t0 + (int64_t)sub * kBandTile;
-          if (ts0 >= M) break;
-          __syncthreads();
-          emit_crossings<2>(sig + 2 * sub * kBandTile, ts0, M, kBandTile, job.edges, job.cap, base_cnt, scan_scratch, flags);
-        }
+        __syncthreads();
+        emit_crossings_block<2, kOlsPer>(sig, t0, M, job.edges, job.cap, base_cnt, scan_scratch, flags);
         __syncthreads();
         if (threadIdx.x < 4) s_cnt[g + c][threadIdx.x] = base_cnt[threadIdx.x];
       }

@@ -94,6 +94,76 @@ __device__ __forceinline__ void emit_crossings(const double* sig, int64_t t0, in
   }
 }
 
+// The same for a tile of PER * 256 positions in ONE pass (one block scan and two barriers whatever the tile length):
+// the first walk only flags the crossings (no divides, nothing kept but four PER-bit masks), the second re-reads the
+// flagged samples and writes the edge positions at the offsets the scan produced.  Used by the overlap-save band
+// walker, whose tiles are 3584 samples (14 positions per thread).
+template <int STRIDE, int PER>
+__device__ __forceinline__ void emit_crossings_block(const double* sig, int64_t t0, int64_t M, double* edges, int64_t cap,
+                                                     int* base_cnt, unsigned long long* scratch,
+                                                     int32_t* overflow_flag) {
+  static_assert(PER <= 16, "masks are 16 bits, counts 16 bits per train");
+  const int tid = threadIdx.x;
+  unsigned m01 = 0, m23 = 0;  // bits [0,16): negative-going, [16,32): positive-going
+  {
+    const int i0 = tid * PER;
+    double a = sig[i0 * STRIDE], b = sig[(i0 + 1) * STRIDE];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const double c = sig[(i0 + q + 2) * STRIDE];
+      const int64_t g = t0 + i0 + q;
+      if (g + 1 < M && a * b < 0) m01 |= (b < a ? 1u : (b > a ? 0x10000u : 0u)) << q;
+      const double d0 = b - a, d1 = c - b;
+      if (g + 2 < M && d0 * d1 < 0) m23 |= (d1 < d0 ? 1u : (d1 > d0 ? 0x10000u : 0u)) << q;
+      a = b;
+      b = c;
+    }
+  }
+  const unsigned long long packed = (unsigned long long)__popc(m01 & 0xFFFFu) | ((unsigned long long)__popc(m01 >> 16) << 16) |
+                                    ((unsigned long long)__popc(m23 & 0xFFFFu) << 32) |
+                                    ((unsigned long long)__popc(m23 >> 16) << 48);
+  const unsigned long long incl = wave_scan_incl_u64(packed);
+  const int w = tid >> 6;
+  __syncthreads();
+  if ((tid & 63) == 63) scratch[w] = incl;
+  __syncthreads();
+  unsigned long long excl = incl - packed;
+  unsigned long long total = 0;
+#pragma unroll
+  for (int i = 0; i < WH_BLOCK / 64; ++i) {
+    if (i < w) excl += scratch[i];
+    total += scratch[i];
+  }
+  int pos[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) pos[t] = base_cnt[t] + (int)((excl >> (16 * t)) & 0xFFFF);
+  unsigned any = (m01 | (m01 >> 16) | m23 | (m23 >> 16)) & 0xFFFFu;
+  while (any) {  // flagged positions only, ascending
+    const int q = __ffs(any) - 1;
+    any &= any - 1;
+    const int i = tid * PER + q;
+    const double a = sig[i * STRIDE], b = sig[(i + 1) * STRIDE], c = sig[(i + 2) * STRIDE];
+    const double at = (double)(t0 + i + 1);
+    if ((m01 >> q) & 0x10001u) {
+      const int t = (m01 >> q) & 1u ? 0 : 1;
+      const double fe = at - a / (b - a);
+      if (pos[t] < cap) edges[(int64_t)t * cap + pos[t]] = fe;
+      else atomicOr(overflow_flag, 1);
+      ++pos[t];
+    }
+    if ((m23 >> q) & 0x10001u) {
+      const int t = (m23 >> q) & 1u ? 2 : 3;
+      const double d0 = b - a, d1 = c - b;
+      const double fe = at - d0 / (d1 - d0);
+      if (pos[t] < cap) edges[(int64_t)t * cap + pos[t]] = fe;
+      else atomicOr(overflow_flag, 1);
+      ++pos[t];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) base_cnt[t] += (int)((total >> (16 * t)) & 0xFFFF);
+}
+
 // Interpolate the four interval-F0 trains at time t (linear, end-segment extrapolation — SciPy's
 // interp1d(..., fill_value='extrapolate') arithmetic) and reduce: mean and, optionally, ddof=1 std.
 // Fewer than 3 intervals in any train → (0, 1000) (dio.py:159-162,182-184).

@@ -26,6 +26,9 @@ constexpr int kMaxC = 15;          // int(152/10 + 0.5): candidate rows per fram
 constexpr int kRows = 7 * kMaxC;   // overlapped candidate rows (shift-major, candidate-minor)
 constexpr int kFPad = 9;           // filtfilt padlen
 constexpr int kHChunk = 1024;
+#ifndef WH_HV_RED_DPP
+#define WH_HV_RED_DPP 1  // 0: fold the 24 partial sums once by DPP, then through an LDS scratch (fewer VALU instructions, but 10.4 vs 9.5 ms measured: the 24 KB of scratch cost a workgroup per CU)
+#endif
 
 struct HvUtt {
   int64_t x_off, n;
@@ -345,7 +348,8 @@ template <bool TWL>
 __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int64_t ybase, int64_t ylen, double fs,
                                               double t0, double f0c, double f0_floor, double f0_ceil,
                                               const double2* __restrict__ tw_base, const char* tw_lds, int tw_n,
-                                              double* out_f0, double* out_sc) {
+                                              const double2* __restrict__ rot_tab, double* red, double* out_f0,
+                                              double* out_sc) {
   const int l16 = threadIdx.x & 15;
   const double hwl_d = ceil(3 * fs / f0c / 2);
   const int hwl = (int)hwl_d;
@@ -426,26 +430,30 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   if (a0 > 1.0 && a0_frac > 1e-6 && a0_frac < 1.0 - 1e-6) {
     // Every index of the frame is positive (all frames but the first few of an utterance): idx_raw, and with it the
     // window phase xw, is linear in j, so this lane's samples j = l16 + 16 i are a fixed rotation of 16*pi*dx apart —
-    // one sincospi to start, a 4-flop rotation per sample after that (<= 43 steps: error growth ~1e-15).
+    // one sincospi to start, a 6-flop rotation per sample after that (<= 24 steps: error growth ~1e-15; the rotation
+    // constants of every window length come from a small per-call table).
     // The derivative window needs the Blackman values of samples j-1 and j+1: those are what the neighbouring lanes
     // of the row hold in the same iteration (lane 0's left neighbour is lane 15's value of the previous iteration,
     // lane 15's right neighbour lane 0's value of the next one, which is therefore computed one iteration ahead), so
-    // they are fetched with two DPP row rotates each instead of being recomputed (2 x (rotation + Blackman) = 16
+    // they are fetched with two DPP row rotates each instead of being recomputed (2 x (rotation + Blackman) = 26
     // FP64 operations per sample in a kernel that is VALU-bound).  All 16 lanes of a row run the same number of
-    // iterations (validity is a predicate), which keeps every source lane of the rotates alive.  The twiddle index
-    // (bin*j) mod nfft advances by a constant per iteration: an add and a mask instead of a 32-bit multiply.
-    double s16, c16, s2, c2;
-    sincospi(16 * dx, &s16, &c16);
+    // iterations (validity is a predicate), which keeps every source lane of the rotates alive.  The twiddle offset
+    // (bin*j mod nfft) advances by a constant per iteration: an add and a mask instead of a 32-bit multiply.
+    // (A lane-contiguous layout, j = l*nb + i, needs no cross-lane traffic at all but multiplies the lane stride of
+    // the twiddle gathers by nb: their LDS bank conflicts made it 20 % slower, measured.)
+    const double2 rot = rot_tab[hwl];  // (sin, cos)(16*pi*dx)
+    const double s16 = rot.x, c16 = rot.y;
+    double s2, c2;
     {
       const double ir0 = idx_raw_at(l16);
       sincospi(2 * ((ir0 - 1) / fs - t0) / wlit, &s2, &c2);
     }
     auto blackman = [](double c) { return 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1); };  // cos(4c) = 2cos^2(2c) - 1
-    // twiddle look-ups as element offsets into the table in use, already scaled by its subsampling shift: the
+    // twiddle look-ups as byte offsets into the table in use, already scaled by its subsampling shift: the
     // offset of harmonic h advances by (16*bin_h mod nfft) << shift per iteration.  All six harmonics are accumulated
     // whatever nh is (the surplus ones, for candidates above fs/12, are simply not read afterwards): no per-harmonic
     // predication inside the loop.
-    int tix[6], tstep[6];  // byte offsets
+    int tix[6], tstep[6];
     const int tmask = ((nfft - 1) << tw_sh);
 #pragma unroll
     for (int h = 0; h < 6; ++h) {
@@ -505,8 +513,12 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   // The four sums of every harmonic go round the row; lane h then evaluates harmonic h alone — instantaneous
   // frequency, amplitude, deviation: five FP64 divides and a square root, ~85 instructions that all sixteen lanes used
   // to repeat for each of the six harmonics — and three more row sums collect the totals.
+  // Reduction of the 24 partial sums: one DPP step folds the row's halves (lanes l and l+8), the folded values go
+  // through the row's LDS scratch (red: [24][8] doubles), and lane h adds up the eight partials of each of harmonic
+  // h's four sums — 72 + 28 VALU instructions where four DPP butterfly steps on all 24 values took 288.
   double sa = 0.0, sb = 0.0, sc_ = 0.0, sd = 0.0;
   int my_bin = 0;
+#if WH_HV_RED_DPP
 #pragma unroll
   for (int h = 0; h < 6; ++h) {
     const double a = row16_sum(xr[h]), b = row16_sum(xi[h]), c = row16_sum(dr[h]), d = row16_sum(di[h]);
@@ -518,11 +530,41 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       my_bin = bins[h];
     }
   }
+#else
+  {
+    const int l8 = l16 & 7;
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      red[(4 * h + 0) * 8 + l8] = xr[h] + dpp_f64<0x128>(xr[h]);  // row_ror:8
+      red[(4 * h + 1) * 8 + l8] = xi[h] + dpp_f64<0x128>(xi[h]);
+      red[(4 * h + 2) * 8 + l8] = dr[h] + dpp_f64<0x128>(dr[h]);
+      red[(4 * h + 3) * 8 + l8] = di[h] + dpp_f64<0x128>(di[h]);
+    }
+    wh::sync<64>();
+    const int hh = l16 < 6 ? l16 : 5;
+    const double2* r2 = reinterpret_cast<const double2*>(red + hh * 32);
+    double acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double2 p0 = r2[c * 4 + 0], p1 = r2[c * 4 + 1], p2 = r2[c * 4 + 2], p3 = r2[c * 4 + 3];
+      acc[c] = ((p0.x + p0.y) + (p1.x + p1.y)) + ((p2.x + p2.y) + (p3.x + p3.y));
+    }
+    sa = acc[0];
+    sb = acc[1];
+    sc_ = acc[2];
+    sd = acc[3];
+#pragma unroll
+    for (int h = 0; h < 6; ++h)
+      if (l16 == h) my_bin = bins[h];
+    wh::sync<64>();  // the scratch is free for the row's next candidate
+  }
+#endif
   double t_num = 0.0, t_den = 0.0, t_var = 0.0;
   if (l16 < nh) {
     const double p = sa * sa + sb * sb;
     const double nm = sa * sd - sb * sc_;
-    const double inst = ((double)my_bin / nfft + nm / p / 2 / M_PI) * fs;
+    // bin / nfft is exact (power of two), and so is the halving
+    const double inst = ((double)my_bin * (1.0 / (double)nfft) + nm / p * 0.5 / M_PI) * fs;
     const double amp = sqrt(p);
     t_num = amp * inst;
     t_den = amp * (double)(l16 + 1);
@@ -540,12 +582,14 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
 }
 
 constexpr int kFramesPerBlock = 4;
+constexpr int kRedRow = WH_HV_RED_DPP ? 0 : 24 * 8;  // doubles of reduction scratch per 16-lane row (hv_refine_row)
 
 template <bool TWL>
 __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
                                                         const double* __restrict__ dc, const int32_t* __restrict__ dcount,
                                                         double fs, double f0_floor, double f0_ceil, int hmax, int seglen,
                                                         const double2* __restrict__ tw_base, int tw_n,
+                                                        const double2* __restrict__ rot_tab,
                                                         double* __restrict__ rf0, double* __restrict__ rsc) {
   // All of the kernel's LDS is the dynamic block, so that it starts at LDS address 0 and the twiddle table's byte
   // offsets are LDS addresses as they stand (hv_refine_lds_bytes mirrors this layout).
@@ -565,6 +609,7 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict_
   int* order = cl_meta + kItems;                             // kItems
   int* bucket = order + kItems;                              // 32
   int& cl_n = bucket[32];
+  double* red = reinterpret_cast<double*>(bucket + 40) + (threadIdx.x >> 4) * kRedRow;  // this row's reduction scratch
   if (TWL)
     for (int i = threadIdx.x; i < tw_n; i += 256) twl[i] = tw_base[tw_n + i];
   const int64_t centre0 = (int64_t)floor(((double)f_first * 1 / 1000) * fs + 0.5);
@@ -630,7 +675,7 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict_
       const int q = cl_meta[src] & 0xffff;
       const int64_t f = f_first + q / kRows;
       double r0, r1;
-      hv_refine_row<TWL>(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem, tw_n, &r0, &r1);
+      hv_refine_row<TWL>(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem, tw_n, rot_tab, red, &r0, &r1);
       if ((threadIdx.x & 15) == 0) {
         rf0[(m.f1_off + f) * kRows + q % kRows] = r0;
         rsc[(m.f1_off + f) * kRows + q % kRows] = r1;
@@ -913,16 +958,28 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     tw_n <<= 1;
     if (tw_n > 2048) tw_n = 0;  // 32 KB of LDS at most for the table; beyond that gather from the global tables
     const size_t lds = sizeof(double2) * (size_t)tw_n + sizeof(double) * (size_t)((seglen + 1) & ~1) +
-                       (sizeof(double) + 2 * sizeof(int)) * (size_t)(kFramesPerBlock * kRows) + sizeof(int) * 40;
+                       (sizeof(double) + 2 * sizeof(int)) * (size_t)(kFramesPerBlock * kRows) + sizeof(int) * 40 +
+                       sizeof(double) * 16 * kRedRow;
+    // 16-sample rotation (sin, cos)(16*pi*dx) of the window phase for every half length (hv_refine_row)
+    double2* d_rot = nullptr;
+    {
+      std::vector<double2> rot(hmax + 2);
+      for (int h = 0; h <= hmax + 1; ++h) {
+        const double wlit = (2 * (double)h + 1) / fs_d;
+        const double dx = 2.0 / (fs_d * wlit);
+        rot[h] = make_double2(sin(M_PI * (16 * dx)), cos(M_PI * (16 * dx)));
+      }
+      if (int rc = wh::persistent_upload(ctx, st, "hv.rot", rot, &d_rot)) return rc;
+    }
     const dim3 grid((unsigned)((max_nf1 + kFramesPerBlock - 1) / kFramesPerBlock), B);
     if (tw_n) {
       if (int rc = wh::allow_lds(&hv_refine_kernel<true>, lds)) return rc;
       wh::KernelTimer _kt(ctx, st, "hv_refine_kernel");
-      hipLaunchKernelGGL(hv_refine_kernel<true>, grid, dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rf0, d_rsc);
+      hipLaunchKernelGGL(hv_refine_kernel<true>, grid, dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rot, d_rf0, d_rsc);
     } else {
       if (int rc = wh::allow_lds(&hv_refine_kernel<false>, lds)) return rc;
       wh::KernelTimer _kt(ctx, st, "hv_refine_kernel");
-      hipLaunchKernelGGL(hv_refine_kernel<false>, grid, dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rf0, d_rsc);
+      hipLaunchKernelGGL(hv_refine_kernel<false>, grid, dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rot, d_rf0, d_rsc);
     }
     WH_LAUNCH_CHECK("hv_refine_kernel");
   }

@@ -170,17 +170,27 @@ __global__ __launch_bounds__(256) void hv_pad_kernel(const HvUtt* __restrict__ m
 
 // One workgroup per (utterance, channel) walks the 1 ms frames in tiles of 256.  The four event trains are sorted
 // and the frames ascending, so the events a tile can need are a window that only moves forward: the workgroup keeps
-// a cursor per train, stages the next kRawChunk edges behind it in LDS with coalesced loads, and every frame searches
-// that window (9 LDS steps) — instead of every (frame, channel, train) walking a 13-deep chain of dependent global
-// loads over the whole list (the kernel was 82 % memory wait, 3 GB of traffic per launch).  A frame whose answer is
-// not inside the staged window (more than ~500 events in 256 ms: impossible for bands up to 880 Hz, but guarded)
-// falls back to the global search.  Same arithmetic as wh::interp_four_trains.
-constexpr int kRawChunk = 512;
+// a cursor per train and, per tile, turns the edges behind it into INTERVALS in LDS — location (e[i]+e[i+1])/2/fs and
+// instantaneous frequency fs/(e[i+1]-e[i]), one thread per interval, coalesced loads — and every frame searches the
+// locations of that window and interpolates between two staged intervals: one LDS read per search step and one divide
+// per (frame, train), where the per-frame form re-derived both neighbouring intervals from four edges (two reads, an
+// add and a multiply per step, three divides).  A band of centre f has ~1.1 f events per second at most, so the
+// window staged for 256 ms is sized by the band (kRawChunk caps it).  A frame whose answer is not inside the staged
+// window falls back to the search over the whole list in global memory (guarded, never taken for speech bands).
+// Same arithmetic as wh::interp_four_trains, value for value.
+#ifndef WH_HV_RAW_SEGS
+#define WH_HV_RAW_SEGS 1
+#endif
+#ifndef WH_HV_RAW_TILE
+#define WH_HV_RAW_TILE 128
+#endif
+constexpr int kRawTile = WH_HV_RAW_TILE;   // frames per tile = threads per workgroup
+constexpr int kRawChunk = 2 * kRawTile;    // intervals staged per train and tile, at most
 
-__global__ __launch_bounds__(256) void hv_raw_kernel(const HvUtt* __restrict__ meta, const wh::BandJob* __restrict__ jobs,
+__global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restrict__ meta, const wh::BandJob* __restrict__ jobs,
                                                      const double* __restrict__ band_f0, int nb, double fs_d,
                                                      double f0_floor, double f0_ceil, double* __restrict__ raw) {
-  __shared__ double ch[4][kRawChunk];
+  __shared__ double2 iv[4][kRawChunk];  // (location, frequency) of interval start + i
   __shared__ int s_next[4];
   const HvUtt m = meta[blockIdx.y];
   const int b = blockIdx.x;
@@ -194,41 +204,81 @@ __global__ __launch_bounds__(256) void hv_raw_kernel(const HvUtt* __restrict__ m
     usable = usable && (cnt[k] - 1 >= 3);
   }
   if (!usable) {  // fewer than 3 intervals in a train: no candidate anywhere (dio.py:159-162)
-    for (int64_t f = threadIdx.x; f < m.nf1; f += 256) out[f] = 0.0;
+    for (int64_t f = threadIdx.x; f < m.nf1; f += kRawTile) out[f] = 0.0;
     return;
   }
   const double bf = band_f0[b];
   const double half_inv_fs = 0.5 / fs_d;
-  int pos[4] = {0, 0, 0, 0};  // per train: number of interval locations before the current tile's first frame
-  for (int64_t f0 = 0; f0 < m.nf1; f0 += 256) {
-    int start[4], have[4];
+  // intervals staged per tile: twice the ~1.1*bf*0.256 a band-limited signal can hold, plus the cursor's slack
+  int need = 2 * (int)(bf * 1.1 * (kRawTile * 0.001) + 1.0) + 8;
+  need = need > kRawChunk ? kRawChunk : need;
+  // blockIdx.z cuts the frames into gridDim.z segments of whole tiles, each with its own workgroup (the tile loop is a
+  // chain of load -> barrier -> search -> barrier; more workgroups in flight hide it).  A segment's first cursors
+  // are found by a search over the whole list.
+  const int64_t tiles_all = (m.nf1 + kRawTile - 1) / kRawTile;
+  const int64_t tiles_seg = (tiles_all + gridDim.z - 1) / gridDim.z;
+  const int64_t f_begin = (int64_t)blockIdx.z * tiles_seg * kRawTile;
+  const int64_t f_end = f_begin + tiles_seg * kRawTile < m.nf1 ? f_begin + tiles_seg * kRawTile : m.nf1;
+  if (f_begin >= m.nf1) return;
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    const double* e = job.edges + (int64_t)k * job.cap;
+    const double t = (double)f_begin * 1 / 1000;
+    int lo = 0, hi = job.counts[k] - 1;
+    if (f_begin == 0) hi = 0;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const double loc = (e[mid] + e[mid + 1]) * half_inv_fs;
+      if (loc < t) lo = mid + 1; else hi = mid;
+    }
+    s_next[k] = lo;
+  }
+  __syncthreads();
+  int pos[4];  // per train: number of interval locations before the current tile's first frame
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pos[k] = s_next[k];
+  __syncthreads();
+  for (int64_t f0 = f_begin; f0 < f_end; f0 += kRawTile) {
+    int start[4], nloc[4];
+    double ea[4][2], eb[4][2];  // all of a tile's edge loads are issued before the first divide consumes one
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       start[k] = pos[k] - 2 > 0 ? pos[k] - 2 : 0;
-      have[k] = cnt[k] - start[k] < kRawChunk ? cnt[k] - start[k] : kRawChunk;  // edges staged
+      const int ni = cnt[k] - 1;
+      nloc[k] = ni - start[k] < need ? ni - start[k] : need;  // intervals staged
       const double* e = job.edges + (int64_t)k * job.cap + start[k];
-      for (int i = threadIdx.x; i < have[k]; i += 256) ch[k][i] = e[i];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int i = threadIdx.x + r * kRawTile;
+        ea[k][r] = i < nloc[k] ? e[i] : 0.0;
+        eb[k][r] = i < nloc[k] ? e[i + 1] : 1.0;
+      }
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int i = threadIdx.x + r * kRawTile;
+        if (i < nloc[k]) iv[k][i] = make_double2((ea[k][r] + eb[k][r]) * half_inv_fs, fs_d / (eb[k][r] - ea[k][r]));
+      }
     __syncthreads();
     const int64_t f = f0 + threadIdx.x;
     int lo_g[4] = {0, 0, 0, 0};
-    if (f < m.nf1) {
+    if (f < f_end) {
       const double t = (double)f * 1 / 1000;  // basic_temporal_positions (harvest.py:21)
       double v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int ni = cnt[k] - 1;       // intervals of the whole train; location i = (e[i]+e[i+1])/2/fs
-        const int nloc = have[k] - 1;    // locations inside the staged window
-        int lo = 0, hi = nloc;           // lower_bound inside the window
+        const int ni = cnt[k] - 1;  // intervals of the whole train; location i = (e[i]+e[i+1])/2/fs
+        int lo = 0, hi = nloc[k];   // lower_bound inside the window
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
-          const double loc = (ch[k][mid] + ch[k][mid + 1]) * half_inv_fs;
-          if (loc < t) lo = mid + 1; else hi = mid;
+          if (iv[k][mid].x < t) lo = mid + 1; else hi = mid;
         }
-        const bool inside = lo < nloc || start[k] + have[k] == cnt[k];
+        const bool inside = lo < nloc[k] || start[k] + nloc[k] == ni;
         const double* e = job.edges + (int64_t)k * job.cap;
         int g = start[k] + lo;  // count of locations < t over the whole train
-        if (!inside) {          // the window ended before t: global search (never taken for speech bands)
+        if (!inside) {          // the window ended before t: global search
           int l2 = g, h2 = ni;
           while (l2 < h2) {
             const int mid = (l2 + h2) >> 1;
@@ -240,22 +290,20 @@ __global__ __launch_bounds__(256) void hv_raw_kernel(const HvUtt* __restrict__ m
         lo_g[k] = g;
         const int ih = g < 1 ? 1 : (g > ni - 1 ? ni - 1 : g);
         const int il = ih - 1;
-        double e0, e1, e2, e3;  // e[il], e[il+1], e[ih], e[ih+1]
-        if (inside && il >= start[k] && ih + 1 < start[k] + have[k]) {
-          e0 = ch[k][il - start[k]];
-          e1 = ch[k][il + 1 - start[k]];
-          e2 = ch[k][ih - start[k]];
-          e3 = ch[k][ih + 1 - start[k]];
+        double x_lo, x_hi, y_lo, y_hi;
+        if (il >= start[k] && ih < start[k] + nloc[k]) {
+          const double2 a = iv[k][il - start[k]], c = iv[k][ih - start[k]];
+          x_lo = a.x;
+          y_lo = a.y;
+          x_hi = c.x;
+          y_hi = c.y;
         } else {
-          e0 = e[il];
-          e1 = e[il + 1];
-          e2 = e[ih];
-          e3 = e[ih + 1];
+          const double e0 = e[il], e1 = e[il + 1], e2 = e[ih], e3 = e[ih + 1];
+          x_lo = (e0 + e1) * half_inv_fs;
+          x_hi = (e2 + e3) * half_inv_fs;
+          y_lo = fs_d / (e1 - e0);
+          y_hi = fs_d / (e3 - e2);
         }
-        const double x_lo = (e0 + e1) * half_inv_fs;
-        const double x_hi = (e2 + e3) * half_inv_fs;
-        const double y_lo = fs_d / (e1 - e0);
-        const double y_hi = fs_d / (e3 - e2);
         const double slope = (y_hi - y_lo) / (x_hi - x_lo);
         v[k] = slope * (t - x_lo) + y_lo;
       }
@@ -264,7 +312,7 @@ __global__ __launch_bounds__(256) void hv_raw_kernel(const HvUtt* __restrict__ m
       out[f] = cand;
     }
     // the last frame of the tile hands its counts to the next tile as the new cursors
-    const int64_t last = f0 + 255 < m.nf1 - 1 ? f0 + 255 : m.nf1 - 1;
+    const int64_t last = f0 + kRawTile - 1 < f_end - 1 ? f0 + kRawTile - 1 : f_end - 1;
     if (f == last) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) s_next[k] = lo_g[k];
@@ -304,17 +352,26 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
   int count = 0;
   int run_start = -1;  // 'st': index of the last dead channel before a live run
   bool prev = false;   // channel 0 is forced dead
-  for (int b = 1; b < nb; ++b) {
-    const bool live = (b < nb - 1) && (col[(int64_t)b * m.nf1] > 0);  // last channel forced dead
-    if (live && !prev) run_start = b - 1;
-    if (!live && prev) {
-      const int ed = b - 1;
-      if (ed - run_start >= 10 && count < kMaxC) {
-        const int n = ed - run_start;
-        out[count++] = np_sum_strided(col + (int64_t)(run_start + 1) * m.nf1, m.nf1, n) / (double)n;
+  // the channel walk is a chain of dependent branches; its loads are not: eight channels are fetched together
+  for (int b0 = 0; b0 < nb; b0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = b0 + q < nb ? col[(int64_t)(b0 + q) * m.nf1] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int b = b0 + q;
+      if (b < 1 || b >= nb) continue;
+      const bool live = (b < nb - 1) && (v[q] > 0);  // last channel forced dead
+      if (live && !prev) run_start = b - 1;
+      if (!live && prev) {
+        const int ed = b - 1;
+        if (ed - run_start >= 10 && count < kMaxC) {
+          const int n = ed - run_start;
+          out[count++] = np_sum_strided(col + (int64_t)(run_start + 1) * m.nf1, m.nf1, n) / (double)n;
+        }
       }
+      prev = live;
     }
-    prev = live;
   }
   dcount[m.f1_off + f] = count;
 }
@@ -685,47 +742,65 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict_
 }
 
 // RemoveUnreliableCandidates (harvest.py:215-234): a candidate survives if some candidate of frame j-1
-// or j+1 lies within 5 %.
-__global__ __launch_bounds__(128) void hv_prune_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ rf0,
+// or j+1 lies within 5 %.  A workgroup takes kPruneFrames consecutive frames: the non-zero candidates of those frames
+// and their two outer neighbours are compacted once into LDS lists (one wave per frame, ballot ranks), then every
+// (frame, row) is tested against the lists of its two neighbours.  (One 128-thread workgroup per frame — 640 k of them
+// for 64 x 10 s — was bound by the rate at which workgroups can be launched, and read every frame three times.)
+constexpr int kPruneFrames = 16;
+
+__global__ __launch_bounds__(256) void hv_prune_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ rf0,
                                                        const double* __restrict__ rsc, double* __restrict__ pf0,
                                                        double* __restrict__ psc) {
-  __shared__ double nb_prev[kRows], nb_next[kRows];  // compacted non-zero candidates of frames j-1 / j+1
-  __shared__ int n_prev, n_next;
+  __shared__ double lst[kPruneFrames + 2][kRows];  // compacted non-zero candidates of frames f_first-1 .. f_first+16
+  __shared__ int ln[kPruneFrames + 2];
   const HvUtt m = meta[blockIdx.y];
-  const int64_t f = blockIdx.x;
-  if (f >= m.nf1) return;
-  const int e = threadIdx.x;
-  const int64_t o = (m.f1_off + f) * kRows;
-  const bool inner = f >= 1 && f <= m.nf1 - 2;
-  if (e == 0) {
-    n_prev = 0;
-    n_next = 0;
-  }
-  __syncthreads();
-  if (e < kRows && inner) {
-    const double a = rf0[o - kRows + e], b = rf0[o + kRows + e];
-    if (a != 0.0) nb_prev[atomicAdd(&n_prev, 1)] = a;  // zeros can never be the nearest candidate
-    if (b != 0.0) nb_next[atomicAdd(&n_next, 1)] = b;
-  }
-  __syncthreads();
-  if (e >= kRows) return;
-  double v = rf0[o + e], s = rsc[o + e];
-  if (inner && v != 0.0) {
-    double e1 = 1.0, e2 = 1.0;  // SelectBestF0 with allowed_range = 1 (a zero candidate gives exactly 1)
-    // min_k |v - nb_k| / v == (min_k |v - nb_k|) / v bit for bit (division by v > 0 is monotone): one divide per
-    // neighbour frame instead of one per neighbour candidate
-    double d1 = INFINITY, d2 = INFINITY;
-    for (int k = 0; k < n_next; ++k) d1 = fmin(d1, fabs(v - nb_next[k]));
-    for (int k = 0; k < n_prev; ++k) d2 = fmin(d2, fabs(v - nb_prev[k]));
-    if (n_next > 0) e1 = fmin(e1, d1 / v);
-    if (n_prev > 0) e2 = fmin(e2, d2 / v);
-    if (fmin(e1, e2) > 0.05) {
-      v = 0.0;
-      s = 0.0;
+  const int64_t f_first = (int64_t)blockIdx.x * kPruneFrames;
+  if (f_first >= m.nf1) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int fr = w; fr < kPruneFrames + 2; fr += 4) {
+    const int64_t f = f_first - 1 + fr;
+    int n = 0;
+    if (f >= 0 && f < m.nf1) {
+      const double* src = rf0 + (m.f1_off + f) * kRows;
+#pragma unroll
+      for (int pass = 0; pass < (kRows + 63) / 64; ++pass) {
+        const int e = lane + 64 * pass;
+        const double a = e < kRows ? src[e] : 0.0;
+        const unsigned long long mk = __ballot(a != 0.0);  // zeros can never be the nearest candidate
+        if (a != 0.0) lst[fr][n + __popcll(mk & ((1ull << lane) - 1))] = a;
+        n += __popcll(mk);
+      }
     }
+    if (lane == 0) ln[fr] = n;
   }
-  pf0[o + e] = v;
-  psc[o + e] = s;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < kPruneFrames * kRows; idx += 256) {
+    const int fl = idx / kRows, e = idx - fl * kRows;
+    const int64_t f = f_first + fl;
+    if (f >= m.nf1) break;
+    const int64_t o = (m.f1_off + f) * kRows;
+    const bool inner = f >= 1 && f <= m.nf1 - 2;
+    double v = rf0[o + e], s = rsc[o + e];
+    if (inner && v != 0.0) {
+      double e1 = 1.0, e2 = 1.0;  // SelectBestF0 with allowed_range = 1 (a zero candidate gives exactly 1)
+      // min_k |v - nb_k| / v == (min_k |v - nb_k|) / v bit for bit (division by v > 0 is monotone): one divide per
+      // neighbour frame instead of one per neighbour candidate
+      const int n_prev = ln[fl], n_next = ln[fl + 2];
+      const double* nb_prev = lst[fl];
+      const double* nb_next = lst[fl + 2];
+      double d1 = INFINITY, d2 = INFINITY;
+      for (int k = 0; k < n_next; ++k) d1 = fmin(d1, fabs(v - nb_next[k]));
+      for (int k = 0; k < n_prev; ++k) d2 = fmin(d2, fabs(v - nb_prev[k]));
+      if (n_next > 0) e1 = fmin(e1, d1 / v);
+      if (n_prev > 0) e2 = fmin(e2, d2 / v);
+      if (fmin(e1, e2) > 0.05) {
+        v = 0.0;
+        s = 0.0;
+      }
+    }
+    pf0[o + e] = v;
+    psc[o + e] = s;
+  }
 }
 
 double tdf2_pole_radius(double a1, double a2, double a3) {
@@ -945,7 +1020,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
                                              d_ti + 2 * n_bands, max_lb, true, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW)) {
     return rc;
   }
-  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B), dim3(256), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw); }
+  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B, WH_HV_RAW_SEGS), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw); }
   WH_LAUNCH_CHECK("hv_raw_kernel");
   if (dbg_raw) WH_CHECK(hipMemcpyAsync(dbg_raw, d_raw, sizeof(double) * f1_tot * n_bands, hipMemcpyDeviceToDevice, st));
   { wh::KernelTimer _kt(ctx, st, "hv_detect_kernel"); hipLaunchKernelGGL(hv_detect_kernel, dim3((unsigned)((max_nf1 + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw, d_dc, d_dn); }
@@ -983,7 +1058,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     }
     WH_LAUNCH_CHECK("hv_refine_kernel");
   }
-  { wh::KernelTimer _kt(ctx, st, "hv_prune_kernel"); hipLaunchKernelGGL(hv_prune_kernel, dim3((unsigned)max_nf1, B), dim3(128), 0, st, d_meta, d_rf0, d_rsc, d_pf0, d_psc); }
+  { wh::KernelTimer _kt(ctx, st, "hv_prune_kernel"); hipLaunchKernelGGL(hv_prune_kernel, dim3((unsigned)((max_nf1 + kPruneFrames - 1) / kPruneFrames), B), dim3(256), 0, st, d_meta, d_rf0, d_rsc, d_pf0, d_psc); }
   WH_LAUNCH_CHECK("hv_prune_kernel");
   // ---- contour, smoothing, 5 ms pick -------------------------------------------------------------------------
   return harvest_contour(ctx, st, B, d_meta, meta, f1_tot, max_nf1, max_nf, d_pf0, d_psc, d_ct, tp, f0_out, vuv_out,

@@ -422,22 +422,29 @@ __global__ __launch_bounds__(256) void hc_smooth_kernel(const HvUtt* __restrict_
     z0 = z1 + xin * b1 - yv * a1; \
     z1 = xin * b2 - yv * a2;      \
   }
+      // the recurrences are chains of ~40 cycles per sample; their operands are fetched 16 at a time, a block ahead
+      // (wh::serial_run), instead of one dependent global load per step
+      auto always = [](int64_t) { return true; };
       for (int i = 0; i < 300; ++i) BW_STEP(c0);
-      for (int j = st; j <= ed; ++j) {
-        BW_STEP(s4[j]);
-        fw[j - st] = yv;
-      }
+      wh::serial_run<16>(
+          st, (int64_t)ed + 1, always, [&](int64_t j) { return s4[j]; }, [&](int64_t j) { return s4[j]; },
+          [&](int64_t j, double v) {
+            BW_STEP(v);
+            fw[j - st] = yv;
+          });
       for (int i = 0; i < 300; ++i) {
         BW_STEP(c1);
         fw[ed - st + 1 + i] = yv;
       }
       z0 = 0.0;
       z1 = 0.0;
-      for (int i = 299; i >= 0; --i) BW_STEP(fw[ed - st + 1 + i]);
-      for (int j = ed; j >= st; --j) {
-        BW_STEP(fw[j - st]);
-        sm[j] = yv;
-      }
+      const int64_t top = (int64_t)ed - st + 300;  // last forward output; the backward pass walks fw[top - i]
+      wh::serial_run<16>(
+          0, top + 1, always, [&](int64_t i) { return fw[top - i]; }, [&](int64_t i) { return fw[top - i]; },
+          [&](int64_t i, double v) {
+            BW_STEP(v);
+            if (i >= 300) sm[ed - (i - 300)] = yv;
+          });
 #undef BW_STEP
     }
   }

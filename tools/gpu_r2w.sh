@@ -1,0 +1,18 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r2w; mkdir -p $O
+timeout 900 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -5 $O/pytest.log
+python bench.py --config 3 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err
+python bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_cfg2.json 2> $O/bench_cfg2.err
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r2w/bench_*.json')):
+    try:
+        d=json.load(open(f)); k=d['kernel_ms']
+        print(f.split('/')[-1], 'ms/step %.3f'%d['ms_per_step'], {a:round(b,3) for a,b in list(k.items())[:6]})
+        if 'north_star' in d: print('  north_star', d['north_star']['ms_per_step'], {a:round(b,1) for a,b in list(d['north_star']['kernel_ms'].items())[:5]})
+    except Exception as e:
+        print(f, 'ERR', e, open(f.replace('.json','.err')).read()[-400:])
+PY

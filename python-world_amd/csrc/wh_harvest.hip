@@ -26,6 +26,9 @@ constexpr int kMaxC = 15;          // int(152/10 + 0.5): candidate rows per fram
 constexpr int kRows = 7 * kMaxC;   // overlapped candidate rows (shift-major, candidate-minor)
 constexpr int kFPad = 9;           // filtfilt padlen
 constexpr int kHChunk = 1024;
+#ifndef WH_HV_WIN_TABLE
+#define WH_HV_WIN_TABLE 1  // 0: always derive the refinement windows per sample (rotation + DPP neighbours)
+#endif
 #ifndef WH_HV_RED_DPP
 #define WH_HV_RED_DPP 1  // 0: fold the 24 partial sums once by DPP, then through an LDS scratch (fewer VALU instructions, but 10.4 vs 9.5 ms measured: the 24 KB of scratch cost a workgroup per CU)
 #endif
@@ -401,12 +404,15 @@ __device__ __forceinline__ double row16_sum(double v) {
 // TWL: the twiddles come from the workgroup's LDS copy (tw_lds, at a compile-time offset of the dynamic LDS block, so
 // that a look-up is one ds_read_b128 whose address register is the running byte offset itself); else from the global
 // tables through tw_base.
-template <bool TWL>
+// WTAB: the frames lie on whole samples of the decimated signal (fs/1000 an integer: 8 / 16 / 32 / 48 kHz inputs), so
+// the Blackman window and its derivative twin depend on the window length alone — (w(j), dw(j)) come from a per-call
+// table (win_tab, row hwl at offset hwl^2) instead of being re-derived per sample by rotation + DPP neighbour exchange.
+template <bool TWL, bool WTAB>
 __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int64_t ybase, int64_t ylen, double fs,
                                               double t0, double f0c, double f0_floor, double f0_ceil,
                                               const double2* __restrict__ tw_base, const char* tw_lds, int tw_n,
-                                              const double2* __restrict__ rot_tab, double* red, double* out_f0,
-                                              double* out_sc) {
+                                              const double2* __restrict__ rot_tab, const double2* __restrict__ win_tab,
+                                              double* red, double* out_f0, double* out_sc) {
   const int l16 = threadIdx.x & 15;
   const double hwl_d = ceil(3 * fs / f0c / 2);
   const int hwl = (int)hwl_d;
@@ -484,7 +490,44 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   // a frame that fails the check takes the general path below.
   const double a0 = idx_raw_at(0);
   const double a0_frac = a0 - floor(a0);
-  if (a0 > 1.0 && a0_frac > 1e-6 && a0_frac < 1.0 - 1e-6) {
+  if (WTAB && a0 > 1.0 && fabs(a0_frac - 0.501) < 1e-6) {
+    // t0*fs is a whole number: index_raw(j) - 1 sits (j - hwl - 0.499)/fs from the frame time whatever the frame,
+    // and the window pair of row hwl applies as tabulated.  The loop is the 24 FMAs, the six twiddle gathers and
+    // one table read (fetched an iteration ahead).
+    const double2* wt = win_tab + hwl * hwl;
+    int tix[6], tstep[6];  // byte offsets into the twiddle table (see the rotation path below)
+    const int tmask = ((nfft - 1) << tw_sh);
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      tix[h] = ((bins[h] * l16) & (nfft - 1)) << tw_sh;
+      tstep[h] = ((bins[h] * 16) & (nfft - 1)) << tw_sh;
+    }
+    const int n_it = (L + 15) >> 4;
+    const int64_t i_first = (int64_t)a0;
+    const int i_lo = (int)(0 - ybase), i_hi = (int)(ylen - 1 - ybase);
+    int si = (int)(i_first - 1 - ybase) + l16;
+    int j = l16;
+    double2 cur = j < L ? wt[j] : make_double2(0.0, 0.0);
+    for (int it = 0; it < n_it; ++it) {
+      const int jn = j + 16;
+      const double2 nxt = jn < L ? wt[jn] : make_double2(0.0, 0.0);
+      const int sc = si < i_lo ? i_lo : (si > i_hi ? i_hi : si);
+      const double smp = j < L ? yl[sc] : 0.0;
+      si += 16;
+      const double a = smp * cur.x, d = smp * cur.y;
+#pragma unroll
+      for (int h = 0; h < 6; ++h) {
+        const double2 w = twiddle(tix[h]);
+        xr[h] = fma(a, w.x, xr[h]);
+        xi[h] = fma(a, w.y, xi[h]);
+        dr[h] = fma(d, w.x, dr[h]);
+        di[h] = fma(d, w.y, di[h]);
+        tix[h] = (tix[h] + tstep[h]) & tmask;
+      }
+      cur = nxt;
+      j = jn;
+    }
+  } else if (!WTAB && a0 > 1.0 && a0_frac > 1e-6 && a0_frac < 1.0 - 1e-6) {
     // Every index of the frame is positive (all frames but the first few of an utterance): idx_raw, and with it the
     // window phase xw, is linear in j, so this lane's samples j = l16 + 16 i are a fixed rotation of 16*pi*dx apart —
     // one sincospi to start, a 6-flop rotation per sample after that (<= 24 steps: error growth ~1e-15; the rotation
@@ -641,12 +684,13 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
 constexpr int kFramesPerBlock = 4;
 constexpr int kRedRow = WH_HV_RED_DPP ? 0 : 24 * 8;  // doubles of reduction scratch per 16-lane row (hv_refine_row)
 
-template <bool TWL>
-__global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
+template <bool TWL, bool WTAB>
+__global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
                                                         const double* __restrict__ dc, const int32_t* __restrict__ dcount,
                                                         double fs, double f0_floor, double f0_ceil, int hmax, int seglen,
                                                         const double2* __restrict__ tw_base, int tw_n,
                                                         const double2* __restrict__ rot_tab,
+                                                        const double2* __restrict__ win_tab,
                                                         double* __restrict__ rf0, double* __restrict__ rsc) {
   // All of the kernel's LDS is the dynamic block, so that it starts at LDS address 0 and the twiddle table's byte
   // offsets are LDS addresses as they stand (hv_refine_lds_bytes mirrors this layout).
@@ -732,7 +776,7 @@ __global__ __launch_bounds__(256) void hv_refine_kernel(const HvUtt* __restrict_
       const int q = cl_meta[src] & 0xffff;
       const int64_t f = f_first + q / kRows;
       double r0, r1;
-      hv_refine_row<TWL>(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem, tw_n, rot_tab, red, &r0, &r1);
+      hv_refine_row<TWL, WTAB>(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem, tw_n, rot_tab, win_tab, red, &r0, &r1);
       if ((threadIdx.x & 15) == 0) {
         rf0[(m.f1_off + f) * kRows + q % kRows] = r0;
         rsc[(m.f1_off + f) * kRows + q % kRows] = r1;
@@ -1046,16 +1090,56 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
       }
       if (int rc = wh::persistent_upload(ctx, st, "hv.rot", rot, &d_rot)) return rc;
     }
-    const dim3 grid((unsigned)((max_nf1 + kFramesPerBlock - 1) / kFramesPerBlock), B);
-    if (tw_n) {
-      if (int rc = wh::allow_lds(&hv_refine_kernel<true>, lds)) return rc;
-      wh::KernelTimer _kt(ctx, st, "hv_refine_kernel");
-      hipLaunchKernelGGL(hv_refine_kernel<true>, grid, dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rot, d_rf0, d_rsc);
-    } else {
-      if (int rc = wh::allow_lds(&hv_refine_kernel<false>, lds)) return rc;
-      wh::KernelTimer _kt(ctx, st, "hv_refine_kernel");
-      hipLaunchKernelGGL(hv_refine_kernel<false>, grid, dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rot, d_rf0, d_rsc);
+    // (w(j), dw(j)) of every window length, row hwl at offset hwl^2 (hv_refine_row, WTAB): only when the 1 ms frames
+    // fall on whole samples of the decimated signal.  Built once per (rate, longest window) and kept on the device.
+    const double2* d_wtab = nullptr;
+    const bool use_wtab = WH_HV_WIN_TABLE && fabs(fs_d / 1000.0 - floor(fs_d / 1000.0 + 0.5)) < 1e-12 && tw_n != 0;
+    if (use_wtab) {
+      char key[96];
+      snprintf(key, sizeof key, "hv.wtab:%.17g:%d", fs_d, hmax);
+      auto it = ctx->tables.find(key);
+      if (it == ctx->tables.end()) {
+        std::vector<double> tab((size_t)2 * (hmax + 2) * (hmax + 2), 0.0);
+        std::vector<double> mw;
+        for (int h = 0; h <= hmax + 1; ++h) {
+          const int Lh = 2 * h + 1;
+          const double wlit = (2 * (double)h + 1) / fs_d;
+          mw.assign(Lh, 0.0);
+          for (int j = 0; j < Lh; ++j) {
+            // index_raw keeps round_matlab's +0.5 and the +0.001 "first-aid" (harvest.py:178, Q1): the window is
+            // evaluated 0.501 samples late
+            const double c = cos(M_PI * (2 * (((double)(j - h) + (0.001 + 0.5) - 1.0) / fs_d) / wlit));
+            mw[j] = 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1);
+          }
+          double* row = tab.data() + 2 * (size_t)h * h;
+          for (int j = 0; j < Lh; ++j) {
+            double dw;
+            if (j == 0) dw = Lh > 1 ? -mw[1] / 2 : 0.0;
+            else if (j == Lh - 1) dw = mw[j - 1] / 2;
+            else dw = -((mw[j + 1] - mw[j]) + (mw[j] - mw[j - 1])) / 2;
+            row[2 * j] = mw[j];
+            row[2 * j + 1] = dw;
+          }
+        }
+        const double* d = nullptr;
+        if (int rc = wh::const_table(ctx, key, tab, &d)) return rc;
+        d_wtab = reinterpret_cast<const double2*>(d);
+      } else {
+        d_wtab = reinterpret_cast<const double2*>(it->second);
+      }
     }
+    const dim3 grid((unsigned)((max_nf1 + kFramesPerBlock - 1) / kFramesPerBlock), B);
+#define WH_REFINE_LAUNCH(TWL_, WTAB_)                                                                                   \
+  {                                                                                                                     \
+    if (int rc = wh::allow_lds(&hv_refine_kernel<TWL_, WTAB_>, lds)) return rc;                                         \
+    wh::KernelTimer _kt(ctx, st, "hv_refine_kernel");                                                                   \
+    hipLaunchKernelGGL((hv_refine_kernel<TWL_, WTAB_>), grid, dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, \
+                       f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rot, d_wtab, d_rf0, d_rsc);                        \
+  }
+    if (tw_n && use_wtab) WH_REFINE_LAUNCH(true, true)
+    else if (tw_n) WH_REFINE_LAUNCH(true, false)
+    else WH_REFINE_LAUNCH(false, false)
+#undef WH_REFINE_LAUNCH
     WH_LAUNCH_CHECK("hv_refine_kernel");
   }
   { wh::KernelTimer _kt(ctx, st, "hv_prune_kernel"); hipLaunchKernelGGL(hv_prune_kernel, dim3((unsigned)((max_nf1 + kPruneFrames - 1) / kPruneFrames), B), dim3(256), 0, st, d_meta, d_rf0, d_rsc, d_pf0, d_psc); }

@@ -392,12 +392,15 @@ __device__ __forceinline__ double dpp_f64(double v) {
   hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-// sum over the 16 lanes of a DPP row, result in every lane: xor-1, xor-2 quad permutes, then the two mirrors
-__device__ __forceinline__ double row16_sum(double v) {
-  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_f64<0x141>(v);  // row_half_mirror
-  v += dpp_f64<0x140>(v);  // row_mirror
+// sum over the RL lanes (a power of two up to 16, aligned) that work on one candidate, result in every lane of the group: xor-1, xor-2
+// quad permutes, then the mirror of the half row and, for 16, of the row
+template <int RL>
+__device__ __forceinline__ double row_sum(double v) {
+  static_assert(RL == 16 || RL == 8 || RL == 4 || RL == 2 || RL == 1, "group of a DPP row");
+  if (RL >= 2) v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (RL >= 4) v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (RL >= 8) v += dpp_f64<0x141>(v);   // row_half_mirror
+  if (RL == 16) v += dpp_f64<0x140>(v);  // row_mirror
   return v;
 }
 
@@ -407,13 +410,21 @@ __device__ __forceinline__ double row16_sum(double v) {
 // WTAB: the frames lie on whole samples of the decimated signal (fs/1000 an integer: 8 / 16 / 32 / 48 kHz inputs), so
 // the Blackman window and its derivative twin depend on the window length alone — (w(j), dw(j)) come from a per-call
 // table (win_tab, row hwl at offset hwl^2) instead of being re-derived per sample by rotation + DPP neighbour exchange.
-template <bool TWL, bool WTAB>
+__device__ __forceinline__ bool rotation_path_ok(bool wtab, double a0, double a0_frac) {
+  return !wtab && a0 > 1.0 && a0_frac > 1e-6 && a0_frac < 1.0 - 1e-6;
+}
+// RL: lanes per candidate.  The set-up before and the reductions after the sample loop are per wave instruction,
+// whatever the number of candidates in the wave, and with the tabulated windows they outweigh the loop (233 + 391
+// against 40 instructions per 16 samples): eight lanes per candidate — eight candidates per wave — halve their share
+// and drop one of the four reduction steps.  The rotation path needs the 16-lane row rotates.
+template <bool TWL, bool WTAB, int RL>
 __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int64_t ybase, int64_t ylen, double fs,
                                               double t0, double f0c, double f0_floor, double f0_ceil,
                                               const double2* __restrict__ tw_base, const char* tw_lds, int tw_n,
                                               const double2* __restrict__ rot_tab, const double2* __restrict__ win_tab,
-                                              double* red, double* out_f0, double* out_sc) {
-  const int l16 = threadIdx.x & 15;
+                                              double* out_f0, double* out_sc) {
+  static_assert(WTAB || RL == 16, "the rotation path exchanges window values with 16-lane row rotates");
+  const int l16 = threadIdx.x & (RL - 1);  // lane within the candidate's group
   const double hwl_d = ceil(3 * fs / f0c / 2);
   const int hwl = (int)hwl_d;
   const int L = 2 * hwl + 1;
@@ -500,20 +511,20 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
 #pragma unroll
     for (int h = 0; h < 6; ++h) {
       tix[h] = ((bins[h] * l16) & (nfft - 1)) << tw_sh;
-      tstep[h] = ((bins[h] * 16) & (nfft - 1)) << tw_sh;
+      tstep[h] = ((bins[h] * RL) & (nfft - 1)) << tw_sh;
     }
-    const int n_it = (L + 15) >> 4;
+    const int n_it = (L + RL - 1) / RL;
     const int64_t i_first = (int64_t)a0;
     const int i_lo = (int)(0 - ybase), i_hi = (int)(ylen - 1 - ybase);
     int si = (int)(i_first - 1 - ybase) + l16;
     int j = l16;
     double2 cur = j < L ? wt[j] : make_double2(0.0, 0.0);
     for (int it = 0; it < n_it; ++it) {
-      const int jn = j + 16;
+      const int jn = j + RL;
       const double2 nxt = jn < L ? wt[jn] : make_double2(0.0, 0.0);
       const int sc = si < i_lo ? i_lo : (si > i_hi ? i_hi : si);
       const double smp = j < L ? yl[sc] : 0.0;
-      si += 16;
+      si += RL;
       const double a = smp * cur.x, d = smp * cur.y;
 #pragma unroll
       for (int h = 0; h < 6; ++h) {
@@ -527,7 +538,8 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       cur = nxt;
       j = jn;
     }
-  } else if (!WTAB && a0 > 1.0 && a0_frac > 1e-6 && a0_frac < 1.0 - 1e-6) {
+  } else if (rotation_path_ok(WTAB, a0, a0_frac)) {
+    if constexpr (!WTAB) {
     // Every index of the frame is positive (all frames but the first few of an utterance): idx_raw, and with it the
     // window phase xw, is linear in j, so this lane's samples j = l16 + 16 i are a fixed rotation of 16*pi*dx apart —
     // one sincospi to start, a 6-flop rotation per sample after that (<= 24 steps: error growth ~1e-15; the rotation
@@ -597,10 +609,11 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       m_prev = m_cur;
       m_cur = m_next;
     }
+    }
   } else {
     sincospi(dx, &sd1, &cd1);
     sincospi(2 * dx, &sd2, &cd2);
-    for (int j = l16; j < L; j += 16) {
+    for (int j = l16; j < L; j += RL) {
       const double ir = idx_raw_at(j);
       const double xw = 2 * ((ir - 1) / fs - t0) / wlit;
       double s2, c2;
@@ -612,65 +625,44 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   }
   // The four sums of every harmonic go round the row; lane h then evaluates harmonic h alone — instantaneous
   // frequency, amplitude, deviation: five FP64 divides and a square root, ~85 instructions that all sixteen lanes used
-  // to repeat for each of the six harmonics — and three more row sums collect the totals.
-  // Reduction of the 24 partial sums: one DPP step folds the row's halves (lanes l and l+8), the folded values go
-  // through the row's LDS scratch (red: [24][8] doubles), and lane h adds up the eight partials of each of harmonic
-  // h's four sums — 72 + 28 VALU instructions where four DPP butterfly steps on all 24 values took 288.
-  double sa = 0.0, sb = 0.0, sc_ = 0.0, sd = 0.0;
-  int my_bin = 0;
-#if WH_HV_RED_DPP
+  // to repeat for each of the six harmonics — and three more row sums collect the totals.  (Folding the 24 partial sums
+  // once by DPP and finishing through an LDS scratch needs a third of the instructions but its 24 KB cost a workgroup
+  // per CU: 9.5 against 8.0 ms, measured.)
+  constexpr int P = (6 + RL - 1) / RL;  // harmonics per lane: lane l takes l, l + RL, ...
+  double sa[P], sb[P], sc_[P], sd[P];
+  int my_bin[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    sa[q] = sb[q] = sc_[q] = sd[q] = 0.0;
+    my_bin[q] = 0;
+  }
 #pragma unroll
   for (int h = 0; h < 6; ++h) {
-    const double a = row16_sum(xr[h]), b = row16_sum(xi[h]), c = row16_sum(dr[h]), d = row16_sum(di[h]);
-    if (l16 == h) {
-      sa = a;
-      sb = b;
-      sc_ = c;
-      sd = d;
-      my_bin = bins[h];
+    const double a = row_sum<RL>(xr[h]), b = row_sum<RL>(xi[h]), c = row_sum<RL>(dr[h]), d = row_sum<RL>(di[h]);
+    if (l16 == h % RL) {
+      sa[h / RL] = a;
+      sb[h / RL] = b;
+      sc_[h / RL] = c;
+      sd[h / RL] = d;
+      my_bin[h / RL] = bins[h];
     }
   }
-#else
-  {
-    const int l8 = l16 & 7;
-#pragma unroll
-    for (int h = 0; h < 6; ++h) {
-      red[(4 * h + 0) * 8 + l8] = xr[h] + dpp_f64<0x128>(xr[h]);  // row_ror:8
-      red[(4 * h + 1) * 8 + l8] = xi[h] + dpp_f64<0x128>(xi[h]);
-      red[(4 * h + 2) * 8 + l8] = dr[h] + dpp_f64<0x128>(dr[h]);
-      red[(4 * h + 3) * 8 + l8] = di[h] + dpp_f64<0x128>(di[h]);
-    }
-    wh::sync<64>();
-    const int hh = l16 < 6 ? l16 : 5;
-    const double2* r2 = reinterpret_cast<const double2*>(red + hh * 32);
-    double acc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const double2 p0 = r2[c * 4 + 0], p1 = r2[c * 4 + 1], p2 = r2[c * 4 + 2], p3 = r2[c * 4 + 3];
-      acc[c] = ((p0.x + p0.y) + (p1.x + p1.y)) + ((p2.x + p2.y) + (p3.x + p3.y));
-    }
-    sa = acc[0];
-    sb = acc[1];
-    sc_ = acc[2];
-    sd = acc[3];
-#pragma unroll
-    for (int h = 0; h < 6; ++h)
-      if (l16 == h) my_bin = bins[h];
-    wh::sync<64>();  // the scratch is free for the row's next candidate
-  }
-#endif
   double t_num = 0.0, t_den = 0.0, t_var = 0.0;
-  if (l16 < nh) {
-    const double p = sa * sa + sb * sb;
-    const double nm = sa * sd - sb * sc_;
-    // bin / nfft is exact (power of two), and so is the halving
-    const double inst = ((double)my_bin * (1.0 / (double)nfft) + nm / p * 0.5 / M_PI) * fs;
-    const double amp = sqrt(p);
-    t_num = amp * inst;
-    t_den = amp * (double)(l16 + 1);
-    t_var = fabs((inst / (double)(l16 + 1) - f0c) / f0c);
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const int h = l16 + q * RL;
+    if (h < nh) {
+      const double p = sa[q] * sa[q] + sb[q] * sb[q];
+      const double nm = sa[q] * sd[q] - sb[q] * sc_[q];
+      // bin / nfft is exact (power of two), and so is the halving
+      const double inst = ((double)my_bin[q] * (1.0 / (double)nfft) + nm / p * 0.5 / M_PI) * fs;
+      const double amp = sqrt(p);
+      t_num += amp * inst;
+      t_den += amp * (double)(h + 1);
+      t_var += fabs((inst / (double)(h + 1) - f0c) / f0c);
+    }
   }
-  const double num = row16_sum(t_num), den = row16_sum(t_den), var = row16_sum(t_var);
+  const double num = row_sum<RL>(t_num), den = row_sum<RL>(t_den), var = row_sum<RL>(t_var);
   double rf = num / den;
   double sc = 1 / (0.000000000001 + var / (double)nh);
   if (rf < f0_floor || rf > f0_ceil || sc < 2.5) {
@@ -681,8 +673,15 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   *out_sc = sc;
 }
 
-constexpr int kFramesPerBlock = 4;
-constexpr int kRedRow = WH_HV_RED_DPP ? 0 : 24 * 8;  // doubles of reduction scratch per 16-lane row (hv_refine_row)
+#ifndef WH_HV_ROW_LANES
+#define WH_HV_ROW_LANES 4
+#endif
+#ifndef WH_HV_TAB_FRAMES
+#define WH_HV_TAB_FRAMES 16
+#endif
+// lanes per candidate and frames per workgroup of the two refinement variants
+constexpr int refine_lanes(bool wtab) { return wtab ? WH_HV_ROW_LANES : 16; }
+constexpr int refine_frames(bool wtab) { return wtab ? WH_HV_TAB_FRAMES : 4; }
 
 template <bool TWL, bool WTAB>
 __global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
@@ -695,6 +694,9 @@ __global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUt
   // All of the kernel's LDS is the dynamic block, so that it starts at LDS address 0 and the twiddle table's byte
   // offsets are LDS addresses as they stand (hv_refine_lds_bytes mirrors this layout).
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RL = refine_lanes(WTAB);
+  constexpr int kFramesPerBlock = refine_frames(WTAB);
+  constexpr int kBuckets = 64;
   const HvUtt m = meta[blockIdx.y];
   const int64_t f_first = (int64_t)blockIdx.x * kFramesPerBlock;
   if (f_first >= m.nf1) return;
@@ -708,9 +710,8 @@ __global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUt
   double* cl_val = yl + ((seglen + 1) & ~1);                 // kItems
   int* cl_meta = reinterpret_cast<int*>(cl_val + kItems);    // kItems
   int* order = cl_meta + kItems;                             // kItems
-  int* bucket = order + kItems;                              // 32
-  int& cl_n = bucket[32];
-  double* red = reinterpret_cast<double*>(bucket + 40) + (threadIdx.x >> 4) * kRedRow;  // this row's reduction scratch
+  int* bucket = order + kItems;                              // kBuckets
+  int& cl_n = bucket[kBuckets];
   if (TWL)
     for (int i = threadIdx.x; i < tw_n; i += 256) twl[i] = tw_base[tw_n + i];
   const int64_t centre0 = (int64_t)floor(((double)f_first * 1 / 1000) * fs + 0.5);
@@ -744,24 +745,24 @@ __global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUt
   }
   __syncthreads();
   const int n_items = cl_n;
-  // A wave refines four candidates at once, one per 16-lane row, and runs as long as its longest one: the window
-  // length goes with 1/f0 (31 ... 340 samples at 8 kHz), and a frame's candidates are typically an f0 with its
-  // octave neighbours.  Counting sort of the work list by iteration count, so that the rows of a wave (consecutive
+  // A wave refines 64 / RL candidates at once, one per group of RL lanes, and runs as long as its longest one: the
+  // window length goes with 1/f0 (31 ... 340 samples at 8 kHz), and a frame's candidates are typically an f0 with its
+  // octave neighbours.  Counting sort of the work list by iteration count, so that the groups of a wave (consecutive
   // entries) carry windows of the same length class.
   {
-    if (threadIdx.x < 32) bucket[threadIdx.x] = 0;
+    if (threadIdx.x < kBuckets) bucket[threadIdx.x] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n_items; i += 256) {
       const int len = 2 * (int)ceil(3 * fs / cl_val[i] / 2) + 1;
-      int key = (len + 15) >> 4;
-      key = key > 31 ? 31 : key;
+      int key = (len + RL - 1) / RL;
+      key = key > kBuckets - 1 ? kBuckets - 1 : key;
       atomicAdd(&bucket[key], 1);
-      cl_meta[i] |= key << 16;  // q < 420 fits 16 bits
+      cl_meta[i] |= key << 16;  // q < 840 fits 16 bits
     }
     __syncthreads();
-    if (threadIdx.x == 0) {  // exclusive scan of 32 counts, longest first (the long items start the block's schedule)
+    if (threadIdx.x == 0) {  // exclusive scan of the counts, longest first (the long items start the block's schedule)
       int run = 0;
-      for (int k = 31; k >= 0; --k) {
+      for (int k = kBuckets - 1; k >= 0; --k) {
         const int c = bucket[k];
         bucket[k] = run;
         run += c;
@@ -770,14 +771,14 @@ __global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUt
     __syncthreads();
     for (int i = threadIdx.x; i < n_items; i += 256) order[atomicAdd(&bucket[cl_meta[i] >> 16], 1)] = i;
     __syncthreads();
-    const int grp_ = threadIdx.x >> 4;
-    for (int it = grp_; it < n_items; it += 16) {
+    for (int it = threadIdx.x / RL; it < n_items; it += 256 / RL) {
       const int src = order[it];
       const int q = cl_meta[src] & 0xffff;
       const int64_t f = f_first + q / kRows;
       double r0, r1;
-      hv_refine_row<TWL, WTAB>(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem, tw_n, rot_tab, win_tab, red, &r0, &r1);
-      if ((threadIdx.x & 15) == 0) {
+      hv_refine_row<TWL, WTAB, RL>(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem,
+                                   tw_n, rot_tab, win_tab, &r0, &r1);
+      if ((threadIdx.x & (RL - 1)) == 0) {
         rf0[(m.f1_off + f) * kRows + q % kRows] = r0;
         rsc[(m.f1_off + f) * kRows + q % kRows] = r1;
       }
@@ -1071,14 +1072,15 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   WH_LAUNCH_CHECK("hv_detect_kernel");
   // ---- refinement + pruning ------------------------------------------------------------------------------
   {
-    const int seglen = 2 * hmax + 8 + (kFramesPerBlock - 1) * ((int)ceil(fs_d / 1000.0) + 1);
     int tw_n = 1;  // transform length of the longest window (harvest.py:171-172): 2 * 2^ceil(log2(2*hmax+1))
     while (tw_n < 2 * hmax + 1) tw_n <<= 1;
     tw_n <<= 1;
     if (tw_n > 2048) tw_n = 0;  // 32 KB of LDS at most for the table; beyond that gather from the global tables
+    const bool use_wtab = WH_HV_WIN_TABLE && fabs(fs_d / 1000.0 - floor(fs_d / 1000.0 + 0.5)) < 1e-12 && tw_n != 0;
+    const int fpb = refine_frames(use_wtab);
+    const int seglen = 2 * hmax + 8 + (fpb - 1) * ((int)ceil(fs_d / 1000.0) + 1);
     const size_t lds = sizeof(double2) * (size_t)tw_n + sizeof(double) * (size_t)((seglen + 1) & ~1) +
-                       (sizeof(double) + 2 * sizeof(int)) * (size_t)(kFramesPerBlock * kRows) + sizeof(int) * 40 +
-                       sizeof(double) * 16 * kRedRow;
+                       (sizeof(double) + 2 * sizeof(int)) * (size_t)(fpb * kRows) + sizeof(int) * 72;
     // 16-sample rotation (sin, cos)(16*pi*dx) of the window phase for every half length (hv_refine_row)
     double2* d_rot = nullptr;
     {
@@ -1093,7 +1095,6 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     // (w(j), dw(j)) of every window length, row hwl at offset hwl^2 (hv_refine_row, WTAB): only when the 1 ms frames
     // fall on whole samples of the decimated signal.  Built once per (rate, longest window) and kept on the device.
     const double2* d_wtab = nullptr;
-    const bool use_wtab = WH_HV_WIN_TABLE && fabs(fs_d / 1000.0 - floor(fs_d / 1000.0 + 0.5)) < 1e-12 && tw_n != 0;
     if (use_wtab) {
       char key[96];
       snprintf(key, sizeof key, "hv.wtab:%.17g:%d", fs_d, hmax);
@@ -1128,7 +1129,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
         d_wtab = reinterpret_cast<const double2*>(it->second);
       }
     }
-    const dim3 grid((unsigned)((max_nf1 + kFramesPerBlock - 1) / kFramesPerBlock), B);
+    const dim3 grid((unsigned)((max_nf1 + fpb - 1) / fpb), B);
 #define WH_REFINE_LAUNCH(TWL_, WTAB_)                                                                                   \
   {                                                                                                                     \
     if (int rc = wh::allow_lds(&hv_refine_kernel<TWL_, WTAB_>, lds)) return rc;                                         \

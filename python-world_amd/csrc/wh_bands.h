@@ -224,7 +224,10 @@ inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs
 #ifndef WH_OLS_MINW
 #define WH_OLS_MINW 3  // waves per SIMD the channel walker's register allocation leaves room for
 #endif
-constexpr int kOlsN = 4096;
+#ifndef WH_OLS_N
+#define WH_OLS_N 4096
+#endif
+constexpr int kOlsN = WH_OLS_N;
 #ifndef WH_OLS_VALID
 #define WH_OLS_VALID 3584
 #endif

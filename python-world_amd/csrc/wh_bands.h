@@ -222,7 +222,9 @@ inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs
 #define WH_OLS_PREFETCH 0
 #endif
 #ifndef WH_OLS_MINW
-#define WH_OLS_MINW 3  // waves per SIMD the channel walker's register allocation leaves room for
+#define WH_OLS_MINW 2  // waves per SIMD the channel walker's register allocation leaves room for: with the spectra of
+                       // the next channel / tile in flight during the crossing pass it needs ~200 VGPRs (3: 148 spilled
+                       // registers, 6.6 ms; 2: none, 4.7 ms at config 3)
 #endif
 #ifndef WH_OLS_N
 #define WH_OLS_N 4096
@@ -303,60 +305,44 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
   __shared__ int s_cnt[kOlsBands][4];
   if (threadIdx.x < kOlsBands * 4) s_cnt[threadIdx.x >> 2][threadIdx.x & 3] = 0;
   __syncthreads();
-#pragma unroll 1
-  for (int64_t tile = 0; tile < tiles; ++tile) {
-    const int64_t t0 = tile * kOlsValid;
-    double2 zr[PER];
-    const double2* zs = zspec + (tile_off[u] + tile) * KS;
+  // Software pipeline over (tile, channel): the tap spectrum of the next channel and, behind a tile's last channel, the
+  // next tile's spectrum are fetched while the current channel's crossings are extracted — the one stretch of the
+  // loop that needs few registers — so neither load's L2 latency (33 KB per channel-tile) sits in front of a product.
+  double2 zr[PER], tr[PER];
+  auto load_spec = [&](double2 (&dst)[PER], const double2* src) {
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int k = threadIdx.x + q * 256;
-      zr[q] = k < KS ? zs[k] : make_double2(0.0, 0.0);
+      dst[q] = k < KS ? src[k] : make_double2(0.0, 0.0);
     }
-#if WH_OLS_PREFETCH
-    double2 tr[PER];  // tap spectrum of the channel about to be filtered, fetched under the previous channel's transform
-    {
-      const double2* ts = tspec + (int64_t)b0 * KS;
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int k = threadIdx.x + q * 256;
-        tr[q] = k < KS ? ts[k] : make_double2(0.0, 0.0);
-      }
-    }
-#endif
+  };
+  const int n_ch = nb - b0 < kOlsBands ? nb - b0 : kOlsBands;
+  load_spec(zr, zspec + tile_off[u] * KS);
+  load_spec(tr, tspec + (int64_t)b0 * KS);
 #pragma unroll 1
-    for (int g = 0; g < kOlsBands; ++g) {
+  for (int64_t tile = 0; tile < tiles; ++tile) {
+    const int64_t t0 = tile * kOlsValid;
+#pragma unroll 1
+    for (int g = 0; g < n_ch; ++g) {
       const int b = b0 + g;
-      if (b >= nb) break;
       const BandJob job = jobs[(int64_t)u * nb + b];
       __syncthreads();  // the previous channel's crossings have been read out of the buffer
       int base_cnt[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) base_cnt[t] = s_cnt[g][t];
-#if WH_OLS_PREFETCH
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int k = threadIdx.x + q * 256;
         if (k < KS) ybuf[k] = cmul(zr[q], tr[q]);
       }
-      if (g + 1 < kOlsBands && b + 1 < nb) {
-        const double2* tn = tspec + (int64_t)(b + 1) * KS;
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-          const int k = threadIdx.x + q * 256;
-          tr[q] = k < KS ? tn[k] : make_double2(0.0, 0.0);
-        }
-      }
-#else
-      const double2* ts = tspec + (int64_t)b * KS;
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int k = threadIdx.x + q * 256;
-        if (k < KS) ybuf[k] = cmul(zr[q], ts[k]);
-      }
-#endif
-      sync_lds<256>();  // LDS-only: the prefetched tap spectrum may still be in flight
+      sync_lds<256>();
       irfft_lds<kOlsN, 256>(ybuf, tw_base);
+      if (g + 1 < n_ch) {
+        load_spec(tr, tspec + (int64_t)(b + 1) * KS);
+      } else {
+        load_spec(tr, tspec + (int64_t)b0 * KS);
+        if (tile + 1 < tiles) load_spec(zr, zspec + (tile_off[u] + tile + 1) * KS);
+      }
       // output i of the block is s[t0 + i - (H + h + 1)]: the tile's outputs start at index H + h + 1
       const double* sig = sig_all + (H + half[b] + 1);
       emit_crossings_block<1, kOlsPer>(sig, t0, M, job.edges, job.cap, base_cnt, scan_scratch, flags);

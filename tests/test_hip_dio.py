@@ -76,3 +76,30 @@ def test_dio_ragged_batch_matches_single():
         single = dio(x, fs)
         assert np.array_equal(f0[f_off[u]:f_off[u + 1]], single["f0"])
     assert rt.take_flags() == [0] * 16
+
+
+def test_dio_long_utterance_matches_oracle():
+    """15 s at 16 kHz (3001 frames): the contour walk's candidate rows no longer fit the CU's LDS and take the global
+    path (contour_kernel), the band walker runs more than one segment per band; a 1.3 s utterance in the same batch
+    takes the LDS path.  Voicing exact, f0 to 1e-6 Hz against the NumPy oracle."""
+    from oracle import pitch_dio
+    from world import _hip, _tables
+    from world._synthetic import synth_utterance
+    from world.dio import dio_device
+
+    fs = 16000
+    xs = [synth_utterance(31, fs, 15.0), synth_utterance(32, fs, 1.3)]
+    rt = _hip.Runtime.get()
+    nfs = [_tables.frame_count(len(x), fs, 5) for x in xs]
+    x_off = np.concatenate([[0], np.cumsum([len(x) for x in xs])])
+    f_off = np.concatenate([[0], np.cumsum(nfs)])
+    batch = rt.make_batch(x_off, f_off)
+    tp = np.concatenate([_tables.frame_times(n, 5) for n in nfs])
+    f0, vuv, _, _ = dio_device(rt, batch, rt.to_device(np.concatenate(xs)), rt.to_device(tp), fs)
+    f0, vuv = f0.cpu().numpy(), vuv.cpu().numpy()
+    for u, x in enumerate(xs):
+        o = pitch_dio.dio_np(x, fs)
+        sl = slice(f_off[u], f_off[u + 1])
+        assert np.array_equal(vuv[sl], o["vuv"])
+        assert np.max(np.abs(f0[sl] - o["f0"])) < 1e-6
+    assert rt.take_flags() == [0] * 16

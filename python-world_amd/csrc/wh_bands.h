@@ -222,9 +222,9 @@ inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs
 #define WH_OLS_PREFETCH 0
 #endif
 #ifndef WH_OLS_MINW
-#define WH_OLS_MINW 2  // waves per SIMD the channel walker's register allocation leaves room for: with the spectra of
-                       // the next channel / tile in flight during the crossing pass it needs ~200 VGPRs (3: 148 spilled
-                       // registers, 6.6 ms; 2: none, 4.7 ms at config 3)
+#define WH_OLS_MINW 3  // waves per SIMD the channel walker's register allocation leaves room for (168 VGPRs; the walker
+                       // needs 169 with the thread index read opaquely — wh_harvest.hip — and ~310 without: 2 -> 4.45 ms,
+                       // 3 -> 3.7 ms at config 3)
 #endif
 #ifndef WH_OLS_N
 #define WH_OLS_N 4096

@@ -15,6 +15,17 @@
 //   hv_prune_kernel  : neighbour-frame consistency test (harvest.py:215-248)
 // Back end (wh_harvest_contour.h): contour tracking, smoothing, 5 ms pick.
 #include <math.h>
+#include <hip/hip_runtime.h>
+
+// The overlap-save walker loops over channel-tiles around an inlined inverse transform: with the plain thread index
+// every per-thread LDS / twiddle address of its passes is a loop invariant that LLVM hoists and keeps alive across the
+// loop (see wh_synthesis.hip).  An opaque read makes each use its own value.
+__device__ __forceinline__ unsigned wh_opaque_tid() {
+  unsigned t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+#define WH_TID wh_opaque_tid()
 
 #include "wh_bands.h"
 #include "wh_device.h"

@@ -25,6 +25,18 @@
 
 namespace wh {
 
+// Loads that are known to address global memory, said so to the compiler.  Kernel-argument pointers are inferred as
+// global on their own, but not once they have been laundered through an empty asm (fresh_table, stage fences), selected
+// at run time, or read out of a by-value argument struct: loads through those compile to flat_load, which ticks BOTH
+// the vector-memory and the LDS counter — every s_waitcnt lgkmcnt(0) in front of an LDS read then also waits for the
+// twiddle fetch that was issued early precisely to overlap with it.
+__device__ __forceinline__ double2 ldg2(const double2* p) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const v2d v = *(const v2d __attribute__((address_space(1)))*)p;
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ double ldg(const double* p) { return *(const double __attribute__((address_space(1)))*)p; }
+
 // Workgroup-wide synchronisation for NT cooperating threads.  A single-wave group (NT == 64) needs no
 // hardware barrier: its lanes run in lockstep, so a compiler-level wavefront fence is enough to order the
 // LDS traffic.  This is what lets the per-frame kernels run as one wave per frame with zero s_barrier.
@@ -356,7 +368,7 @@ __device__ __forceinline__ void fft_pass_twiddles(const double2* __restrict__ tw
         const int k = j & (NS - 1);
 #pragma unroll
         for (int r = 1; r < R; ++r) {
-          double2 t = tw[(k * r * STEP) & (N - 1)];
+          double2 t = ldg2(tw + ((k * r * STEP) & (N - 1)));
           if (INV) t.y = -t.y;
           w[p][r] = t;
         }
@@ -452,7 +464,7 @@ __device__ __forceinline__ void rfft_lds(double2* z, const double2* __restrict__
       const double2 a = z[k], b = z[N / 2 - k];
       const double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);  // E = (A + conj(B))/2   (even samples)
       const double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);  // D = (A - conj(B))/2 ; O = -i*D (odd samples)
-      const double2 wk = w[k];
+      const double2 wk = ldg2(w + k);
       const double tr = fma(wk.x, di, wk.y * dr);   // T = W^k * O,  O = (di, -dr)
       const double ti = fma(wk.y, di, -(wk.x * dr));
       z[k] = make_double2(er + tr, ei + ti);
@@ -476,7 +488,7 @@ __device__ __forceinline__ void irfft_lds(double2* z, const double2* __restrict_
     }
     const double er = a.x + b.x, ei = a.y - b.y;  // 2E = A + conj(B)
     const double dr = a.x - b.x, di = a.y + b.y;  // 2D = A - conj(B)
-    const double2 wk = w[k];
+    const double2 wk = ldg2(w + k);
     const double orr = fma(dr, wk.x, di * wk.y);     // 2O = 2D * conj(W^k),  conj(wk) = (wk.x, -wk.y)
     const double oi = fma(di, wk.x, -(dr * wk.y));
     z[k] = make_double2(er - oi, ei + orr);                      // Z[k]     = 2E + i*2O

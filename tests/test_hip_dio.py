@@ -103,3 +103,21 @@ def test_dio_long_utterance_matches_oracle():
         assert np.array_equal(vuv[sl], o["vuv"])
         assert np.max(np.abs(f0[sl] - o["f0"])) < 1e-6
     assert rt.take_flags() == [0] * 16
+
+
+@pytest.mark.parametrize("kw", [dict(f0_floor=50, f0_ceil=500), dict(channels_in_octave=4, frame_period=10),
+                                dict(f0_floor=100, f0_ceil=1000, allowed_range=0.2, frame_period=2)])
+def test_dio_other_parameters(kw):
+    """Non-default search range / band density / hop: band count, tap lengths (odd and even) and the contour's
+    minimum voiced run all follow from them."""
+    from oracle import pitch_dio
+    from world._synthetic import synth_utterance
+    from world.dio import dio
+
+    fs = 16000
+    x = synth_utterance(42, fs, 1.7)
+    o = pitch_dio.dio_np(x, fs, **kw)
+    d = dio(x, fs, **kw)
+    assert np.array_equal(d["temporal_positions"], o["temporal_positions"])
+    assert np.array_equal(d["vuv"], o["vuv"])
+    assert np.max(np.abs(d["f0"] - o["f0"])) < 1e-6

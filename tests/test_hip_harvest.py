@@ -53,3 +53,20 @@ def test_harvest_mwm_config1(golden):
     ref = g["f0"]  # after cheaptrick/d4c bookkeeping: 0 where unvoiced
     voiced = g["vuv"] != 0
     assert np.max(np.abs(h["f0"][voiced] - ref[voiced]) / ref[voiced]) < 1e-8
+
+
+@pytest.mark.parametrize("floor,ceil,period", [(40, 600, 5), (90, 400, 10), (71, 800, 2)])
+def test_harvest_other_search_ranges(floor, ceil, period):
+    """Non-default f0 range / frame period: the longest refinement window, the band set (and with a 40 Hz floor the
+    direct-FIR fallback of the band filters: taps longer than an overlap-save tile allows) all change with them."""
+    from oracle import pitch_harvest
+    from world._synthetic import synth_utterance
+    from world.harvest import harvest
+
+    fs = 16000
+    x = synth_utterance(41, fs, 1.6)
+    o = pitch_harvest.harvest_np(x, fs, f0_floor=floor, f0_ceil=ceil, frame_period=period)
+    d = harvest(x, fs, f0_floor=floor, f0_ceil=ceil, frame_period=period)
+    assert np.array_equal(d["temporal_positions"], o["temporal_positions"])
+    assert np.array_equal(d["vuv"], o["vuv"])
+    assert np.max(np.abs(d["f0"] - o["f0"])) < 1e-6

@@ -60,12 +60,13 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, const double* __restrict__ f0_in, double* __restrict__ f0_out, double fs,
     const double* __restrict__ qtime, int kmax, const double2* __restrict__ tw_base, int32_t* __restrict__ err,
-    long long n_frames) {
+    const uint8_t* __restrict__ only, long long n_frames) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* sm = reinterpret_cast<double*>(smem);  // x*main window
   double* sd = sm + (2 * kmax + 1);              // x*derivative window
   const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
   if (f >= n_frames) return;
+  if (only && !only[f]) return;  // second launch behind stonemask_tab_kernel: the frames it left
   const double f0i = f0_in[f];
   const int lane = threadIdx.x;
   if (f0i == 0.0) {
@@ -158,6 +159,187 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
   if (lane == 0) f0_out[f] = refined;
 }
 
+// ---- tabulated form ------------------------------------------------------------------------------------------------
+// When a frame time falls on a whole sample (t0*fs integral: the standard 5 ms grid at 8 / 16 / 32 / 48 kHz) the
+// window pair of a frame depends on its half length alone and the sample picks on the tap index alone:
+//   wt_j = (idx_raw_j - 1)/fs - t0 = bt_k - 0.5/fs,   idx_j = floor(t0*fs + bt_k*fs + 0.5) = T + off_k,   k = j - hwl
+// (bt_k the reference's 4-decimal quantised times, stonemask.py:38; off_k is not k: at 16 kHz the quantisation moves
+// picks by up to a sample).  (w, dw) come from a host-built table (row hwl at offset hwl^2), off_k from a second one;
+// nothing is staged: four lanes per frame accumulate the 2, then the 6, harmonic bins straight from global memory with
+// LDS twiddles — the shape of hv_refine_row's tabulated path (wh_harvest.hip), where the per-wave-pass set-up and
+// cross-lane sums are shared by 16 frames instead of being paid per frame by a whole wave (32 wave-wide reductions
+// per frame were half of the staged kernel's instructions).  Frames the table does not cover (times off the sample
+// grid, windows reaching before the signal start, f0 below the table's floor) are flagged in `todo` and taken by
+// stonemask_kernel in a second launch.
+constexpr int kSmLanes = 4;
+
+template <int CTRL>
+__device__ __forceinline__ double sm_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+  v += sm_dpp<0xB1>(v);  // quad_perm [1,0,3,2]
+  v += sm_dpp<0x4E>(v);  // quad_perm [2,3,0,1]
+  return v;
+}
+
+// X[b], D[b] for NB bins, this lane's share (j = lane, lane + 4, ...), then summed over the quad
+template <int NB>
+__device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long long xn, long long T, int hwl, int L,
+                                         const double2* __restrict__ wt, const int32_t* __restrict__ offk, int nfft,
+                                         int tw_sh, const int* bins, double2* X, double2* D) {
+  const int l4 = threadIdx.x & (kSmLanes - 1);
+  int tix[NB], tstep[NB];
+  const int tmask = (nfft - 1) << tw_sh;
+#pragma unroll
+  for (int h = 0; h < NB; ++h) {
+    X[h] = make_double2(0.0, 0.0);
+    D[h] = make_double2(0.0, 0.0);
+    tix[h] = ((bins[h] * l4) & (nfft - 1)) << tw_sh;
+    tstep[h] = ((bins[h] * kSmLanes) & (nfft - 1)) << tw_sh;
+  }
+  const int n_it = (L + kSmLanes - 1) / kSmLanes;
+  int j = l4;
+  double2 cur = j < L ? wt[j] : make_double2(0.0, 0.0);
+  int oc = j < L ? offk[j - hwl] : 0;
+  for (int it = 0; it < n_it; ++it) {
+    const int jn = j + kSmLanes;
+    const double2 nxt = jn < L ? wt[jn] : make_double2(0.0, 0.0);
+    const int on = jn < L ? offk[jn - hwl] : 0;
+    long long idx = T + oc;  // 1-based pick, clamped like the reference (stonemask.py:41)
+    idx = idx < 1 ? 1 : (idx > xn ? xn : idx);
+    const double smp = j < L ? xu[idx - 1] : 0.0;
+    const double a = smp * cur.x, d = smp * cur.y;
+#pragma unroll
+    for (int h = 0; h < NB; ++h) {
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      const v2d w = *(const v2d __attribute__((address_space(3)))*)(size_t)(uint32_t)tix[h];  // table at LDS address 0
+      X[h].x = fma(a, w.x, X[h].x);
+      X[h].y = fma(a, w.y, X[h].y);
+      D[h].x = fma(d, w.x, D[h].x);
+      D[h].y = fma(d, w.y, D[h].y);
+      tix[h] = (tix[h] + tstep[h]) & tmask;
+    }
+    cur = nxt;
+    oc = on;
+    j = jn;
+  }
+#pragma unroll
+  for (int h = 0; h < NB; ++h) {
+    X[h].x = quad_sum(X[h].x);
+    X[h].y = quad_sum(X[h].y);
+    D[h].x = quad_sum(D[h].x);
+    D[h].y = quad_sum(D[h].y);
+  }
+}
+
+__global__ __launch_bounds__(256) void stonemask_tab_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
+    const double* __restrict__ tp, const double* __restrict__ f0_in, double* __restrict__ f0_out, double fs, int kmax,
+    const double2* __restrict__ win_tab, const int32_t* __restrict__ offk_tab, const double2* __restrict__ tw_base,
+    int tw_n, uint8_t* __restrict__ todo, long long n_frames) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // the twiddle table of tw_n points, at LDS address 0
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+  double2* twl = reinterpret_cast<double2*>(smem);
+  for (int i = threadIdx.x; i < tw_n; i += 256) twl[i] = tw_base[tw_n + i];
+  __syncthreads();
+  constexpr int kPerBlock = 256 / kSmLanes;
+  const long long n_blocks = (n_frames + kPerBlock - 1) / kPerBlock;
+  const long long blk = wh::xcd_unit(blockIdx.x, n_blocks);
+  if (blk >= n_blocks) return;
+  const long long f = blk * kPerBlock + threadIdx.x / kSmLanes;
+  const int l4 = threadIdx.x & (kSmLanes - 1);
+  const bool live = f < n_frames;  // the quad stays together through the DPP sums
+  const double f0i = live ? f0_in[f] : 0.0;
+  bool work = live && f0i != 0.0;
+  if (live && l4 == 0) todo[f] = 0;
+  if (live && f0i == 0.0 && l4 == 0) f0_out[f] = f0i;
+  double hwl_d = 1.0, t0 = 0.0;
+  long long T = 0, xn = 1;
+  const double* xu = x;
+  if (work) {
+    hwl_d = ceil(3 * fs / f0i / 2);
+    t0 = tp[f];
+    const double Tf = t0 * fs;
+    const double Tr = rint(Tf);
+    T = (long long)Tr;
+    const int u = frame_utt[f];
+    xu = x + x_off[u];
+    xn = x_off[u + 1] - x_off[u];
+    // the table holds: windows up to kmax, frame times on the sample grid, every tap at a positive time
+    if (!(hwl_d <= (double)kmax) || fabs(Tf - Tr) > 1e-9 * fmax(1.0, Tr) || !(Tr - hwl_d - 2.0 > 0.0)) {
+      if (l4 == 0) todo[f] = 1;
+      work = false;
+    }
+  }
+  const int hwl = work ? (int)hwl_d : 1;
+  const int L = work ? 2 * hwl + 1 : 0;
+  int nfft = 4;
+  {
+    int e = 0;
+    while ((1 << e) < L) ++e;
+    nfft = 1 << (e + 1);
+  }
+  const int tw_sh = (__ffs(tw_n) - __ffs(nfft)) + 4;  // table subsampling, and elements -> bytes
+  const double2* wt = win_tab + (long long)hwl * hwl;
+  const int32_t* offk = offk_tab + kmax;
+  int bins[6];
+  double2 X[6], D[6];
+  auto weighted = [&](int nbins) -> double {  // lane l evaluates bins l and l + 4, the quad adds up
+    double num = 0.0, den = 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int h = l4 + q * kSmLanes;
+      double2 Xh = make_double2(0.0, 0.0), Dh = make_double2(0.0, 0.0);
+      int bh = 0;
+#pragma unroll
+      for (int hh = 0; hh < 6; ++hh)
+        if (hh == h) {
+          Xh = X[hh];
+          Dh = D[hh];
+          bh = bins[hh];
+        }
+      if (h < nbins) {
+        double p = Xh.x * Xh.x + Xh.y * Xh.y;
+        if (p == 0.0) p = 2.220446049250313e-16;  // stonemask.py:54
+        const double nm = Xh.x * Dh.y - Xh.y * Dh.x;
+        const double inst = ((double)bh / nfft * fs) + nm / p * fs / 2 / M_PI;
+        const double amp = sqrt(p);
+        num += amp * inst;
+        den += amp * (double)(h + 1);
+      }
+    }
+    return quad_sum(num) / quad_sum(den);
+  };
+  // harmonics 1-2 around the initial f0 (stonemask.py:57-62)
+#pragma unroll
+  for (int h = 0; h < 6; ++h) bins[h] = 0;
+  for (int h = 0; h < 2; ++h) bins[h] = (int)(f0i * nfft / fs * (h + 1) + 0.5);
+  tab_bins<2>(xu, xn, T, hwl, L, wt, offk, nfft, tw_sh, bins, X, D);
+  const double f_first = weighted(2);
+  double refined = 0.0;
+  bool second = work && !(f_first < 0);
+  if (second) {
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      const double b = f_first * nfft / fs * (h + 1);
+      bins[h] = (int)(b > 0 ? b + 0.5 : b - 0.5);
+      if (bins[h] >= nfft || bins[h] < 0) second = false;  // the reference would raise IndexError: keep the input f0
+    }
+  }
+  // (the quad is uniform in `second`: every lane derived it from the same sums)
+  tab_bins<6>(xu, xn, T, hwl, second ? L : 0, wt, offk, nfft, tw_sh, bins, X, D);
+  if (second) refined = weighted(6);
+  else (void)weighted(6);
+  if (work) {
+    if (fabs(refined - f0i) / f0i > 0.2) refined = f0i;  // stonemask.py:25
+    if (l4 == 0) f0_out[f] = refined;
+  }
+}
+
 }  // namespace
 
 extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const double* tp,
@@ -178,8 +360,70 @@ extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   if (int rc = wh::const_table(ctx, key, qt, &d_qt)) return rc;
   int32_t* err = ctx->d_flags + WH_FLAG_STONEMASK_WINDOW;
   if (int rc = wh::allow_lds(&stonemask_kernel, lds)) return rc;
+  // Tabulated form first (see stonemask_tab_kernel); it needs every quantised tap to land clear of a rounding
+  // boundary (bt*fs + 0.5 at least 1e-6 from a whole number: true at 8 / 16 / 32 / 48 kHz) and the largest transform's
+  // twiddles in LDS.
+  const uint8_t* d_only = nullptr;
+#ifndef WH_STONEMASK_TABLE
+#define WH_STONEMASK_TABLE 1
+#endif
+  int tw_n = 1;
+  while (tw_n < 2 * kmax + 1) tw_n <<= 1;
+  tw_n <<= 1;
+  bool use_tab = WH_STONEMASK_TABLE && tw_n <= 2048;
+  std::vector<int32_t> offk(2 * kmax + 1);
+  for (int i = 0; use_tab && i < 2 * kmax + 1; ++i) {
+    const double yv = qt[i] * fs + 0.5;
+    const double fl = floor(yv);
+    if (yv - fl < 1e-6 || fl + 1.0 - yv < 1e-6) use_tab = false;
+    offk[i] = (int32_t)fl;
+  }
+  if (use_tab) {
+    snprintf(key, sizeof key, "smtab:%.3f:%d", fs, kmax);
+    const double2* d_wtab = nullptr;
+    auto it = ctx->tables.find(key);
+    if (it == ctx->tables.end()) {
+      std::vector<double> tab((size_t)2 * (kmax + 1) * (kmax + 1), 0.0), mw;
+      const double inv_fs = 1.0 / fs;
+      for (int h = 1; h <= kmax; ++h) {
+        const int Lh = 2 * h + 1;
+        const double wlit = (2 * (double)h + 1) / fs, two_over_wlit = 2.0 / wlit;
+        mw.assign(Lh, 0.0);
+        for (int j = 0; j < Lh; ++j) {
+          const double wt = qt[(j - h) + kmax] - 0.5 * inv_fs;  // (idx_raw - 1)/fs - t0 with t0*fs integral
+          const double c = cos(M_PI * (wt * two_over_wlit));
+          mw[j] = 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1);
+        }
+        double* row = tab.data() + 2 * (size_t)h * h;
+        for (int j = 0; j < Lh; ++j) {
+          const double left = j > 0 ? mw[j - 1] : 0.0, right = j + 1 < Lh ? mw[j + 1] : 0.0;
+          row[2 * j] = mw[j];
+          row[2 * j + 1] = -((mw[j] - left) + (right - mw[j])) / 2;  // stonemask.py:46
+        }
+      }
+      const double* d = nullptr;
+      if (int rc = wh::const_table(ctx, key, tab, &d)) return rc;
+      d_wtab = reinterpret_cast<const double2*>(d);
+    } else {
+      d_wtab = reinterpret_cast<const double2*>(it->second);
+    }
+    int32_t* d_offk = nullptr;
+    if (int rc = wh::persistent_upload(ctx, st, "sm.offk", offk, &d_offk)) return rc;
+    if (int rc = wh::ws_reserve(ctx, (size_t)b->total_frames + 256)) return rc;
+    uint8_t* d_todo = reinterpret_cast<uint8_t*>(ctx->ws);
+    const size_t lds_tab = sizeof(double2) * (size_t)tw_n;
+    const long long n_blocks = (b->total_frames + 63) / 64;
+    {
+      wh::KernelTimer _kt(ctx, st, "stonemask_tab_kernel");
+      hipLaunchKernelGGL(stonemask_tab_kernel, dim3((unsigned)wh::xcd_grid(n_blocks)), dim3(256), lds_tab, st, x, b->d_x_off,
+                         b->d_frame_utt, tp, f0, refined_f0, fs, kmax, d_wtab, d_offk, ctx->d_twiddle, tw_n, d_todo,
+                         (long long)b->total_frames);
+    }
+    WH_LAUNCH_CHECK("stonemask_tab_kernel");
+    d_only = d_todo;
+  }
   { wh::KernelTimer _kt(ctx, st, "stonemask_kernel"); hipLaunchKernelGGL(stonemask_kernel, dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(64), lds, st, x, b->d_x_off,
-                     b->d_frame_utt, tp, f0, refined_f0, fs, d_qt, kmax, ctx->d_twiddle, err, (long long)b->total_frames); }
+                     b->d_frame_utt, tp, f0, refined_f0, fs, d_qt, kmax, ctx->d_twiddle, err, d_only, (long long)b->total_frames); }
   WH_LAUNCH_CHECK("stonemask_kernel");
   return 0;
 }

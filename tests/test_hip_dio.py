@@ -121,3 +121,25 @@ def test_dio_other_parameters(kw):
     assert np.array_equal(d["temporal_positions"], o["temporal_positions"])
     assert np.array_equal(d["vuv"], o["vuv"])
     assert np.max(np.abs(d["f0"] - o["f0"])) < 1e-6
+
+
+@pytest.mark.parametrize("fs", [16000, 48000])
+def test_stonemask_mixed_time_grids(fs):
+    """Frame times on the sample grid take the tabulated kernel, everything else (times off the grid, windows that
+    reach before the signal start) the staged one, frame by frame within one call: both against the oracle."""
+    from oracle import pitch_dio
+    from world._synthetic import synth_utterance
+    from world.stonemask import stonemask
+
+    x = synth_utterance(43, fs, 1.4)
+    d = pitch_dio.dio_np(x, fs)
+    tp = d["temporal_positions"].copy()
+    f0 = d["f0"].copy()
+    f0[:4] = 180.0                      # voiced frames whose windows reach before sample 1
+    tp[1::3] += 0.37 / fs               # every third frame between two samples
+    tp[2::3] *= 1.0 + 1e-13             # ... and one within rounding of the grid
+    ref = pitch_dio.stonemask_np(x, fs, tp, f0)
+    out = stonemask(x, fs, tp, f0)
+    assert np.array_equal(out == 0, ref == 0)
+    v = ref != 0
+    assert np.max(np.abs(out[v] - ref[v]) / ref[v]) < 1e-9

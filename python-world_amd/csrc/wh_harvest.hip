@@ -418,9 +418,9 @@ __device__ __forceinline__ double row_sum(double v) {
 // TWL: the twiddles come from the workgroup's LDS copy (tw_lds, at a compile-time offset of the dynamic LDS block, so
 // that a look-up is one ds_read_b128 whose address register is the running byte offset itself); else from the global
 // tables through tw_base.
-// WTAB: the frames lie on whole samples of the decimated signal (fs/1000 an integer: 8 / 16 / 32 / 48 kHz inputs), so
-// the Blackman window and its derivative twin depend on the window length alone — (w(j), dw(j)) come from a per-call
-// table (win_tab, row hwl at offset hwl^2) instead of being re-derived per sample by rotation + DPP neighbour exchange.
+// WTAB: the Blackman window and its derivative twin depend on the window length alone (the frame time cancels out of the
+// reference's window argument, see the tabulated loop) — (w(j), dw(j)) come from a per-call table (win_tab, row hwl at
+// offset hwl^2) instead of being re-derived per sample by rotation + DPP neighbour exchange.
 __device__ __forceinline__ bool rotation_path_ok(bool wtab, double a0, double a0_frac) {
   return !wtab && a0 > 1.0 && a0_frac > 1e-6 && a0_frac < 1.0 - 1e-6;
 }
@@ -512,10 +512,12 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   // a frame that fails the check takes the general path below.
   const double a0 = idx_raw_at(0);
   const double a0_frac = a0 - floor(a0);
-  if (WTAB && a0 > 1.0 && fabs(a0_frac - 0.501) < 1e-6) {
-    // t0*fs is a whole number: index_raw(j) - 1 sits (j - hwl - 0.499)/fs from the frame time whatever the frame,
-    // and the window pair of row hwl applies as tabulated.  The loop is the 24 FMAs, the six twiddle gathers and
-    // one table read (fetched an iteration ahead).
+  if (WTAB && a0 > 1.0 && a0_frac > 1e-6 && a0_frac < 1.0 - 1e-6) {
+    // index_raw(j) = t0*fs + (j - hwl) + 0.501 is never truncated before it enters the window argument
+    // (index_raw - 1)/fs - t0 = (j - hwl - 0.499)/fs: the frame time cancels, whatever its position between two
+    // samples, and the window pair of row hwl applies as tabulated (only the sample PICK floor(index_raw) depends on
+    // the frame, through i_first below).  The loop is the 24 FMAs, the six twiddle gathers and one table read
+    // (fetched an iteration ahead).
     const double2* wt = win_tab + hwl * hwl;
     int tix[6], tstep[6];  // byte offsets into the twiddle table (see the rotation path below)
     const int tmask = ((nfft - 1) << tw_sh);
@@ -1087,7 +1089,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     while (tw_n < 2 * hmax + 1) tw_n <<= 1;
     tw_n <<= 1;
     if (tw_n > 2048) tw_n = 0;  // 32 KB of LDS at most for the table; beyond that gather from the global tables
-    const bool use_wtab = WH_HV_WIN_TABLE && fabs(fs_d / 1000.0 - floor(fs_d / 1000.0 + 0.5)) < 1e-12 && tw_n != 0;
+    const bool use_wtab = WH_HV_WIN_TABLE && tw_n != 0;
     const int fpb = refine_frames(use_wtab);
     const int seglen = 2 * hmax + 8 + (fpb - 1) * ((int)ceil(fs_d / 1000.0) + 1);
     const size_t lds = sizeof(double2) * (size_t)tw_n + sizeof(double) * (size_t)((seglen + 1) & ~1) +
@@ -1103,8 +1105,8 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
       }
       if (int rc = wh::persistent_upload(ctx, st, "hv.rot", rot, &d_rot)) return rc;
     }
-    // (w(j), dw(j)) of every window length, row hwl at offset hwl^2 (hv_refine_row, WTAB): only when the 1 ms frames
-    // fall on whole samples of the decimated signal.  Built once per (rate, longest window) and kept on the device.
+    // (w(j), dw(j)) of every window length, row hwl at offset hwl^2 (hv_refine_row, WTAB).  Built once per (rate,
+    // longest window) and kept on the device.
     const double2* d_wtab = nullptr;
     if (use_wtab) {
       char key[96];

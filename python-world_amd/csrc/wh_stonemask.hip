@@ -160,17 +160,17 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
 }
 
 // ---- tabulated form ------------------------------------------------------------------------------------------------
-// When a frame time falls on a whole sample (t0*fs integral: the standard 5 ms grid at 8 / 16 / 32 / 48 kHz) the
-// window pair of a frame depends on its half length alone and the sample picks on the tap index alone:
-//   wt_j = (idx_raw_j - 1)/fs - t0 = bt_k - 0.5/fs,   idx_j = floor(t0*fs + bt_k*fs + 0.5) = T + off_k,   k = j - hwl
-// (bt_k the reference's 4-decimal quantised times, stonemask.py:38; off_k is not k: at 16 kHz the quantisation moves
-// picks by up to a sample).  (w, dw) come from a host-built table (row hwl at offset hwl^2), off_k from a second one;
-// nothing is staged: four lanes per frame accumulate the 2, then the 6, harmonic bins straight from global memory with
-// LDS twiddles — the shape of hv_refine_row's tabulated path (wh_harvest.hip), where the per-wave-pass set-up and
-// cross-lane sums are shared by 16 frames instead of being paid per frame by a whole wave (32 wave-wide reductions
-// per frame were half of the staged kernel's instructions).  Frames the table does not cover (times off the sample
-// grid, windows reaching before the signal start, f0 below the table's floor) are flagged in `todo` and taken by
-// stonemask_kernel in a second launch.
+// index_raw_j = (t0 + bt_k)*fs + 0.5 is never truncated before it enters the window argument
+//   wt_j = (index_raw_j - 1)/fs - t0 = bt_k - 0.5/fs,   k = j - hwl
+// (bt_k the reference's 4-decimal quantised times, stonemask.py:38): the frame time cancels, so the window pair of a
+// frame depends on its half length alone and comes from a host-built table (row hwl at offset hwl^2); only the sample
+// PICK floor(index_raw_j) depends on the frame and is evaluated per tap exactly as the reference does (the
+// quantisation moves picks by up to a sample at 16 kHz).  Nothing is staged: four lanes per frame accumulate the 2,
+// then the 6, harmonic bins straight from global memory with LDS twiddles — the shape of hv_refine_row's tabulated
+// path (wh_harvest.hip), where the per-wave-pass set-up and cross-lane sums are shared by 16 frames instead of being
+// paid per frame by a whole wave (32 wave-wide reductions per frame were half of the staged kernel's instructions).
+// Frames the table does not cover (windows reaching before the signal start, where the reference's rounding changes
+// sign, or f0 below the table's floor) are flagged in `todo` and taken by stonemask_kernel in a second launch.
 constexpr int kSmLanes = 4;
 
 template <int CTRL>
@@ -188,8 +188,8 @@ __device__ __forceinline__ double quad_sum(double v) {
 
 // X[b], D[b] for NB bins, this lane's share (j = lane, lane + 4, ...), then summed over the quad
 template <int NB>
-__device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long long xn, long long T, int hwl, int L,
-                                         const double2* __restrict__ wt, const int32_t* __restrict__ offk, int nfft,
+__device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long long xn, double t0, double fs, int hwl, int L,
+                                         const double2* __restrict__ wt, const double* __restrict__ qt, int nfft,
                                          int tw_sh, const int* bins, double2* X, double2* D) {
   const int l4 = threadIdx.x & (kSmLanes - 1);
   int tix[NB], tstep[NB];
@@ -203,15 +203,17 @@ __device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long lon
   }
   const int n_it = (L + kSmLanes - 1) / kSmLanes;
   int j = l4;
+  const double xn_d = (double)xn;
   double2 cur = j < L ? wt[j] : make_double2(0.0, 0.0);
-  int oc = j < L ? offk[j - hwl] : 0;
+  double bc = j < L ? qt[j - hwl] : 0.0;
   for (int it = 0; it < n_it; ++it) {
     const int jn = j + kSmLanes;
     const double2 nxt = jn < L ? wt[jn] : make_double2(0.0, 0.0);
-    const int on = jn < L ? offk[jn - hwl] : 0;
-    long long idx = T + oc;  // 1-based pick, clamped like the reference (stonemask.py:41)
-    idx = idx < 1 ? 1 : (idx > xn ? xn : idx);
-    const double smp = j < L ? xu[idx - 1] : 0.0;
+    const double bn = jn < L ? qt[jn - hwl] : 0.0;
+    // 1-based pick floor((t0 + bt)*fs + 0.5), clamped like the reference (stonemask.py:39-41; every tap time is
+    // positive here: the kernel checked it)
+    const double ir = fmax(1.0, fmin(xn_d, (t0 + bc) * fs + 0.5));
+    const double smp = j < L ? xu[(long long)ir - 1] : 0.0;
     const double a = smp * cur.x, d = smp * cur.y;
 #pragma unroll
     for (int h = 0; h < NB; ++h) {
@@ -224,7 +226,7 @@ __device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long lon
       tix[h] = (tix[h] + tstep[h]) & tmask;
     }
     cur = nxt;
-    oc = on;
+    bc = bn;
     j = jn;
   }
 #pragma unroll
@@ -239,7 +241,7 @@ __device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long lon
 __global__ __launch_bounds__(256) void stonemask_tab_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, const double* __restrict__ f0_in, double* __restrict__ f0_out, double fs, int kmax,
-    const double2* __restrict__ win_tab, const int32_t* __restrict__ offk_tab, const double2* __restrict__ tw_base,
+    const double2* __restrict__ win_tab, const double* __restrict__ qtime, const double2* __restrict__ tw_base,
     int tw_n, uint8_t* __restrict__ todo, long long n_frames) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // the twiddle table of tw_n points, at LDS address 0
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
@@ -258,19 +260,17 @@ __global__ __launch_bounds__(256) void stonemask_tab_kernel(
   if (live && l4 == 0) todo[f] = 0;
   if (live && f0i == 0.0 && l4 == 0) f0_out[f] = f0i;
   double hwl_d = 1.0, t0 = 0.0;
-  long long T = 0, xn = 1;
+  long long xn = 1;
   const double* xu = x;
   if (work) {
     hwl_d = ceil(3 * fs / f0i / 2);
     t0 = tp[f];
-    const double Tf = t0 * fs;
-    const double Tr = rint(Tf);
-    T = (long long)Tr;
     const int u = frame_utt[f];
     xu = x + x_off[u];
     xn = x_off[u + 1] - x_off[u];
-    // the table holds: windows up to kmax, frame times on the sample grid, every tap at a positive time
-    if (!(hwl_d <= (double)kmax) || fabs(Tf - Tr) > 1e-9 * fmax(1.0, Tr) || !(Tr - hwl_d - 2.0 > 0.0)) {
+    // the table holds windows up to kmax; every tap must sit at a positive time (the quantisation moves a tap by less
+    // than a sample)
+    if (!(hwl_d <= (double)kmax) || !(t0 * fs - hwl_d - 2.0 > 0.0)) {
       if (l4 == 0) todo[f] = 1;
       work = false;
     }
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void stonemask_tab_kernel(
   }
   const int tw_sh = (__ffs(tw_n) - __ffs(nfft)) + 4;  // table subsampling, and elements -> bytes
   const double2* wt = win_tab + (long long)hwl * hwl;
-  const int32_t* offk = offk_tab + kmax;
+  const double* qt = qtime + kmax;
   int bins[6];
   double2 X[6], D[6];
   auto weighted = [&](int nbins) -> double {  // lane l evaluates bins l and l + 4, the quad adds up
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void stonemask_tab_kernel(
 #pragma unroll
   for (int h = 0; h < 6; ++h) bins[h] = 0;
   for (int h = 0; h < 2; ++h) bins[h] = (int)(f0i * nfft / fs * (h + 1) + 0.5);
-  tab_bins<2>(xu, xn, T, hwl, L, wt, offk, nfft, tw_sh, bins, X, D);
+  tab_bins<2>(xu, xn, t0, fs, hwl, L, wt, qt, nfft, tw_sh, bins, X, D);
   const double f_first = weighted(2);
   double refined = 0.0;
   bool second = work && !(f_first < 0);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void stonemask_tab_kernel(
     }
   }
   // (the quad is uniform in `second`: every lane derived it from the same sums)
-  tab_bins<6>(xu, xn, T, hwl, second ? L : 0, wt, offk, nfft, tw_sh, bins, X, D);
+  tab_bins<6>(xu, xn, t0, fs, hwl, second ? L : 0, wt, qt, nfft, tw_sh, bins, X, D);
   if (second) refined = weighted(6);
   else (void)weighted(6);
   if (work) {
@@ -360,9 +360,7 @@ extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   if (int rc = wh::const_table(ctx, key, qt, &d_qt)) return rc;
   int32_t* err = ctx->d_flags + WH_FLAG_STONEMASK_WINDOW;
   if (int rc = wh::allow_lds(&stonemask_kernel, lds)) return rc;
-  // Tabulated form first (see stonemask_tab_kernel); it needs every quantised tap to land clear of a rounding
-  // boundary (bt*fs + 0.5 at least 1e-6 from a whole number: true at 8 / 16 / 32 / 48 kHz) and the largest transform's
-  // twiddles in LDS.
+  // Tabulated form first (see stonemask_tab_kernel); it needs the largest transform's twiddles in LDS.
   const uint8_t* d_only = nullptr;
 #ifndef WH_STONEMASK_TABLE
 #define WH_STONEMASK_TABLE 1
@@ -370,14 +368,7 @@ extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   int tw_n = 1;
   while (tw_n < 2 * kmax + 1) tw_n <<= 1;
   tw_n <<= 1;
-  bool use_tab = WH_STONEMASK_TABLE && tw_n <= 2048;
-  std::vector<int32_t> offk(2 * kmax + 1);
-  for (int i = 0; use_tab && i < 2 * kmax + 1; ++i) {
-    const double yv = qt[i] * fs + 0.5;
-    const double fl = floor(yv);
-    if (yv - fl < 1e-6 || fl + 1.0 - yv < 1e-6) use_tab = false;
-    offk[i] = (int32_t)fl;
-  }
+  const bool use_tab = WH_STONEMASK_TABLE && tw_n <= 2048;
   if (use_tab) {
     snprintf(key, sizeof key, "smtab:%.3f:%d", fs, kmax);
     const double2* d_wtab = nullptr;
@@ -407,8 +398,6 @@ extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const 
     } else {
       d_wtab = reinterpret_cast<const double2*>(it->second);
     }
-    int32_t* d_offk = nullptr;
-    if (int rc = wh::persistent_upload(ctx, st, "sm.offk", offk, &d_offk)) return rc;
     if (int rc = wh::ws_reserve(ctx, (size_t)b->total_frames + 256)) return rc;
     uint8_t* d_todo = reinterpret_cast<uint8_t*>(ctx->ws);
     const size_t lds_tab = sizeof(double2) * (size_t)tw_n;
@@ -416,7 +405,7 @@ extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const 
     {
       wh::KernelTimer _kt(ctx, st, "stonemask_tab_kernel");
       hipLaunchKernelGGL(stonemask_tab_kernel, dim3((unsigned)wh::xcd_grid(n_blocks)), dim3(256), lds_tab, st, x, b->d_x_off,
-                         b->d_frame_utt, tp, f0, refined_f0, fs, kmax, d_wtab, d_offk, ctx->d_twiddle, tw_n, d_todo,
+                         b->d_frame_utt, tp, f0, refined_f0, fs, kmax, d_wtab, d_qt, ctx->d_twiddle, tw_n, d_todo,
                          (long long)b->total_frames);
     }
     WH_LAUNCH_CHECK("stonemask_tab_kernel");

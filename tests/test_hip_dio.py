@@ -125,8 +125,9 @@ def test_dio_other_parameters(kw):
 
 @pytest.mark.parametrize("fs", [16000, 48000])
 def test_stonemask_mixed_time_grids(fs):
-    """Frame times on the sample grid take the tabulated kernel, everything else (times off the grid, windows that
-    reach before the signal start) the staged one, frame by frame within one call: both against the oracle."""
+    """Frame times on and off the sample grid (the tabulated kernel evaluates the sample picks per tap like the
+    reference; its windows do not depend on the frame time) and windows that reach before the signal start (left to
+    the staged kernel), frame by frame within one call: against the oracle."""
     from oracle import pitch_dio
     from world._synthetic import synth_utterance
     from world.stonemask import stonemask

@@ -94,3 +94,28 @@ def test_resynthesis_tracks_input(full_batch):
         ex = np.sqrt(np.mean(xs[u].reshape(-1, 1600) ** 2, axis=1))
         ey = np.sqrt(np.mean(seg.reshape(-1, 1600) ** 2, axis=1))
         assert np.corrcoef(ex, ey)[0, 1] > 0.9
+
+
+def test_harvest_batch_rows_equal_single_utterance():
+    """Harvest on a ragged batch of 24 utterances of 9-10 s (config 3's shape at a size every stage's grid is busy:
+    utterance-fastest band walkers, 16-frame refinement / pruning blocks that straddle utterance ends): every utterance
+    inside the batch == the same utterance alone, bitwise; no device flag."""
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+
+    xs = [synth_utterance(100 + u, FS, 9.0 + 0.043 * u) for u in range(24)]
+    wb = WorldBatch()
+    enc = wb.encode(xs, FS, f0_method="harvest")
+    assert wb.rt.take_flags() == [0] * 16
+    fo = enc.batch.frame_off
+    for u in (0, 11, 23):
+        single = WorldBatch().encode([xs[u]], FS, f0_method="harvest")
+        s = slice(int(fo[u]), int(fo[u + 1]))
+        for name in ("f0", "vuv", "spectrogram", "aperiodicity"):
+            a = getattr(enc, name)[s].cpu().numpy()
+            b = getattr(single, name).cpu().numpy()
+            assert np.array_equal(a, b), (u, name)
+    f0 = enc.f0.cpu().numpy()
+    vuv = enc.vuv.cpu().numpy()
+    voiced = f0[vuv != 0]
+    assert len(voiced) > 0.5 * len(f0) and 60 < voiced.min() and voiced.max() < 900

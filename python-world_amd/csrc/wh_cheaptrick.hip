@@ -48,11 +48,20 @@ __global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
   // results move by an ulp)
   const double inv_span = 1.0 / fs / 1.5;
   double s_w2 = 0.0;
-  for (int j = threadIdx.x; j < L; j += FT) {
-    const double t = (double)(j - hwl) * inv_span;
-    const double w = 0.5 * cospi(t * f0) + 0.5;  // cos(pi*t*f0)
-    s_w2 += w * w;
-    if (j < N) zr[j] = w;
+  {
+    // cos(pi*f0*t_j) for this thread's samples j = tid, tid + FT, ...: one sincospi for the first, a fixed rotation by
+    // FT samples after that (at most N/FT + 1 steps: error growth ~1e-15) instead of a cospi per sample
+    double sn, cs, rs = 0.0, rc = 1.0;
+    sincospi(((double)((int)threadIdx.x - hwl) * inv_span) * f0, &sn, &cs);
+    if (L > FT) sincospi(((double)FT * inv_span) * f0, &rs, &rc);  // frame-uniform
+    for (int j = threadIdx.x; j < L; j += FT) {
+      const double w = 0.5 * cs + 0.5;
+      s_w2 += w * w;
+      if (j < N) zr[j] = w;
+      const double cn = cs * rc - sn * rs;
+      sn = sn * rc + cs * rs;
+      cs = cn;
+    }
   }
   const double norm = sqrt(wh::block_sum<FT>(s_w2, scratch));
   const double inv_norm = 1.0 / norm;
@@ -121,15 +130,21 @@ __global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
   for (int n = threadIdx.x; n < N; n += FT) zr[n] = aux[n <= N / 2 ? n : N - n];
   wh::sync<FT>();
   const double inv_fs = 1.0 / fs;
-  for (int m = threadIdx.x; m < K; m += FT) {
-    const double q = (double)m * inv_fs;
-    double sl = 1.0, sn = 0.0;
-    if (m > 0) {
-      sn = sinpi(f0 * q);  // sin(pi*f0*q)
-      sl = sn / (M_PI * f0 * q);
+  {
+    // sin(pi*f0*q_m) for m = tid, tid + FT, ...: start value + rotation by FT bins, as for the window
+    double sn, cs, rs, rc;
+    sincospi(f0 * ((double)threadIdx.x * inv_fs), &sn, &cs);
+    sincospi(f0 * ((double)FT * inv_fs), &rs, &rc);
+    for (int m = threadIdx.x; m < K; m += FT) {
+      const double q = (double)m * inv_fs;
+      double sl = 1.0;
+      if (m > 0) sl = sn / (M_PI * f0 * q);
+      const double cl = (1 - 2 * q1) + 2 * q1 * (1 - 2 * sn * sn);  // cos(2*pi*q*f0) = 1 - 2 sin^2(pi*q*f0)
+      aux[m] = sl * cl;
+      const double cn = cs * rc - sn * rs;
+      sn = sn * rc + cs * rs;
+      cs = cn;
     }
-    const double cl = (1 - 2 * q1) + 2 * q1 * (1 - 2 * sn * sn);  // cos(2*pi*q*f0) = 1 - 2 sin^2(pi*q*f0)
-    aux[m] = sl * cl;
   }
   wh::rfft_lds<N, FT>(zb, tw_base);
   for (int k = threadIdx.x; k < K; k += FT) {

@@ -218,9 +218,6 @@ inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs
 // spectrum is fetched once into registers and reused for its channels.  The inverse transform is left unnormalised:
 // the crossing detector only looks at signs and ratios.
 // ------------------------------------------------------------------------------------------------------------
-#ifndef WH_OLS_PREFETCH
-#define WH_OLS_PREFETCH 0
-#endif
 #ifndef WH_OLS_MINW
 #define WH_OLS_MINW 3  // waves per SIMD the channel walker's register allocation leaves room for (168 VGPRs; the walker
                        // needs 169 with the thread index read opaquely — wh_harvest.hip — and ~310 without: 2 -> 4.45 ms,

@@ -40,9 +40,6 @@ constexpr int kHChunk = 1024;
 #ifndef WH_HV_WIN_TABLE
 #define WH_HV_WIN_TABLE 1  // 0: always derive the refinement windows per sample (rotation + DPP neighbours)
 #endif
-#ifndef WH_HV_RED_DPP
-#define WH_HV_RED_DPP 1  // 0: fold the 24 partial sums once by DPP, then through an LDS scratch (fewer VALU instructions, but 10.4 vs 9.5 ms measured: the 24 KB of scratch cost a workgroup per CU)
-#endif
 
 struct HvUtt {
   int64_t x_off, n;

@@ -55,10 +55,11 @@ def test_harvest_mwm_config1(golden):
     assert np.max(np.abs(h["f0"][voiced] - ref[voiced]) / ref[voiced]) < 1e-8
 
 
-@pytest.mark.parametrize("floor,ceil,period", [(40, 600, 5), (90, 400, 10), (71, 800, 2)])
+@pytest.mark.parametrize("floor,ceil,period", [(40, 600, 5), (90, 400, 10), (71, 800, 2), (20, 400, 5)])
 def test_harvest_other_search_ranges(floor, ceil, period):
     """Non-default f0 range / frame period: the longest refinement window, the band set (and with a 40 Hz floor the
-    direct-FIR fallback of the band filters: taps longer than an overlap-save tile allows) all change with them."""
+    direct-FIR fallback of the band filters: taps longer than an overlap-save tile allows) all change with them; at a
+    20 Hz floor the refinement's transform tables no longer fit LDS (global twiddles, rotation windows)."""
     from oracle import pitch_harvest
     from world._synthetic import synth_utterance
     from world.harvest import harvest

@@ -389,7 +389,8 @@ def main():
             out["cpu_baseline"] = cpu
         if world == 1 and not args.no_extras and args.config == 2 and args.scaling == "weak":
             del graph
-            blocks = [("with_transfers", lambda: with_transfers_block(torch, wl, xs, FS))]
+            blocks = [("with_transfers", lambda: with_transfers_block(torch, wl, xs, FS)),
+                      ("with_transfers_pipelined", lambda: with_transfers_pipelined_block(torch, wl, xs, FS))]
             if args.transfer_lanes > 1:  # measured 41 ms with 4 lanes against 36.5 ms serial: off by default
                 blocks.append(("with_transfers_overlapped",
                                lambda: with_transfers_lanes_block(torch, local_rank, xs, FS, args.transfer_lanes)))
@@ -491,6 +492,37 @@ def with_transfers_block(torch, wl, xs, fs, steps=5):
             "h2d_MB_per_step": x_pin.numel() * 8 / 1e6, "d2h_MB_per_step": nbytes_d2h / 1e6,
             "note": "config 2 step incl. H2D of x and D2H of f0/vuv/spectrogram/aperiodicity/out via pinned host "
                     "buffers on one stream (no overlap); 'ps spectrogram' is not materialised"}
+
+
+def with_transfers_pipelined_block(torch, wl, xs, fs, steps=6):
+    """The host-buffer step as a streaming caller runs it (WorldBatch.download_async): the D2H of step k's results
+    goes out on a second stream (its own copy engine) while step k+1 is uploaded and computed — results
+    double-buffered in pinned memory.  The steady state is the slower of (H2D + kernels) and D2H, not their sum."""
+    wb = wl.lanes[0]
+    batch, x_d, tp_d = wl.resident[0]
+    x_pin = torch.from_numpy(np.concatenate(xs)).pin_memory()
+
+    def one(k):
+        x_d.copy_(x_pin, non_blocking=True)
+        e = wb.encode_device(batch, x_d, tp_d, fs, f0_method="dio", check=False)
+        yy, _ = wb.decode_device(e, seed=10 + k, check=False)
+        return wb.download_async((e.f0, e.vuv, e.spectrogram, e.aperiodicity, yy), slot=k % 2)
+
+    one(0)
+    one(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        one(2 + k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    wb.check("with_transfers_pipelined")
+    frames = batch.total_frames
+    return {"ms_per_step": dt * 1e3, "value": frames / dt, "unit": "frames/s",
+            "x_realtime": len(xs) * len(xs[0]) / fs / dt, "steps": steps,
+            "note": "with_transfers with the D2H of one step's results on a second stream under the upload + kernels "
+                    "of the next (WorldBatch.download_async, double-buffered pinned results): throughput of a "
+                    "streaming host-buffer caller"}
 
 
 def with_transfers_lanes_block(torch, device_index, xs, fs, lanes=4, steps=5):

@@ -215,8 +215,10 @@ inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs
 // H = max half-length before the tile so that one block serves every channel's delay), and per channel a tile costs a
 // spectrum product and one inverse real FFT (2048-point complex, four radix-8/4 passes in LDS): ~34 flops per output
 // and channel instead of 82-986.  A workgroup walks the tiles of kOlsBands channels of one utterance; the tile's
-// spectrum is fetched once into registers and reused for its channels.  The inverse transform is left unnormalised:
-// the crossing detector only looks at signs and ratios.
+// spectrum is fetched once into registers and reused for its channels, the spectra the next channel / tile needs are
+// fetched under the current channel's crossing pass, and the crossings of a tile's kOlsValid outputs are extracted in
+// one pass (emit_crossings_block).  The inverse transform is left unnormalised: the crossing detector only looks at
+// signs and ratios.
 // ------------------------------------------------------------------------------------------------------------
 #ifndef WH_OLS_MINW
 #define WH_OLS_MINW 3  // waves per SIMD the channel walker's register allocation leaves room for (168 VGPRs; the walker

@@ -6,13 +6,17 @@
 //                      (harvest.py:58-71,584-609)
 //   band_events      : 152 band-pass channels + zero-crossing compaction (wh_bands.h): overlap-save FFT products
 //                      (one forward transform per 4096-sample tile shared by all channels), direct FIR as fallback
-//   hv_raw_kernel    : per (1 ms frame, channel) interpolation of the four interval-F0 trains (harvest.py:252-278)
+//   hv_raw_kernel    : per (1 ms frame, channel) interpolation of the four interval-F0 trains (harvest.py:252-278),
+//                      from (location, frequency) intervals staged per 128-frame tile
 //   hv_detect_kernel : per frame: runs of >= 10 live channels -> candidate = mean (harvest.py:88-110)
-//   hv_refine_kernel : per frame: every overlapped candidate (+-3 frames, harvest.py:114-125) refined by
-//                      instantaneous frequency at <= 6 harmonics.  The reference farms ~178 k two-FFT calls per
-//                      10 s utterance to a process pool (harvest.py:131-211); here a wave stages the two
-//                      windowed sequences in LDS and evaluates only the harmonic bins as direct DFT sums.
-//   hv_prune_kernel  : neighbour-frame consistency test (harvest.py:215-248)
+//   hv_refine_kernel : every overlapped candidate (+-3 frames, harvest.py:114-125) refined by instantaneous frequency
+//                      at <= 6 harmonics.  The reference farms ~178 k two-FFT calls per 10 s utterance to a process
+//                      pool (harvest.py:131-211); here four lanes per candidate accumulate only the harmonic bins as
+//                      direct DFT sums — window pairs from a per-length table (the frame time cancels out of the
+//                      reference's window argument), twiddles from an LDS table, samples from an LDS stage of the
+//                      16 frames a workgroup takes; a 16-lane rotation form remains for f0 floors whose tables do not
+//                      fit LDS
+//   hv_prune_kernel  : neighbour-frame consistency test (harvest.py:215-248), 16 frames per workgroup
 // Back end (wh_harvest_contour.h): contour tracking, smoothing, 5 ms pick.
 #include <math.h>
 #include <hip/hip_runtime.h>

@@ -1,8 +1,12 @@
-// StoneMask F0 refinement — one 64-lane wave per voiced frame.
+// StoneMask F0 refinement.
 // The reference takes two zero-padded FFTs per frame and then reads at most 8 bins of them
-// (world/stonemask.py:30-76).  Here the Blackman-windowed frame and its derivative-windowed twin
-// are staged once in LDS and only those bins are evaluated as direct DFT sums with table twiddles
-// (same maths, no FFT), so a frame costs ~L*8 complex MACs instead of 2*N*log2(N).
+// (world/stonemask.py:30-76).  Here only those bins are evaluated, as direct DFT sums with table twiddles (same
+// maths, no FFT), so a frame costs ~L*8 complex MACs instead of 2*N*log2(N).  Two kernels:
+//   stonemask_tab_kernel : four lanes per frame, window pairs from a per-length table, nothing staged (the default
+//                          for every frame whose window lies at positive times);
+//   stonemask_kernel     : one wave per frame, the Blackman-windowed frame and its derivative-windowed twin staged
+//                          in LDS, windows evaluated per sample — the general form, run on the frames the first
+//                          kernel leaves (and on all frames when its tables would not fit LDS).
 #include "wh_host.h"
 #include "wh_device.h"
 

@@ -204,13 +204,15 @@ constexpr int kRawChunk = 2 * kRawTile;    // intervals staged per train and til
 
 __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restrict__ meta, const wh::BandJob* __restrict__ jobs,
                                                      const double* __restrict__ band_f0, int nb, double fs_d,
-                                                     double f0_floor, double f0_ceil, double* __restrict__ raw) {
+                                                     double f0_floor, double f0_ceil, double* __restrict__ raw,
+                                                     uint8_t* __restrict__ live) {
   __shared__ double2 iv[4][kRawChunk];  // (location, frequency) of interval start + i
   __shared__ int s_next[4];
   const HvUtt m = meta[blockIdx.y];
   const int b = blockIdx.x;
   const wh::BandJob job = jobs[(int64_t)blockIdx.y * nb + b];
   double* out = raw + m.f1_off * nb + (int64_t)b * m.nf1;
+  uint8_t* lv = live + m.f1_off * nb + (int64_t)b * m.nf1;  // 1 where a candidate survives: what hv_detect scans
   int cnt[4];
   bool usable = true;
 #pragma unroll
@@ -219,7 +221,10 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
     usable = usable && (cnt[k] - 1 >= 3);
   }
   if (!usable) {  // fewer than 3 intervals in a train: no candidate anywhere (dio.py:159-162)
-    for (int64_t f = threadIdx.x; f < m.nf1; f += kRawTile) out[f] = 0.0;
+    for (int64_t f = threadIdx.x; f < m.nf1; f += kRawTile) {
+      out[f] = 0.0;
+      lv[f] = 0;
+    }
     return;
   }
   const double bf = band_f0[b];
@@ -325,6 +330,7 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
       double cand = (((v[0] + v[1]) + v[2]) + v[3]) / 4;
       if (cand > bf * 1.1 || cand < bf * 0.9 || cand > f0_ceil || cand < f0_floor) cand = 0.0;  // harvest.py:273-276
       out[f] = cand;
+      lv[f] = cand > 0 ? 1 : 0;
     }
     // the last frame of the tile hands its counts to the next tile as the new cursors
     const int64_t last = f0 + kRawTile - 1 < f_end - 1 ? f0 + kRawTile - 1 : f_end - 1;
@@ -355,23 +361,32 @@ __device__ __forceinline__ double np_sum_strided(const double* __restrict__ a, i
   return res;
 }
 
+// The channel walk reads hv_raw's byte map (1 = a candidate survived the band's range test) instead of the candidates
+// themselves — an eighth of the bytes of a pass that runs at HBM speed — and fetches the values only for the runs that
+// count.
 __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict__ meta, int nb,
-                                                        const double* __restrict__ raw, double* __restrict__ dc,
+                                                        const double* __restrict__ raw,
+                                                        const uint8_t* __restrict__ live_map, double* __restrict__ dc,
                                                         int32_t* __restrict__ dcount) {
   const HvUtt m = meta[blockIdx.y];
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (f >= m.nf1) return;
   const double* col = raw + m.f1_off * nb + f;  // element b at col[b * nf1]
+  const uint8_t* lcol = live_map + m.f1_off * nb + f;
   double* out = dc + (m.f1_off + f) * kMaxC;
-  for (int c = 0; c < kMaxC; ++c) out[c] = 0.0;
+  // Phase 1: the runs.  Phase 2 sums them run by run: every lane of the wave is then inside the same summation loop at
+  // the same time (its loads in flight together), where summing a run the moment the walk finds its end made the wave
+  // go through one summation — two or three dependent rounds of global loads — per distinct end position among its
+  // 64 lanes.
+  __shared__ unsigned short runs[kMaxC][256];  // (first live channel) << 8 | length
   int count = 0;
   int run_start = -1;  // 'st': index of the last dead channel before a live run
   bool prev = false;   // channel 0 is forced dead
   // the channel walk is a chain of dependent branches; its loads are not: eight channels are fetched together
   for (int b0 = 0; b0 < nb; b0 += 8) {
-    double v[8];
+    uint8_t v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = b0 + q < nb ? col[(int64_t)(b0 + q) * m.nf1] : 0.0;
+    for (int q = 0; q < 8; ++q) v[q] = b0 + q < nb ? lcol[(int64_t)(b0 + q) * m.nf1] : 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int b = b0 + q;
@@ -380,13 +395,19 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
       if (live && !prev) run_start = b - 1;
       if (!live && prev) {
         const int ed = b - 1;
-        if (ed - run_start >= 10 && count < kMaxC) {
-          const int n = ed - run_start;
-          out[count++] = np_sum_strided(col + (int64_t)(run_start + 1) * m.nf1, m.nf1, n) / (double)n;
-        }
+        if (ed - run_start >= 10 && count < kMaxC) runs[count++][threadIdx.x] = (unsigned short)(((run_start + 1) << 8) | (ed - run_start));
       }
       prev = live;
     }
+  }
+  for (int c = 0; c < kMaxC; ++c) {
+    double val = 0.0;
+    if (c < count) {
+      const int rr = runs[c][threadIdx.x];
+      const int n = rr & 0xff;
+      val = np_sum_strided(col + (int64_t)(rr >> 8) * m.nf1, m.nf1, n) / (double)n;
+    }
+    out[c] = val;
   }
   dcount[m.f1_off + f] = count;
 }
@@ -973,6 +994,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t o_e = off; off += al(sizeof(double) * e_tot);
   const size_t o_cnt = off; off += al(sizeof(int32_t) * (size_t)B * n_bands * 4);
   const size_t o_raw = off; off += al(sizeof(double) * f1_tot * n_bands);
+  const size_t o_live = off; off += al((size_t)f1_tot * n_bands);
   const size_t o_dc = off; off += al(sizeof(double) * f1_tot * kMaxC);
   const size_t o_dn = off; off += al(sizeof(int32_t) * f1_tot);
   const size_t o_rf0 = off; off += al(sizeof(double) * f1_tot * kRows);
@@ -1009,6 +1031,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   int32_t* d_cnt = reinterpret_cast<int32_t*>(ws + o_cnt);
   wh::BandJob* d_jobs = nullptr;
   double* d_raw = reinterpret_cast<double*>(ws + o_raw);
+  uint8_t* d_live = reinterpret_cast<uint8_t*>(ws + o_live);
   double* d_dc = reinterpret_cast<double*>(ws + o_dc);
   int32_t* d_dn = reinterpret_cast<int32_t*>(ws + o_dn);
   double* d_rf0 = reinterpret_cast<double*>(ws + o_rf0);
@@ -1079,10 +1102,10 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
                                              d_ti + 2 * n_bands, max_lb, true, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW)) {
     return rc;
   }
-  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B, WH_HV_RAW_SEGS), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw); }
+  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B, WH_HV_RAW_SEGS), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw, d_live); }
   WH_LAUNCH_CHECK("hv_raw_kernel");
   if (dbg_raw) WH_CHECK(hipMemcpyAsync(dbg_raw, d_raw, sizeof(double) * f1_tot * n_bands, hipMemcpyDeviceToDevice, st));
-  { wh::KernelTimer _kt(ctx, st, "hv_detect_kernel"); hipLaunchKernelGGL(hv_detect_kernel, dim3((unsigned)((max_nf1 + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw, d_dc, d_dn); }
+  { wh::KernelTimer _kt(ctx, st, "hv_detect_kernel"); hipLaunchKernelGGL(hv_detect_kernel, dim3((unsigned)((max_nf1 + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw, d_live, d_dc, d_dn); }
   WH_LAUNCH_CHECK("hv_detect_kernel");
   // ---- refinement + pruning ------------------------------------------------------------------------------
   {

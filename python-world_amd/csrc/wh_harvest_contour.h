@@ -166,33 +166,49 @@ __global__ __launch_bounds__(256) void hc_sections_kernel(const HvUtt* __restric
   }
 }
 
-// SelectBestF0 (harvest.py:238-248) over one frame's kRows candidates, wave-parallel.
-__device__ __forceinline__ double select_best_wave(double ref, const double* __restrict__ col, double allowed) {
+// SelectBestF0 (harvest.py:238-248) over one frame's kRows candidates, wave-parallel: c0 / c1 are this lane's two
+// candidates (rows lane and lane + 64, 0 beyond kRows).  A frame holds a handful of non-zero candidates and at most a
+// few within the allowed range, so the cross-lane stage walks the lanes that hold one (ballot + readlane, scalar) instead
+// of a six-step butterfly on three values.  Smallest error wins, the later row on ties.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double select_best_regs(double ref, double c0, double c1, double allowed) {
   const int lane = threadIdx.x & 63;
   double best_err = INFINITY, best_val = 0.0;
   int best_idx = -1;
-  for (int e = lane; e < kRows; e += 64) {
-    const double c = col[e];
-    const double err = fabs(ref - c) / ref;
+  {
+    const double err = fabs(ref - c0) / ref;
+    if (!(err > allowed)) {
+      best_err = err;
+      best_val = c0;
+      best_idx = lane;
+    }
+  }
+  if (lane + 64 < kRows) {
+    const double err = fabs(ref - c1) / ref;
     if (!(err > allowed) && !(err > best_err)) {  // later entries win ties
       best_err = err;
-      best_val = c;
-      best_idx = e;
+      best_val = c1;
+      best_idx = lane + 64;
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double oe = __shfl_xor(best_err, o, 64);
-    const double ov = __shfl_xor(best_val, o, 64);
-    const int oi = __shfl_xor(best_idx, o, 64);
-    const bool take = (oi >= 0) && (best_idx < 0 || oe < best_err || (oe == best_err && oi > best_idx));
-    if (take) {
-      best_err = oe;
-      best_val = ov;
-      best_idx = oi;
+  unsigned long long mk = __ballot(best_idx >= 0);
+  double be = INFINITY, bv = 0.0;
+  int bi = -1;
+  while (mk) {
+    const int l = __ffsll((long long)mk) - 1;
+    mk &= mk - 1;
+    const double oe = readlane_f64(best_err, l), ov = readlane_f64(best_val, l);
+    const int oi = __builtin_amdgcn_readlane(best_idx, l);
+    if (bi < 0 || oe < be || (oe == be && oi > bi)) {
+      be = oe;
+      bv = ov;
+      bi = oi;
     }
   }
-  return best_idx >= 0 ? best_val : 0.0;
+  return bi >= 0 ? bv : 0.0;
 }
 
 // FixStep3, first half: extend every section forward then backward through the candidate map
@@ -219,20 +235,42 @@ __global__ __launch_bounds__(64) void hc_extend_kernel(const HvUtt* __restrict__
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const double* cands = pf0 + m.f1_off * kRows;
+  // The walk is a chain (the next step's reference value is this step's pick), but which rows it will read is known:
+  // the candidate rows of the next kAhead frames are fetched together, so a step waits for global memory once in
+  // kAhead instead of every time.
+  constexpr int kAhead = 4;
+  auto load_rows = [&](int64_t first, int dir, int count, double (&c0)[kAhead], double (&c1)[kAhead]) {
+#pragma unroll
+    for (int q = 0; q < kAhead; ++q) {
+      const int64_t fr = first + (int64_t)dir * q;
+      const bool ok = q < count && fr >= 0 && fr < n;
+      const double* col = cands + fr * kRows;
+      c0[q] = ok ? col[lane] : 0.0;
+      c1[q] = (ok && lane + 64 < kRows) ? col[lane + 64] : 0.0;
+    }
+  };
   // forward
   int r1 = s.ed;
   {
     double cur = ch[s.ed - s.w0];
     int miss = 0;
     int last = (int)(n - 2 < (int64_t)s.ed + 100 ? n - 2 : (int64_t)s.ed + 100) + 1;
-    for (int i = s.ed; i < last; ++i) {
-      const double b = select_best_wave(cur, cands + (int64_t)(i + 1) * kRows, 0.18);
-      if (lane == 0) ch[i + 1 - s.w0] = b;
-      if (b != 0.0) {
-        cur = b;
-        miss = 0;
-        r1 = i + 1;
-      } else if (++miss == 4) break;
+    bool stop = false;
+    for (int i0 = s.ed; i0 < last && !stop; i0 += kAhead) {
+      double c0[kAhead], c1[kAhead];
+      load_rows((int64_t)i0 + 1, +1, last - i0, c0, c1);
+#pragma unroll
+      for (int q = 0; q < kAhead; ++q) {
+        const int i = i0 + q;
+        if (i >= last || stop) break;
+        const double b = select_best_regs(cur, c0[q], c1[q], 0.18);
+        if (lane == 0) ch[i + 1 - s.w0] = b;
+        if (b != 0.0) {
+          cur = b;
+          miss = 0;
+          r1 = i + 1;
+        } else if (++miss == 4) stop = true;
+      }
     }
   }
   // backward
@@ -241,14 +279,22 @@ __global__ __launch_bounds__(64) void hc_extend_kernel(const HvUtt* __restrict__
     double cur = ch[s.st - s.w0];
     int miss = 0;
     int last = (s.st - 100 > 1 ? s.st - 100 : 1) - 1;
-    for (int i = s.st; i > last; --i) {
-      const double b = select_best_wave(cur, cands + (int64_t)(i - 1) * kRows, 0.18);
-      if (lane == 0) ch[i - 1 - s.w0] = b;
-      if (b != 0.0) {
-        cur = b;
-        miss = 0;
-        r0 = i - 1;
-      } else if (++miss == 4) break;
+    bool stop = false;
+    for (int i0 = s.st; i0 > last && !stop; i0 -= kAhead) {
+      double c0[kAhead], c1[kAhead];
+      load_rows((int64_t)i0 - 1, -1, i0 - last, c0, c1);
+#pragma unroll
+      for (int q = 0; q < kAhead; ++q) {
+        const int i = i0 - q;
+        if (i <= last || stop) break;
+        const double b = select_best_regs(cur, c0[q], c1[q], 0.18);
+        if (lane == 0) ch[i - 1 - s.w0] = b;
+        if (b != 0.0) {
+          cur = b;
+          miss = 0;
+          r0 = i - 1;
+        } else if (++miss == 4) stop = true;
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

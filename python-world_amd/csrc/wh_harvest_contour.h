@@ -319,8 +319,19 @@ __device__ __forceinline__ double chan_at(const double* __restrict__ chan_u, con
 // SerachScore (harvest.py:490-495)
 __device__ __forceinline__ double search_score(double f0, const double* __restrict__ cf, const double* __restrict__ cs) {
   double sc = 0.0;
-  for (int e = 0; e < kRows; ++e)
-    if (f0 == cf[e] && sc < cs[e]) sc = cs[e];
+  // the candidates are fetched eight at a time (one wait per block instead of one per row); a score is only read for
+  // the row or two that match
+  for (int e0 = 0; e0 < kRows; e0 += 8) {
+    double c[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) c[q] = e0 + q < kRows ? cf[e0 + q] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (e0 + q < kRows && f0 == c[q]) {
+        const double v = cs[e0 + q];
+        if (sc < v) sc = v;
+      }
+  }
   return sc;
 }
 

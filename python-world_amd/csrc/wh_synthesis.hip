@@ -916,12 +916,7 @@ __global__ __launch_bounds__(256) void req_linap_kernel(const double* __restrict
 
 // bracketing frames of time t (SciPy interp1d linear + extrapolate)
 __device__ __forceinline__ void bracket(const double* __restrict__ tp, int64_t nf, double t, int64_t* il, int64_t* ih) {
-  int64_t lo = 0, hi = nf;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (tp[mid] < t) lo = mid + 1; else hi = mid;
-  }
-  *ih = lo < 1 ? 1 : (lo > nf - 1 ? nf - 1 : lo);
+  *ih = lerp_segment(tp, nf, t);  // guess from the grid's mean step, checked; bisection otherwise
   *il = *ih - 1;
 }
 
@@ -953,8 +948,12 @@ __global__ __launch_bounds__(256) void req_pulse_kernel(const SynUtt* __restrict
                                                         const int64_t* __restrict__ p_idx, const int32_t* __restrict__ p_count,
                                                         const int64_t* __restrict__ p_base, int n_utt,
                                                         const uint8_t* __restrict__ vuv_s, double* __restrict__ exc) {
+  // One WAVE per pulse: a pulse starts with a chain of a dozen dependent look-ups (utterance, pulse index, voicing,
+  // bracketing frames, band weights) before its 512 adds; four independent chains per workgroup hide each other
+  // better than one (0.37 -> 0.34 ms at config 4; what remains is the rate of the 37 M global atomic adds).
   const int64_t total = p_base[n_utt];
-  for (int64_t gp = blockIdx.x; gp < total; gp += gridDim.x) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t gp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); gp < total; gp += (int64_t)gridDim.x * 4) {
     int u;
     {
       int lo = 0, hi = n_utt;
@@ -986,7 +985,7 @@ __global__ __launch_bounds__(256) void req_pulse_kernel(const SynUtt* __restrict
     const int64_t ns = nxt - pidx;
     const double gain = sqrt((double)(ns > 1 ? ns : 1));
     double* eu = exc + m.y_off;
-    for (int mm = threadIdx.x; mm < pfft; mm += 256) {
+    for (int mm = lane; mm < pfft; mm += 64) {
       double r = 0.0;
       for (int b = 0; b < nb; ++b) r += pulse_seed[(int64_t)mm * nb + b] * (1 - w[b]);
       r *= gain;

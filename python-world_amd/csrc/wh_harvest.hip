@@ -40,7 +40,10 @@ namespace {
 constexpr int kMaxC = 15;          // int(152/10 + 0.5): candidate rows per frame before overlapping
 constexpr int kRows = 7 * kMaxC;   // overlapped candidate rows (shift-major, candidate-minor)
 constexpr int kFPad = 9;           // filtfilt padlen
-constexpr int kHChunk = 1024;
+#ifndef WH_HV_IIR_CHUNK
+#define WH_HV_IIR_CHUNK 256
+#endif
+constexpr int kHChunk = WH_HV_IIR_CHUNK;  // filter outputs per lane of the chunked decimation IIR (+ warm-up before each chunk)
 #ifndef WH_HV_WIN_TABLE
 #define WH_HV_WIN_TABLE 1  // 0: always derive the refinement windows per sample (rotation + DPP neighbours)
 #endif

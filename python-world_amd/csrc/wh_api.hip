@@ -93,6 +93,21 @@ int persistent_upload(wh_ctx* ctx, hipStream_t st, const std::string& slot, cons
   *dptr = e.d;
   return 0;
 }
+int persistent_scratch(wh_ctx* ctx, const std::string& slot, size_t bytes, void** dptr) {
+  wh_ctx::Persist& e = ctx->persist[slot];
+  if (e.cap < bytes || !e.d) {
+    if (e.d) {
+      WH_CHECK(hipDeviceSynchronize());  // kernels of earlier calls may still use the buffer that is about to go
+      WH_CHECK(hipFree(e.d));
+      e.d = nullptr;
+    }
+    const size_t want = bytes < 256 ? 256 : bytes + bytes / 4;
+    WH_CHECK(hipMalloc(&e.d, want));
+    e.cap = want;
+  }
+  *dptr = e.d;
+  return 0;
+}
 }  // namespace wh
 
 extern "C" {

@@ -64,6 +64,9 @@ int const_table(wh_ctx* ctx, const std::string& key, const std::vector<double>& 
 // (no device synchronisation; a context is driven from one stream at a time, so stream order protects readers of
 // the old content).  Only growing the buffer synchronises (hipFree).
 int persistent_upload(wh_ctx* ctx, hipStream_t st, const std::string& slot, const void* host, size_t bytes, void** dptr);
+// A persistent device buffer of at least `bytes` under the name `slot`, contents unspecified (per-call scratch whose size
+// follows the batch shape).  Growing it synchronises the device once (earlier kernels may still use the old buffer).
+int persistent_scratch(wh_ctx* ctx, const std::string& slot, size_t bytes, void** dptr);
 template <typename T>
 inline int persistent_upload(wh_ctx* ctx, hipStream_t st, const std::string& slot, const std::vector<T>& v, T** dptr) {
   void* p = nullptr;

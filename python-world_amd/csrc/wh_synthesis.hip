@@ -2,7 +2,7 @@
 //
 //   prep_kernel     : per output sample: f0/vuv linear interpolation at t_i, phase increment
 //                     2*pi*f0/fs (synthesis.py:121-128).  Embarrassingly parallel.
-//   phase_kernel    : per utterance: the cumulative phase is a SEQUENTIAL float64 sum in the reference
+//   phase scan      : per utterance: the cumulative phase is a SEQUENTIAL float64 sum in the reference
 //                     (np.cumsum); reproduced bit for bit by an integer prefix sum per binade of the running
 //                     sum (exact_cumsum_block), so the pulse positions derived from it are NumPy's.
 //   pulse_*_kernel  : wrap phase, detect pulses (|d wrap| > pi), ordered compaction, 1-based sample index and
@@ -145,12 +145,13 @@ __device__ __forceinline__ int wave_min_int(int v) {
 // p[0..n): in place.  xin / xout: kXLds doubles of LDS each; scr: 32 doubles.  One workgroup of kXThreads.
 // All integer quantities (r_j, their prefix sums, V_j < 2^53) are carried as integer-valued doubles: exact, and
 // the whole pass stays on the FP64 pipe.
-__device__ __forceinline__ void exact_cumsum_block(double* __restrict__ p, int64_t n, double* xin, double* xout,
-                                                   double* scr) {
+// carry_in: the running sum in front of p[0] (0 at the start of a sequence); returns the running sum behind p[n-1].
+__device__ __forceinline__ double exact_cumsum_block(double* __restrict__ p, int64_t n, double* xin, double* xout,
+                                                     double* scr, double carry_in = 0.0) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   constexpr double kTop = 0x1p53;  // V reaches this: the sum has left the binade
-  double carry = 0.0;              // the running sum before the current tile (uniform)
+  double carry = carry_in;         // the running sum before the current tile (uniform)
   double pre[kXPer];               // the next tile, in flight from global memory while this one is scanned
 #pragma unroll
   for (int q = 0; q < kXPer; ++q) {
@@ -246,18 +247,260 @@ __device__ __forceinline__ void exact_cumsum_block(double* __restrict__ p, int64
     for (int i = tid; i < cnt; i += kXThreads) p[base + i] = xout[xpad(i)];
     __syncthreads();
   }
+  return carry;
 }
 
-__global__ __launch_bounds__(kXThreads) void phase_kernel(const SynUtt* __restrict__ meta, double* __restrict__ phase) {
+// The same scan over (begin, end) pairs: pairs[2i] .. pairs[2i+1].
+__global__ __launch_bounds__(kXThreads) void exact_cumsum_pairs_kernel(double* __restrict__ data,
+                                                                       const int64_t* __restrict__ pairs) {
   __shared__ double xin[kXLds], xout[kXLds], scr[32];
-  const SynUtt m = meta[blockIdx.x];
-  exact_cumsum_block(phase + m.y_off, m.ny, xin, xout, scr);
+  exact_cumsum_block(data + pairs[2 * blockIdx.x], pairs[2 * blockIdx.x + 1] - pairs[2 * blockIdx.x], xin, xout, scr);
 }
 
-// Test / utility entry: the same scan over independent segments off[i] .. off[i+1].
-__global__ __launch_bounds__(kXThreads) void exact_cumsum_kernel(double* __restrict__ data, const int64_t* __restrict__ off) {
+// ---- the same scan, tile-parallel -----------------------------------------------------------------------------------
+// One workgroup per sequence leaves the chip idle for long sequences (60 s at 48 kHz after scale_duration(2): 5.76 M
+// samples on each of 16 workgroups, 4.7 ms).  Inside a binade every partial sum is carry + q * (integer prefix of
+// r_j = RN(x_j / q)), and r_j does not depend on the carry unless x_j / q is an exact tie — so a tile of kXTile samples
+// that (i) lies inside one binade and (ii) holds no tie needs nothing from its predecessors but the carry, as an
+// additive constant.  Five passes:
+//   xs_tile_sum_kernel   : plain floating-point tile sums S_t                                  (all tiles in parallel)
+//   xs_prefix_kernel     : their running sums A_t per sequence: the carry in front of tile t to ~1e-12, enough to name
+//                          its binade unless it sits on a power of two                          (one lane per sequence)
+//   xs_tile_total_kernel : with the binade of A_t: T_t = sum r_j (exact integer), tile flagged if a tie, an over-long
+//                          step or a zero / subnormal carry shows                               (all tiles in parallel)
+//   xs_carry_kernel      : per sequence, in order: a lane walks the unflagged tiles with EXACT carries — checking that
+//                          the true carry has the assumed exponent and that carry/q + T_t stays below 2^53 — and
+//                          stores each tile's carry; at a flagged tile, or one that fails the check, the whole
+//                          workgroup runs the sequential-equivalent exact_cumsum_block on that tile with the exact
+//                          carry (a few dozen tiles per sequence: the binade crossings and the ties)
+//   xs_apply_kernel      : carry + q * (local integer prefix) for the tiles the walk accepted   (all tiles in parallel)
+// Bit-identical to np.cumsum by the same argument as exact_cumsum_block; nothing is accepted on the approximate sums
+// alone.
+struct XsTile {
+  double T;     // sum of r_j in units of q (integer-valued), valid when flag == 0
+  int32_t sh;   // x / q = x * 2^sh for the assumed binade
+  int32_t flag; // 0: candidate for the closed form, 1: needs the exact block scan, 2: done by xs_carry_kernel
+};
+
+__device__ __forceinline__ int xs_find_seq(const int64_t* __restrict__ tile_base, int n_seg, int64_t t) {
+  int lo = 0, hi = n_seg;  // largest s with tile_base[s] <= t
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_base[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// pairs: sequence sq is data[pairs[2 sq] .. pairs[2 sq + 1]); tile_base[sq]: number of tiles in front of it.
+__global__ __launch_bounds__(256) void xs_tile_sum_kernel(const double* __restrict__ data, const int64_t* __restrict__ pairs,
+                                                          const int64_t* __restrict__ tile_base, int n_seg,
+                                                          double* __restrict__ S) {
+  __shared__ double red[8];
+  const int64_t t = blockIdx.x;
+  const int sq = xs_find_seq(tile_base, n_seg, t);
+  const int64_t begin = pairs[2 * sq] + (t - tile_base[sq]) * kXTile;
+  const int64_t end = begin + kXTile < pairs[2 * sq + 1] ? begin + kXTile : pairs[2 * sq + 1];
+  double acc = 0.0;
+  for (int64_t i = begin + threadIdx.x; i < end; i += 256) acc += data[i];
+  acc = wh::block_sum<256>(acc, red);
+  if (threadIdx.x == 0) S[t] = acc;
+}
+
+__global__ __launch_bounds__(64) void xs_prefix_kernel(const int64_t* __restrict__ tile_base, int n_seg,
+                                                       double* __restrict__ S) {
+  const int sq = blockIdx.x * 64 + threadIdx.x;
+  if (sq >= n_seg) return;
+  double run = 0.0;  // S[t] becomes the (approximate) carry in front of tile t
+  wh::serial_run<16>(
+      tile_base[sq], tile_base[sq + 1], [](int64_t) { return true; }, [&](int64_t t) { return S[t]; },
+      [&](int64_t t) { return S[t]; },
+      [&](int64_t t, double v) {
+        S[t] = run;
+        run += v;
+      });
+}
+
+__global__ __launch_bounds__(256) void xs_tile_total_kernel(const double* __restrict__ data, const int64_t* __restrict__ pairs,
+                                                            const int64_t* __restrict__ tile_base, int n_seg,
+                                                            const double* __restrict__ A, XsTile* __restrict__ tiles) {
+  __shared__ double red[8];
+  __shared__ int bad_any;
+  const int64_t t = blockIdx.x;
+  const int sq = xs_find_seq(tile_base, n_seg, t);
+  const int64_t begin = pairs[2 * sq] + (t - tile_base[sq]) * kXTile;
+  const int64_t end = begin + kXTile < pairs[2 * sq + 1] ? begin + kXTile : pairs[2 * sq + 1];
+  const double a = A[t];
+  const int ebits = (int)((__double_as_longlong(a) >> 52) & 0x7ff);
+  if (threadIdx.x == 0) bad_any = 0;
+  __syncthreads();
+  XsTile out;
+  out.T = 0.0;
+  out.sh = 0;
+  out.flag = 1;
+  if (ebits != 0 && ebits != 0x7ff && a > 0.0) {
+    const int sh = 52 - (ebits - 1023);
+    double acc = 0.0;
+    bool bad = false;
+    for (int64_t i = begin + threadIdx.x; i < end; i += 256) {
+      const double x = data[i];
+      const double sc = fmin(ldexp(x, sh), 0x1p54);
+      const double fl = floor(sc);
+      const double fr = sc - fl;
+      bad = bad || fr == 0.5 || !(sc < 0x1p52) || !(x >= 0.0);  // a tie, a step of a whole binade, a negative / NaN addend
+      acc += fl + (fr > 0.5 ? 1.0 : 0.0);
+    }
+    if (bad) bad_any = 1;
+    acc = wh::block_sum<256>(acc, red);  // (two barriers: bad_any is visible behind them)
+    out.T = acc;
+    out.sh = sh;
+    out.flag = (bad_any || !(acc < 0x1p52)) ? 1 : 0;  // partial sums below 2^52: every addition was exact
+  }
+  if (threadIdx.x == 0) tiles[t] = out;
+}
+
+__global__ __launch_bounds__(kXThreads) void xs_carry_kernel(double* __restrict__ data, const int64_t* __restrict__ pairs,
+                                                             const int64_t* __restrict__ tile_base,
+                                                             XsTile* __restrict__ tiles, double* __restrict__ C) {
+  constexpr int kWin = 1024;  // tile records staged per round for the walking lane
   __shared__ double xin[kXLds], xout[kXLds], scr[32];
-  exact_cumsum_block(data + off[blockIdx.x], off[blockIdx.x + 1] - off[blockIdx.x], xin, xout, scr);
+  __shared__ XsTile win[kWin];
+  __shared__ long long sh_t;
+  __shared__ double sh_a;
+  const int sq = blockIdx.x;
+  const int64_t t0 = tile_base[sq], t1 = tile_base[sq + 1];
+  double a = 0.0;  // exact running sum in front of tile t (block-uniform)
+  int64_t t = t0;
+  while (t < t1) {
+    const int nw = (int)(t1 - t < kWin ? t1 - t : kWin);
+    for (int i = threadIdx.x; i < nw; i += kXThreads) win[i] = tiles[t + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int i = 0;
+      double aa = a;
+      for (; i < nw; ++i) {
+        const XsTile cur = win[i];
+        if (cur.flag != 0) break;
+        const int ebits = (int)((__double_as_longlong(aa) >> 52) & 0x7ff);
+        if (ebits == 0 || 52 - (ebits - 1023) != cur.sh) break;  // the true carry is not in the binade the tile assumed
+        const double v = ldexp(aa, cur.sh) + cur.T;                // carry/q + T: both integers below 2^53, exact
+        if (!(v < 0x1p53)) break;                                   // the tile would leave the binade
+        C[t + i] = aa;
+        aa = ldexp(v, -cur.sh);
+      }
+      sh_t = t + i;
+      sh_a = aa;
+    }
+    __syncthreads();
+    const int64_t tn = sh_t;
+    a = sh_a;
+    const bool stopped = tn < t + nw;  // inside the window: tile tn needs the sequential-equivalent scan
+    t = tn;
+    __syncthreads();
+    if (stopped) {
+      const int64_t begin = pairs[2 * sq] + (t - t0) * kXTile;
+      const int64_t end = begin + kXTile < pairs[2 * sq + 1] ? begin + kXTile : pairs[2 * sq + 1];
+      a = exact_cumsum_block(data + begin, end - begin, xin, xout, scr, a);
+      if (threadIdx.x == 0) tiles[t].flag = 2;
+      ++t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void xs_apply_kernel(double* __restrict__ data, const int64_t* __restrict__ pairs,
+                                                       const int64_t* __restrict__ tile_base, int n_seg,
+                                                       const XsTile* __restrict__ tiles, const double* __restrict__ C) {
+  constexpr int PER = kXTile / 256;
+  __shared__ double buf[kXTile + kXTile / PER];  // thread-contiguous runs of PER at an odd stride (bank conflicts)
+  __shared__ double wsum[4];
+  auto pad = [](int i) { return i + i / PER; };
+  const int64_t t = blockIdx.x;
+  const XsTile tl = tiles[t];
+  if (tl.flag != 0) return;
+  const int sq = xs_find_seq(tile_base, n_seg, t);
+  const int64_t begin = pairs[2 * sq] + (t - tile_base[sq]) * kXTile;
+  const int64_t end = begin + kXTile < pairs[2 * sq + 1] ? begin + kXTile : pairs[2 * sq + 1];
+  const int cnt = (int)(end - begin);
+  const int sh = tl.sh;
+  // coalesced in, thread-contiguous through LDS (the order of an integer prefix sum is free), coalesced out
+  for (int i = threadIdx.x; i < cnt; i += 256) buf[pad(i)] = data[begin + i];
+  __syncthreads();
+  double r[PER];
+  double run = 0.0;
+  const int i0 = threadIdx.x * PER;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int idx = i0 + j;
+    double rj = 0.0;
+    if (idx < cnt) {
+      const double sc = ldexp(buf[pad(idx)], sh);
+      const double fl = floor(sc);
+      rj = fl + (sc - fl > 0.5 ? 1.0 : 0.0);
+    }
+    run += rj;
+    r[j] = run;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double incl = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  double before = ldexp(C[t], sh) + (incl - run);  // all integers below 2^53: exact
+  for (int i = 0; i < w; ++i) before += wsum[i];
+  const double q = ldexp(1.0, -sh);
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int idx = i0 + j;
+    if (idx < cnt) buf[pad(idx)] = (before + r[j]) * q;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cnt; i += 256) data[begin + i] = buf[pad(i)];
+}
+
+// Host side of the scan: sequences of more than kXsMinTiles tiles take the tile-parallel passes (all of them in one
+// set of launches), the rest the one-workgroup-per-sequence kernel (10 s at 16 kHz is 40 tiles, a dozen of which hold a
+// binade crossing or a tie: 0.21 ms either way; 120 s at 48 kHz is 1407 tiles: 1.2 against 4.7 ms).
+// h_off: n_seg + 1 offsets into d_data (HOST).
+#ifndef WH_XS_MIN_TILES
+#define WH_XS_MIN_TILES 64
+#endif
+constexpr int kXsMinTiles = WH_XS_MIN_TILES;
+int exact_cumsum_segments(wh_ctx* ctx, hipStream_t st, double* d_data, const int64_t* h_off, int n_seg) {
+  std::vector<int64_t> s_pairs, l_pairs, tb{0};
+  for (int i = 0; i < n_seg; ++i) {
+    const int64_t tiles = (h_off[i + 1] - h_off[i] + kXTile - 1) / kXTile;
+    std::vector<int64_t>& dst = tiles > kXsMinTiles ? l_pairs : s_pairs;
+    dst.push_back(h_off[i]);
+    dst.push_back(h_off[i + 1]);
+    if (tiles > kXsMinTiles) tb.push_back(tb.back() + tiles);
+  }
+  if (!s_pairs.empty()) {
+    int64_t* d_sp = nullptr;
+    if (int rc = wh::persistent_upload(ctx, st, "cumsum.short", s_pairs, &d_sp)) return rc;
+    { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(exact_cumsum_pairs_kernel, dim3((unsigned)(s_pairs.size() / 2)), dim3(kXThreads), 0, st, d_data, d_sp); }
+    WH_LAUNCH_CHECK("exact_cumsum_pairs_kernel");
+  }
+  if (l_pairs.empty()) return 0;
+  const int ns = (int)(l_pairs.size() / 2);
+  const int64_t nt = tb[ns];
+  int64_t *d_lp = nullptr, *d_tb = nullptr;
+  if (int rc = wh::persistent_upload(ctx, st, "cumsum.long", l_pairs, &d_lp)) return rc;
+  if (int rc = wh::persistent_upload(ctx, st, "cumsum.tiles", tb, &d_tb)) return rc;
+  void* d_scr = nullptr;  // per tile: S / A, C (doubles) and the tile record
+  if (int rc = wh::persistent_scratch(ctx, "cumsum.scratch", (size_t)nt * (2 * sizeof(double) + sizeof(XsTile)), &d_scr)) return rc;
+  double* d_S = reinterpret_cast<double*>(d_scr);
+  double* d_C = d_S + nt;
+  XsTile* d_tiles = reinterpret_cast<XsTile*>(d_C + nt);
+  { wh::KernelTimer _kt(ctx, st, "xs_tile_sum_kernel"); hipLaunchKernelGGL(xs_tile_sum_kernel, dim3((unsigned)nt), dim3(256), 0, st, d_data, d_lp, d_tb, ns, d_S); }
+  { wh::KernelTimer _kt(ctx, st, "xs_prefix_kernel"); hipLaunchKernelGGL(xs_prefix_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st, d_tb, ns, d_S); }
+  { wh::KernelTimer _kt(ctx, st, "xs_tile_total_kernel"); hipLaunchKernelGGL(xs_tile_total_kernel, dim3((unsigned)nt), dim3(256), 0, st, d_data, d_lp, d_tb, ns, d_S, d_tiles); }
+  { wh::KernelTimer _kt(ctx, st, "xs_carry_kernel"); hipLaunchKernelGGL(xs_carry_kernel, dim3((unsigned)ns), dim3(kXThreads), 0, st, d_data, d_lp, d_tb, d_tiles, d_C); }
+  { wh::KernelTimer _kt(ctx, st, "xs_apply_kernel"); hipLaunchKernelGGL(xs_apply_kernel, dim3((unsigned)nt), dim3(256), 0, st, d_data, d_lp, d_tb, ns, d_tiles, d_C); }
+  WH_LAUNCH_CHECK("xs_apply_kernel");
+  return 0;
 }
 
 // Pulse detection (synthesis.py:129-138) in four launches, none of them serial in the utterance length:
@@ -1122,8 +1365,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
                      d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
-  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(kXThreads), 0, st, d_meta, d_phase); }
-  WH_LAUNCH_CHECK("phase_kernel");
+  if (int rc = exact_cumsum_segments(ctx, st, d_phase, h_y_off, B)) return rc;
   if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ws + o_px)) return rc;
   { wh::KernelTimer _kt(ctx, st, "pulse_base_kernel"); hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb); }
   WH_LAUNCH_CHECK("pulse_base_kernel");
@@ -1213,12 +1455,7 @@ extern "C" int wh_cumsum_exact(wh_ctx* ctx, void* stream, double* d_data, const 
   WH_ENTER(ctx);
   if (n_seg == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  std::vector<int64_t> off(h_off, h_off + n_seg + 1);
-  int64_t* d_off = nullptr;
-  if (int rc = wh::persistent_upload(ctx, st, "cumsum.off", off, &d_off)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "exact_cumsum_kernel"); hipLaunchKernelGGL(exact_cumsum_kernel, dim3(n_seg), dim3(kXThreads), 0, st, d_data, d_off); }
-  WH_LAUNCH_CHECK("exact_cumsum_kernel");
-  return 0;
+  return exact_cumsum_segments(ctx, st, d_data, h_off, n_seg);
 }
 
 // Pulse bookkeeping only (no responses): per-utterance pulse count and total noise draws
@@ -1272,8 +1509,7 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
                      d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
-  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(kXThreads), 0, st, d_meta, d_phase); }
-  WH_LAUNCH_CHECK("phase_kernel");
+  if (int rc = exact_cumsum_segments(ctx, st, d_phase, h_y_off, B)) return rc;
   if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, reinterpret_cast<double*>(ws + o_pt), d_pi,
                              reinterpret_cast<double*>(ws + o_ps), d_pn, d_pc, ws + o_px)) return rc;
   WH_CHECK(hipMemcpyAsync(h_pulse_count, d_pc, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st));
@@ -1363,8 +1599,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs, d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
-  { wh::KernelTimer _kt(ctx, st, "phase_kernel"); hipLaunchKernelGGL(phase_kernel, dim3(B), dim3(kXThreads), 0, st, d_meta, d_phase); }
-  WH_LAUNCH_CHECK("phase_kernel");
+  if (int rc = exact_cumsum_segments(ctx, st, d_phase, h_y_off, B)) return rc;
   if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ws + o_px)) return rc;
   { wh::KernelTimer _kt(ctx, st, "pulse_base_kernel"); hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb); }
   WH_LAUNCH_CHECK("pulse_base_kernel");

@@ -161,14 +161,28 @@ __global__ __launch_bounds__(256) void hv_copy_kernel(const double* __restrict__
   if (i < m.ylen) y[m.y_off + i] = x[m.x_off + i];
 }
 
-__global__ __launch_bounds__(256) void hv_mean_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
-                                                      double* __restrict__ mean) {
+// mean of the decimated signal in two steps: kMeanParts partial sums per utterance (fixed association: the result does
+// not depend on the launch), then their sum / length
+constexpr int kMeanParts = 32;
+__global__ __launch_bounds__(256) void hv_mean_part_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
+                                                           double* __restrict__ part) {
   __shared__ double scratch[16];
-  const HvUtt m = meta[blockIdx.x];
+  const HvUtt m = meta[blockIdx.y];
+  const int64_t chunk = (m.ylen + kMeanParts - 1) / kMeanParts;
+  const int64_t begin = (int64_t)blockIdx.x * chunk;
+  const int64_t end = begin + chunk < m.ylen ? begin + chunk : m.ylen;
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < m.ylen; i += 256) s += y[m.y_off + i];
+  for (int64_t i = begin + threadIdx.x; i < end; i += 256) s += y[m.y_off + i];
   s = wh::block_sum(s, scratch);
-  if (threadIdx.x == 0) mean[blockIdx.x] = s / (double)m.ylen;
+  if (threadIdx.x == 0) part[(int64_t)blockIdx.y * kMeanParts + blockIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void hv_mean_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ part,
+                                                     int n_utt, double* __restrict__ mean) {
+  const int u = blockIdx.x * 64 + threadIdx.x;
+  if (u >= n_utt) return;
+  double s = 0.0;
+  for (int k = 0; k < kMeanParts; ++k) s += part[(int64_t)u * kMeanParts + k];
+  mean[u] = s / (double)meta[u].ylen;
 }
 
 // z = [zeros(pad), y - mean, zeros(pad)]; also rewrites y itself mean-removed (the refinement reads it)
@@ -993,7 +1007,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t o_tmp = off; off += al(sizeof(double) * t_tot);
   const size_t o_y = off; off += al(sizeof(double) * y_tot);
   const size_t o_z = off; off += al(sizeof(double) * z_tot);
-  const size_t o_mean = off; off += al(sizeof(double) * B);
+  const size_t o_mean = off; off += al(sizeof(double) * B * (1 + kMeanParts));  // means, then the partial sums
   const size_t o_e = off; off += al(sizeof(double) * e_tot);
   const size_t o_cnt = off; off += al(sizeof(int32_t) * (size_t)B * n_bands * 4);
   const size_t o_raw = off; off += al(sizeof(double) * f1_tot * n_bands);
@@ -1086,7 +1100,8 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     { wh::KernelTimer _kt(ctx, st, "hv_copy_kernel"); hipLaunchKernelGGL(hv_copy_kernel, dim3((unsigned)((max_ylen + 255) / 256), B), dim3(256), 0, st, x, d_meta, d_y); }
     WH_LAUNCH_CHECK("hv_copy_kernel");
   }
-  { wh::KernelTimer _kt(ctx, st, "hv_mean_kernel"); hipLaunchKernelGGL(hv_mean_kernel, dim3(B), dim3(256), 0, st, d_meta, d_y, d_mean); }
+  { wh::KernelTimer _kt(ctx, st, "hv_mean_kernel"); hipLaunchKernelGGL(hv_mean_part_kernel, dim3(kMeanParts, B), dim3(256), 0, st, d_meta, d_y, d_mean + B); }
+  { wh::KernelTimer _kt(ctx, st, "hv_mean_kernel"); hipLaunchKernelGGL(hv_mean_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, d_meta, d_mean + B, B, d_mean); }
   WH_LAUNCH_CHECK("hv_mean_kernel");
   { wh::KernelTimer _kt(ctx, st, "hv_pad_kernel"); hipLaunchKernelGGL(hv_pad_kernel, dim3((unsigned)((max_ylen + 2 * pad + 255) / 256), B), dim3(256), 0, st, d_meta, d_y, d_mean, pad, d_z); }
   WH_LAUNCH_CHECK("hv_pad_kernel");

@@ -845,11 +845,15 @@ __global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUt
 // for 64 x 10 s — was bound by the rate at which workgroups can be launched, and read every frame three times.)
 constexpr int kPruneFrames = 16;
 
+// The result is a 128-bit keep mask per frame (bit e: candidate e survives, i.e. is non-zero and passed the test): the
+// contour kernels read the refined arrays through it (wh_harvest_contour.h: kept()), which spares this pass — it runs at
+// HBM speed — the score array and two dense copies (2.1 GB -> 0.55 GB of traffic for 64 x 10 s).
 __global__ __launch_bounds__(256) void hv_prune_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ rf0,
-                                                       const double* __restrict__ rsc, double* __restrict__ pf0,
-                                                       double* __restrict__ psc) {
+                                                       uint32_t* __restrict__ keep) {
   __shared__ double lst[kPruneFrames + 2][kRows];  // compacted non-zero candidates of frames f_first-1 .. f_first+16
   __shared__ int ln[kPruneFrames + 2];
+  __shared__ uint32_t mk[kPruneFrames][4];
+  if (threadIdx.x < kPruneFrames * 4) mk[threadIdx.x >> 2][threadIdx.x & 3] = 0;
   const HvUtt m = meta[blockIdx.y];
   const int64_t f_first = (int64_t)blockIdx.x * kPruneFrames;
   if (f_first >= m.nf1) return;
@@ -877,7 +881,7 @@ __global__ __launch_bounds__(256) void hv_prune_kernel(const HvUtt* __restrict__
     if (f >= m.nf1) break;
     const int64_t o = (m.f1_off + f) * kRows;
     const bool inner = f >= 1 && f <= m.nf1 - 2;
-    double v = rf0[o + e], s = rsc[o + e];
+    double v = rf0[o + e];
     if (inner && v != 0.0) {
       double e1 = 1.0, e2 = 1.0;  // SelectBestF0 with allowed_range = 1 (a zero candidate gives exactly 1)
       // min_k |v - nb_k| / v == (min_k |v - nb_k|) / v bit for bit (division by v > 0 is monotone): one divide per
@@ -890,13 +894,14 @@ __global__ __launch_bounds__(256) void hv_prune_kernel(const HvUtt* __restrict__
       for (int k = 0; k < n_prev; ++k) d2 = fmin(d2, fabs(v - nb_prev[k]));
       if (n_next > 0) e1 = fmin(e1, d1 / v);
       if (n_prev > 0) e2 = fmin(e2, d2 / v);
-      if (fmin(e1, e2) > 0.05) {
-        v = 0.0;
-        s = 0.0;
-      }
+      if (fmin(e1, e2) > 0.05) v = 0.0;
     }
-    pf0[o + e] = v;
-    psc[o + e] = s;
+    if (v != 0.0) atomicOr(&mk[fl][e >> 5], 1u << (e & 31));
+  }
+  __syncthreads();
+  if (threadIdx.x < kPruneFrames * 4) {
+    const int64_t f = f_first + (threadIdx.x >> 2);
+    if (f < m.nf1) keep[(m.f1_off + f) * 4 + (threadIdx.x & 3)] = mk[threadIdx.x >> 2][threadIdx.x & 3];
   }
 }
 
@@ -1016,8 +1021,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t o_dn = off; off += al(sizeof(int32_t) * f1_tot);
   const size_t o_rf0 = off; off += al(sizeof(double) * f1_tot * kRows);
   const size_t o_rsc = off; off += al(sizeof(double) * f1_tot * kRows);
-  const size_t o_pf0 = off; off += al(sizeof(double) * f1_tot * kRows);
-  const size_t o_psc = off; off += al(sizeof(double) * f1_tot * kRows);
+  const size_t o_keep = off; off += al(sizeof(uint32_t) * 4 * f1_tot);
   const size_t o_ct = off; off += al(contour_workspace_bytes(f1_tot, B));
   // overlap-save band filters: tile spectra of every utterance + the channels' tap spectra
   std::vector<int64_t> tile_off(B + 1, 0);
@@ -1053,8 +1057,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   int32_t* d_dn = reinterpret_cast<int32_t*>(ws + o_dn);
   double* d_rf0 = reinterpret_cast<double*>(ws + o_rf0);
   double* d_rsc = reinterpret_cast<double*>(ws + o_rsc);
-  double* d_pf0 = reinterpret_cast<double*>(ws + o_pf0);
-  double* d_psc = reinterpret_cast<double*>(ws + o_psc);
+  uint32_t* d_keep = reinterpret_cast<uint32_t*>(ws + o_keep);
   double* d_taps = nullptr;
   double* d_bf = nullptr;
   int32_t* d_ti = nullptr;
@@ -1198,9 +1201,9 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
 #undef WH_REFINE_LAUNCH
     WH_LAUNCH_CHECK("hv_refine_kernel");
   }
-  { wh::KernelTimer _kt(ctx, st, "hv_prune_kernel"); hipLaunchKernelGGL(hv_prune_kernel, dim3((unsigned)((max_nf1 + kPruneFrames - 1) / kPruneFrames), B), dim3(256), 0, st, d_meta, d_rf0, d_rsc, d_pf0, d_psc); }
+  { wh::KernelTimer _kt(ctx, st, "hv_prune_kernel"); hipLaunchKernelGGL(hv_prune_kernel, dim3((unsigned)((max_nf1 + kPruneFrames - 1) / kPruneFrames), B), dim3(256), 0, st, d_meta, d_rf0, d_keep); }
   WH_LAUNCH_CHECK("hv_prune_kernel");
   // ---- contour, smoothing, 5 ms pick -------------------------------------------------------------------------
-  return harvest_contour(ctx, st, B, d_meta, meta, f1_tot, max_nf1, max_nf, d_pf0, d_psc, d_ct, tp, f0_out, vuv_out,
+  return harvest_contour(ctx, st, B, d_meta, meta, f1_tot, max_nf1, max_nf, d_rf0, d_rsc, d_keep, d_ct, tp, f0_out, vuv_out,
                          dbg_f0_1ms);
 }

@@ -2,7 +2,7 @@
 // The reference takes two zero-padded FFTs per frame and then reads at most 8 bins of them
 // (world/stonemask.py:30-76).  Here only those bins are evaluated, as direct DFT sums with table twiddles (same
 // maths, no FFT), so a frame costs ~L*8 complex MACs instead of 2*N*log2(N).  Two kernels:
-//   stonemask_tab_kernel : four lanes per frame, window pairs from a per-length table, nothing staged (the default
+//   stonemask_tab_kernel : eight lanes per frame, window pairs from a per-length table, nothing staged (the default
 //                          for every frame whose window lies at positive times);
 //   stonemask_kernel     : one wave per frame, the Blackman-windowed frame and its derivative-windowed twin staged
 //                          in LDS, windows evaluated per sample — the general form, run on the frames the first
@@ -169,13 +169,16 @@ __global__ __launch_bounds__(64) void stonemask_kernel(
 // (bt_k the reference's 4-decimal quantised times, stonemask.py:38): the frame time cancels, so the window pair of a
 // frame depends on its half length alone and comes from a host-built table (row hwl at offset hwl^2); only the sample
 // PICK floor(index_raw_j) depends on the frame and is evaluated per tap exactly as the reference does (the
-// quantisation moves picks by up to a sample at 16 kHz).  Nothing is staged: four lanes per frame accumulate the 2,
+// quantisation moves picks by up to a sample at 16 kHz).  Nothing is staged: eight lanes per frame accumulate the 2,
 // then the 6, harmonic bins straight from global memory with LDS twiddles — the shape of hv_refine_row's tabulated
-// path (wh_harvest.hip), where the per-wave-pass set-up and cross-lane sums are shared by 16 frames instead of being
+// path (wh_harvest.hip), where the per-wave-pass set-up and cross-lane sums are shared by 8 frames instead of being
 // paid per frame by a whole wave (32 wave-wide reductions per frame were half of the staged kernel's instructions).
 // Frames the table does not cover (windows reaching before the signal start, where the reference's rounding changes
 // sign, or f0 below the table's floor) are flagged in `todo` and taken by stonemask_kernel in a second launch.
-constexpr int kSmLanes = 4;
+#ifndef WH_SM_LANES
+#define WH_SM_LANES 8
+#endif
+constexpr int kSmLanes = WH_SM_LANES;  // lanes per frame (2 / 4 / 8 / 16: 0.48 / 0.38 / 0.31 / 0.31 ms at config 2)
 
 template <int CTRL>
 __device__ __forceinline__ double sm_dpp(double v) {
@@ -184,29 +187,31 @@ __device__ __forceinline__ double sm_dpp(double v) {
   hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double quad_sum(double v) {
-  v += sm_dpp<0xB1>(v);  // quad_perm [1,0,3,2]
-  v += sm_dpp<0x4E>(v);  // quad_perm [2,3,0,1]
+__device__ __forceinline__ double group_sum(double v) {  // over the kSmLanes lanes of a frame
+  v += sm_dpp<0xB1>(v);                        // quad_perm [1,0,3,2]
+  if (kSmLanes >= 4) v += sm_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+  if (kSmLanes >= 8) v += sm_dpp<0x141>(v);    // row_half_mirror
+  if (kSmLanes >= 16) v += sm_dpp<0x140>(v);   // row_mirror
   return v;
 }
 
-// X[b], D[b] for NB bins, this lane's share (j = lane, lane + 4, ...), then summed over the quad
+// X[b], D[b] for NB bins, this lane's share (j = lane, lane + 4, ...), then summed over the group
 template <int NB>
 __device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long long xn, double t0, double fs, int hwl, int L,
                                          const double2* __restrict__ wt, const double* __restrict__ qt, int nfft,
                                          int tw_sh, const int* bins, double2* X, double2* D) {
-  const int l4 = threadIdx.x & (kSmLanes - 1);
+  const int lg = threadIdx.x & (kSmLanes - 1);
   int tix[NB], tstep[NB];
   const int tmask = (nfft - 1) << tw_sh;
 #pragma unroll
   for (int h = 0; h < NB; ++h) {
     X[h] = make_double2(0.0, 0.0);
     D[h] = make_double2(0.0, 0.0);
-    tix[h] = ((bins[h] * l4) & (nfft - 1)) << tw_sh;
+    tix[h] = ((bins[h] * lg) & (nfft - 1)) << tw_sh;
     tstep[h] = ((bins[h] * kSmLanes) & (nfft - 1)) << tw_sh;
   }
   const int n_it = (L + kSmLanes - 1) / kSmLanes;
-  int j = l4;
+  int j = lg;
   const double xn_d = (double)xn;
   double2 cur = j < L ? wt[j] : make_double2(0.0, 0.0);
   double bc = j < L ? qt[j - hwl] : 0.0;
@@ -235,10 +240,10 @@ __device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long lon
   }
 #pragma unroll
   for (int h = 0; h < NB; ++h) {
-    X[h].x = quad_sum(X[h].x);
-    X[h].y = quad_sum(X[h].y);
-    D[h].x = quad_sum(D[h].x);
-    D[h].y = quad_sum(D[h].y);
+    X[h].x = group_sum(X[h].x);
+    X[h].y = group_sum(X[h].y);
+    D[h].x = group_sum(D[h].x);
+    D[h].y = group_sum(D[h].y);
   }
 }
 
@@ -257,12 +262,12 @@ __global__ __launch_bounds__(256) void stonemask_tab_kernel(
   const long long blk = wh::xcd_unit(blockIdx.x, n_blocks);
   if (blk >= n_blocks) return;
   const long long f = blk * kPerBlock + threadIdx.x / kSmLanes;
-  const int l4 = threadIdx.x & (kSmLanes - 1);
-  const bool live = f < n_frames;  // the quad stays together through the DPP sums
+  const int lg = threadIdx.x & (kSmLanes - 1);
+  const bool live = f < n_frames;  // the group stays together through the DPP sums
   const double f0i = live ? f0_in[f] : 0.0;
   bool work = live && f0i != 0.0;
-  if (live && l4 == 0) todo[f] = 0;
-  if (live && f0i == 0.0 && l4 == 0) f0_out[f] = f0i;
+  if (live && lg == 0) todo[f] = 0;
+  if (live && f0i == 0.0 && lg == 0) f0_out[f] = f0i;
   double hwl_d = 1.0, t0 = 0.0;
   long long xn = 1;
   const double* xu = x;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void stonemask_tab_kernel(
     // the table holds windows up to kmax; every tap must sit at a positive time (the quantisation moves a tap by less
     // than a sample)
     if (!(hwl_d <= (double)kmax) || !(t0 * fs - hwl_d - 2.0 > 0.0)) {
-      if (l4 == 0) todo[f] = 1;
+      if (lg == 0) todo[f] = 1;
       work = false;
     }
   }
@@ -292,11 +297,11 @@ __global__ __launch_bounds__(256) void stonemask_tab_kernel(
   const double* qt = qtime + kmax;
   int bins[6];
   double2 X[6], D[6];
-  auto weighted = [&](int nbins) -> double {  // lane l evaluates bins l and l + 4, the quad adds up
+  auto weighted = [&](int nbins) -> double {  // lane l evaluates bins l and l + 4, the group adds up
     double num = 0.0, den = 0.0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int h = l4 + q * kSmLanes;
+    for (int q = 0; q < (6 + kSmLanes - 1) / kSmLanes; ++q) {
+      const int h = lg + q * kSmLanes;
       double2 Xh = make_double2(0.0, 0.0), Dh = make_double2(0.0, 0.0);
       int bh = 0;
 #pragma unroll
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(256) void stonemask_tab_kernel(
         den += amp * (double)(h + 1);
       }
     }
-    return quad_sum(num) / quad_sum(den);
+    return group_sum(num) / group_sum(den);
   };
   // harmonics 1-2 around the initial f0 (stonemask.py:57-62)
 #pragma unroll
@@ -334,13 +339,13 @@ __global__ __launch_bounds__(256) void stonemask_tab_kernel(
       if (bins[h] >= nfft || bins[h] < 0) second = false;  // the reference would raise IndexError: keep the input f0
     }
   }
-  // (the quad is uniform in `second`: every lane derived it from the same sums)
+  // (the group is uniform in `second`: every lane derived it from the same sums)
   tab_bins<6>(xu, xn, t0, fs, hwl, second ? L : 0, wt, qt, nfft, tw_sh, bins, X, D);
   if (second) refined = weighted(6);
   else (void)weighted(6);
   if (work) {
     if (fabs(refined - f0i) / f0i > 0.2) refined = f0i;  // stonemask.py:25
-    if (l4 == 0) f0_out[f] = refined;
+    if (lg == 0) f0_out[f] = refined;
   }
 }
 
@@ -405,7 +410,7 @@ extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const 
     if (int rc = wh::ws_reserve(ctx, (size_t)b->total_frames + 256)) return rc;
     uint8_t* d_todo = reinterpret_cast<uint8_t*>(ctx->ws);
     const size_t lds_tab = sizeof(double2) * (size_t)tw_n;
-    const long long n_blocks = (b->total_frames + 63) / 64;
+    const long long n_blocks = (b->total_frames + 256 / kSmLanes - 1) / (256 / kSmLanes);
     {
       wh::KernelTimer _kt(ctx, st, "stonemask_tab_kernel");
       hipLaunchKernelGGL(stonemask_tab_kernel, dim3((unsigned)wh::xcd_grid(n_blocks)), dim3(256), lds_tab, st, x, b->d_x_off,

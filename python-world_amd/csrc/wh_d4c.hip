@@ -20,6 +20,9 @@
 #ifndef WH_D4C_MAXR
 #define WH_D4C_MAXR 4
 #endif
+#ifndef WH_LOVE_MAXR
+#define WH_LOVE_MAXR 8
+#endif
 #ifndef WH_D4C_MINBLK
 #define WH_D4C_MINBLK 4
 #endif
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
   wh::sync<FT>();
   d4c_window<true, NLT, false, 1>(xu, wtab, win_thread_phase(wtab[9]), scratch, zr, [&](int j, double val) { zr[j] = val; });
   wh::sync<FT>();
-  wh::rfft_lds<NLT, FT, FT, WH_D4C_MAXR>(zb, tw_base);
+  wh::rfft_lds<NLT, FT, FT, WH_LOVE_MAXR>(zb, tw_base);  // (66 VGPRs here: the radix-8 plan fits, unlike in d4c_kernel)
   const int b0 = (int)(ceil(100.0 / (fs / NLT)) + 1);
   const int b1 = (int)(ceil(4000.0 / (fs / NLT)) + 1);
   const int b2 = (int)(ceil(7900.0 / (fs / NLT)) + 1);

@@ -15,10 +15,10 @@
 #define WH_D4C_ABLATE 0
 #endif
 #ifndef WH_D4C_RMAXR
-#define WH_D4C_RMAXR 4
+#define WH_D4C_RMAXR 8
 #endif
 #ifndef WH_D4C_MAXR
-#define WH_D4C_MAXR 4
+#define WH_D4C_MAXR 8
 #endif
 #ifndef WH_LOVE_MAXR
 #define WH_LOVE_MAXR 8

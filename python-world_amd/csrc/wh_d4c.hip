@@ -14,12 +14,17 @@
 #ifndef WH_D4C_ABLATE
 #define WH_D4C_ABLATE 0
 #endif
+// FFT radix caps of d4c_kernel by transform length.  At 128 VGPRs (four workgroups per CU) the radix-8 plan fits
+// N <= 1024 without spilling; at N = 2048 / 4096 it spills ~23 registers — still 2 % faster, but the spills are HBM
+// traffic (1.86 GB per launch where the kernel's compulsory bytes are 0.61 GB), so those lengths keep radix 4.
 #ifndef WH_D4C_RMAXR
-#define WH_D4C_RMAXR 8
+#define WH_D4C_RMAXR 0  // 0: by length (below); 4 / 8: forced
 #endif
 #ifndef WH_D4C_MAXR
-#define WH_D4C_MAXR 8
+#define WH_D4C_MAXR 0
 #endif
+constexpr int d4c_maxr(int n) { return WH_D4C_MAXR ? WH_D4C_MAXR : (n <= 1024 ? 8 : 4); }
+constexpr int d4c_rmaxr(int n) { return WH_D4C_RMAXR ? WH_D4C_RMAXR : (n <= 1024 ? 8 : 4); }
 #ifndef WH_LOVE_MAXR
 #define WH_LOVE_MAXR 8
 #endif
@@ -504,7 +509,7 @@ __device__ __forceinline__ void add_centroid(const double* xu, const double* wta
   d4c_window<true, N, true, 2>(xu, wtab, e_tid, scratch, reinterpret_cast<double*>(buf),
                                [&](int j, double val) { buf[j] = make_double2(val, val * (double)(j + 1)); });
   wh::sync<FT>();
-  wh::fft_lds<N, false, FT, FT, WH_D4C_MAXR>(buf, fresh_table(tw_base) + N);
+  wh::fft_lds<N, false, FT, FT, d4c_maxr(N)>(buf, fresh_table(tw_base) + N);
   const int k0 = threadIdx.x * KR;
 #pragma unroll
   for (int r = 0; r < KR; ++r) {
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     d4c_window<false, N, false, 2>(xu, wtab + kWinTab, e_frame, scratch, zr + 1, [&](int j, double val) { zr[2 * j + 1] = val; });
     STAGE_MARK(7)
     wh::sync<FT>();
-    wh::fft_lds<N, false, FT, FT, WH_D4C_MAXR>(buf, fresh_table(tw_base) + N);
+    wh::fft_lds<N, false, FT, FT, d4c_maxr(N)>(buf, fresh_table(tw_base) + N);
     STAGE_MARK(8)
     const int b0 = (int)(ceil(100.0 / (fs / N)) + 1);
     const int b1 = (int)(ceil(4000.0 / (fs / N)) + 1);
@@ -643,7 +648,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   if (!FUSED) {
     d4c_window<false, N, false, 1>(xu, wtab + kWinTab, e_frame, scratch, zr, [&](int j, double val) { zr[j] = val; });
     wh::sync<FT>();
-    wh::rfft_lds<N, FT, FT, WH_D4C_RMAXR>(buf, fresh_table(tw_base));
+    wh::rfft_lds<N, FT, FT, d4c_rmaxr(N)>(buf, fresh_table(tw_base));
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
       if (k0 + r < K) {
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
       zr[j] = val;
     }
     wh::sync<FT>();
-    wh::rfft_lds<N, FT, FT, WH_D4C_RMAXR>(buf, fresh_table(tw_base));
+    wh::rfft_lds<N, FT, FT, d4c_rmaxr(N)>(buf, fresh_table(tw_base));
     double px[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {

@@ -318,8 +318,7 @@ __device__ __forceinline__ void dft_small(double2 (&v)[R]) {
 // transform on 256 threads is faster as 4-4-4-4-2 on 128 lanes than as 8-8-8 on 64: its passes are latency-,
 // not throughput-bound), else 4, else 2.
 // MAXR caps the radix for a kernel whose register budget is set elsewhere (radix-4 butterflies hold half as many
-// operands).  d4c_kernel ran radix 4 for most of round 2; at 128 VGPRs the radix-8 plan spills ~23 registers at
-// N = 2048 (none at N = 1024) and is still 2 % faster end to end (a third fewer LDS round trips), so it is the default.
+// operands): d4c_kernel at 128 VGPRs takes the radix-8 plan up to N = 1024 and radix 4 beyond (wh_d4c.hip).
 template <int N, int NT, int NS, int MAXR = 8>
 struct FftRadix {
   static constexpr int value = (MAXR >= 8 && NS * 8 <= N && N / 8 >= NT / 2) ? 8 : (NS * 4 <= N ? 4 : 2);

@@ -867,9 +867,9 @@ __global__ __launch_bounds__(256) void hv_prune_kernel(const HvUtt* __restrict__
       for (int pass = 0; pass < (kRows + 63) / 64; ++pass) {
         const int e = lane + 64 * pass;
         const double a = e < kRows ? src[e] : 0.0;
-        const unsigned long long mk = __ballot(a != 0.0);  // zeros can never be the nearest candidate
-        if (a != 0.0) lst[fr][n + __popcll(mk & ((1ull << lane) - 1))] = a;
-        n += __popcll(mk);
+        const unsigned long long nz = __ballot(a != 0.0);  // zeros can never be the nearest candidate
+        if (a != 0.0) lst[fr][n + __popcll(nz & ((1ull << lane) - 1))] = a;
+        n += __popcll(nz);
       }
     }
     if (lane == 0) ln[fr] = n;

@@ -268,8 +268,8 @@ __global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
   constexpr int FT = ft_of(NLT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2* zb = reinterpret_cast<double2*>(smem);  // NLT/2+1 complex after the real FFT
-  double* zr = reinterpret_cast<double*>(smem);    // 2*NLT doubles while windowing
-  double* scratch = zr + 2 * NLT;
+  double* zr = reinterpret_cast<double*>(smem);    // the NLT real samples, then the half spectrum (NLT + 2 doubles)
+  double* scratch = zr + NLT + 2;
   double* wtab = scratch + 48;  // window set-up table (kWinTab doubles)
   const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
   if (f >= n_frames) return;
@@ -785,7 +785,7 @@ std::vector<double> nuttall(int n) {
 template <int NLT>
 int launch_lt(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, const double* tp, double* f0,
               const double* vuv, double fs, double thr, int32_t* gate) {
-  const size_t lds = sizeof(double) * (2 * NLT + 48 + kWinTab);
+  const size_t lds = sizeof(double) * (NLT + 2 + 48 + kWinTab);  // 17 KB at 2048: the 66 VGPRs, not LDS, set the occupancy
   if (int rc = wh::allow_lds(&love_train_kernel<NLT>, lds)) return rc;
   { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_of(NLT)), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, fs, thr, ctx->d_twiddle, gate, (long long)b->total_frames); }

@@ -14,8 +14,15 @@ namespace {
 // Threads cooperating on one frame: 128 up to N = 1024, 256 from N = 2048 (measured on configs 2 and 5).
 constexpr int ft_ct(int n) { return n >= 2048 ? 2 * WH_FT_CHEAPTRICK : WH_FT_CHEAPTRICK; }
 
+// waves per SIMD the register allocation leaves room for: at N <= 1024 the kernel wants 84 VGPRs (5 waves); capped at
+// 80 it runs 6 (1.31 -> 1.25 ms at config 2; 7 -> 72 VGPRs, 2 spilled: 1.28; 8: 1.46).  Longer transforms keep what
+// they ask for.
+#ifndef WH_CT_MINW
+#define WH_CT_MINW 6
+#endif
+constexpr int ct_minw(int n) { return n <= 1024 ? WH_CT_MINW : 1; }
 template <int N>
-__global__ __launch_bounds__(ft_ct(N)) void cheaptrick_kernel(
+__global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv, double fs, double q1,
     double f0_low_limit, const double2* __restrict__ tw_base, double* __restrict__ spec_out,

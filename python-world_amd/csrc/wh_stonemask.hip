@@ -247,7 +247,10 @@ __device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long lon
   }
 }
 
-__global__ __launch_bounds__(256) void stonemask_tab_kernel(
+#ifndef WH_SM_MINW
+#define WH_SM_MINW 1  // (5: 96 VGPRs but 24 spilled, 0.30 -> 0.29 ms — not taken; 6: 0.76 ms)
+#endif
+__global__ __launch_bounds__(256, WH_SM_MINW) void stonemask_tab_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, const double* __restrict__ f0_in, double* __restrict__ f0_out, double fs, int kmax,
     const double2* __restrict__ win_tab, const double* __restrict__ qtime, const double2* __restrict__ tw_base,

@@ -20,7 +20,10 @@ constexpr int ft_ct(int n) { return n >= 2048 ? 2 * WH_FT_CHEAPTRICK : WH_FT_CHE
 #ifndef WH_CT_MINW
 #define WH_CT_MINW 6
 #endif
-constexpr int ct_minw(int n) { return n <= 1024 ? WH_CT_MINW : 1; }
+#ifndef WH_CT_MINW_MAXN
+#define WH_CT_MINW_MAXN 1024
+#endif
+constexpr int ct_minw(int n) { return n <= WH_CT_MINW_MAXN ? WH_CT_MINW : 1; }
 template <int N>
 __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,

@@ -140,3 +140,43 @@ def test_arange_length_memo_is_numpy():
                               (0.005, 1.2 + 1 / 22050, 1 / 22050)):
         for _ in range(2):
             assert _arange_len(start, stop, step) == len(np.arange(start, stop, step))
+
+
+def test_refinement_windows_do_not_depend_on_the_frame_time():
+    """The tabulated windows of hv_refine_kernel / stonemask_tab_kernel rest on one observation: the reference's
+    index_raw enters the window argument un-truncated, so the frame time cancels.  Checked here against the oracle's
+    own expressions (oracle/pitch_harvest.py:134-136 = world/harvest.py:178-183; oracle/pitch_dio.py stonemask =
+    world/stonemask.py:38-45) for frame times on and off the sample grid, at the decimated rates 8000 and 7350 Hz and
+    the full rates 16 / 44.1 / 48 kHz."""
+    import math
+
+    from oracle import common as C
+    from oracle import pitch_dio
+
+    rng = np.random.RandomState(5)
+    # Harvest: common = pi*((index_raw - 1)/fs - t0)/(L/fs), index_raw = half_up((t0 + k/fs)*fs + 0.001)
+    for fs_d in (8000.0, 7350.0):
+        for _ in range(40):
+            h = int(rng.randint(8, 190))
+            t0 = float(rng.uniform(0.05, 59.0)) if rng.rand() < 0.5 else float(rng.randint(50, 59000)) / 1000
+            k = np.arange(-h, h + 1)
+            ln = 2 * h + 1
+            idx_raw = C.half_up((t0 + k / fs_d) * fs_d + 0.001)
+            common = math.pi * ((idx_raw - 1) / fs_d - t0) / (ln / fs_d)
+            ref = 0.42 + 0.5 * np.cos(2 * common) + 0.08 * np.cos(4 * common)
+            j = np.arange(ln)
+            c = np.cos(math.pi * (2 * ((j - h + (0.001 + 0.5) - 1.0) / fs_d) / (ln / fs_d)))   # wh_harvest.hip, host table
+            tab = 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1)
+            assert np.max(np.abs(tab - ref)) < 5e-12 * max(1.0, t0)   # the cancellation noise of the reference itself (measured: 3e-13 * t0)
+    # StoneMask: wt = (index_raw - 1)/fs - t0 with index_raw = half_up((t0 + bt)*fs), bt the 4-decimal quantised times
+    for fs in (16000.0, 44100.0, 48000.0):
+        for _ in range(30):
+            h = int(rng.randint(20, 600))
+            t0 = float(rng.uniform(0.1, 30.0)) if rng.rand() < 0.5 else float(rng.randint(20, 6000)) * 0.005
+            qt = pitch_dio.quantised_time_table(fs, h)
+            bt = qt[np.arange(-h, h + 1) + h]
+            idx_raw = C.half_up((t0 + bt) * fs)
+            wlit = (2 * h + 1) / fs
+            ref = np.cos(2 * math.pi * ((idx_raw - 1) / fs - t0) / wlit)
+            tab = np.cos(math.pi * ((bt - 0.5 / fs) * (2.0 / wlit)))                           # wh_stonemask.hip, host table
+            assert np.max(np.abs(tab - ref)) < 2e-11 * max(1.0, t0)  # measured: 1e-12 * t0

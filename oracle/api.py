@@ -15,6 +15,10 @@ def encode_np(fs, x, f0_method="harvest", f0_floor=71, f0_ceil=800, channels_in_
         src["f0"] = pitch_dio.stonemask_np(x, fs, src["temporal_positions"], src["f0"])
     elif f0_method == "harvest":
         src = pitch_harvest.harvest_np(x, fs, f0_floor, f0_ceil, frame_period)
+    elif f0_method == "swipe":  # world/main.py:134-135: default dt = 5 ms whatever frame_period is
+        from . import pitch_swipe
+
+        src = pitch_swipe.swipe_np(fs, x, [f0_floor, f0_ceil], sTHR=0.3)
     else:
         raise Exception
     tp, vuv = src["temporal_positions"], src["vuv"]

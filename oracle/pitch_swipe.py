@@ -19,9 +19,15 @@ def erbs2hz(erbs):
     return (10 ** (erbs / 21.4) - 1) * 229  # swipe.py:153-155
 
 
-def primes_upto(n):
-    """swipe.py:158-172 (`sieve`): the primes in [2, n]."""
-    return [p for p in range(2, n + 1) if all(p % q for q in range(2, int(p ** 0.5) + 1))]
+def sieve_as_reference(n):
+    """swipe.py:158-172 (`sieve`).  NOT the primes in [2, n]: the reference strikes multiples of p only `while p <
+    sqrt(n)`, so for n = p*p (p prime) the number n itself survives — sieve(9) = [2, 3, 5, 7, 9], sieve(25) ends in 25.
+    Restated as: the numbers in [2, n] with no divisor d, 2 <= d, d*d <= m, except that for m == n only d*d < n counts."""
+    out = []
+    for m in range(2, n + 1):
+        if all(m % d for d in range(2, m) if (d * d < m or (d * d == m and m != n))):
+            out.append(m)
+    return out
 
 
 def candidate_kernel(f, pc):
@@ -29,7 +35,7 @@ def candidate_kernel(f, pc):
     n = int(np.fix(f[-1] / pc - 0.75))
     k = np.zeros(len(f))
     q = f / pc
-    for i in [1] + primes_upto(n):
+    for i in [1] + sieve_as_reference(n):
         a = np.abs(q - i)
         peak = a < 0.25
         k[peak] = np.cos(2 * np.pi * q[peak])

@@ -46,3 +46,16 @@ def synth_utterance(u: int, fs: int = 16000, seconds: float = 10.0) -> np.ndarra
 def synth_batch(count: int, fs: int = 16000, seconds: float = 10.0, first: int = 0) -> np.ndarray:
     """(count, N) float64 batch, utterance indices first … first+count-1."""
     return np.stack([synth_utterance(first + i, fs, seconds) for i in range(count)])
+
+
+def harmonic_tone(fs: int, f0: float, seconds: float = 0.8, vibrato: float = 0.03) -> np.ndarray:
+    """Harmonic tone (1/k partials up to 0.45 fs) whose pitch sweeps f0 x (1 +- vibrato) at 2.5 Hz, with a 1e-3 white
+    floor; seeded by (fs, f0).  Test input for pitch estimators: the sweep walks the argmax over the candidates
+    around f0 (tests/golden/make_golden.py swipe_fixture)."""
+    t = np.arange(int(round(fs * seconds))) / fs
+    phi = 2.0 * np.pi * np.cumsum(f0 * (1.0 + vibrato * np.sin(2.0 * np.pi * 2.5 * t))) / fs
+    x = np.zeros(len(t))
+    for k in range(1, int(0.45 * fs // (f0 * (1.0 + vibrato))) + 1):
+        x += np.cos(k * phi + 0.37 * k * k) / k
+    x = 0.4 * x / np.max(np.abs(x))
+    return x + 1e-3 * np.random.RandomState(int(fs + f0)).randn(len(t))

@@ -151,6 +151,15 @@ class BatchEncoding:
         return out
 
 
+SWIPE_DT = 0.005  # swipe()'s default dt, the only one World.encode ever uses (world/main.py:134-135)
+
+
+def _require_swipe_period(frame_period):
+    if frame_period != 5:
+        raise ValueError("f0_method='swipe' runs on swipe()'s 5 ms grid (the reference ignores frame_period there); "
+                         "got frame_period=%r" % (frame_period,))
+
+
 def _on_lane_stream(fn):
     """Run a WorldBatch method with its lane's HIP stream as torch's current stream."""
     import functools
@@ -167,15 +176,21 @@ class WorldBatch:
         self.rt = _hip.Runtime.get(device_index, lane)
 
     @_on_lane_stream
-    def upload(self, xs, fs, frame_period=5):
-        """Concatenate and upload a list of 1-D waveforms (or a 2-D array).  Returns (batch, x_d, tp_d)."""
+    def upload(self, xs, fs, frame_period=5, swipe_grid=False):
+        """Concatenate and upload a list of 1-D waveforms (or a 2-D array).  Returns (batch, x_d, tp_d).
+        ``swipe_grid``: build the frame times as swipe() does, arange * 0.005 (world/swipe.py:16-17), instead of
+        arange * frame_period / 1000 (world/dio.py:28-29): the two expressions differ in the last bit on some frames."""
         rt = self.rt
         xs = [np.asarray(x, dtype=np.float64) for x in xs]
         lens = [len(x) for x in xs]
         nfs = [_tables.frame_count(n, fs, frame_period) for n in lens]
         batch = rt.make_batch(np.concatenate([[0], np.cumsum(lens)]), np.concatenate([[0], np.cumsum(nfs)]))
         x_d = rt.to_device(np.concatenate(xs))
-        tp_h = np.concatenate([_tables.frame_times(n, frame_period) for n in nfs])
+        if swipe_grid:
+            _require_swipe_period(frame_period)
+            tp_h = np.concatenate([np.arange(0, n) * SWIPE_DT for n in nfs])
+        else:
+            tp_h = np.concatenate([_tables.frame_times(n, frame_period) for n in nfs])
         tp_d = rt.to_device(tp_h)
         batch.tp_d, batch.tp_host = tp_d, tp_h  # the frame grid belongs to the batch descriptor (no pointer-keyed lookup)
         return batch, x_d, tp_d
@@ -201,7 +216,10 @@ class WorldBatch:
             f0_d, vuv_d = harvest_device(rt, batch, x_d, tp_d, fs, f0_floor, f0_ceil, frame_period)
         elif f0_method == 'swipe':
             from .swipe import swipe_device
-            f0_d, vuv_d = swipe_device(rt, batch, x_d, fs, (f0_floor, f0_ceil), frame_period / 1000, 0.3)  # main.py:134-135
+            # world/main.py:134-135 calls swipe() with its default dt = 5 ms whatever frame_period says, and every
+            # later stage runs on swipe's own 5 ms grid: a batch grid of another period cannot reproduce that
+            _require_swipe_period(frame_period)
+            f0_d, vuv_d = swipe_device(rt, batch, x_d, fs, (f0_floor, f0_ceil), SWIPE_DT, 0.3)
         else:
             raise Exception
         if f0_done is not None:
@@ -261,7 +279,7 @@ class WorldBatch:
             return self.rt.check_flags(where)
 
     def encode(self, xs, fs, **kw):
-        batch, x_d, tp_d = self.upload(xs, fs, kw.get('frame_period', 5))
+        batch, x_d, tp_d = self.upload(xs, fs, kw.get('frame_period', 5), swipe_grid=kw.get('f0_method') == 'swipe')
         return self.encode_device(batch, x_d, tp_d, fs, **kw)
 
     @_on_lane_stream

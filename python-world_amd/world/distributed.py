@@ -93,6 +93,7 @@ class ShardedWorldBatch:
         self.backend = backend
         self.range = (0, 0)
         self.lengths = None
+        self.enc = None  # this rank's encoding once encode() has run (decode / gather_f0 before that: None)
 
     def shard(self, lengths):
         """[start, end) of this rank for a batch with the given utterance lengths (samples)."""

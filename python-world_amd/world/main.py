@@ -97,14 +97,20 @@ class World(object):
         return out
 
     # ---- batched convenience (not in the reference; SURVEY.md §8(b): "World.encode_batch/decode_batch") ----------
-    def encode_batch(self, fs, xs, **kw):
-        """encode() for a list of utterances in one pass per kernel.  Under an initialised torch.distributed process
-        group (one process per GPU) the batch is sharded by utterance over the ranks and the list holds only this
-        rank's utterances; use ``world.distributed.ShardedWorldBatch`` directly to keep results on the device."""
+    def encode_batch(self, fs, xs, f0_method='harvest', f0_floor=71, f0_ceil=800, channels_in_octave=2, target_fs=4000,
+                     frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False):
+        """encode() — same arguments, same defaults (Harvest) — for a list of utterances in one pass per kernel.
+        Each dict has encode()'s keys except 'ps spectrogram' (the complex pitch-synchronous spectra, fft_size x frames
+        x 16 B per utterance, are not kept by the batch pipeline; call cheaptrick() for them).  Under an initialised
+        torch.distributed process group (one process per GPU) the batch is sharded by utterance over the ranks and the
+        list holds only this rank's utterances; use ``world.distributed.ShardedWorldBatch`` directly to keep results
+        on the device."""
         from .distributed import ShardedWorldBatch
 
         sb = ShardedWorldBatch()
-        enc = sb.encode(xs, fs, **kw)
+        enc = sb.encode(xs, fs, f0_method=f0_method, f0_floor=f0_floor, f0_ceil=f0_ceil,
+                        channels_in_octave=channels_in_octave, target_fs=target_fs, frame_period=frame_period,
+                        allowed_range=allowed_range, fft_size=fft_size, is_requiem=is_requiem)
         dats = enc.to_dicts() if enc is not None else []
         for d in dats:
             d['_batch_range'] = sb.range
@@ -112,7 +118,13 @@ class World(object):
 
     def decode_batch(self, dats, **kw):
         """decode() for a list of encode()/encode_batch() dicts that share fs / is_requiem / fft size: one batched
-        synthesis; adds 'out' to every dict (peak-normalised like decode()) and returns the list."""
+        synthesis; adds 'out' to every dict (peak-normalised like decode()) and returns the list.
+        Randomness differs from decode() unless asked otherwise: the noise comes from the device Philox stream
+        (``seed=``) and Requiem batches use device-built seed tables with the noise cursor restarted at 0 on every
+        call, whereas decode() draws from NumPy's global stream / get_seeds_signals() and keeps
+        ``synthesisRequiem.generate_noise.current_index`` across calls.  For sample-comparable output pass
+        ``noise=[randn arrays]`` (pulse-wise) or ``seeds=get_seeds_signals(fs), cursor=...`` (Requiem): keywords of
+        ``WorldBatch.decode_device``."""
         from .batch import BatchEncoding, WorldBatch
 
         if not dats:

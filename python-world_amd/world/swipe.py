@@ -36,13 +36,21 @@ def _erbs2hz(erbs):
     return (10 ** (erbs / 21.4) - 1) * 229
 
 
-def _primes(n):
-    sieve = np.ones(max(n + 1, 2), dtype=bool)
-    sieve[:2] = False
+def _sieve_harmonics(n):
+    """Harmonic numbers > 1 of a candidate's kernel = what the reference's `sieve(n)` returns (world/swipe.py:158-172,
+    called at :130).  That sieve strikes the multiples of each prime p only while p < sqrt(n) — strictly — so when n
+    is itself the square of a prime (4, 9, 25, 49, 121, 169, 289, ...) nothing ever strikes n and it stays in the list
+    next to the true primes.  The kernels are defined by that list, quirk included (19 of the 336 candidates at 16 kHz)."""
+    flags = np.ones(max(n + 1, 2), dtype=bool)
+    flags[:2] = False
     for p in range(2, int(n ** 0.5) + 1):
-        if sieve[p]:
-            sieve[p * p::p] = False
-    return [int(p) for p in np.nonzero(sieve)[0] if p <= n]
+        if flags[p]:
+            flags[p * p::p] = False
+    out = [int(p) for p in np.nonzero(flags)[0] if p <= n]
+    r = int(round(n ** 0.5)) if n >= 4 else 0
+    if r * r == n and flags[r]:
+        out.append(n)
+    return out
 
 
 def _kernel(f, pc):
@@ -50,7 +58,7 @@ def _kernel(f, pc):
     n = int(np.fix(f[-1] / pc - 0.75))
     k = np.zeros(len(f))
     q = f / pc
-    for i in [1] + _primes(n):
+    for i in [1] + _sieve_harmonics(n):
         a = np.abs(q - i)
         peak = a < 0.25
         k[peak] = np.cos(2 * np.pi * q[peak])

@@ -249,6 +249,9 @@ def modifiers_fixture():
     print("modifiers written", len(y))
 
 
+TONE_CASES = ((16000, (158, 300, 304, 760)), (22050, (90, 218, 420)), (48000, (195, 476)))
+
+
 def swipe_fixture():
     """SWIPE' (world/swipe.py:9-105) as World.encode calls it (plim = [f0_floor, f0_ceil], sTHR = 0.3) on the synthetic
     utterances and the reference's own test wav, plus one call without a threshold."""
@@ -274,6 +277,17 @@ def swipe_fixture():
     out["enc_vuv"] = dat["vuv"]
     out["enc_spec_colsum"] = dat["spectrogram"].sum(axis=0)
     out["enc_ap_colsum"] = dat["aperiodicity"].sum(axis=0)
+    # the reference's sieve(n) keeps n when n is the square of a prime (world/swipe.py:158-172): harmonic tones whose
+    # pitch sits on a candidate with such an n, at each rate, so that an affected kernel wins the argmax
+    out["tone_cases"] = np.array([(fs, f0) for fs, f0s in TONE_CASES for f0 in f0s])
+    for fs, f0s in TONE_CASES:
+        for f0 in f0s:
+            r = R.swipe.swipe(fs, _syn.harmonic_tone(fs, f0), [71, 800], 0.005, 0.3)
+            out["tone_f0_%d_%d" % (fs, f0)] = r["f0"]
+            out["tone_vuv_%d_%d" % (fs, f0)] = r["vuv"]
+    lists = [R.swipe.sieve(n) for n in range(401)]
+    out["sieve_flat"] = np.array([v for l in lists for v in l], dtype=np.int32)
+    out["sieve_off"] = np.cumsum([0] + [len(l) for l in lists]).astype(np.int32)
     np.savez_compressed(os.path.join(HERE, "golden_swipe.npz"), **out)
     print("swipe written", {k: int(v.sum()) for k, v in out.items() if k.startswith("vuv")})
 
@@ -316,6 +330,90 @@ def longform_fixture():
     print("longform written", h["f0"].shape, int(h["vuv"].sum()), "voiced")
 
 
+def differential_draws(count=12, seed=SEED + 3):
+    """The seeded (utterance, fs, seconds, f0_method, is_requiem, frame_period, f0_floor) draws of the differential
+    run: every rate the reference is used at, the three estimators, both aperiodicity / synthesis paths."""
+    rng = np.random.RandomState(seed)
+    rates = (8000, 16000, 22050, 44100, 48000)
+    methods = ("harvest", "dio", "swipe")
+    draws = []
+    for i in range(count):
+        fs = rates[i % len(rates)] if i < 2 * len(rates) else int(rng.choice(rates))
+        method = methods[i % 3]
+        draws.append((200 + int(rng.randint(0, 800)), fs, float(np.round(0.5 + 0.5 * rng.rand(), 2)), method,
+                      bool((i // 3) % 2) and fs > 12000,  # d4cRequiem asserts >= 1 band: fs/2 - 3000 >= 3000
+                      5 if (i % 4 or method == "swipe") else 4, 71 if i % 5 else 90))
+    return draws
+
+
+def _worst(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2) / max(np.mean(b ** 2), 1e-300))), float(np.max(np.abs(a - b)))
+
+
+def differential_fixture():
+    """Reference vs oracle on draws no other fixture touches: the unmodified reference's encode() + seeded decode()
+    against oracle/api.py on the same input.  Stores (a) the worst error per tensor over the draws, measured here,
+    and (b) per draw the reference's f0 / vuv and compact sums of its dense tensors, so that the CPU suite re-runs
+    the oracle against the reference on a subset without the reference (tests/test_oracle_differential.py)."""
+    from oracle import api
+
+    W = R.main.World()
+    draws = differential_draws()
+    out = {"draw_utt": np.array([d[0] for d in draws]), "draw_fs": np.array([d[1] for d in draws]),
+           "draw_seconds": np.array([d[2] for d in draws]), "draw_method": np.array([d[3] for d in draws]),
+           "draw_requiem": np.array([d[4] for d in draws]), "draw_frame_period": np.array([d[5] for d in draws]),
+           "draw_f0_floor": np.array([d[6] for d in draws]), "seed": SEED}
+    worst = {}
+    for i, (u, fs, sec, method, req, fp, floor) in enumerate(draws):
+        x = _syn.synth_utterance(u, fs, sec)
+        kw = dict(f0_method=method, is_requiem=req, frame_period=fp, f0_floor=floor)
+        ref = W.encode(fs, x.copy(), **kw)
+        mine = api.encode_np(fs, x.copy(), **kw)
+        random.seed(SEED + i)
+        np.random.seed(SEED + i)
+        R.synthesisRequiem.generate_noise.current_index = None
+        ref_y = W.decode({k: (v.copy() if hasattr(v, "copy") else v) for k, v in ref.items()})["out"]
+        random.seed(SEED + i)
+        np.random.seed(SEED + i)
+        my_y = api.decode_np({k: (v.copy() if hasattr(v, "copy") else v) for k, v in mine.items()})["out"]
+        errs = {"vuv_mismatch": float(np.sum(ref["vuv"] != mine["vuv"])),
+                "frames_mismatch": float(len(ref["f0"]) != len(mine["f0"])),
+                "out_len_mismatch": float(len(ref_y) != len(my_y)),
+                "f0_maxrel": float(np.max(np.abs(mine["f0"] - ref["f0"]) / np.maximum(ref["f0"], 1.0))),
+                "tp_maxabs": _worst(mine["temporal_positions"], ref["temporal_positions"])[1],
+                "spectrogram_relrms": _worst(mine["spectrogram"], ref["spectrogram"])[0],
+                "aperiodicity_maxabs": _worst(mine["aperiodicity"], ref["aperiodicity"])[1],
+                "out_relrms": _worst(my_y, ref_y)[0] if len(ref_y) == len(my_y) else 1.0}
+        for k, v in errs.items():
+            out.setdefault("err_" + k, []).append(v)
+            worst[k] = max(worst.get(k, 0.0), v)
+        out["f0_%d" % i] = ref["f0"].copy()
+        out["vuv_%d" % i] = ref["vuv"].copy()
+        out["spec_colsum_%d" % i] = ref["spectrogram"].sum(axis=0)
+        out["spec_rowsum_%d" % i] = ref["spectrogram"].sum(axis=1)
+        out["ap_colsum_%d" % i] = ref["aperiodicity"].sum(axis=0)
+        out["ap_rowsum_%d" % i] = ref["aperiodicity"].sum(axis=1)
+        out["out_len_%d" % i] = len(ref_y)
+        out["out_blocksum_%d" % i] = np.add.reduceat(ref_y, np.arange(0, len(ref_y), 256))
+        # the same draw seeded ONCE, before encode: cheaptrick's rand(K) per frame (world/cheaptrick.py:117) moves the
+        # global stream before synthesis draws from it — what world.cheaptrick.CONSUME_REFERENCE_RNG reproduces
+        random.seed(SEED + 100 + i)
+        np.random.seed(SEED + 100 + i)
+        R.synthesisRequiem.generate_noise.current_index = None
+        chain_y = W.decode(W.encode(fs, x.copy(), **kw))["out"]
+        out["chain_blocksum_%d" % i] = np.add.reduceat(chain_y, np.arange(0, len(chain_y), 256))
+        print(i, (u, fs, sec, method, req, fp, floor), {k: "%.2e" % v for k, v in errs.items()})
+    for k in list(out):
+        if k.startswith("err_"):
+            out[k] = np.array(out[k])
+    for k, v in worst.items():
+        out["worst_" + k] = v
+    np.savez_compressed(os.path.join(HERE, "golden_differential.npz"), **out)
+    print("differential written; worst", {k: "%.2e" % v for k, v in worst.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected fixtures only: python make_golden.py getters heads ...
         for name in sys.argv[1:]:
@@ -330,3 +428,4 @@ if __name__ == "__main__":
     swipe_fixture()
     modifiers_fixture()
     longform_fixture()
+    differential_fixture()

@@ -84,6 +84,39 @@ def test_world_encode_batch_decode_batch():
         assert rel_rms(d['out'], y) < 1e-10
 
 
+def test_encode_batch_defaults_are_encodes():
+    """encode_batch(fs, xs) without keywords = encode(fs, x) without keywords: Harvest (world/main.py:106)."""
+    from world import main
+    from world._synthetic import synth_utterance
+
+    fs = 16000
+    xs = [synth_utterance(55 + i, fs, 0.5 + 0.2 * i) for i in range(2)]
+    W = main.World()
+    dats = W.encode_batch(fs, xs)
+    for x, d in zip(xs, dats):
+        one = W.encode(fs, x)
+        assert np.array_equal(d['vuv'], one['vuv'])
+        assert np.array_equal(d['f0'], one['f0'])
+        assert set(one) - set(d) == {'ps spectrogram'}
+
+
+def test_swipe_batch_runs_on_swipes_own_grid():
+    """f0_method='swipe' in a batch: frame times are swipe()'s arange * 0.005 and another frame_period is refused
+    (the reference ignores frame_period on that path, world/main.py:134-135)."""
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+    from world.swipe import swipe
+
+    fs = 16000
+    x = synth_utterance(58, fs, 0.7)
+    wb = WorldBatch()
+    enc = wb.encode([x], fs, f0_method='swipe')
+    one = swipe(fs, x, [71, 800], sTHR=0.3)
+    assert np.array_equal(enc.temporal_positions.cpu().numpy(), one["temporal_positions"])
+    with pytest.raises(ValueError):
+        wb.encode([x], fs, f0_method='swipe', frame_period=4)
+
+
 def test_download_async_double_buffer():
     """WorldBatch.download_async: results of consecutive steps leave through alternating pinned slots on a private
     copy stream; what arrives equals a plain .cpu() of the same tensors, slot re-use waits for the previous copy."""

@@ -100,6 +100,28 @@ def test_facade_surface():
         W.encode(16000, np.zeros(1600), f0_method="nope")
 
 
+def test_encode_batch_mirrors_encode_signature():
+    """encode_batch must default to the same estimator and parameters as encode()."""
+    import inspect
+
+    from world import main
+
+    a = inspect.signature(main.World.encode).parameters
+    b = inspect.signature(main.World.encode_batch).parameters
+    assert [k for k in a if k not in ("self", "fs", "x")] == [k for k in b if k not in ("self", "fs", "xs")]
+    for k in b:
+        if k not in ("self", "fs", "xs"):
+            assert a[k].default == b[k].default, k
+    assert b["f0_method"].default == "harvest"
+
+
+def test_sharded_batch_before_encode_is_none():
+    from world.distributed import ShardedWorldBatch
+
+    sb = ShardedWorldBatch(backend=object())
+    assert sb.enc is None and sb.decode() is None and sb.gather_f0() == []
+
+
 def test_shard_ranges_properties():
     from world.distributed import shard_ranges
 

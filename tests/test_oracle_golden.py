@@ -171,3 +171,35 @@ def test_swipe_oracle_vs_reference(golden, tag):
     r = pitch_swipe.swipe_np(int(fs), synth_utterance(int(u), int(fs), float(sec)), [71, 800], 0.005, 0.3)
     assert np.array_equal(r["vuv"], g["vuv_" + tag])
     assert np.array_equal(r["f0"], g["f0_" + tag])
+
+
+def _sieve_fixture(g):
+    off = g["sieve_off"]
+    return [list(map(int, g["sieve_flat"][off[n]:off[n + 1]])) for n in range(len(off) - 1)]
+
+
+def test_sieve_quirk_is_restated(golden):
+    """world/swipe.py:158-172 keeps n when n is the square of a prime; the oracle's and the product's harmonic lists
+    must be the reference's for every n the candidate kernels can ask for (fixture: the reference's sieve(0..400))."""
+    from oracle.pitch_swipe import sieve_as_reference
+    from world.swipe import _sieve_harmonics
+
+    ref = _sieve_fixture(golden("swipe"))
+    assert ref[9] == [2, 3, 5, 7, 9] and ref[4] == [2, 3, 4] and ref[25][-1] == 25 and ref[27][-1] == 23
+    for n, want in enumerate(ref):
+        assert sieve_as_reference(n) == want, n
+        assert _sieve_harmonics(n) == want, n
+
+
+def test_swipe_oracle_on_quirk_candidates(golden):
+    """Tones sweeping over the candidates whose kernel holds a prime square (157-158, 297-305, 737-798 Hz at 16 kHz;
+    their counterparts at 22.05 and 48 kHz): the oracle must give the reference's f0 on every frame, bit for bit.
+    (With true primes instead of the reference's sieve up to 42 of 161 frames move by a grid step.)"""
+    from oracle import pitch_swipe
+    from world._synthetic import harmonic_tone
+
+    g = golden("swipe")
+    for fs, f0 in g["tone_cases"]:
+        r = pitch_swipe.swipe_np(int(fs), harmonic_tone(int(fs), float(f0)), [71, 800], 0.005, 0.3)
+        assert np.array_equal(r["f0"], g["tone_f0_%d_%d" % (fs, f0)]), (fs, f0)
+        assert np.array_equal(r["vuv"], g["tone_vuv_%d_%d" % (fs, f0)])

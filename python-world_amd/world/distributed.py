@@ -64,6 +64,37 @@ def max_over_ranks(value, device=None, group=None):
     return float(t.item())
 
 
+def all_gather_ragged(t, group=None):
+    """Typed all-gather of one 1-D tensor per rank with a different length on every rank (possibly 0): the lengths
+    travel first (one int64 each), then the tensors padded to the longest — two fixed-size ``all_gather`` collectives
+    on the tensors' own device (RCCL over xGMI for device tensors, gloo for CPU ones), no pickling, no host staging.
+    Returns the list of per-rank tensors, in rank order, on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(v.item()) for v in sizes]
+    width = max(sizes)
+    if width == 0:
+        return [t.new_zeros((0,)) for _ in range(world)]
+    padded = t.new_zeros((width,))
+    padded[:t.numel()] = t.reshape(-1)
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return [p[:k] for p, k in zip(parts, sizes)]
+
+
+def collective_device(fallback, group=None):
+    """Device the process group's collectives run on: the caller's GPU under "nccl" (= RCCL), the CPU under gloo."""
+    import torch
+    import torch.distributed as dist
+
+    return fallback if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
 class ShardedWorldBatch:
     """One 1024-utterance (or any) batch over the GPUs of a node: rank r encodes / decodes the contiguous utterance
     range shard_ranges gives it on its own GPU, with no collective on the data path; the dense
@@ -126,12 +157,38 @@ class ShardedWorldBatch:
         return gather_small(list(per_utterance), group=self.group, dst=dst)
 
     def gather_f0(self, enc=None, dst=0):
-        """[(f0, vuv)] per utterance of the whole batch on ``dst`` (None elsewhere): <= 16 B per frame over xGMI."""
+        """[(f0, vuv)] per utterance of the whole batch on ``dst`` (None elsewhere): <= 16 B per frame over xGMI.
+        Typed collectives on the device tensors themselves (``all_gather_ragged``): the frame counts, then f0 and vuv
+        stacked — the contours never pass through pickle or a host buffer on their way between GPUs."""
         enc = self.enc if enc is None else enc
-        local = []
-        if enc is not None:
+        if self.world == 1:
+            if enc is None:
+                return []
             fo = enc.batch.frame_off
             f0, vuv = enc.f0.cpu().numpy(), enc.vuv.cpu().numpy()
-            local = [(f0[int(fo[u]):int(fo[u + 1])].copy(), vuv[int(fo[u]):int(fo[u + 1])].copy())
-                     for u in range(enc.n_utt)]
-        return self.gather_small(local, dst=dst)
+            return [(f0[int(fo[u]):int(fo[u + 1])].copy(), vuv[int(fo[u]):int(fo[u + 1])].copy())
+                    for u in range(enc.n_utt)]
+        import torch
+
+        if enc is not None:
+            dev = collective_device(enc.f0.device, self.group)
+            counts = torch.as_tensor(np.diff(np.asarray(enc.batch.frame_off)), dtype=torch.int64, device=dev)
+            both = torch.cat([enc.f0.reshape(-1).to(dev), enc.vuv.reshape(-1).to(dev)])
+        else:  # an empty shard still takes part in the collectives
+            dev = collective_device(torch.device("cuda", torch.cuda.current_device())
+                                    if torch.cuda.is_available() else torch.device("cpu"), self.group)
+            counts = torch.zeros((0,), dtype=torch.int64, device=dev)
+            both = torch.zeros((0,), dtype=torch.float64, device=dev)
+        all_counts = all_gather_ragged(counts, self.group)
+        all_both = all_gather_ragged(both, self.group)
+        if self.rank != dst:
+            return None
+        out = []
+        for cnt, vals in zip(all_counts, all_both):
+            cnt = cnt.cpu().numpy()
+            vals = vals.cpu().numpy()
+            half = len(vals) // 2
+            off = np.concatenate([[0], np.cumsum(cnt)])
+            for u in range(len(cnt)):
+                out.append((vals[int(off[u]):int(off[u + 1])].copy(), vals[half + int(off[u]):half + int(off[u + 1])].copy()))
+        return out

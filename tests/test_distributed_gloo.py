@@ -120,6 +120,62 @@ def test_two_rank_sharded_world_batch():
     assert ret["ok0"] and ret["ok1"] and ret["n"] == len(lengths) and ret["order_ok"]
 
 
+def _ragged_worker(rank, world, port, lengths, ret):
+    import torch
+    import torch.distributed as dist
+
+    from world.distributed import ShardedWorldBatch, all_gather_ragged, shard_ranges
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # typed ragged all-gather on its own: rank r contributes r*3 values (rank 0: none)
+    parts = all_gather_ragged(torch.arange(rank * 3, dtype=torch.float64) + 100 * rank)
+    ok = [p.tolist() for p in parts] == [[100.0 * r + i for i in range(3 * r)] for r in range(world)]
+    sb = ShardedWorldBatch(backend=_StubBackend())
+    enc = sb.encode(lambda u: np.full(lengths[u], float(u)), 16000, lengths=lengths)
+    lo, hi = shard_ranges(lengths, world)[rank]
+    ok = ok and sb.range == (lo, hi) and ((enc is None) == (lo == hi))
+    ok = ok and ((sb.decode() is None) == (lo == hi))
+    got = sb.gather_f0(dst=0)
+    if rank == 0:
+        ret["n"] = len(got)
+        ret["order_ok"] = all(np.all(f0 == float(u)) and np.all(vuv == 1.0)
+                              and len(f0) == len(vuv) == int(1000 * lengths[u] / 16000 / 5 + 1)
+                              for u, (f0, vuv) in enumerate(got))
+    else:
+        ok = ok and got is None
+    ret["ok%d" % rank] = bool(ok)
+    ret["empty%d" % rank] = lo == hi
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_uneven_lengths_and_an_empty_shard():
+    """world_size 4 with fewer utterances than ranks: one rank gets an empty shard and still takes part in the typed
+    collectives; the others hold uneven frame counts; rank 0 receives every contour in utterance order."""
+    import torch.multiprocessing as mp
+
+    lengths = [160000, 30000, 95000]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ragged_worker, args=(4, _free_port(), lengths, ret), nprocs=4, join=True)
+    assert all(ret["ok%d" % r] for r in range(4))
+    assert sum(ret["empty%d" % r] for r in range(4)) == 1
+    assert ret["n"] == len(lengths) and ret["order_ok"]
+
+
+def test_four_ranks_many_uneven_utterances():
+    import torch.multiprocessing as mp
+
+    lengths = [160000, 80000, 120000, 160000, 40000, 90000, 160000, 20000, 155000, 64000, 31000]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ragged_worker, args=(4, _free_port(), lengths, ret), nprocs=4, join=True)
+    assert all(ret["ok%d" % r] for r in range(4)) and not any(ret["empty%d" % r] for r in range(4))
+    assert ret["n"] == len(lengths) and ret["order_ok"]
+
+
 def test_sharded_world_batch_single_process():
     from world.distributed import ShardedWorldBatch
 

@@ -45,6 +45,15 @@ int wh_memcpy_h2d(void* dst, const void* h_src, size_t bytes, void* stream);
 int wh_memcpy_d2h(void* h_dst, const void* src, size_t bytes, void* stream);
 int wh_memset(void* dst, int value, size_t bytes, void* stream);
 int wh_stream_sync(void* stream);
+/* Pinned, device-mapped host memory (hipHostMalloc): the GPU can read and write it through the same address. */
+int wh_host_alloc(void** h_ptr, size_t bytes);
+int wh_host_free(void* h_ptr);
+/* Copy `bytes` (a multiple of 8) between two device-ACCESSIBLE pointers with a kernel on `stream`: either side may be
+ * device memory or pinned host memory from wh_host_alloc / torch's pin_memory().  Unlike wh_memcpy_* this never
+ * touches a DMA engine queue: an upload issued this way cannot be serialised behind a long download that another
+ * stream has queued on the same engine (bench.py with_transfers_pipelined).  `max_blocks` <= 0 picks 64 workgroups
+ * (enough to saturate PCIe, a quarter of the CUs at most). */
+int wh_copy_mapped(wh_ctx* ctx, void* stream, void* dst, const void* src, size_t bytes, int max_blocks);
 
 /* Sticky device-side condition flags raised by kernels instead of failing silently; reading them
  * synchronises the stream and clears them.  h_flags16[WH_FLAG_*] != 0 means the condition occurred. */
@@ -200,6 +209,13 @@ int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b, const dou
  * the mel warp of main.py:335-337 / 351-356 folded in — built by the host with the reference's own expressions. */
 int wh_feature_matmul(wh_ctx* ctx, void* stream, const double* a, int64_t n_rows, int ka, int64_t lda, int prologue,
                       const double* h_p, double pscale, const double* h_w, int nw, int epilogue, double* out, int64_t ldo);
+/* The same product with the weight table identified by the caller: `table_tag` != 0 promises that every call with this
+ * tag (and the same ka x nw) passes the same h_w content.  The padded matrix is then built and uploaded on the first
+ * call only and every later call is a look-up — no re-padding, no comparison of the host bytes (7 MB per SWIPE' call
+ * at 16 kHz otherwise).  Tables of different content MUST carry different tags; table_tag == 0 is wh_feature_matmul. */
+int wh_feature_matmul_tagged(wh_ctx* ctx, void* stream, const double* a, int64_t n_rows, int ka, int64_t lda, int prologue,
+                             const double* h_p, double pscale, const double* h_w, int nw, int epilogue, double* out,
+                             int64_t ldo, uint64_t table_tag);
 /* get_context (main.py:360-365): out[i][j*d + c] = x[clamp(i + j - w, 0, n_rows-1)][c], j = 0..2w.  DEVICE pointers. */
 int wh_context_frames(wh_ctx* ctx, void* stream, const double* x, int64_t n_rows, int d, int w, double* out);
 
@@ -213,6 +229,7 @@ typedef struct wh_swipe_window {
   const double* h_interp;   /* [ws/2+1][n_erb]    magnitude bins -> ERB grid: interp1d(kind='cubic') as a matrix, k-major */
   const double* h_kernels;  /* [n_erb][n_c]       candidate kernels (pitchStrengthOneCandidate, swipe.py:127-146), k-major */
   const double* h_mu;       /* [n_c]              window-size membership weights (swipe.py:62-66) */
+  uint64_t table_tag;       /* != 0: identity of (h_interp, h_kernels) for wh_feature_matmul_tagged (content-stable per tag) */
 } wh_swipe_window;
 /* x: concatenated waveforms (DEVICE); the batch's frame grid is the output grid t = arange(nf) * dt with
  * nf = int(1000*n/fs/(dt*1000) + 1).  HOST tables: h_pc[n_cand] candidate pitches, h_win[n_win], and for the parabolic

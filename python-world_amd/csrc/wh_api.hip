@@ -19,6 +19,15 @@ __global__ void frame_utt_kernel(const int64_t* __restrict__ frame_off, int n_ut
     out[i] = lo;
   }
 }
+
+// 16 bytes per thread and step; the tail (bytes % 16 == 8) by one thread
+__global__ void copy_mapped_kernel(double2* __restrict__ dst, const double2* __restrict__ src, size_t n16, double* dst_tail,
+                                   const double* src_tail) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n16; i += stride) dst[i] = src[i];
+  if (dst_tail && blockIdx.x == 0 && threadIdx.x == 0) *dst_tail = *src_tail;
+}
 }  // namespace
 
 namespace wh {
@@ -112,7 +121,7 @@ int persistent_scratch(wh_ctx* ctx, const std::string& slot, size_t bytes, void*
 
 extern "C" {
 
-int wh_version(void) { return 100; }
+int wh_version(void) { return 101; }
 const char* wh_last_error(void) { return g_last_error.c_str(); }
 
 int wh_device_count(int* count) {
@@ -233,6 +242,35 @@ int wh_memset(void* dst, int value, size_t bytes, void* stream) {
 }
 int wh_stream_sync(void* stream) {
   WH_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int wh_host_alloc(void** h_ptr, size_t bytes) {
+  if (!h_ptr) return wh::fail_msg("wh_host_alloc", "null argument");
+  WH_CHECK(hipHostMalloc(h_ptr, bytes ? bytes : 8, hipHostMallocDefault));
+  return 0;
+}
+int wh_host_free(void* h_ptr) {
+  if (h_ptr) WH_CHECK(hipHostFree(h_ptr));
+  return 0;
+}
+int wh_copy_mapped(wh_ctx* ctx, void* stream, void* dst, const void* src, size_t bytes, int max_blocks) {
+  if (!ctx || (bytes && (!dst || !src))) return wh::fail_msg("wh_copy_mapped", "null argument");
+  if (bytes % 8 || ((uintptr_t)dst % 16) || ((uintptr_t)src % 16))
+    return wh::fail_msg("wh_copy_mapped", "bytes must be a multiple of 8 and both pointers 16-byte aligned");
+  if (!bytes) return 0;
+  WH_ENTER(ctx);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n16 = bytes / 16;
+  const bool tail = bytes % 16 != 0;
+  int blocks = max_blocks > 0 ? max_blocks : 64;
+  const size_t need = (n16 + 255) / 256;
+  if ((size_t)blocks > need) blocks = need ? (int)need : 1;
+  wh::KernelTimer t(ctx, st, "copy_mapped_kernel");
+  copy_mapped_kernel<<<blocks, 256, 0, st>>>((double2*)dst, (const double2*)src, n16,
+                                            tail ? (double*)dst + 2 * n16 : nullptr,
+                                            tail ? (const double*)src + 2 * n16 : nullptr);
+  WH_LAUNCH_CHECK("copy_mapped_kernel");
   return 0;
 }
 

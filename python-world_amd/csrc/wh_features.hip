@@ -120,9 +120,9 @@ int launch_epi(int epi, dim3 grid, hipStream_t st, const double* A, long long n_
 
 }  // namespace
 
-extern "C" int wh_feature_matmul(wh_ctx* ctx, void* stream, const double* a, int64_t n_rows, int ka, int64_t lda,
-                                 int prologue, const double* h_p, double pscale, const double* h_w, int nw, int epilogue,
-                                 double* out, int64_t ldo) {
+extern "C" int wh_feature_matmul_tagged(wh_ctx* ctx, void* stream, const double* a, int64_t n_rows, int ka, int64_t lda,
+                                        int prologue, const double* h_p, double pscale, const double* h_w, int nw,
+                                        int epilogue, double* out, int64_t ldo, uint64_t table_tag) {
   if (!ctx || !a || !h_w || !out) return wh::fail_msg("wh_feature_matmul", "null argument");
   WH_ENTER(ctx);
   if (n_rows <= 0) return 0;
@@ -131,15 +131,25 @@ extern "C" int wh_feature_matmul(wh_ctx* ctx, void* stream, const double* a, int
   hipStream_t st = (hipStream_t)stream;
   const int kpad = ((ka + kFeatKC - 1) / kFeatKC) * kFeatKC;
   const int npad = ((nw + 15) / 16) * 16;
-  std::vector<double> wp((size_t)kpad * npad, 0.0);  // zero padding: the surplus k rows / n columns contribute nothing
-  for (int k = 0; k < ka; ++k)
-    for (int n = 0; n < nw; ++n) wp[(size_t)k * npad + n] = h_w[(size_t)k * nw + n];
+  const std::string shape = std::to_string(ka) + "x" + std::to_string(nw);
   double* d_w = nullptr;
   double* d_p = nullptr;
-  if (int rc = wh::persistent_upload(ctx, st, "feat.w." + std::to_string(prologue) + std::to_string(epilogue) + "." + std::to_string(ka) + "x" + std::to_string(nw), wp, &d_w)) return rc;
+  const std::string slot = table_tag ? "feat.t." + std::to_string(table_tag) + "." + shape
+                                     : "feat.w." + std::to_string(prologue) + std::to_string(epilogue) + "." + shape;
+  if (table_tag) {  // a tagged table that is already resident: a pointer look-up
+    auto it = ctx->persist.find(slot);
+    if (it != ctx->persist.end() && it->second.d && it->second.host.size() == (size_t)kpad * npad * sizeof(double))
+      d_w = reinterpret_cast<double*>(it->second.d);
+  }
+  if (!d_w) {
+    std::vector<double> wp((size_t)kpad * npad, 0.0);  // zero padding: the surplus k rows / n columns contribute nothing
+    for (int k = 0; k < ka; ++k)
+      for (int n = 0; n < nw; ++n) wp[(size_t)k * npad + n] = h_w[(size_t)k * nw + n];
+    if (int rc = wh::persistent_upload(ctx, st, slot, wp, &d_w)) return rc;
+  }
   if (prologue == 1) {
     std::vector<double> pv(h_p, h_p + ka);
-    if (int rc = wh::persistent_upload(ctx, st, "feat.p", pv, &d_p)) return rc;
+    if (int rc = wh::persistent_upload(ctx, st, "feat.p." + std::to_string(ka), pv, &d_p)) return rc;
   }
   const dim3 grid((unsigned)((n_rows + kFeatRows - 1) / kFeatRows), (unsigned)((npad / 16 + kFeatNT - 1) / kFeatNT));
   int rc;
@@ -155,6 +165,12 @@ extern "C" int wh_feature_matmul(wh_ctx* ctx, void* stream, const double* a, int
   if (rc) return rc;
   WH_LAUNCH_CHECK("feature_matmul_kernel");
   return 0;
+}
+
+extern "C" int wh_feature_matmul(wh_ctx* ctx, void* stream, const double* a, int64_t n_rows, int ka, int64_t lda,
+                                 int prologue, const double* h_p, double pscale, const double* h_w, int nw, int epilogue,
+                                 double* out, int64_t ldo) {
+  return wh_feature_matmul_tagged(ctx, stream, a, n_rows, ka, lda, prologue, h_p, pscale, h_w, nw, epilogue, out, ldo, 0);
 }
 
 extern "C" int wh_context_frames(wh_ctx* ctx, void* stream, const double* x, int64_t n_rows, int d, int w, double* out) {

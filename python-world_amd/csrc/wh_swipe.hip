@@ -19,9 +19,6 @@
 #include "wh_device.h"
 #include "wh_host.h"
 
-extern "C" int wh_feature_matmul(wh_ctx* ctx, void* stream, const double* a, int64_t n_rows, int ka, int64_t lda,
-                                 int prologue, const double* h_p, double pscale, const double* h_w, int nw, int epilogue,
-                                 double* out, int64_t ldo);
 
 namespace {
 
@@ -254,10 +251,11 @@ extern "C" int wh_swipe(wh_ctx* ctx, void* stream, const wh_batch* b, const doub
     WH_LAUNCH_CHECK("swipe_stft_kernel");
     const int nbins = w.ws / 2 + 1;
     // loudness = sqrt(max(0, spline resampling of the magnitude row))            (epilogue 3)
-    if (int rc = wh_feature_matmul(ctx, stream, d_mag, total_seg, nbins, nbins, 0, nullptr, 1.0, w.h_interp, n_erb, 3, d_L, n_erb)) return rc;
+    const uint64_t tag_i = w.table_tag ? w.table_tag * 2 + 1 : 0, tag_k = w.table_tag ? w.table_tag * 2 + 2 : 0;
+    if (int rc = wh_feature_matmul_tagged(ctx, stream, d_mag, total_seg, nbins, nbins, 0, nullptr, 1.0, w.h_interp, n_erb, 3, d_L, n_erb, tag_i)) return rc;
     { wh::KernelTimer _kt(ctx, st, "swipe_normalise_kernel"); hipLaunchKernelGGL(swipe_normalise_kernel, dim3((unsigned)total_seg), dim3(256), 0, st, d_L, total_seg, n_erb); }
     WH_LAUNCH_CHECK("swipe_normalise_kernel");
-    if (int rc = wh_feature_matmul(ctx, stream, d_L, total_seg, n_erb, n_erb, 0, nullptr, 1.0, w.h_kernels, w.n_c, 0, d_si, w.n_c)) return rc;
+    if (int rc = wh_feature_matmul_tagged(ctx, stream, d_L, total_seg, n_erb, n_erb, 0, nullptr, 1.0, w.h_kernels, w.n_c, 0, d_si, w.n_c, tag_k)) return rc;
     { wh::KernelTimer _kt(ctx, st, "swipe_accumulate_kernel"); hipLaunchKernelGGL(swipe_accumulate_kernel, dim3((unsigned)max_nf, B), dim3(256), 0, st, d_meta, d_si, w.n_c, w.j0, d_mu, w.ws, w.hop, fs, dt, n_cand, d_S); }
     WH_LAUNCH_CHECK("swipe_accumulate_kernel");
   }

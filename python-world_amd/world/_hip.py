@@ -33,6 +33,9 @@ SIGNATURES = {
     "wh_memcpy_d2h": (_int, [_vp, _vp, ctypes.c_size_t, _vp]),
     "wh_memset": (_int, [_vp, _int, ctypes.c_size_t, _vp]),
     "wh_stream_sync": (_int, [_vp]),
+    "wh_host_alloc": (_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
+    "wh_host_free": (_int, [_vp]),
+    "wh_copy_mapped": (_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, _int]),
     "wh_batch_create": (_int, [_vp, _int, _c_i64p, _c_i64p, ctypes.POINTER(_vp)]),
     "wh_batch_destroy": (_int, [_vp]),
     "wh_num_frames": (ctypes.c_int64, [ctypes.c_int64, _dbl, _dbl]),
@@ -58,6 +61,8 @@ SIGNATURES = {
     "wh_d4c_requiem": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int, _vp]),
     "wh_feature_matmul": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, ctypes.c_int64, _int, _vp, _dbl, _vp, _int, _int, _vp,
                                  ctypes.c_int64]),
+    "wh_feature_matmul_tagged": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, ctypes.c_int64, _int, _vp, _dbl, _vp, _int, _int,
+                                        _vp, ctypes.c_int64, ctypes.c_uint64]),
     "wh_context_frames": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _int, _vp]),
     "wh_warp_spectrum": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _vp, _vp, _vp]),
     "wh_modify_duration": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
@@ -107,6 +112,19 @@ def load_library():
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+def table_tag(*arrays):
+    """64-bit content tag (never 0) of host tables for wh_feature_matmul_tagged / wh_swipe_window.table_tag: computed
+    ONCE where a cached table is built, so that equal tags mean equal content by construction."""
+    import hashlib
+
+    h = hashlib.blake2b(digest_size=8)
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    return (int.from_bytes(h.digest(), "little") >> 2) | 1  # the library derives tag*2+1 / tag*2+2 from it
 
 
 def check(rc):

@@ -236,7 +236,19 @@ class WorldBatch:
         return BatchEncoding(rt, batch, fs, tp_d.clone(), f0_d, vuv_d, spec_d, ap_d, ct_fft, is_requiem, frame_period,
                              tp_host=None if tp_host is None else tp_host.copy())
 
-    def download_async(self, tensors, slot=0):
+    @_on_lane_stream
+    def refill_from_pinned(self, x_d, x_pin):
+        """Overwrite the resident waveform tensor ``x_d`` from the pinned host tensor ``x_pin`` with a KERNEL that reads
+        the mapped host memory (wh_copy_mapped), stream-ordered on the lane's stream.  A plain ``copy_`` would queue
+        the upload on a DMA engine; when a long download from ``download_async`` sits on the same engine the upload —
+        and with it the whole next step — waits for it (observed as 33-36 instead of 24 ms per pipelined step)."""
+        rt = self.rt
+        assert x_pin.is_pinned() and x_pin.numel() == x_d.numel() and x_pin.dtype == x_d.dtype
+        _hip.check(rt.lib.wh_copy_mapped(rt.ctx, rt.stream(), rt.ptr(x_d), _hip._vp(x_pin.data_ptr()),
+                                         x_d.numel() * x_d.element_size(), 0))
+        return x_d
+
+    def download_async(self, tensors, slot=0, mapped=False):
         """Start copying device ``tensors`` into this object's pinned host buffers of ``slot`` (two slots) on a private
         copy stream, behind everything enqueued so far on the lane's stream, and return ``(host_tensors, event)``:
         the lane can go on with the next batch at once, ``event.synchronize()`` (or ``download_wait``) says when the
@@ -262,7 +274,13 @@ class WorldBatch:
         with torch.cuda.stream(st["stream"]):
             st["stream"].wait_event(ready)
             for p, t in zip(pins, tensors):
-                p.copy_(t, non_blocking=True)
+                if mapped and t.is_contiguous() and (t.numel() * t.element_size()) % 8 == 0:
+                    # a few workgroups write the pinned buffer through its device mapping: no DMA queue involved
+                    _hip.check(self.rt.lib.wh_copy_mapped(self.rt.ctx, _hip._vp(st["stream"].cuda_stream),
+                                                          _hip._vp(p.data_ptr()), self.rt.ptr(t),
+                                                          t.numel() * t.element_size(), 16))
+                else:
+                    p.copy_(t, non_blocking=True)
                 t.record_stream(st["stream"])
             done = torch.cuda.Event()
             done.record(st["stream"])

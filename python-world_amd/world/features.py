@@ -37,6 +37,15 @@ def get_filterbanks(nfilt=20, nfft=512, samplerate=16000, lowfreq=0, highfreq=No
     return fbank
 
 
+class _Tagged:
+    """A cached weight table with its content tag (world._hip.table_tag), computed once when the table is built."""
+
+    def __init__(self, w):
+        self.w = np.ascontiguousarray(w, dtype=np.float64)
+        self.w.setflags(write=False)
+        self.tag = _hip.table_tag(self.w)
+
+
 @functools.lru_cache(maxsize=16)
 def _lfbank_tables(d, prefac, fs, nfilt, lowfreq, highfreq):
     from scipy.signal import freqz
@@ -44,7 +53,7 @@ def _lfbank_tables(d, prefac, fs, nfilt, lowfreq, highfreq):
     nfft = (d - 1) * 2
     _, h = freqz([1, -prefac], [1], d)  # pre-emphasis response on the D bins (main.py:313)
     fb = get_filterbanks(nfilt, nfft, fs, lowfreq, highfreq)
-    return np.ascontiguousarray(np.abs(h)), np.ascontiguousarray(fb.T), 1 / nfft
+    return np.ascontiguousarray(np.abs(h)), _Tagged(fb.T), 1 / nfft
 
 
 @functools.lru_cache(maxsize=16)
@@ -62,7 +71,7 @@ def _mcep_matrix(d, n0, fs, lowhz, highhz):
     basis[d - 1, :] = np.cos(np.pi * m[0]) / n            # Nyquist bin: (-1)^m
     w = np.zeros((d, n0))
     np.add.at(w, src, basis)
-    return np.ascontiguousarray(w)
+    return _Tagged(w)
 
 
 @functools.lru_cache(maxsize=16)
@@ -79,18 +88,24 @@ def _imcep_matrix(n0, fft_size):
     knots = np.floor(fft_size * mel2hz(np.linspace(hz2mel(0), hz2mel(8000), k_bins)) / 16000)
     eye = np.eye(k_bins)
     interp = np.array([np.interp(np.arange(k_bins), knots, row) for row in eye])  # (K source bins, K outputs)
-    return np.ascontiguousarray(cos_rows @ interp)
+    return _Tagged(cos_rows @ interp)
 
 
 def feature_matmul_device(rt, a_d, n_rows, ka, lda, w, prologue=0, p=None, pscale=1.0, epilogue=0):
-    """out[f][n] = epi(sum_k pro(A[f][k]) * w[k][n]) on the device; a_d is a device tensor, w / p host arrays."""
+    """out[f][n] = epi(sum_k pro(A[f][k]) * w[k][n]) on the device; a_d is a device tensor, w / p host arrays.
+    ``w`` may be a ``_Tagged`` table: the device copy of the padded matrix is then looked up by tag instead of being
+    re-padded and compared on every call."""
+    tag = 0
+    if isinstance(w, _Tagged):
+        w, tag = w.w, w.tag
     w = np.ascontiguousarray(w, dtype=np.float64)
     nw = w.shape[1]
     out = rt.empty((int(n_rows), nw))
     vp = ctypes.c_void_p
     pp = np.ascontiguousarray(p, dtype=np.float64).ctypes.data_as(vp) if p is not None else vp(None)
-    _hip.check(rt.lib.wh_feature_matmul(rt.ctx, rt.stream(), rt.ptr(a_d), int(n_rows), int(ka), int(lda), int(prologue), pp,
-                                        float(pscale), w.ctypes.data_as(vp), int(nw), int(epilogue), rt.ptr(out), int(nw)))
+    _hip.check(rt.lib.wh_feature_matmul_tagged(rt.ctx, rt.stream(), rt.ptr(a_d), int(n_rows), int(ka), int(lda),
+                                               int(prologue), pp, float(pscale), w.ctypes.data_as(vp), int(nw),
+                                               int(epilogue), rt.ptr(out), int(nw), int(tag)))
     return out
 
 

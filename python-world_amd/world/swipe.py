@@ -21,7 +21,7 @@ _FINE = 20  # refinement grid slots per candidate (the 1/768-octave grid over tw
 class _Window(ctypes.Structure):
     _fields_ = [("ws", ctypes.c_int32), ("hop", ctypes.c_int32), ("j0", ctypes.c_int32), ("n_c", ctypes.c_int32),
                 ("h_window", ctypes.c_void_p), ("h_interp", ctypes.c_void_p), ("h_kernels", ctypes.c_void_p),
-                ("h_mu", ctypes.c_void_p)]
+                ("h_mu", ctypes.c_void_p), ("table_tag", ctypes.c_uint64)]
 
 
 def _round_half_up(v):
@@ -108,6 +108,8 @@ def swipe_tables(fs, plim_lo, plim_hi):
                         "window": np.ascontiguousarray(np.hanning(w_size + 2)[1:-1]),
                         "interp": np.ascontiguousarray(interp.T), "kernels": np.ascontiguousarray(kernels.T),
                         "mu": np.ascontiguousarray(mu)})
+        # identity of the two matrices for the library's table cache: content hash, taken once per cached table set
+        windows[-1]["tag"] = _hip.table_tag(windows[-1]["interp"], windows[-1]["kernels"])
     ntc = np.zeros((len(pc), 3))
     fine = np.zeros((len(pc), _FINE))
     n_fine = np.zeros(len(pc), dtype=np.int32)
@@ -135,6 +137,7 @@ def swipe_device(rt, batch, x_d, fs, plim=(71, 800), dt=0.005, sTHR=float("-inf"
         s.h_interp = w["interp"].ctypes.data
         s.h_kernels = w["kernels"].ctypes.data
         s.h_mu = w["mu"].ctypes.data
+        s.table_tag = w["tag"]
     f0 = rt.empty((batch.total_frames,))
     vuv = rt.empty((batch.total_frames,))
     thr = float(sTHR) if np.isfinite(sTHR) else -1.0e308

@@ -48,6 +48,6 @@ def cheaptrick(x, fs, source_object, q1=-0.15, fft_size=None):
     if CONSUME_REFERENCE_RNG:
         np.random.rand(nf * (fft_size // 2 + 1))  # one rand(K) per frame in the reference: same stream position
     return {'temporal_positions': tp,
-            'spectrogram': np.ascontiguousarray(spec.cpu().numpy().T),
+            'spectrogram': rt.to_host(spec, transpose=True),
             'fs': fs,
-            'ps spectrogram': np.ascontiguousarray(ps.cpu().numpy().T)}
+            'ps spectrogram': rt.to_host(ps, transpose=True)}

@@ -33,6 +33,6 @@ def d4c(x, fs, f0_object, threshold=0.85, fft_size_for_spectrum=None):
     ap, coarse = d4c_device(rt, batch, rt.to_device(x), rt.to_device(f0_object['temporal_positions']), f0_d,
                             rt.to_device(f0_object['vuv']), fs, threshold, int(fft_size_for_spectrum), want_coarse=True)
     f0[...] = f0_d.cpu().numpy()
-    f0_object['aperiodicity'] = np.ascontiguousarray(ap.cpu().numpy().T)
-    f0_object['coarse_ap'] = np.ascontiguousarray(coarse.cpu().numpy().T)
+    f0_object['aperiodicity'] = rt.to_host(ap, transpose=True)
+    f0_object['coarse_ap'] = rt.to_host(coarse, transpose=True)
     return f0_object

@@ -26,5 +26,5 @@ def d4cRequiem(x, fs, f0_object, threshold=0.85, fft_size=None):
     band = d4c_requiem_device(rt, batch, rt.to_device(x), rt.to_device(f0_object['temporal_positions']), f0_d,
                               rt.to_device(f0_object['vuv']), fs, threshold, fft_size)
     f0[...] = f0_d.cpu().numpy()
-    f0_object['aperiodicity'] = np.ascontiguousarray(band.cpu().numpy().T)
+    f0_object['aperiodicity'] = rt.to_host(band, transpose=True)
     return f0_object

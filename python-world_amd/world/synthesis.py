@@ -98,4 +98,4 @@ def synthesis(source_object, filter_object):
     y, _ = synthesis_device(rt, batch, tp_d, f0_d, vuv_d, spec_d, ap_d, fs, fft_size, [ny], [t0], [dt],
                             noise_d=rt.to_device(noise), noise_off=[0, len(noise)], pulse_cap=cap)
     rt.check_flags("synthesis")
-    return y.cpu().numpy()
+    return rt.to_host(y)

@@ -131,4 +131,4 @@ def synthesisRequiem(source_object, filter_object, seeds_signals):
                                   np.array([generate_noise.current_index]), pulse_cap=safe_pulse_cap([geo[0][0]]))
     rt.check_flags("synthesisRequiem")
     generate_noise.current_index = _advance(np.asarray(generate_noise.current_index, dtype=np.float64), geo[0][0], nlen)
-    return y.cpu().numpy()
+    return rt.to_host(y)

@@ -8,6 +8,19 @@
 // Replaces d4c() (world/d4c.py:10-64) and d4cRequiem() (world/d4cRequiem.py:9-44).
 #include <map>
 
+#include <hip/hip_runtime.h>
+// The thread index as the FFT / reduction helpers of wh_device.h see it: an opaque read.  d4c_kernel runs four
+// transforms and four windows per frame through the same helpers; with the plain threadIdx.x the compiler recognises
+// the per-thread LDS addresses (eight swizzled store addresses and eight load addresses per radix-8 pass), twiddle
+// offsets and index-to-double conversions as common subexpressions of all of them, computes them once and parks them
+// in registers for the whole kernel (193 VGPRs wanted where four workgroups per CU allow 128).  Re-deriving them per
+// use costs a few integer instructions.
+__device__ __forceinline__ int wh_opaque_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+#define WH_TID wh_opaque_tid()
 #include "wh_host.h"
 #include "wh_spectral.h"
 
@@ -17,14 +30,17 @@
 // FFT radix caps of d4c_kernel by transform length.  At 128 VGPRs (four workgroups per CU) the radix-8 plan fits
 // N <= 1024 without spilling; at N = 2048 / 4096 it spills ~23 registers — still 2 % faster, but the spills are HBM
 // traffic (1.86 GB per launch where the kernel's compulsory bytes are 0.61 GB), so those lengths keep radix 4.
+#ifndef WH_D4C_REGFED
+#define WH_D4C_REGFED 1  // windows keep their samples in registers and feed the first (radix-8) FFT pass directly
+#endif
 #ifndef WH_D4C_RMAXR
 #define WH_D4C_RMAXR 0  // 0: by length (below); 4 / 8: forced
 #endif
 #ifndef WH_D4C_MAXR
 #define WH_D4C_MAXR 0
 #endif
-constexpr int d4c_maxr(int n) { return WH_D4C_MAXR ? WH_D4C_MAXR : (n <= 1024 ? 8 : 4); }
-constexpr int d4c_rmaxr(int n) { return WH_D4C_RMAXR ? WH_D4C_RMAXR : (n <= 1024 ? 8 : 4); }
+constexpr int d4c_maxr(int n) { return WH_D4C_MAXR ? WH_D4C_MAXR : ((n <= 1024 || WH_D4C_REGFED) ? 8 : 4); }
+constexpr int d4c_rmaxr(int n) { return WH_D4C_RMAXR ? WH_D4C_RMAXR : ((n <= 1024 || WH_D4C_REGFED) ? 8 : 4); }
 #ifndef WH_LOVE_MAXR
 #define WH_LOVE_MAXR 8
 #endif
@@ -33,9 +49,6 @@ constexpr int d4c_rmaxr(int n) { return WH_D4C_RMAXR ? WH_D4C_RMAXR : (n <= 1024
 #endif
 #ifndef WH_D4C_WIN_UNROLL
 #define WH_D4C_WIN_UNROLL 4
-#endif
-#ifndef WH_D4C_REGFFT
-#define WH_D4C_REGFFT 1
 #endif
 // -DWH_D4C_STAGE_TIMER: thread 0 of every workgroup adds the shader-clock cycles between stage boundaries to
 // g_d4c_stage[] (read with wh_debug_d4c_stages, tools/d4c_stage_timer.py) — the per-stage latencies quoted in DESIGN.md.
@@ -259,6 +272,108 @@ __device__ __forceinline__ void d4c_window(const double* __restrict__ xu, const 
     }
   }
 }
+
+// The register-fed form (N = 8 * FT: the lengths D4C runs at from 16 kHz up).  A thread's Q = N / FT samples
+// j = tid + q*FT are exactly the operands of its radix-8 butterfly in the FIRST pass of the transform that follows, so
+// the windowed frame never exists in LDS: one round of global loads into registers, walk 1 (the sums) and walk 2 (the
+// DC-removed, normalised values) over those registers, and out[q] goes straight into wh::fft_lds_from_regs.  Against
+// d4c_window this removes, per frame and window, the parking store (2048 x 8 B), both walks' LDS reads, the emit of
+// 2048 complex values and the first pass's read of them — stores are what an FFT pass costs on this LDS (~80 B/clk per
+// CU, MI355X_MICROARCH.md) — and the walks stop at the window's end: rows q >= ceil(L / FT) are zeros (a window spans
+// 4 pitch periods, ~640 of the 2048 samples at 100 Hz), uniformly for the workgroup.
+template <bool BLACKMAN, int N, bool ENERGY>
+__device__ __forceinline__ void d4c_window_regs(const double* __restrict__ xu, const double* tab, double2 e_tid,
+                                                double* scratch, double (&out)[N / ft_of(N)]) {
+  constexpr int FT = ft_of(N);
+  constexpr int Q = N / FT;
+  const WinSetup ws = win_load(tab);
+  const int hwl = ws.hwl, L = ws.L, rlo = ws.rlo, rhi = ws.rhi;
+  const double inv_span = ws.inv_span, phase = ws.phase, cf = ws.cf;
+  auto shape = [](double c1) -> double {
+    return BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);  // cos(2a) = 2cos^2(a)-1
+  };
+  auto win = [&](int j) -> double { return shape(cospi(((double)(j - hwl) * inv_span + phase) * cf)); };
+  const double* xb = xu + (ws.centre - 1);
+  auto sample = [&](int j) -> double {
+    int rel = j - hwl;
+    rel = rel < rlo ? rlo : rel;
+    rel = rel > rhi ? rhi : rel;
+    return xb[rel];
+  };
+  const int nq = L >= N ? Q : (L + FT - 1) / FT;  // rows that hold window samples (workgroup-uniform)
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    out[q] = 0.0;
+    if (q < nq) out[q] = sample(threadIdx.x + q * FT);  // clamped: always a valid address; all loads in flight at once
+  }
+  const double rot_s = ws.rot_s, rot_c = ws.rot_c;
+  const double c0 = ws.base_c * e_tid.y - ws.base_s * e_tid.x;  // phase of this thread's first sample: base * E[tid]
+  const double s0 = ws.base_s * e_tid.y + ws.base_c * e_tid.x;
+  double s_sw = 0.0, s_w = 0.0, s_swsw = 0.0, s_sww = 0.0, s_ww = 0.0;
+  {
+    double c = c0, sn = s0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (q < nq) {
+        const int j = threadIdx.x + q * FT;
+        if (j < L) {
+          const double w = shape(c);
+          const double sw = out[q] * w;
+          s_sw += sw;
+          s_w += w;
+          if (ENERGY) {
+            s_swsw += sw * sw;
+            s_sww += sw * w;
+            s_ww += w * w;
+          }
+        }
+        const double cn = c * rot_c - sn * rot_s;
+        sn = sn * rot_c + c * rot_s;
+        c = cn;
+      }
+    }
+    for (int j = N + threadIdx.x; j < L; j += FT) {  // rows longer than N: cropped, but they count in the sums
+      const double w = win(j);
+      const double sw = sample(j) * w;
+      s_sw += sw;
+      s_w += w;
+      if (ENERGY) {
+        s_swsw += sw * sw;
+        s_sww += sw * w;
+        s_ww += w * w;
+      }
+    }
+  }
+  STAGE_MARK(10)
+  if (ENERGY) wh::block_sum5<FT>(s_sw, s_w, s_swsw, s_sww, s_ww, scratch);
+  else wh::block_sum2<FT>(s_sw, s_w, scratch);
+  STAGE_MARK(11)
+  const double mean_sw = s_sw / (double)L;
+  const double mean_w = s_w / (double)L;
+  const double dc = mean_sw / mean_w;
+  const double inv_nrm = ENERGY ? 1.0 / sqrt((s_swsw - 2.0 * dc * s_sww) + dc * dc * s_ww) : 1.0;
+  {
+    double c = c0, sn = s0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (q < nq) {
+        const int j = threadIdx.x + q * FT;
+        double val = 0.0;
+        if (j < L) {
+          const double w = shape(c);
+          val = out[q] * w - w * dc;
+          if (ENERGY) val *= inv_nrm;
+        }
+        out[q] = val;
+        const double cn = c * rot_c - sn * rot_s;
+        sn = sn * rot_c + c * rot_s;
+        c = cn;
+      }
+    }
+  }
+}
+template <int N>
+constexpr bool d4c_regfed() { return WH_D4C_REGFED && N == 8 * ft_of(N); }
 
 template <int NLT>
 __global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
@@ -508,11 +623,21 @@ __device__ __forceinline__ void add_centroid(const double* xu, const double* wta
                                              double2* buf, double (&cent)[Runs<N>::KR], bool first,
                                              const double2* tw_base, double* scratch) {
   constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
-  // z[j] = x[j] + i*(j+1)*x[j] (n is 1-based), normalised frame, written straight into the transform buffer
-  d4c_window<true, N, true, 2>(xu, wtab, e_tid, scratch, reinterpret_cast<double*>(buf),
-                               [&](int j, double val) { buf[j] = make_double2(val, val * (double)(j + 1)); });
-  wh::sync<FT>();
-  wh::fft_lds<N, false, FT, FT, d4c_maxr(N)>(buf, fresh_table(tw_base) + N);
+  // z[j] = x[j] + i*(j+1)*x[j] (n is 1-based), normalised frame
+  if constexpr (d4c_regfed<N>()) {
+    double val[N / FT];
+    d4c_window_regs<true, N, true>(xu, wtab, e_tid, scratch, val);
+    double2 zin[N / FT];
+#pragma unroll
+    for (int q = 0; q < N / FT; ++q) zin[q] = make_double2(val[q], val[q] * (double)(WH_TID + q * FT + 1));
+    wh::fft_lds_from_regs<N, false, FT, 8>(zin, buf, fresh_table(tw_base) + N);
+  } else {
+    // written straight into the transform buffer
+    d4c_window<true, N, true, 2>(xu, wtab, e_tid, scratch, reinterpret_cast<double*>(buf),
+                                 [&](int j, double val) { buf[j] = make_double2(val, val * (double)(j + 1)); });
+    wh::sync<FT>();
+    wh::fft_lds<N, false, FT, FT, d4c_maxr(N)>(buf, fresh_table(tw_base) + N);
+  }
   const int k0 = threadIdx.x * KR;
 #pragma unroll
   for (int r = 0; r < KR; ++r) {
@@ -585,11 +710,22 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   if (voiced) e_frame = win_thread_phase(wtab[kWinTab + 9]);
   if (FUSED && voiced) {
     // love-train frame (Blackman, 3*T0, f0 floored at 40 Hz) and smoothed-power frame (Hann, 4*T0) in one FFT
-    d4c_window<true, N, false, 2>(xu, wtab, win_thread_phase(wtab[9]), scratch, zr, [&](int j, double val) { zr[2 * j] = val; });
-    d4c_window<false, N, false, 2>(xu, wtab + kWinTab, e_frame, scratch, zr + 1, [&](int j, double val) { zr[2 * j + 1] = val; });
-    STAGE_MARK(7)
-    wh::sync<FT>();
-    wh::fft_lds<N, false, FT, FT, d4c_maxr(N)>(buf, fresh_table(tw_base) + N);
+    if constexpr (d4c_regfed<N>()) {
+      double va[N / FT], vb[N / FT];
+      d4c_window_regs<true, N, false>(xu, wtab, win_thread_phase(wtab[9]), scratch, va);
+      d4c_window_regs<false, N, false>(xu, wtab + kWinTab, e_frame, scratch, vb);
+      STAGE_MARK(7)
+      double2 zin[N / FT];
+#pragma unroll
+      for (int q = 0; q < N / FT; ++q) zin[q] = make_double2(va[q], vb[q]);
+      wh::fft_lds_from_regs<N, false, FT, 8>(zin, buf, fresh_table(tw_base) + N);
+    } else {
+      d4c_window<true, N, false, 2>(xu, wtab, win_thread_phase(wtab[9]), scratch, zr, [&](int j, double val) { zr[2 * j] = val; });
+      d4c_window<false, N, false, 2>(xu, wtab + kWinTab, e_frame, scratch, zr + 1, [&](int j, double val) { zr[2 * j + 1] = val; });
+      STAGE_MARK(7)
+      wh::sync<FT>();
+      wh::fft_lds<N, false, FT, FT, d4c_maxr(N)>(buf, fresh_table(tw_base) + N);
+    }
     STAGE_MARK(8)
     const int b0 = (int)(ceil(100.0 / (fs / N)) + 1);
     const int b1 = (int)(ceil(4000.0 / (fs / N)) + 1);

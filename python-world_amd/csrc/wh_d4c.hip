@@ -86,7 +86,11 @@ __device__ __forceinline__ double stage_fence(double v) {
 #endif
 // Threads cooperating on one frame: 256 up to N = 2048; 512 at N = 4096 (48 kHz), where the 96 KB of LDS per frame
 // leave one workgroup per CU and the thread count is the only occupancy there is.
-constexpr int ft_of(int n) { return n >= 4096 ? 2 * WH_FT_D4C : WH_FT_D4C; }
+// At N = 1024 (D4C-Requiem at 16 kHz) 128 threads make N = 8 * FT, the shape of the register-fed windows.
+#ifndef WH_FT_D4C_1024
+#define WH_FT_D4C_1024 (WH_D4C_REGFED ? WH_FT_D4C / 2 : WH_FT_D4C)
+#endif
+constexpr int ft_of(int n) { return n >= 4096 ? 2 * WH_FT_D4C : (n == 1024 ? WH_FT_D4C_1024 : WH_FT_D4C); }
 // Waves per SIMD the register allocation must leave room for (HIP's second __launch_bounds__ argument is
 // MIN_WAVES_PER_EU).  LDS per frame is the 2N-double transform buffer (33 KB at N = 2048: 4 workgroups of 4 waves
 // per CU, 66 KB at N = 4096: 2 workgroups of 8 waves), i.e. 4 waves per SIMD either way -> 128 VGPRs.
@@ -94,9 +98,11 @@ constexpr int ft_of(int n) { return n >= 4096 ? 2 * WH_FT_D4C : WH_FT_D4C; }
 #define WH_D4C_MINBLK4096 4
 #endif
 #ifndef WH_D4C_MINBLK1024
-#define WH_D4C_MINBLK1024 5  // N <= 1024 (D4C-Requiem at 16 kHz): 96 VGPRs, five workgroups per CU (17 KB of LDS each): 3.60 -> 3.33 ms
+// N <= 1024 (D4C-Requiem at 16 kHz).  Staged form: 96 VGPRs, five 4-wave workgroups per CU (17 KB of LDS each).  Register-
+// fed form (two waves per frame): the radix-8 butterflies need the 128-register budget; eight workgroups per CU.
+#define WH_D4C_MINBLK1024 (WH_D4C_REGFED ? 4 : 5)
 #endif
-constexpr int minblk_of(int n) { return n >= 4096 ? WH_D4C_MINBLK4096 : (n <= 1024 ? WH_D4C_MINBLK1024 : WH_D4C_MINBLK); }
+constexpr int minblk_of(int n) { return n >= 4096 ? WH_D4C_MINBLK4096 : (n == 1024 ? WH_D4C_MINBLK1024 : (n < 1024 ? 5 : WH_D4C_MINBLK)); }
 
 // Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110).  emit(j, value) is called for every sample
 // j = tid + q*FT < N (zero beyond the window; rows longer than N are cropped like np.fft.fft(x, n), Q7) — the callers
@@ -851,7 +857,9 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
       zr[j] = val;
     }
     wh::sync<FT>();
+    STAGE_MARK(12)
     wh::rfft_lds<N, FT, FT, d4c_rmaxr(N)>(buf, fresh_table(tw_base));
+    STAGE_MARK(13)
     double px[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {

@@ -24,7 +24,7 @@ for it in range(3):
 v = np.array(list(buf), dtype=np.float64)
 order = [(7, "start-up + the two stage-1 windows"), (8, "fused gate/power FFT"), (0, "gate reduction + power fold"),
          (1, "centroid A (window + FFT + fold)"), (2, "centroid B"), (3, "low-band replica (cent)"),
-         (4, "smoothing: power replica + 3 sliding windows"), (9, "band window + real FFT + power"), (5, "rank select"),
+         (4, "smoothing: power replica + 3 sliding windows"), (12, "band: shaped group delay x Nuttall window -> buffer"), (13, "band: real FFT"), (9, "band: power"), (5, "rank select"),
          (6, "outputs"), (10, "  (inside the 4 windows: set-up + first walk)"), (11, "  (inside the 4 windows: reduction)")]
 tot = v.sum()
 voiced = float((enc.vuv.cpu().numpy() != 0).sum())

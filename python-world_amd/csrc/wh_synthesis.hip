@@ -802,6 +802,101 @@ __device__ __forceinline__ void min_phase_half(double* amp, double2* zb, const d
   wh::sync<FT>();
 }
 
+// The same chain as the pulse responses run it, from the mirrored log-amplitude to the INPUT of the last inverse complex
+// transform, with the O(N) passes between the three transforms fused (synthesis.py:100-116):
+//   in : zr[n] = log|S[min(n, N-n)]| / 2, n < N (real, even), visible;  out: time-domain response N * h[n] in zr.
+//   (1) forward transform of a real EVEN sequence: its spectrum is real, so the post-pass of the half-size transform
+//       computes real parts only, and writes them where the next transform wants them — folded onto the upper half,
+//       doubled (cepstrum fold) — instead of: post-pass -> copy real parts -> fold (three LDS round trips, three barriers);
+//   (2) after the second transform a thread holds the pair of bins (k, N/2-k) in registers through the post-pass, the
+//       complex exponential AND the pre-pass of the inverse real transform: exp(r.x/N) * cis(-r.y/N - delay*k), where
+//       `delay_pi` (units of pi per bin) is the pulse's fractional delay — the reference multiplies the spectrum by
+//       exp(-i*coef*shift*k) afterwards (synthesis.py:61-64); folding it into the angle saves one sincospi and one
+//       complex product per bin, and the four passes over the half spectrum become one.
+template <int N, int GT>
+__device__ __forceinline__ void min_phase_response(double2* zb, const double2* tw_base, double delay_pi) {
+  constexpr int FT = ft_syn(N);
+  constexpr int M = N / 2;
+  constexpr int PP = (M / 2 + 1 + GT - 1) / GT;  // bin pairs (k, M-k), k <= M/2, per thread
+  double* zr = reinterpret_cast<double*>(zb);
+  const int gt = WH_TID & (GT - 1);
+  const double2* __restrict__ w = tw_base + N;
+  wh::fft_lds<M, false, GT, FT>(zb, tw_base + M);
+  {
+    double ck[PP], cm[PP];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      const int k = gt + p * GT;
+      ck[p] = cm[p] = 0.0;
+      if (k <= M / 2) {
+        const double2 a = zb[k], b = zb[M - k];
+        if (k == 0) {
+          ck[p] = a.x + a.y;
+          cm[p] = a.x - a.y;
+        } else {
+          const double er = 0.5 * (a.x + b.x), dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
+          const double2 wk = wh::ldg2(w + k);
+          const double tr = fma(wk.x, di, wk.y * dr);
+          ck[p] = er + tr;  // Re X[k]
+          cm[p] = er - tr;  // Re X[M-k]
+        }
+      }
+    }
+    wh::sync<FT>();  // every pair has been read
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      const int k = gt + p * GT;
+      if (k <= M / 2) {
+        if (k == 0) {
+          zr[0] = ck[p];
+          zr[M] = 2 * cm[p];
+        } else {
+          zr[N - k] = 2 * ck[p];
+          zr[M + k] = 2 * cm[p];  // (k = M/2: the same slot, the same value)
+        }
+      }
+    }
+    for (int n = 1 + gt; n < M; n += GT) zr[n] = 0.0;
+    wh::sync<FT>();
+  }
+  wh::fft_lds<M, false, GT, FT>(zb, tw_base + M);
+#pragma unroll 1
+  for (int k = gt; k <= M / 2; k += GT) {
+    const double2 a = zb[k], b = zb[M - k];
+    double2 x0, x1;  // R[k], R[M-k]: spectrum of the folded cepstrum
+    const double2 wk = wh::ldg2(w + k);
+    if (k == 0) {
+      x0 = make_double2(a.x + a.y, 0.0);
+      x1 = make_double2(a.x - a.y, 0.0);
+    } else {
+      const double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);
+      const double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
+      const double tr = fma(wk.x, di, wk.y * dr);
+      const double ti = fma(wk.y, di, -(wk.x * dr));
+      x0 = make_double2(er + tr, ei + ti);
+      x1 = make_double2(er - tr, ti - ei);
+    }
+    // minimum-phase spectrum exp(conj(R) / N) with the fractional delay in the angle (both in units of pi)
+    const double e0 = exp_call(x0.x / N), e1 = exp_call(x1.x / N);
+    const double2 s0 = sincospi_call(-x0.y / N * M_1_PI - delay_pi * (double)k);
+    const double2 s1 = sincospi_call(-x1.y / N * M_1_PI - delay_pi * (double)(M - k));
+    double2 A = make_double2(e0 * s0.y, e0 * s0.x), B = make_double2(e1 * s1.y, e1 * s1.x);
+    if (k == 0) {  // DC and Nyquist bins: only their real parts reach a real output
+      A.y = 0.0;
+      B.y = 0.0;
+    }
+    // pre-pass of the inverse real transform (wh::irfft_lds) on the pair
+    const double er = A.x + B.x, ei = A.y - B.y;
+    const double dr = A.x - B.x, di = A.y + B.y;
+    const double orr = fma(dr, wk.x, di * wk.y);
+    const double oi = fma(di, wk.x, -(dr * wk.y));
+    zb[k] = make_double2(er - oi, ei + orr);
+    if (k != 0) zb[M - k] = make_double2(er + oi, orr - ei);
+  }
+  wh::sync<FT>();
+  wh::fft_lds<M, true, GT, FT>(zb, tw_base + M);
+}
+
 // padded index of the aperiodic response for the register-tiled convolution: 2 doubles of padding every 32
 // keep the 16-byte pair reads of lanes that are 4..8 samples apart on different LDS banks
 __device__ __forceinline__ int rap_index(int i) { return i + 2 * (i >> 5); }
@@ -885,12 +980,9 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   double* zrA = reinterpret_cast<double*>(smem);
   double2* zbP = zbA + (N / 2 + 1);                                 // N/2+1 complex: periodic chain
   double* zrP = reinterpret_cast<double*>(zbP);
-  double* rap = zrP + (N + 2);                                      // N + N/16 + 2: padded aperiodic response ...
-  double* spec = rap;                                               // ... aliasing the two K+7 amplitude arrays,
-  double* asp = rap + (K + 7);                                      //     dead once both spectra exist
+  double* rap = zrP + (N + 2);                                      // N + N/16 + 2: padded aperiodic response
   double* nz = rap + (N + N / 16 + 2);                              // NZ
   double* scratch = nz + NZ;                                        // 16
-  static_assert(2 * (K + 7) <= N + N / 16 + 2, "amplitude arrays must fit under the padded response");
 
   RSTAGE_BEGIN
   wh::sync<FT>();
@@ -934,10 +1026,18 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
     const double ap = same ? al : a * al + b * ah;
     double v = sp * pe;  // periodic spectrum
     if (v == 0.0) v = 2.220446049250313e-16;
-    spec[k] = v;
     double w = voiced ? sp * ap : sp;  // aperiodic spectrum
     if (w == 0.0) w = 2.220446049250313e-16;
-    asp[k] = w;
+    // log|.| / 2 of the Hermitian-mirrored spectrum (synthesis.py:103-105), written where the chain's first
+    // transform reads it: no amplitude arrays, no separate log and mirror passes
+    const double lw = log_call(fabs(w)) / 2;
+    zrA[k] = lw;
+    if (k > 0 && k < N / 2) zrA[N - k] = lw;
+    if (voiced) {
+      const double lv = log_call(fabs(v)) / 2;
+      zrP[k] = lv;
+      if (k > 0 && k < N / 2) zrP[N - k] = lv;
+    }
   }
   // ---- noise for this pulse: max(3, noise_size) samples, zero-mean (synthesis.py:93-95) -----------
   const int64_t nd = noise_size > 3 ? noise_size : 3;
@@ -964,41 +1064,18 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   // ---- minimum-phase responses (synthesis.py:86-116): aperiodic chain on thread group 0, periodic chain on
   //      group 1, advancing through the same barrier phases (with a single group: one after the other) --------
 #if WH_RESP_ABLATE == 2
-  if (WH_TID == 0) A.y[m.y_off] = spec[3] + asp[5] + mean;
+  if (WH_TID == 0) A.y[m.y_off] = zrA[3] + zrP[5] + mean;
   return;
 #endif
   const double coef_pi = 2.0 * fs / N;  // coefficient = 2*pi*fs/N (synthesis.py:59), kept in units of pi
   if (NG == 2 && voiced) {
     const int g = WH_TID / GT;
-    min_phase_half<N, GT>(g == 0 ? asp : spec, g == 0 ? zbA : zbP, tw_base);
-    if (g == 1) {
-#pragma unroll WH_RESP_TRANS_UNROLL
-      for (int k = WH_TID & (GT - 1); k <= N / 2; k += GT) {
-        const double2 sc = sincospi_call(coef_pi * shift * (double)k);  // angle coef*shift*k expressed in units of pi
-        const double sn = sc.x, cs = sc.y;
-        const double2 z = zbP[k];
-        zbP[k] = make_double2(z.x * cs + z.y * sn, z.y * cs - z.x * sn);  // z * exp(-i th): fractional delay
-      }
-    }
-    wh::sync<FT>();
-    RSTAGE_MARK(1)
-    wh::irfft_lds<N, GT, FT>(g == 0 ? zbA : zbP, tw_base);
+    min_phase_response<N, GT>(g == 0 ? zbA : zbP, tw_base, g == 0 ? 0.0 : coef_pi * shift);
   } else {
     // an unvoiced pulse has no periodic response (synthesis.py:69-75): one chain, on all the threads — 40 % of the
     // pulses of speech-like input (the 500 Hz default rate of unvoiced stretches) do half the transform work
-    min_phase_half<N, FT>(asp, zbA, tw_base);
-    wh::irfft_lds<N, FT, FT>(zbA, tw_base);
-    if (voiced) {
-      min_phase_half<N, FT>(spec, zbP, tw_base);
-      for (int k = WH_TID; k <= N / 2; k += FT) {
-        const double2 sc = sincospi_call(coef_pi * shift * (double)k);  // angle coef*shift*k expressed in units of pi
-        const double sn = sc.x, cs = sc.y;
-        const double2 z = zbP[k];
-        zbP[k] = make_double2(z.x * cs + z.y * sn, z.y * cs - z.x * sn);
-      }
-      wh::sync<FT>();
-      wh::irfft_lds<N, FT, FT>(zbP, tw_base);
-    }
+    min_phase_response<N, FT>(zbA, tw_base, 0.0);
+    if (voiced) min_phase_response<N, FT>(zbP, tw_base, coef_pi * shift);
   }
   RSTAGE_MARK(2)
   // zrA[n] = N * aperiodic response, zrP[n] = N * periodic response (both before fftshift)

@@ -759,6 +759,25 @@ __device__ __attribute__((noinline)) double normal_at(uint64_t seed, uint64_t q)
   return (q & 1) ? rr * s : rr * c;
 }
 
+// Both normals of one Philox block (normal_at(seed, 2*blk) and normal_at(seed, 2*blk + 1), bit for bit): the pulse's
+// noise run is generated block-wise, one Box-Muller evaluation per pair instead of one per sample.
+__device__ __attribute__((noinline)) double2 normal_pair(uint64_t seed, uint64_t blk) {
+  uint32_t c0 = (uint32_t)blk, c1 = (uint32_t)(blk >> 32), c2 = 0x9E3779B9u, c3 = 0x243F6A88u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const double u1 = ((double)c0 * 4294967296.0 + (double)c1 + 0.5) * (1.0 / 18446744073709551616.0);
+  const double u2 = ((double)c2 * 4294967296.0 + (double)c3 + 0.5) * (1.0 / 18446744073709551616.0);
+  const double rr = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincospi(2 * u2, &s, &c);
+  return make_double2(rr * c, rr * s);
+}
+
 // Transcendentals of the per-pulse loop as real calls: inlined, their polynomial coefficients (64-bit literals live in
 // VGPR pairs) are loop invariants of response_kernel's pulse loop and get parked in registers across the whole body.
 __device__ __attribute__((noinline)) double log_call(double x) { return log(x); }
@@ -973,7 +992,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   constexpr int K = N / 2 + 1;
   constexpr int NZ = 256;
   constexpr int R = N / FT;  // consecutive output samples per thread
-  static_assert(R % 2 == 0, "pairwise reads need an even number of outputs per thread");
+  static_assert(R % 2 == 0 && NZ % (2 * R) == 0, "pairwise reads; whole blocks of 2R noise samples");
   constexpr int GT = FT >= 256 ? FT / 2 : FT;  // threads per chain: the periodic and aperiodic chains run side by side
   constexpr int NG = FT / GT;
   double2* zbA = reinterpret_cast<double2*>(smem);                 // N/2+1 complex: aperiodic chain
@@ -1052,12 +1071,30 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   double mean;
   {
     double part = 0.0;
-    for (int64_t j = WH_TID; j < nd; j += FT) {
-      const double v = noise_at(j);
-      part += v;
-      if (j < NZ) nz[j] = v;  // the usual case nd <= NZ: generate / fetch each sample once
+    if (noise) {
+      for (int64_t j = WH_TID; j < nd; j += FT) {
+        const double v = noise_at(j);
+        part += v;
+        if (j < NZ) nz[j] = v;  // the usual case nd <= NZ: generate / fetch each sample once
+      }
+    } else {
+      // device stream: sample q of the utterance is one half of Philox block q >> 1 — walk the blocks the run touches
+      const uint64_t key = seed * 0x9E3779B97F4A7C15ull + (uint64_t)u * 0xD1B54A32D192ED03ull + 1;
+      const int64_t b1 = (noff + nd - 1) >> 1;
+      for (int64_t blk = (noff >> 1) + WH_TID; blk <= b1; blk += FT) {
+        const double2 z = normal_pair(key, (uint64_t)blk);
+        const int64_t j = 2 * blk - noff;  // index of the block's first half within this pulse's run (-1 .. nd-1)
+        if (j >= 0) {
+          part += z.x;
+          if (j < NZ) nz[j] = z.x;
+        }
+        if (j + 1 < nd) {
+          part += z.y;
+          if (j + 1 < NZ) nz[j + 1] = z.y;
+        }
+      }
     }
-    mean = wh::block_sum<FT>(part, scratch) / (double)nd;  // barriers: spec/asp/nz visible
+    mean = wh::block_sum<FT>(part, scratch) / (double)nd;  // barriers: the log spectra and nz are visible
   }
 
   RSTAGE_MARK(0)
@@ -1101,28 +1138,69 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
       nz[j] = v;  // zero padded to an even count
     }
     wh::sync<FT>();
-    double r[R];
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const int idx = m0 + q - (int)j0;
-      r[q] = idx >= 0 ? rap[rap_index(idx)] : 0.0;
-    }
-    const int steps = (cnt + 1) & ~1;
-    for (int j = 0; j < steps; j += 2) {
-      const double2 nn = *reinterpret_cast<const double2*>(nz + j);
-      const int inew = m0 - (int)j0 - j - 2;  // even: (ra[inew], ra[inew+1]) is an aligned pair
-      double2 fresh = make_double2(0.0, 0.0);
-      if (inew >= 0) fresh = *reinterpret_cast<const double2*>(rap + rap_index(inew));
-#pragma unroll
-      for (int q = 0; q < R; ++q) acc[q] = fma(nn.x, r[q], acc[q]);
-#pragma unroll
-      for (int q = R - 1; q > 0; --q) r[q] = r[q - 1];
-      r[0] = fresh.y;  // ra[m0 - g - 1]
-#pragma unroll
-      for (int q = 0; q < R; ++q) acc[q] = fma(nn.y, r[q], acc[q]);
-#pragma unroll
-      for (int q = R - 1; q > 0; --q) r[q] = r[q - 1];
-      r[0] = fresh.x;  // ra[m0 - g - 2]
+    if constexpr (R <= 4) {
+      // Aligned groups of R response samples around the thread's outputs: hi = ra[mb .. mb+R-1], lo = ra[mb-R .. mb-1],
+      // mb = m0 - j0 - j.  A block of R noise samples needs exactly these two groups (output q at step s reads
+      // ra[mb + q - s]); for the next block lo becomes hi and ONE new group is fetched — into the registers of the group
+      // that just died, so nothing is ever shifted (the two-step version moved 2(R-1) doubles per pair of steps).
+      auto load_group = [&](int base, double (&g)[R]) {  // base is a multiple of R: a group is all-valid or all before the start
+  #pragma unroll
+        for (int t = 0; t < R; t += 2) {
+          double2 v = make_double2(0.0, 0.0);
+          if (base >= 0) v = *reinterpret_cast<const double2*>(rap + rap_index(base + t));
+          g[t] = v.x;
+          g[t + 1] = v.y;
+        }
+      };
+      auto block = [&](int j, const double (&hi)[R], const double (&lo)[R]) {
+        double n[R];
+  #pragma unroll
+        for (int t = 0; t < R; t += 2) {
+          const double2 v = *reinterpret_cast<const double2*>(nz + j + t);
+          n[t] = v.x;
+          n[t + 1] = v.y;
+        }
+  #pragma unroll
+        for (int sft = 0; sft < R; ++sft)
+  #pragma unroll
+          for (int q = 0; q < R; ++q) acc[q] = fma(n[sft], q - sft >= 0 ? hi[q - sft] : lo[R + q - sft], acc[q]);
+      };
+      double ga[R], gb[R];
+      const int mb0 = m0 - (int)j0;
+      load_group(mb0, ga);
+      load_group(mb0 - R, gb);
+      const int steps = ((cnt + 2 * R - 1) / (2 * R)) * (2 * R);  // nz is zero-padded up to NZ, a multiple of 2R
+      for (int j = 0; j < steps; j += 2 * R) {
+        block(j, ga, gb);
+        load_group(mb0 - j - 2 * R, ga);
+        block(j + R, gb, ga);
+        load_group(mb0 - j - 3 * R, gb);
+      }
+    } else {
+      // (R = 8, fft size 4096: the 64-FMA blocks of the shift-free form do not fit the register budget)
+      double r[R];
+  #pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int idx = m0 + q - (int)j0;
+        r[q] = idx >= 0 ? rap[rap_index(idx)] : 0.0;
+      }
+      const int steps = (cnt + 1) & ~1;
+      for (int j = 0; j < steps; j += 2) {
+        const double2 nn = *reinterpret_cast<const double2*>(nz + j);
+        const int inew = m0 - (int)j0 - j - 2;  // even: (ra[inew], ra[inew+1]) is an aligned pair
+        double2 fresh = make_double2(0.0, 0.0);
+        if (inew >= 0) fresh = *reinterpret_cast<const double2*>(rap + rap_index(inew));
+  #pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] = fma(nn.x, r[q], acc[q]);
+  #pragma unroll
+        for (int q = R - 1; q > 0; --q) r[q] = r[q - 1];
+        r[0] = fresh.y;  // ra[m0 - g - 1]
+  #pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] = fma(nn.y, r[q], acc[q]);
+  #pragma unroll
+        for (int q = R - 1; q > 0; --q) r[q] = r[q - 1];
+        r[0] = fresh.x;  // ra[m0 - g - 2]
+      }
     }
   }
 

@@ -427,24 +427,25 @@ __global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
 // Sum of the m smallest of K non-negative values and their total, without sorting and without LDS atomics.
 // The reference sorts the K powers and prefix-sums them (world/d4c.py:206-208); only the VALUES of the m smallest
 // enter the sum, and m = K - (boundary + 1) is close to K, so the kernel finds the few LARGE values to leave out:
-//   (1) block maximum of the IEEE exponents (one shuffle reduction + one LDS hop);
-//   (2) per wave, population counts of the 16 exponents at and below it by ballot (scalar unit), summed over the
-//       waves through LDS; the window slides further down in the (pathological) case that the K - m largest span
-//       more than 16 octaves;
-//   (3) the one exponent bin that holds the threshold is compacted into a list at offsets derived from the same
-//       ballots (no atomic counter) and its members are ranked against each other; equal values are
+//   (1) per wave, the maximum IEEE exponent (shuffles) and the population counts of the 8 exponents at and below it
+//       by ballot (scalar unit); counts AND the wave's maximum go through LDS together, so one hop yields the block
+//       maximum and the block's counts; the window slides further down in the rare case that the K - m largest span
+//       more than 8 octaves;
+//   (2) the one exponent bin that holds the threshold is compacted into a list at offsets derived from the same
+//       ballots (no atomic counter) and its members are ranked against each other (~11 on speech); equal values are
 //       interchangeable in a sum, so ties need no index rule.
 // Each thread then adds its own kept elements in a fixed order -> deterministic sums.
-// x[q] = value of element i = tid + q*FT (i < K) in the caller's registers.  work: >= 64 ints + K doubles of free
-// LDS; scratch: 32 doubles.  Five barrier phases instead of the nine + contended LDS atomics of the histogram version.
+// x[q] = value of element i = tid + q*FT (i < K) in the caller's registers.  work: >= 80 ints + K doubles of free
+// LDS; scratch: 32 doubles.  Four barrier phases.
 template <int K, int FT, int PER>
 __device__ __forceinline__ void sum_smallest(const double (&x)[PER], int m, void* work, double* scratch,
                                              double* s_small, double* s_total) {
   constexpr int NW = FT / 64;
-  constexpr int WIN = 16;
-  int* cnts = reinterpret_cast<int*>(work);                     // [NW][WIN]
-  double* list = reinterpret_cast<double*>(cnts + NW * WIN + (NW * WIN & 1));
-  int* iscr = reinterpret_cast<int*>(scratch);
+  // exponents per round.  On speech the K - m (~22) largest bins lie within 4 octaves of the maximum on average, 7 at
+  // most (measured on the oracle's spectra): one round of 8 almost always; the loop below slides on otherwise.
+  constexpr int WIN = 8;
+  int* cnts = reinterpret_cast<int*>(work);                     // [NW][WIN + 1]: counts per exponent, then the wave's top
+  double* list = reinterpret_cast<double*>(cnts + NW * (WIN + 1) + (NW * (WIN + 1) & 1));
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int key[PER];
   int kmax = 0;
@@ -461,14 +462,14 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], int m, void
     const int u = __shfl_xor(kmax, o, 64);
     kmax = u > kmax ? u : kmax;
   }
-  if (lane == 0) iscr[w] = kmax;
-  wh::sync<FT>();
-#pragma unroll
-  for (int i = 0; i < NW; ++i) kmax = iscr[i] > kmax ? iscr[i] : kmax;
   const int drop = K - m;  // how many of the largest values are left out (>= 1)
-  int top = kmax;          // exponent at the top of the current 16-wide window
+  // Round 0 counts below the WAVE's own maximum and publishes that maximum next to the counts: one LDS hop gives every
+  // thread the block maximum and all counts (a wave whose maximum is lower has nothing above its own window, and its
+  // window reaches at least as far down as the block's).  Further rounds (rare) count below the common `top`.
+  int top = kmax;          // exponent at the top of this wave's current window
   int above = 0;           // elements with an exponent above the window
   int tbin = -1, wave_before = 0, in_bin = 0;
+  bool first = true;
   while (true) {
     int mine[WIN];
 #pragma unroll
@@ -478,35 +479,43 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], int m, void
       for (int q = 0; q < PER; ++q) c += __popcll(__ballot(key[q] == top - e));  // key -1 = padding lane
       mine[e] = top - e >= 0 ? c : 0;
     }
-    wh::sync<FT>();  // previous window's counts (and iscr) have been read by everyone
-    if (lane < WIN) {
-      int c = 0;
+    wh::sync<FT>();  // the work area is free (previous round's counts have been read by everyone)
+    if (lane <= WIN) {
+      int c = top;
 #pragma unroll
       for (int e = 0; e < WIN; ++e) c = lane == e ? mine[e] : c;
-      cnts[w * WIN + lane] = c;
+      cnts[w * (WIN + 1) + lane] = c;
     }
     wh::sync<FT>();
+    int gtop = top;
+    if (first) {
+#pragma unroll
+      for (int i = 0; i < NW; ++i) gtop = cnts[i * (WIN + 1) + WIN] > gtop ? cnts[i * (WIN + 1) + WIN] : gtop;
+    }
     int run = above;
 #pragma unroll
-    for (int e = 0; e < WIN; ++e) {
+    for (int e = 0; e < WIN; ++e) {  // e: offset below the BLOCK's top
       int tot = 0, before = 0;
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
-        const int c = cnts[i * WIN + e];
+        // wave i counted exponent gtop - e at its own offset e - (gtop - top_i)
+        const int sh = first ? gtop - cnts[i * (WIN + 1) + WIN] : 0;
+        const int c = e - sh >= 0 ? cnts[i * (WIN + 1) + (e - sh)] : 0;
         before += i < w ? c : 0;
         tot += c;
       }
       if (tbin < 0 && run + tot >= drop) {
-        tbin = top - e;
+        tbin = gtop - e;
         above = run;
         wave_before = before;
         in_bin = tot;
       }
       run += tot;
     }
-    if (tbin >= 0 || top - WIN < 0) break;
+    if (tbin >= 0 || gtop - WIN < 0) break;
     above = run;
-    top -= WIN;
+    top = gtop - WIN;  // every wave continues below the common window
+    first = false;
   }
   // tbin < 0 cannot happen (every element has an exponent in [0, kmax]); guard anyway: drop nothing more
   const int need = tbin >= 0 ? drop - above : 0;  // members of the threshold bin that belong to the large set
@@ -858,7 +867,9 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     }
     wh::sync<FT>();
     STAGE_MARK(12)
+#if WH_D4C_ABLATE != 6  // (timing experiment: no band transform)
     wh::rfft_lds<N, FT, FT, d4c_rmaxr(N)>(buf, fresh_table(tw_base));
+#endif
     STAGE_MARK(13)
     double px[PER];
 #pragma unroll
@@ -873,7 +884,12 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     wh::sync<FT>();  // the spectrum has been read: the lower part of the buffer becomes the selection's work area
     STAGE_MARK(9)
     double s_small, s_total;
+#if WH_D4C_ABLATE == 5  // (timing experiment: no rank selection)
+    s_small = px[0];
+    s_total = px[1] + 1.0;
+#else
     sum_smallest<K, FT, PER>(px, N / 2 - boundary, zr, scratch, &s_small, &s_total);
+#endif
     if (threadIdx.x == 0) band[b] = -10 * log10(s_small / s_total);
     wh::sync<FT>();
   }

@@ -32,3 +32,45 @@ def test_d4c_requiem(golden, tag):
     out = d4cRequiem(g["x"], fs, src)
     assert out["aperiodicity"].shape == g["req_band_ap"].shape
     assert np.max(np.abs(out["aperiodicity"] - g["req_band_ap"])) < 1e-6  # dB
+
+
+@pytest.mark.parametrize("fs", [16000, 48000])
+def test_d4c_rank_select_wide_dynamic_range(fs):
+    """The band stage sums the smallest N/2 - boundary of the K power bins (world/d4c.py:206-208); the kernel selects
+    by IEEE exponent in rounds of 8 octaves.  Inputs whose band spectra spread over far more than 8 octaves — a clean
+    harmonic tone with a tiny floor, a click train, and digital near-silence with one loud burst — must walk the
+    further rounds and still agree with the oracle (which sorts)."""
+    from oracle import aperiodicity as oap
+    from oracle import common as C
+    from world.d4c import d4c
+    from world.d4cRequiem import d4cRequiem
+
+    n = int(0.5 * fs)
+    t = np.arange(n) / fs
+    rng = np.random.RandomState(5)
+    # (checked on the oracle's spectra: on the frames that pass the love-train gate the 22 largest bins of these inputs
+    # span up to 12 / 14 / 20 octaves — two and three selection rounds)
+    clicks = np.zeros(n)
+    clicks[:: int(fs / 110)] = 0.8
+    soft = np.convolve(clicks, np.hanning(9), mode="same") + 1e-6 * rng.randn(n)
+    clicks = clicks + 1e-5 * rng.randn(n)
+    burst = 1e-6 * rng.randn(n)
+    nb = int(0.025 * fs)
+    burst[n // 2:n // 2 + nb] += 0.5 * np.sin(2 * np.pi * 200.0 * t[:nb])
+    for x in (clicks, soft, burst):
+        nf = C.frame_count(len(x), fs, 5)
+        tp = C.frame_times(nf, 5)
+        f0 = np.full(nf, 115.0)
+        vuv = np.ones(nf)
+        want_ap, want_coarse, _ = oap.d4c_np(x, fs, f0.copy(), vuv, tp)
+        assert np.isfinite(want_coarse).all() and (want_coarse != 0).any()
+        src = {"f0": f0.copy(), "vuv": vuv.copy(), "temporal_positions": tp.copy()}
+        got = d4c(x, fs, src)
+        assert np.array_equal(got["coarse_ap"] != 0, want_coarse != 0)  # the same frames pass the gate
+        assert np.max(np.abs(got["coarse_ap"] - want_coarse)) < 1e-6
+        assert np.max(np.abs(got["aperiodicity"] - want_ap)) < 1e-7
+        want_band, _ = oap.d4c_requiem_np(x, fs, f0.copy(), vuv, tp)
+        src = {"f0": f0.copy(), "vuv": vuv.copy(), "temporal_positions": tp.copy()}
+        got_band = d4cRequiem(x, fs, src)["aperiodicity"]
+        assert np.isfinite(want_band).all()
+        assert np.max(np.abs(got_band - want_band)) < 1e-6

@@ -235,7 +235,14 @@ constexpr int kOlsN = WH_OLS_N;
 constexpr int kOlsValid = WH_OLS_VALID;  // outputs kept per block: 256 x 14 positions (+2 look-ahead samples); the longest
                                          // filter (493 taps) leaves 4096 - 495 = 3601
 constexpr int kOlsPer = kOlsValid / 256;
-constexpr int kOlsBands = 4;
+#ifndef WH_OLS_BANDS
+#define WH_OLS_BANDS 1
+#endif
+// Channels per workgroup (they share the tile spectrum of each tile).  One: 152 x n_utt short workgroups instead of 38 x n_utt
+// long ones — at 64 utterances the 2432 long workgroups were 3.2 rounds of the 768 the chip holds, i.e. a quarter of
+// the kernel ran with CUs idle behind the last round (3.69 -> 3.27 ms at config 3) — and the channel's tap spectrum is
+// loaded once and stays in registers for all tiles.
+constexpr int kOlsBands = WH_OLS_BANDS;
 
 // T_b = rfft(taps_b zero-padded to kOlsN): [nb][kOlsN/2+1] complex
 static __global__ __launch_bounds__(256) void band_taps_fft_kernel(const double* __restrict__ taps_all,
@@ -339,7 +346,7 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
       if (g + 1 < n_ch) {
         load_spec(tr, tspec + (int64_t)(b + 1) * KS);
       } else {
-        load_spec(tr, tspec + (int64_t)b0 * KS);
+        if (kOlsBands > 1) load_spec(tr, tspec + (int64_t)b0 * KS);  // (a single channel's tap spectrum never leaves the registers)
         if (tile + 1 < tiles) load_spec(zr, zspec + (tile_off[u] + tile + 1) * KS);
       }
       // output i of the block is s[t0 + i - (H + h + 1)]: the tile's outputs start at index H + h + 1

@@ -256,9 +256,7 @@ __device__ __forceinline__ void d4c_window(const double* __restrict__ xu, const 
   if (ENERGY) wh::block_sum5<FT>(s_sw, s_w, s_swsw, s_sww, s_ww, scratch);
   else wh::block_sum2<FT>(s_sw, s_w, scratch);
   STAGE_MARK(11)
-  const double mean_sw = s_sw / (double)L;
-  const double mean_w = s_w / (double)L;
-  const double dc = mean_sw / mean_w;
+  const double dc = s_sw / s_w;  // = mean(x w) / mean(w): the two divisions by L cancel (two FP64 divides less per window)
   const double inv_nrm = ENERGY ? 1.0 / sqrt((s_swsw - 2.0 * dc * s_sww) + dc * dc * s_ww) : 1.0;
   {
     double c = c0, sn = s0;
@@ -354,9 +352,7 @@ __device__ __forceinline__ void d4c_window_regs(const double* __restrict__ xu, c
   if (ENERGY) wh::block_sum5<FT>(s_sw, s_w, s_swsw, s_sww, s_ww, scratch);
   else wh::block_sum2<FT>(s_sw, s_w, scratch);
   STAGE_MARK(11)
-  const double mean_sw = s_sw / (double)L;
-  const double mean_w = s_w / (double)L;
-  const double dc = mean_sw / mean_w;
+  const double dc = s_sw / s_w;  // = mean(x w) / mean(w): the two divisions by L cancel (two FP64 divides less per window)
   const double inv_nrm = ENERGY ? 1.0 / sqrt((s_swsw - 2.0 * dc * s_sww) + dc * dc * s_ww) : 1.0;
   {
     double c = c0, sn = s0;
@@ -576,39 +572,45 @@ __device__ __forceinline__ void low_band_replica_runs(double (&p)[Runs<N>::KR], 
   if (nlow > K) nlow = K;                // (the reference indexes the half spectrum: bins beyond it do not exist)
   while (nlow > 0 && !(((double)(nlow - 1) / N * fs) < reach)) --nlow;
   double* add = tmp + ((nlow + 1) & ~1);
+  // The bins below `reach` (1.2 f0 <= 960 Hz: a few dozen) all belong to the first lanes of wave 0.  When they fit one
+  // wave — always, at the supported rates — that wave does the whole correction with wave-level ordering and the other
+  // waves only meet it at the closing barrier: one barrier instead of three, and three waves skip the code.
+  const bool one_wave = nlow <= 64 * KR;
+  if (!one_wave || threadIdx.x < 64) {
 #pragma unroll
-  for (int r = 0; r < KR; ++r)
-    if (k0 + r < nlow) tmp[k0 + r] = p[r];
-  wh::sync<FT>();
+    for (int r = 0; r < KR; ++r)
+      if (k0 + r < nlow) tmp[k0 + r] = p[r];
+    if (one_wave) wh::sync<64>(); else wh::sync<FT>();
 #pragma unroll 1
-  for (int kk = threadIdx.x; kk < nlow; kk += FT) {
-    const double fk = (double)kk / N * fs;
-    double inc = 0.0;
-    if (nlow >= 2 && fk < f0) {
-      // ascending nodes a_m = f0 - f_{nlow-1-m}; hi = clamp(#nodes < fk, 1, nlow-1).  The node predicate
-      // a_m < fk is monotone in m, so the count is its boundary: estimated in closed form, then settled with
-      // the exact floating-point predicate (the estimate is within one of the truth).
-      auto below = [&](int mm) { return (f0 - ((double)(nlow - 1 - mm) / N * fs)) < fk; };
-      int cnt = (int)ceil((double)(nlow - 1) - (f0 - fk) / fs * N);
-      cnt = cnt < 0 ? 0 : (cnt > nlow ? nlow : cnt);
-      while (cnt > 0 && !below(cnt - 1)) --cnt;
-      while (cnt < nlow && below(cnt)) ++cnt;
-      const int hi = cnt < 1 ? 1 : (cnt > nlow - 1 ? nlow - 1 : cnt);
-      const int lo = hi - 1;
-      const double a_lo = f0 - ((double)(nlow - 1 - lo) / N * fs);
-      const double a_hi = f0 - ((double)(nlow - 1 - hi) / N * fs);
-      const double y_lo = tmp[nlow - 1 - lo];
-      const double y_hi = tmp[nlow - 1 - hi];
-      const double slope = (y_hi - y_lo) / (a_hi - a_lo);
-      inc = slope * (fk - a_lo) + y_lo;
+    for (int kk = threadIdx.x; kk < nlow; kk += (one_wave ? 64 : FT)) {
+      const double fk = (double)kk / N * fs;
+      double inc = 0.0;
+      if (nlow >= 2 && fk < f0) {
+        // ascending nodes a_m = f0 - f_{nlow-1-m}; hi = clamp(#nodes < fk, 1, nlow-1).  The node predicate
+        // a_m < fk is monotone in m, so the count is its boundary: estimated in closed form, then settled with
+        // the exact floating-point predicate (the estimate is within one of the truth).
+        auto below = [&](int mm) { return (f0 - ((double)(nlow - 1 - mm) / N * fs)) < fk; };
+        int cnt = (int)ceil((double)(nlow - 1) - (f0 - fk) / fs * N);
+        cnt = cnt < 0 ? 0 : (cnt > nlow ? nlow : cnt);
+        while (cnt > 0 && !below(cnt - 1)) --cnt;
+        while (cnt < nlow && below(cnt)) ++cnt;
+        const int hi = cnt < 1 ? 1 : (cnt > nlow - 1 ? nlow - 1 : cnt);
+        const int lo = hi - 1;
+        const double a_lo = f0 - ((double)(nlow - 1 - lo) / N * fs);
+        const double a_hi = f0 - ((double)(nlow - 1 - hi) / N * fs);
+        const double y_lo = tmp[nlow - 1 - lo];
+        const double y_hi = tmp[nlow - 1 - hi];
+        const double slope = (y_hi - y_lo) / (a_hi - a_lo);
+        inc = slope * (fk - a_lo) + y_lo;
+      }
+      add[kk] = inc;
     }
-    add[kk] = inc;
-  }
-  wh::sync<FT>();
+    if (one_wave) wh::sync<64>(); else wh::sync<FT>();
 #pragma unroll
-  for (int r = 0; r < KR; ++r) {
-    const int kk = k0 + r;
-    if (kk < nlow && nlow >= 2 && ((double)kk / N * fs) < f0) p[r] = add[kk] + p[r];
+    for (int r = 0; r < KR; ++r) {
+      const int kk = k0 + r;
+      if (kk < nlow && nlow >= 2 && ((double)kk / N * fs) < f0) p[r] = add[kk] + p[r];
+    }
   }
   wh::sync<FT>();  // tmp is reused by the caller
 }

@@ -116,10 +116,36 @@ __device__ __forceinline__ void serial_run(int64_t i0, int64_t i1, Interior inte
   for (; i < i1; ++i) body(i, slow(i));
 }
 
+// Sum over the 64 lanes of a wave, result in every lane.  DPP form (default): butterflies inside the rows of 16 lanes by
+// quad permutes and row mirrors, then row_bcast:15 / row_bcast:31 carry the row totals up to lane 63, whose value is
+// broadcast through the scalar unit — 12 v_mov_dpp + 6 v_add_f64 + 2 v_readlane, all on the VALU.  The shuffle form
+// (WH_WAVE_SUM_DPP=0) is 12 ds_bpermute_b32 through the LDS crossbar with a wait in front of every add; the window
+// reductions of d4c_kernel run five of these sums four times per frame.  (tools/ubench/wave_sum_check.hip)
+#ifndef WH_WAVE_SUM_DPP
+#define WH_WAVE_SUM_DPP 1
+#endif
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);  // lanes outside the mask / without a source: 0
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
+#if WH_WAVE_SUM_DPP
+  v += dpp_or_zero<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_or_zero<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_or_zero<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_or_zero<0x140, 0xF>(v);  // row_mirror: every lane holds its row's total
+  v += dpp_or_zero<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_or_zero<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+#else
 #pragma unroll
   for (int o = WH_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WH_WAVE);
   return v;
+#endif
 }
 
 // Sum over the whole 256-thread block; result broadcast to every thread.

@@ -374,6 +374,24 @@ __device__ __forceinline__ void d4c_window_regs(const double* __restrict__ xu, c
     }
   }
 }
+// Quantities of a launch that depend on the sampling rate and the transform length alone, evaluated once on the host
+// with the reference's expressions (d4c.py:78-80, 197-199) instead of by every wave of every frame (FP64 divides and
+// ceil / floor: ~60 VALU instructions per frame that no lane needs to repeat).
+struct D4cLaunchConst {
+  int b0, b1, b2;      // love-train band edges: ceil(100 | 4000 | 7900 / (fs / N)) + 1
+  int boundary;        // int(N / wlen * 8 + 0.5)
+  int centre[8];       // per band: floor(interval * (b + 1) / (fs / N))
+};
+inline D4cLaunchConst d4c_launch_const(double fs, int n, int wlen, int interval, int nap) {
+  D4cLaunchConst c;
+  c.b0 = (int)(ceil(100.0 / (fs / n)) + 1);
+  c.b1 = (int)(ceil(4000.0 / (fs / n)) + 1);
+  c.b2 = (int)(ceil(7900.0 / (fs / n)) + 1);
+  c.boundary = (int)((double)n / wlen * 8 + 0.5);
+  for (int b = 0; b < 8; ++b) c.centre[b] = b < nap ? (int)floor((double)interval * (b + 1) / (fs / n)) : 0;
+  return c;
+}
+
 template <int N>
 constexpr bool d4c_regfed() { return WH_D4C_REGFED && N == 8 * ft_of(N); }
 
@@ -682,7 +700,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     const int32_t* __restrict__ gate, double threshold, double fs, int nap, int interval,
     const double* __restrict__ window, int wlen, const double2* __restrict__ tw_base,
     int k_spec,                       // >0: dense amplitude output [F][k_spec]; 0: Requiem band output [F][nap+2]
-    double* __restrict__ out, double* __restrict__ coarse_dbg, long long n_frames) {
+    double* __restrict__ out, double* __restrict__ coarse_dbg, long long n_frames, D4cLaunchConst lc) {
   constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2* buf = reinterpret_cast<double2*>(smem);   // N complex (centroid FFT) / N/2+1 complex (real FFTs)
@@ -744,9 +762,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
       wh::fft_lds<N, false, FT, FT, d4c_maxr(N)>(buf, fresh_table(tw_base) + N);
     }
     STAGE_MARK(8)
-    const int b0 = (int)(ceil(100.0 / (fs / N)) + 1);
-    const int b1 = (int)(ceil(4000.0 / (fs / N)) + 1);
-    const int b2 = (int)(ceil(7900.0 / (fs / N)) + 1);
+    const int b0 = lc.b0, b1 = lc.b1, b2 = lc.b2;
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
@@ -852,11 +868,11 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
 #endif
   STAGE_MARK(4)
   // ---- band-wise aperiodicity (d4c.py:192-209) -----------------------------------------------
-  const int boundary = (int)((double)N / wlen * 8 + 0.5);
+  const int boundary = lc.boundary;
   const int half = wlen / 2;
   constexpr int PER = (K + FT - 1) / FT;
   for (int b = 0; b < nap; ++b) {
-    const int centre = (int)floor((double)interval * (b + 1) / (fs / N));
+    const int centre = lc.centre[b];
     for (int j = threadIdx.x; j < N; j += FT) {
       double val = 0.0;
       if (j < wlen) {
@@ -907,8 +923,13 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     if (coarse_dbg) for (int b = threadIdx.x; b < nap; b += FT) coarse_dbg[f * nap + b] = -fmax(0.0, band[b] - tilt);
     double* o = out + f * (int64_t)k_spec;
     const int nn = nap + 2;  // nodes: 0, interval, ..., interval*nap, fs/2
+    // k * fs / (2 (K-1)): the divisor is a power of two for every FFT size, so k * (fs / divisor) is the same double
+    // (both roundings are of the exact quotient) without a divide per bin
+    const int qden = 2 * (k_spec - 1);
+    const bool qexact = (qden & (qden - 1)) == 0;
+    const double qstep = fs / (double)qden;
     for (int k = threadIdx.x; k < k_spec; k += FT) {
-      const double q = (double)k * fs / (double)(2 * (k_spec - 1));
+      const double q = qexact ? (double)k * qstep : (double)k * fs / (double)qden;
       int cnt = 0;  // searchsorted-left over the coarse axis
       for (int m = 0; m < nn; ++m) {
         const double am = m <= nap ? (double)(m * interval) : fs / 2;
@@ -963,7 +984,7 @@ int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x,
   if (int rc = wh::allow_lds(&d4c_kernel<N, FUSED>, lds)) return rc;
   { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL((d4c_kernel<N, FUSED>), dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_of(N)), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, gate, thr, fs, nap, interval, win, wlen, ctx->d_twiddle, k_spec, out,
-                     coarse, (long long)b->total_frames); }
+                     coarse, (long long)b->total_frames, d4c_launch_const(fs, N, wlen, interval, nap)); }
   WH_LAUNCH_CHECK("d4c_kernel");
   return 0;
 }

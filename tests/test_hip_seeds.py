@@ -122,3 +122,63 @@ def test_requiem_decode_with_device_seeds():
         rb = np.sqrt(np.mean(b[off[u]:off[u + 1]] ** 2))
         assert abs(rb / ra - 1) < 0.1  # the voiced part is deterministic, the noise part has the same level
     assert wb.rt.take_flags() == [0] * 16
+
+
+@pytest.mark.parametrize("fs", [16000, 48000])
+def test_device_velvet_noise_whiteness(fs):
+    """The velvet noise must be as white as the reference's: its power spectrum flat (spectral flatness = geometric /
+    arithmetic mean of the periodogram averaged over 64 blocks) and its autocorrelation free of structure beyond what
+    the construction itself puts there (one impulse per 4-sample cell: lags 1-3 are slightly negative).  Compared with
+    host-generated velvet noise of the same construction, lag by lag."""
+    from world.get_seeds_signals import get_seeds_signals_device
+
+    from world.get_seeds_signals import _modified_velvet_noise
+
+    def host_velvet(n, seed):  # the host mirror of the reference's construction, on the reference's RNG streams
+        random.seed(seed)
+        np.random.seed(seed)
+        return _modified_velvet_noise(n, fs)
+
+    def stats(v):
+        blocks = v[:len(v) // 64 * 64].reshape(64, -1)
+        psd = np.mean(np.abs(np.fft.rfft(blocks, axis=1)) ** 2, axis=0)[1:]
+        flat = np.exp(np.mean(np.log(psd))) / np.mean(psd)
+        v0 = v - v.mean()
+        ac = np.array([np.dot(v0[:-k], v0[k:]) for k in range(1, 33)]) / np.dot(v0, v0)
+        return flat, ac
+
+    dev = get_seeds_signals_device(fs, seed=21, want_velvet=True)["velvet_d"].cpu().numpy()
+    flat_d, ac_d = stats(dev)
+    refs = [stats(host_velvet(len(dev), 300 + s)) for s in range(6)]
+    flat_h = np.mean([r[0] for r in refs])
+    ac_h = np.mean([r[1] for r in refs], axis=0)
+    ac_sd = np.std([r[1] for r in refs], axis=0) + 1.0 / np.sqrt(len(dev) / 4)
+    assert flat_d > 0.97 * flat_h and flat_d > 0.9, (flat_d, flat_h)
+    assert np.all(np.abs(ac_d - ac_h) < 5 * ac_sd + 0.01), (ac_d[:6], ac_h[:6])
+    # nothing beyond the 4-sample cell structure: the estimate of a zero correlation from n/4 impulses has sigma 1/sqrt(n/4)
+    assert np.all(np.abs(ac_d[4:]) < 4.5 / np.sqrt(len(dev) / 4))
+
+
+def test_philox_synthesis_noise_is_standard_normal_and_white():
+    """The noise of the pulse-wise decode's default path (on-device Philox + Box-Muller; bench.py times this path):
+    decode an all-unvoiced encoding with a flat spectrum and unit aperiodicity, so that the output is the noise itself
+    shaped only by the (flat) minimum-phase response — then check mean, variance ratio between seeds, whiteness."""
+    from world.batch import BatchEncoding, WorldBatch
+
+    fs, nf, k = 16000, 401, 513
+    wb = WorldBatch()
+    dat = {"f0": np.zeros(nf), "vuv": np.zeros(nf), "temporal_positions": np.arange(nf) * 0.005,
+           "spectrogram": np.ones((k, nf)), "aperiodicity": np.full((k, nf), 1 - 1e-12), "fs": fs, "is_requiem": False}
+    enc = BatchEncoding.from_dicts(wb.rt, [dat])
+    ys = [wb.decode_device(enc, seed=s)[0].cpu().numpy() for s in (1, 2)]
+    for y in ys:
+        body = y[2000:-2000]
+        assert abs(body.mean()) < 0.02 * body.std()
+        blocks = body[:len(body) // 32 * 32].reshape(32, -1)
+        psd = np.mean(np.abs(np.fft.rfft(blocks, axis=1)) ** 2, axis=0)[2:-2]
+        flat = np.exp(np.mean(np.log(psd))) / np.mean(psd)
+        assert flat > 0.9, flat  # a white sequence averaged over 32 blocks gives ~0.98
+        z = (body - body.mean()) / body.std()
+        assert abs(np.mean(z ** 3)) < 0.1 and abs(np.mean(z ** 4) - 3.0) < 0.3  # Gaussian moments
+    assert abs(ys[0].std() / ys[1].std() - 1) < 0.05
+    assert abs(np.corrcoef(ys[0][2000:-2000], ys[1][2000:-2000])[0, 1]) < 0.02  # seeds are independent streams

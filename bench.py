@@ -26,6 +26,7 @@ Rank 0 prints ONE JSON line.  On a single GPU it also carries (each timed by thi
                    `value_with_transfers` — SURVEY §8(d) defines the metric with the API's transfers in it;
   config1_latency: the reference's own benchmark (test/speed.py:13-18): ONE World().encode(fs, x, 'harvest') and one
                    decode on test-mwm.wav through the drop-in facade, first call and warm, with the kernel share;
+  other_configs  : BASELINE configs 3, 4 and 5 at their single-GPU sizes (ms per step, frames/s, heaviest kernels);
   feature_heads, swipe : the SURVEY §8(f) kernels on the config-2 batch (lfbank + mcep + imcep on the FP64 matrix
                    cores; f0_method='swipe');
   north_star     : BASELINE.json's target workload on ONE GPU — 1024 x 10 s, Harvest + CheapTrick + D4C-Requiem
@@ -258,6 +259,12 @@ def main():
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline and args.config == 2:
         cpu = cpu_baseline(xs_distinct, FS, args.cpu_utts)
+    xs_cfg5 = None
+    if world == 1 and not args.no_extras and args.config == 2 and args.scaling == "weak":
+        try:  # the long-form inputs of the other_configs block are generated here, before any GPU state exists (fork)
+            xs_cfg5 = make_inputs(0, 16, 48000, 60.0)
+        except Exception:
+            xs_cfg5 = None
 
     import torch
     import torch.distributed as dist
@@ -418,6 +425,7 @@ def main():
             blocks.append(("config1_latency", lambda: config1_latency_block(torch)))
             blocks.append(("feature_heads", lambda: feature_heads_block(torch, wl, FS)))
             blocks.append(("swipe", lambda: swipe_block(torch, wl, FS)))
+            blocks.append(("other_configs", lambda: other_configs_block(torch, local_rank, xs_distinct, xs_cfg5)))
             for key, fn in blocks + [("north_star", lambda: north_star_block(torch, local_rank, xs_distinct, FS, args))]:
                 try:
                     out[key] = fn()
@@ -768,6 +776,47 @@ def swipe_block(torch, wl, fs, reps=3):
             "host_enqueue_ms": host_ms, "matmul_TFLOPs": flops / (agg.get("feature_matmul_kernel", ms)) / 1e9,
             "matmul_flops": flops, "window_sizes": [w["ws"] for w in tb["windows"]], "candidates": len(tb["pc"]),
             "kernel_ms": {k: round(v, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])}}
+
+
+def other_configs_block(torch, device_index, xs16, xs48):
+    """BASELINE configs 3, 4 and 5 at their single-GPU sizes, timed by this process like the headline (eager launches,
+    barrier-free single rank): 3 = Harvest only on 64 x 10 s; 4 = Harvest + CheapTrick + D4C-Requiem encode + Requiem
+    decode on 64 x 10 s; 5 = 16 x 60 s at 48 kHz, Harvest encode, scale_pitch(1.5), scale_duration(2.0), decode."""
+    import types
+
+    from world.batch import WorldBatchLanes
+
+    out = {}
+    for cfg, xs, fs, steps in ((3, xs16, 16000, 5), (4, xs16, 16000, 5), (5, xs48, 48000, 2)):
+        if xs is None:
+            out["config%d" % cfg] = {"error": "inputs unavailable"}
+            continue
+        wl = WorldBatchLanes(device_index, lanes=1)
+        wl.upload(xs, fs)
+        step = make_step(types.SimpleNamespace(config=cfg, no_stagger=True), wl, fs)
+        step(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(1 + k)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        rt = wl.lanes[0].rt
+        rt.profile(True)
+        step(99)
+        agg = {}
+        for name, ms in rt.profile_collect():
+            agg[name] = agg.get(name, 0.0) + ms
+        rt.profile(False)
+        wl.lanes[0].check("other_configs %d" % cfg)
+        frames = wl.total_frames
+        out["config%d" % cfg] = {"utterances": len(xs), "seconds": len(xs[0]) / fs, "fs": fs, "steps": steps,
+                                 "ms_per_step": dt * 1e3, "value": frames / dt, "unit": "frames/s",
+                                 "x_realtime": len(xs) * len(xs[0]) / fs / dt,
+                                 "kernel_ms": {k: round(v, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:6]}}
+        del wl, step
+        torch.cuda.empty_cache()
+    return out
 
 
 def north_star_block(torch, device_index, xs_distinct, fs, args, steps=3):

@@ -236,13 +236,15 @@ constexpr int kOlsValid = WH_OLS_VALID;  // outputs kept per block: 256 x 14 pos
                                          // filter (493 taps) leaves 4096 - 495 = 3601
 constexpr int kOlsPer = kOlsValid / 256;
 #ifndef WH_OLS_BANDS
-#define WH_OLS_BANDS 1
+#define WH_OLS_BANDS 0  // 0: by batch size (below); 1 / 4: forced
 #endif
-// Channels per workgroup (they share the tile spectrum of each tile).  One: 152 x n_utt short workgroups instead of 38 x n_utt
-// long ones — at 64 utterances the 2432 long workgroups were 3.2 rounds of the 768 the chip holds, i.e. a quarter of
-// the kernel ran with CUs idle behind the last round (3.69 -> 3.27 ms at config 3) — and the channel's tap spectrum is
-// loaded once and stays in registers for all tiles.
-constexpr int kOlsBands = WH_OLS_BANDS;
+// Channels per workgroup of band_events_ols_kernel (they share the tile spectrum of each tile): a template parameter,
+// chosen per launch.  Small batches take ONE: 152 x n_utt short workgroups instead of 38 x n_utt long ones — at 64
+// utterances the 2432 long workgroups were 3.2 rounds of the 768 the chip holds, so a quarter of the kernel ran with CUs
+// idle behind the last round (3.69 -> 3.27 ms at config 3) — and the channel's tap spectrum stays in registers for all
+// tiles.  Large batches (1024 utterances: 155 k short workgroups) keep FOUR: rounds no longer matter there and every
+// channel of a one-channel workgroup fetches its own copy of each tile spectrum (54.5 against 52.4 ms).
+constexpr int kOlsBands = 4;  // band_events_ols2_kernel (the pair variant); band_events_ols_kernel is templated on it
 
 // T_b = rfft(taps_b zero-padded to kOlsN): [nb][kOlsN/2+1] complex
 static __global__ __launch_bounds__(256) void band_taps_fft_kernel(const double* __restrict__ taps_all,
@@ -284,6 +286,7 @@ static __global__ __launch_bounds__(256) void band_tile_fft_kernel(const BandJob
   for (int k = threadIdx.x; k <= kOlsN / 2; k += 256) out[k] = z[k];
 }
 
+template <int kOlsBands>
 static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kernel(const BandJob* __restrict__ jobs, int nb, int H,
                                                                      const int32_t* __restrict__ half,
                                                                      const double2* __restrict__ tspec,
@@ -459,7 +462,13 @@ inline int launch_band_events_ols(wh_ctx* ctx, hipStream_t st, const BandJob* d_
   { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_ols2_kernel, dim3(n_utt, (nb + kOlsBands - 1) / kOlsBands), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag); }
 #else
   const size_t lds = sizeof(double2) * (kOlsN / 2 + 2) + 64;
-  { KernelTimer _kt(ctx, st, "band_events_kernel"); hipLaunchKernelGGL(band_events_ols_kernel, dim3(n_utt, (nb + kOlsBands - 1) / kOlsBands), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag); }
+  // one channel per workgroup while four-channel workgroups would be fewer than ~16 rounds of the chip (3 per CU): measured better at 64 and 256 utterances, worse at 1024
+  const bool single = WH_OLS_BANDS == 1 || (WH_OLS_BANDS == 0 && (int64_t)n_utt * ((nb + 3) / 4) < 16 * 3 * 256);
+  {
+    KernelTimer _kt(ctx, st, "band_events_kernel");
+    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(n_utt, nb), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+    else hipLaunchKernelGGL(band_events_ols_kernel<4>, dim3(n_utt, (nb + 3) / 4), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+  }
 #endif
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("band_events_ols_kernel", e);

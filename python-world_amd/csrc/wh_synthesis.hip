@@ -788,41 +788,8 @@ __device__ __attribute__((noinline)) double2 sincospi_call(double x) {
   return make_double2(s, c);
 }
 
-// Minimum-phase half spectrum (synthesis.py:103-111) from K = N/2+1 amplitude-like bins:
-// log|.|/2 (in place, amp is destroyed) → real FFT → fold the cepstrum onto its upper half (x2, bin 0 kept)
-// → inverse transform of that REAL sequence = conj of its real FFT → complex exp.  Both transforms are
-// N/2-point complex FFTs.  Result: zb[k], k = 0..N/2 (the rest of the spectrum is its Hermitian mirror).
-// GT threads (thread index modulo GT) work on this (amp, zb) pair; barriers span all FT threads, so FT/GT
-// independent chains on different buffers run side by side through the same barrier phases.
-template <int N, int GT>
-__device__ __forceinline__ void min_phase_half(double* amp, double2* zb, const double2* tw_base) {
-  constexpr int FT = ft_syn(N);
-  double* zr = reinterpret_cast<double*>(zb);
-  const int gt = WH_TID & (GT - 1);
-#pragma unroll WH_RESP_TRANS_UNROLL
-  for (int k = gt; k <= N / 2; k += GT) amp[k] = log_call(fabs(amp[k])) / 2;
-  wh::sync<FT>();
-  for (int n = gt; n < N; n += GT) zr[n] = amp[n <= N / 2 ? n : N - n];
-  wh::sync<FT>();
-  wh::rfft_lds<N, GT, FT>(zb, tw_base);
-  for (int k = gt; k <= N / 2; k += GT) amp[k] = zb[k].x;  // real cepstrum (even)
-  wh::sync<FT>();
-  for (int n = gt; n < N; n += GT) zr[n] = n == 0 ? amp[0] : (n >= N / 2 ? 2 * amp[N - n] : 0.0);
-  wh::sync<FT>();
-  wh::rfft_lds<N, GT, FT>(zb, tw_base);
-#pragma unroll WH_RESP_TRANS_UNROLL
-  for (int k = gt; k <= N / 2; k += GT) {
-    const double2 r = zb[k];  // sum c[n] e^{+i..} = conj(r)
-    const double e = exp_call(r.x / N);
-    const double2 sc = sincospi_call(-r.y / N * M_1_PI);  // small angle in units of pi: cheap exact range reduction
-    const double sn = sc.x, cs = sc.y;
-    zb[k] = make_double2(e * cs, e * sn);
-  }
-  wh::sync<FT>();
-}
-
-// The same chain as the pulse responses run it, from the mirrored log-amplitude to the INPUT of the last inverse complex
-// transform, with the O(N) passes between the three transforms fused (synthesis.py:100-116):
+// Minimum-phase response (synthesis.py:100-116; synthesisRequiem.py:112-118) from the mirrored log-amplitude to the time
+// domain, with the O(N) passes between the three transforms fused:
 //   in : zr[n] = log|S[min(n, N-n)]| / 2, n < N (real, even), visible;  out: time-domain response N * h[n] in zr.
 //   (1) forward transform of a real EVEN sequence: its spectrum is real, so the post-pass of the half-size transform
 //       computes real parts only, and writes them where the next transform wants them — folded onto the upper half,
@@ -832,8 +799,13 @@ __device__ __forceinline__ void min_phase_half(double* amp, double2* zb, const d
 //       `delay_pi` (units of pi per bin) is the pulse's fractional delay — the reference multiplies the spectrum by
 //       exp(-i*coef*shift*k) afterwards (synthesis.py:61-64); folding it into the angle saves one sincospi and one
 //       complex product per bin, and the four passes over the half spectrum become one.
-template <int N, int GT>
-__device__ __forceinline__ void min_phase_response(double2* zb, const double2* tw_base, double delay_pi) {
+// `mul(k, E)`: what the minimum-phase bin k (0 <= k <= N/2) is multiplied with before the inverse transform — identity
+// for the pulse responses, the excitation frame's spectrum in the Requiem filter (synthesisRequiem.py:112-118).
+struct SpectrumIdentity {
+  __device__ __forceinline__ double2 operator()(int, double2 e) const { return e; }
+};
+template <int N, int GT, class Mul = SpectrumIdentity>
+__device__ __forceinline__ void min_phase_response(double2* zb, const double2* tw_base, double delay_pi, Mul mul = Mul()) {
   constexpr int FT = ft_syn(N);
   constexpr int M = N / 2;
   constexpr int PP = (M / 2 + 1 + GT - 1) / GT;  // bin pairs (k, M-k), k <= M/2, per thread
@@ -899,7 +871,7 @@ __device__ __forceinline__ void min_phase_response(double2* zb, const double2* t
     const double e0 = exp_call(x0.x / N), e1 = exp_call(x1.x / N);
     const double2 s0 = sincospi_call(-x0.y / N * M_1_PI - delay_pi * (double)k);
     const double2 s1 = sincospi_call(-x1.y / N * M_1_PI - delay_pi * (double)(M - k));
-    double2 A = make_double2(e0 * s0.y, e0 * s0.x), B = make_double2(e1 * s1.y, e1 * s1.x);
+    double2 A = mul(k, make_double2(e0 * s0.y, e0 * s0.x)), B = mul(M - k, make_double2(e1 * s1.y, e1 * s1.x));
     if (k == 0) {  // DC and Nyquist bins: only their real parts reach a real output
       A.y = 0.0;
       B.y = 0.0;
@@ -1406,7 +1378,6 @@ __global__ __launch_bounds__(ft_syn(N)) void req_filter_kernel(const SynUtt* __r
   double2* zb = reinterpret_cast<double2*>(smem);        // minimum-phase half spectrum (N/2+1 complex)
   double2* sb = zb + (N / 2 + 1);                         // windowed excitation frame / its half spectrum
   double* sr = reinterpret_cast<double*>(sb);
-  double* amp = reinterpret_cast<double*>(sb + (N / 2 + 1));  // K
   const SynUtt m = meta[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x + 2;  // frames 2 .. F-2  (synthesisRequiem.py:83)
   if (i > m.nf - 2) return;
@@ -1426,14 +1397,17 @@ __global__ __launch_bounds__(ft_syn(N)) void req_filter_kernel(const SynUtt* __r
     sr[j] = v;
   }
   const double* sp = spectrogram + (m.f_off + (i - 1)) * K;
-  for (int k = threadIdx.x; k < K; k += FT) amp[k] = sp[k];
+  double* zr = reinterpret_cast<double*>(zb);
+  for (int k = threadIdx.x; k < K; k += FT) {  // log|S| / 2, Hermitian-mirrored: the input of the chain's first transform
+    const double lw = log_call(fabs(sp[k])) / 2;
+    zr[k] = lw;
+    if (k > 0 && k < N / 2) zr[N - k] = lw;
+  }
   wh::sync<FT>();
   wh::rfft_lds<N, FT>(sb, tw_base);
-  min_phase_half<N, FT>(amp, zb, tw_base);
-  for (int k = threadIdx.x; k < K; k += FT) zb[k] = wh::cmul(zb[k], sb[k]);  // both Hermitian → product Hermitian
-  wh::sync<FT>();
-  wh::irfft_lds<N, FT>(zb, tw_base);
-  const double* zr = reinterpret_cast<const double*>(zb);
+  // minimum-phase spectrum x excitation spectrum (both Hermitian, so is the product), straight into the inverse
+  // transform: the fused chain of the pulse responses with the product applied to the register-held bin pairs
+  min_phase_response<N, FT>(zb, tw_base, 0.0, [&](int k, double2 e) { return wh::cmul(e, sb[k]); });
   double* yu = y + m.y_off;
   for (int mm = threadIdx.x; mm < N; mm += FT) {
     const int64_t tgt = origin + mm;
@@ -1447,7 +1421,7 @@ __global__ __launch_bounds__(ft_syn(N)) void req_filter_kernel(const SynUtt* __r
 template <int N>
 int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, const SynUtt* d_meta, const ReqUtt* d_rq,
                       const double* spec, const double* exc, double* y) {
-  const size_t lds = sizeof(double2) * 2 * (N / 2 + 1) + sizeof(double) * (N / 2 + 8);
+  const size_t lds = sizeof(double2) * 2 * (N / 2 + 1) + 64;  // the chain's buffer and the excitation frame's
   if (int rc = wh::allow_lds(&req_filter_kernel<N>, lds)) return rc;
   if (max_nf < 4) return 0;
   { wh::KernelTimer _kt(ctx, st, "req_filter_kernel"); hipLaunchKernelGGL(req_filter_kernel<N>, dim3((unsigned)(max_nf - 3), B), dim3(ft_syn(N)), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, y); }

@@ -186,10 +186,10 @@ __device__ __forceinline__ double2 win_thread_phase(double delta) {
 
 // slot / STRIDE: sample j is parked at slot[j * STRIDE] (LDS) between the gather and the second walk — the place emit()
 // overwrites with the final value, so the park costs no extra memory.
-template <bool BLACKMAN, int N, bool ENERGY, int STRIDE, class Emit>
+template <bool BLACKMAN, int N, bool ENERGY, int STRIDE, int FT_ = 0, class Emit>
 __device__ __forceinline__ void d4c_window(const double* __restrict__ xu, const double* tab, double2 e_tid,
                                            double* scratch, double* slot, Emit emit) {
-  constexpr int FT = ft_of(N);
+  constexpr int FT = FT_ ? FT_ : ft_of(N);
   constexpr int Q = N / FT;
   const WinSetup ws = win_load(tab);
   const int hwl = ws.hwl, L = ws.L, rlo = ws.rlo, rhi = ws.rhi;
@@ -395,12 +395,18 @@ inline D4cLaunchConst d4c_launch_const(double fs, int n, int wlen, int interval,
 template <int N>
 constexpr bool d4c_regfed() { return WH_D4C_REGFED && N == 8 * ft_of(N); }
 
+// Threads per frame of the stand-alone gate kernel: its one transform is real (N/2 complex points), so N/16 threads are
+// one radix-8 butterfly each — half of d4c_kernel's count.
+#ifndef WH_FT_LOVE_DIV
+#define WH_FT_LOVE_DIV 2
+#endif
+constexpr int ft_love(int n) { return ft_of(n) / WH_FT_LOVE_DIV < 64 ? 64 : ft_of(n) / WH_FT_LOVE_DIV; }
 template <int NLT>
-__global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
+__global__ __launch_bounds__(ft_love(NLT)) void love_train_kernel(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv, double fs,
     double threshold, const double2* __restrict__ tw_base, int32_t* __restrict__ gate, long long n_frames) {
-  constexpr int FT = ft_of(NLT);
+  constexpr int FT = ft_love(NLT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2* zb = reinterpret_cast<double2*>(smem);  // NLT/2+1 complex after the real FFT
   double* zr = reinterpret_cast<double*>(smem);    // the NLT real samples, then the half spectrum (NLT + 2 doubles)
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(ft_of(NLT)) void love_train_kernel(
   const double cf = fmax(f0, 40.0);
   if (threadIdx.x == 0) win_setup(wtab, xn, fs, cf, tp[f], 1.5, FT);
   wh::sync<FT>();
-  d4c_window<true, NLT, false, 1>(xu, wtab, win_thread_phase(wtab[9]), scratch, zr, [&](int j, double val) { zr[j] = val; });
+  d4c_window<true, NLT, false, 1, FT>(xu, wtab, win_thread_phase(wtab[9]), scratch, zr, [&](int j, double val) { zr[j] = val; });
   wh::sync<FT>();
   wh::rfft_lds<NLT, FT, FT, WH_LOVE_MAXR>(zb, tw_base);  // (66 VGPRs here: the radix-8 plan fits, unlike in d4c_kernel)
   const int b0 = (int)(ceil(100.0 / (fs / NLT)) + 1);
@@ -970,7 +976,7 @@ int launch_lt(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x, c
               const double* vuv, double fs, double thr, int32_t* gate) {
   const size_t lds = sizeof(double) * (NLT + 2 + 48 + kWinTab);  // 17 KB at 2048: the 66 VGPRs, not LDS, set the occupancy
   if (int rc = wh::allow_lds(&love_train_kernel<NLT>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_of(NLT)), lds, st, x, b->d_x_off,
+  { wh::KernelTimer _kt(ctx, st, "love_train_kernel"); hipLaunchKernelGGL(love_train_kernel<NLT>, dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_love(NLT)), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, fs, thr, ctx->d_twiddle, gate, (long long)b->total_frames); }
   WH_LAUNCH_CHECK("love_train_kernel");
   return 0;

@@ -8,11 +8,11 @@
 //   encode_lfbank : pro = (a * |H(k)|)^2 / nfft (pre-emphasis, power), W = fb^T,           epi = log (0 -> eps)
 //   encode_mcep   : pro = log a,                                     W = warp + irfft rows, epi = none
 //   decode_mcep   : pro = none,                                      W = rfft rows + warp,  epi = exp
-// feature_matmul_kernel runs it on the FP64 matrix cores (v_mfma_f64_16x16x4_f64): a workgroup of four waves takes
-// 64 frames, each wave a 16-frame strip; the A strip of a 32-wide k chunk is staged in LDS through coalesced loads
-// with the prologue applied on the way in, W (k-major, zero-padded to multiples of 32 x 16) is read straight from L2.
-// The products are HBM-bound (4104 B in per 32 x 8 B out for the filterbank), the matrix cores just keep the
-// arithmetic off the critical path.
+// feature_matmul_kernel runs it on the FP64 matrix cores (v_mfma_f64_16x16x4_f64): a workgroup of four waves takes a
+// 128 x 64 output tile, each wave 32 x 64 of it; 16-wide k strips of A (prologue applied on the way in) and of W
+// (k-major, zero-padded to multiples of 32 x 16) are staged in double-buffered LDS, fetched a step ahead of the MFMAs.
+// The heads are HBM-bound (4104 B in per 32 x 8 B out for the filterbank); SWIPE's products (513-1025 x 326, 326 x ~150
+// per window size) are where the matrix cores carry weight.
 //
 // MFMA operand layout (measured, tools/ubench/mfma_check.hip): A[i][k] in lane 16k+i, B[k][j] in lane 16k+j,
 // D[4r + l/16][l%16] in register r of lane l.
@@ -25,32 +25,49 @@ namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kFeatKC = 32;   // k chunk staged in LDS
-constexpr int kFeatNT = 4;    // 16-column tiles per workgroup (accumulators: 4 x 4 doubles per lane)
-constexpr int kFeatRows = 64;
+constexpr int kFeatKC = 32;   // W is zero-padded on the host side to multiples of 32 (k) x 16 (n)
+constexpr int kFeatKS = 16;   // k step staged in LDS per pipeline stage
+constexpr int kFeatNT = 4;    // 16-column tiles per workgroup: a 128 x 64 output tile
+constexpr int kFeatRows = 128;  // rows per workgroup: each of the four waves owns 32 x 64 = 2 x 4 MFMA tiles
+constexpr int kFeatAS = kFeatKS + 1;        // row stride of the staged A strip in doubles: 16 rows x 4 k land on distinct banks
+constexpr int kFeatBS = 16 * kFeatNT + 16;  // row stride of the staged W strip: k rows 32 banks apart
 
+// One product with prologue / epilogue, tiled for the FP64 matrix cores.  Per 16-wide k step a workgroup stages a
+// 128 x 16 strip of A (prologue applied on the way in) and the 16 x 64 strip of W in LDS — both fetched from global
+// memory into registers ONE STEP AHEAD, while the 32 MFMAs per wave of the current step run out of the other LDS buffer —
+// so the matrix pipe waits neither for HBM (A) nor for L2 (W): the first version read W from L2 in front of every MFMA and
+// single-buffered A (5.6 TFLOP/s on SWIPE's products).  Each wave keeps 8 accumulator tiles (64 VGPRs): an A operand
+// feeds four MFMAs, a W operand two.  One barrier per step.
 template <int PRO, int EPI>
 __global__ __launch_bounds__(256) void feature_matmul_kernel(const double* __restrict__ A, long long n_rows, int ka,
                                                              long long lda, const double* __restrict__ P, double pscale,
                                                              const double* __restrict__ W, int kpad, int npad, int nw,
                                                              double* __restrict__ out, long long ldo) {
-  __shared__ double As[kFeatRows][kFeatKC + 1];
+  __shared__ double As[2][kFeatRows * kFeatAS];
+  __shared__ double Bs[2][kFeatKS * kFeatBS];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long f0 = (long long)blockIdx.x * kFeatRows;
   const int nt0 = blockIdx.y * kFeatNT;
   const int ntiles = npad / 16;
-  double4_t acc[kFeatNT];
+  const int nt_here = ntiles - nt0 < kFeatNT ? ntiles - nt0 : kFeatNT;  // column tiles this workgroup really has
+  double4_t acc[2][kFeatNT];
 #pragma unroll
-  for (int t = 0; t < kFeatNT; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-  for (int kc = 0; kc < kpad; kc += kFeatKC) {
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < kFeatRows * kFeatKC; idx += 256) {
-      const int r = idx / kFeatKC, c = idx % kFeatKC;
-      const long long f = f0 + r;
-      const int k = kc + c;
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int t = 0; t < kFeatNT; ++t) acc[mt][t] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // staging roles: thread t fetches 8 consecutive k of A row t/2 and 4 consecutive columns of W row t/16
+  const int ar = threadIdx.x >> 1, ak = (threadIdx.x & 1) * 8;
+  const int bk = threadIdx.x >> 4, bc = (threadIdx.x & 15) * 4;
+  const long long arow = f0 + ar;
+  const bool a_ok = arow < n_rows;
+  double areg[8], breg[4];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = kc + ak + i;
       double v = 0.0;
-      if (f < n_rows && k < ka) {
-        v = A[f * lda + k];
+      if (a_ok && k < ka) {
+        v = A[arow * lda + k];
         if (PRO == 1) {
           v = v * P[k];
           v = pscale * (v * v);  // 1 / nfft * np.square(spec * |h|)  (main.py:314-316)
@@ -58,39 +75,63 @@ __global__ __launch_bounds__(256) void feature_matmul_kernel(const double* __res
           v = log(v);
         }
       }
-      As[r][c] = v;
+      areg[i] = v;
     }
-    __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < kFeatKC / 4; ++kk) {
-      const double a = As[16 * w + (lane & 15)][4 * kk + (lane >> 4)];
-      const double* wrow = W + (long long)(kc + 4 * kk + (lane >> 4)) * npad + (lane & 15);
+    for (int i = 0; i < 4; ++i) {
+      const int n = 16 * nt0 + bc + i;
+      breg[i] = n < npad ? W[(long long)(kc + bk) * npad + n] : 0.0;
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) As[buf][ar * kFeatAS + ak + i] = areg[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Bs[buf][bk * kFeatBS + bc + i] = breg[i];
+  };
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  const int steps = kpad / kFeatKS;
+  for (int st = 0; st < steps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < steps) fetch((st + 1) * kFeatKS);  // in flight under this step's MFMAs
+    const double* as = As[buf] + (32 * w + (lane & 15)) * kFeatAS + (lane >> 4);
+    const double* bs = Bs[buf] + (lane >> 4) * kFeatBS + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < kFeatKS / 4; ++kk) {
+      const double a0 = as[4 * kk], a1 = as[16 * kFeatAS + 4 * kk];
 #pragma unroll
       for (int t = 0; t < kFeatNT; ++t) {
-        if (nt0 + t < ntiles) {
-          const double b = wrow[16 * (nt0 + t)];
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        if (t < nt_here) {
+          const double b = bs[4 * kk * kFeatBS + 16 * t];
+          acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][t], 0, 0, 0);
         }
       }
     }
+    if (st + 1 < steps) stage(buf ^ 1);  // the other buffer was last read a step ago, before the barrier below
+    __syncthreads();
   }
 #pragma unroll
-  for (int t = 0; t < kFeatNT; ++t) {
-    const int n = 16 * (nt0 + t) + (lane & 15);
-    if (nt0 + t < ntiles && n < nw) {
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long long f = f0 + 16 * w + 4 * r + (lane >> 4);
-        if (f < n_rows) {
-          double v = acc[t][r];
-          if (EPI == 1) v = log(v == 0.0 ? 2.220446049250313e-16 : v);  // np.where(feat == 0, eps, feat); np.log
-          else if (EPI == 2) v = exp(v);
-          else if (EPI == 3) v = sqrt(fmax(0.0, v));  // SWIPE' loudness: np.sqrt(np.maximum(0, .)) (swipe.py:42-44)
-          out[f * ldo + n] = v;
+    for (int t = 0; t < kFeatNT; ++t) {
+      const int n = 16 * (nt0 + t) + (lane & 15);
+      if (t < nt_here && n < nw) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long f = f0 + 32 * w + 16 * mt + 4 * r + (lane >> 4);
+          if (f < n_rows) {
+            double v = acc[mt][t][r];
+            if (EPI == 1) v = log(v == 0.0 ? 2.220446049250313e-16 : v);  // np.where(feat == 0, eps, feat); np.log
+            else if (EPI == 2) v = exp(v);
+            else if (EPI == 3) v = sqrt(fmax(0.0, v));  // SWIPE' loudness: np.sqrt(np.maximum(0, .)) (swipe.py:42-44)
+            out[f * ldo + n] = v;
+          }
         }
       }
     }
-  }
 }
 
 // get_context (main.py:360-365): out[i] = rows i-w .. i+w of X side by side, the first / last row repeated at the ends

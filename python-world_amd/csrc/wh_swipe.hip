@@ -79,8 +79,10 @@ __global__ __launch_bounds__(256) void swipe_accumulate_kernel(const SwUtt* __re
                                                                int n_c, int j0, const double* __restrict__ mu, int ws,
                                                                int hop, double fs, double dt, int n_cand,
                                                                double* __restrict__ S) {
+  // four output frames per workgroup, one wave each (n_c is 100-200 candidates: a 256-thread workgroup per frame left
+  // half of its lanes idle and made the launch 640 k tiny workgroups per window size)
   const SwUtt m = meta[blockIdx.y];
-  const int64_t t = blockIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= m.nf) return;
   const double tt = (double)t * dt;
   auto ti_at = [&](int64_t k) -> double { return k == 0 ? 0.0 : ((double)((k - 1) * hop) + ws / 2.0) / fs; };
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void swipe_accumulate_kernel(const SwUtt* __re
   const double x0 = ti_at(k0), x1 = ti_at(k0 + 1);
   const double* r0 = si + (m.seg_off + k0) * n_c;
   const double* r1 = r0 + n_c;
-  for (int c = threadIdx.x; c < n_c; c += 256) {
+  for (int c = threadIdx.x & 63; c < n_c; c += 64) {
     double v;
     if (beyond) v = NAN;  // interp1d(bounds_error=False, fill_value=nan)
     else {
@@ -256,7 +258,7 @@ extern "C" int wh_swipe(wh_ctx* ctx, void* stream, const wh_batch* b, const doub
     { wh::KernelTimer _kt(ctx, st, "swipe_normalise_kernel"); hipLaunchKernelGGL(swipe_normalise_kernel, dim3((unsigned)total_seg), dim3(256), 0, st, d_L, total_seg, n_erb); }
     WH_LAUNCH_CHECK("swipe_normalise_kernel");
     if (int rc = wh_feature_matmul_tagged(ctx, stream, d_L, total_seg, n_erb, n_erb, 0, nullptr, 1.0, w.h_kernels, w.n_c, 0, d_si, w.n_c, tag_k)) return rc;
-    { wh::KernelTimer _kt(ctx, st, "swipe_accumulate_kernel"); hipLaunchKernelGGL(swipe_accumulate_kernel, dim3((unsigned)max_nf, B), dim3(256), 0, st, d_meta, d_si, w.n_c, w.j0, d_mu, w.ws, w.hop, fs, dt, n_cand, d_S); }
+    { wh::KernelTimer _kt(ctx, st, "swipe_accumulate_kernel"); hipLaunchKernelGGL(swipe_accumulate_kernel, dim3((unsigned)((max_nf + 3) / 4), B), dim3(256), 0, st, d_meta, d_si, w.n_c, w.j0, d_mu, w.ws, w.hop, fs, dt, n_cand, d_S); }
     WH_LAUNCH_CHECK("swipe_accumulate_kernel");
   }
   std::vector<double> pc(h_pc, h_pc + n_cand), ntc(h_ntc, h_ntc + (size_t)n_cand * 3), fine(h_fine, h_fine + (size_t)n_cand * kFine);

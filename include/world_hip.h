@@ -165,6 +165,24 @@ int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp,
                  const double* spectrogram, const double* aperiodicity, double fs, int fft_size, const int64_t* h_y_off,
                  const double* h_t0, const double* h_dt, int64_t pulse_cap, const double* noise,
                  const int64_t* h_noise_off, uint64_t seed, double* y, int32_t* pulse_count_out);
+/* wh_synthesis in two halves, so that the half that depends on the time base alone can run early, on another stream:
+ *   wh_synthesis_timebase — phase increments, the exact cumulative phase (np.cumsum, bit for bit), pulse positions and
+ *     fractional shifts, noise offsets, per-pulse frame pairs (synthesis.py:118-152).  Inputs tp / f0 / vuv only.  The
+ *     results stay in ctx's workspace until another call of that context uses the workspace.  f0_low_limit > 0: f0 is
+ *     the F0 stage's output and is read as World.encode leaves it after CheapTrick and D4C (vuv == 0 -> 0, f0 <
+ *     f0_low_limit = 3 fs / (fft_size - 3) -> 500 Hz), i.e. the call can be issued before those two stages have run.
+ *   wh_synthesis_render — the spectral half: one response per pulse of the time base held by timebase_ctx (the same
+ *     context or another one of the same device), overlap-added into y.  The caller orders it behind the time base
+ *     (same stream, or an event wait).  Fails if timebase_ctx holds no time base for this batch / pulse_cap.
+ * wh_synthesis(ctx, ...) == wh_synthesis_timebase(ctx, ..., 0) followed by wh_synthesis_render(ctx, ..., ctx, ...). */
+int wh_synthesis_timebase(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,
+                          const double* vuv, double fs, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
+                          int64_t pulse_cap, double f0_low_limit);
+int wh_synthesis_render(wh_ctx* ctx, void* stream, const wh_batch* b, const wh_ctx* timebase_ctx, const double* tp,
+                        const double* spectrogram, const double* aperiodicity, double fs, int fft_size,
+                        const int64_t* h_y_off, const double* h_t0, const double* h_dt, int64_t pulse_cap,
+                        const double* noise, const int64_t* h_noise_off, uint64_t seed, double* y,
+                        int32_t* pulse_count_out);
 /* Pulse bookkeeping only (synchronous): per-utterance pulse count and the exact number of normal
  * samples the reference would draw, sum_i max(3, noise_size_i).  HOST outputs. */
 int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,

@@ -42,6 +42,7 @@ int fail_msg(const char* where, const char* msg) {
 }
 int ws_reserve(wh_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return 0;
+  ctx->timebase.valid = false;  // the arena moves: a stored time base goes with it
   if (ctx->ws) {
     WH_CHECK(hipDeviceSynchronize());
     WH_CHECK(hipFree(ctx->ws));
@@ -121,7 +122,7 @@ int persistent_scratch(wh_ctx* ctx, const std::string& slot, size_t bytes, void*
 
 extern "C" {
 
-int wh_version(void) { return 101; }
+int wh_version(void) { return 102; }
 const char* wh_last_error(void) { return g_last_error.c_str(); }
 
 int wh_device_count(int* count) {

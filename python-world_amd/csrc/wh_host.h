@@ -32,6 +32,13 @@ struct wh_ctx {
     int next_stage = 0;
   };
   std::map<std::string, Persist> persist;
+  // what the last wh_synthesis_timebase left in this context's workspace (wh_synthesis_render of ANY context reads it)
+  struct TimeBase {
+    bool valid = false;
+    int n_utt = 0;
+    int64_t pulse_cap = 0, ny_tot = 0, frames = 0;
+    size_t o_vuv = 0, o_pt = 0, o_pi = 0, o_ps = 0, o_pn = 0, o_pc = 0, o_pb = 0, o_pf = 0, o_pw = 0, o_pu = 0;
+  } timebase;
   // optional per-kernel timing (HIP events on the launch stream), see wh_profile_*
   bool prof = false;
   std::vector<hipEvent_t> prof_events;    // pool, two per record

@@ -90,16 +90,30 @@ __device__ __forceinline__ double lerp_on(const double* __restrict__ tp, const d
   return slope * (t - tp[il]) + v[il];
 }
 
+// f0_low_limit > 0: f0 is the F0 stage's output and is read as World.encode leaves it after CheapTrick (unvoiced or
+// below 3 fs / (fft - 3) -> 500 Hz, cheaptrick.py:26-27,32-33) and D4C (unvoiced -> 0, d4c.py:32): the time base can
+// then be computed while those two kernels are still running.
 __global__ __launch_bounds__(256) void prep_kernel(const SynUtt* __restrict__ meta, const double* __restrict__ tp,
                                                    const double* __restrict__ f0, const double* __restrict__ vuv,
-                                                   double fs, double* __restrict__ phase, uint8_t* __restrict__ vuv_s) {
+                                                   double fs, double f0_low_limit, double* __restrict__ phase,
+                                                   uint8_t* __restrict__ vuv_s) {
   const SynUtt m = meta[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= m.ny) return;
   const double t = m.t0 + (double)i * m.dt;
   const double* tpu = tp + m.f_off;
   const int64_t ih = lerp_segment(tpu, m.nf, t);  // one search serves both interpolants
-  const double f_raw = lerp_on(tpu, f0 + m.f_off, ih, t);
+  double f_raw;
+  if (f0_low_limit > 0.0) {
+    const double* fu = f0 + m.f_off;
+    const double* vu = vuv + m.f_off;
+    auto final_f0 = [&](int64_t k) { return vu[k] == 0.0 ? 0.0 : (fu[k] < f0_low_limit ? 500.0 : fu[k]); };
+    const int64_t il = ih - 1;
+    const double slope = (final_f0(ih) - final_f0(il)) / (tpu[ih] - tpu[il]);
+    f_raw = slope * (t - tpu[il]) + final_f0(il);
+  } else {
+    f_raw = lerp_on(tpu, f0 + m.f_off, ih, t);
+  }
   const bool v = lerp_on(tpu, vuv + m.f_off, ih, t) > 0.5;
   double fi = f_raw * (v ? 1.0 : 0.0);
   if (fi == 0.0) fi = fi + 500.0;  // default_f0, synthesis.py:126
@@ -1245,10 +1259,8 @@ template <int N>
 int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynUtt* d_meta, const double* tp,
                 const double* spec, const double* ap, double fs, const double* p_time, const int64_t* p_idx,
                 const double* p_shift, const int64_t* p_noff, const int32_t* p_count, const int64_t* p_base,
-                const uint8_t* vuv_s, const double* noise, uint64_t seed, double* y, int64_t* p_frames,
-                double* p_weight, int32_t* p_utt) {
-  { wh::KernelTimer _kt(ctx, st, "pulse_frames_kernel"); hipLaunchKernelGGL(pulse_frames_kernel, dim3((unsigned)((pcap_max + 255) / 256), B), dim3(256), 0, st, d_meta, tp, p_time, p_count, p_base, p_frames, p_weight, p_utt); }
-  WH_LAUNCH_CHECK("pulse_frames_kernel");
+                const uint8_t* vuv_s, const double* noise, uint64_t seed, double* y, const int64_t* p_frames,
+                const double* p_weight, const int32_t* p_utt) {
   std::vector<double> dc(N);
   double sum = 0.0;
   for (int n = 0; n < N; ++n) {  // hanning(N+2)[1:-1] normalised (synthesis.py:57-58)
@@ -1431,25 +1443,18 @@ int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, const 
 
 }  // namespace
 
-extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,
-                            const double* vuv, const double* spectrogram, const double* aperiodicity, double fs,
-                            int fft_size, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
-                            int64_t pulse_cap, const double* noise, const int64_t* h_noise_off, uint64_t seed, double* y,
-                            int32_t* pulse_count_out) {
-  if (!ctx || !b || !tp || !f0 || !vuv || !spectrogram || !aperiodicity || !h_y_off || !h_t0 || !h_dt || !y)
-    return wh::fail_msg("wh_synthesis", "null argument");
-  WH_ENTER(ctx);
-  if (noise && !h_noise_off) return wh::fail_msg("wh_synthesis", "noise given without h_noise_off");
-  if (pulse_cap < 1) return wh::fail_msg("wh_synthesis", "pulse_cap must be >= 1");
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+int fill_syn_meta(const char* who, const wh_batch* b, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
+                  int64_t pulse_cap, const double* noise, const int64_t* h_noise_off, std::vector<SynUtt>& meta,
+                  int64_t* max_ny) {
   const int B = b->n_utt;
-  std::vector<SynUtt> meta(B);
-  int64_t max_ny = 0;
+  meta.resize(B);
+  *max_ny = 0;
   for (int u = 0; u < B; ++u) {
     SynUtt& m = meta[u];
     m.f_off = b->h_frame_off[u];
     m.nf = b->h_frame_off[u + 1] - b->h_frame_off[u];
-    if (m.nf < 2) return wh::fail_msg("wh_synthesis", "an utterance has fewer than 2 frames");
+    if (m.nf < 2) return wh::fail_msg(who, "an utterance has fewer than 2 frames");
     m.y_off = h_y_off[u];
     m.ny = h_y_off[u + 1] - h_y_off[u];
     m.p_off = (int64_t)u * pulse_cap;
@@ -1458,8 +1463,27 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
     m.noise_len = noise ? h_noise_off[u + 1] - h_noise_off[u] : -1;
     m.t0 = h_t0[u];
     m.dt = h_dt[u];
-    max_ny = std::max(max_ny, m.ny);
+    *max_ny = std::max(*max_ny, m.ny);
   }
+  return 0;
+}
+}  // namespace
+
+// Time base of synthesis(): everything that depends on tp / f0 / vuv alone (synthesis.py:118-140, 144-152) — phase
+// increments, the exact cumulative phase, pulse positions and fractional shifts, noise offsets, per-pulse frame pairs.
+// The results stay in ctx's workspace (ctx->timebase records where) until another call lays the workspace out again.
+extern "C" int wh_synthesis_timebase(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,
+                                     const double* vuv, double fs, const int64_t* h_y_off, const double* h_t0,
+                                     const double* h_dt, int64_t pulse_cap, double f0_low_limit) {
+  if (!ctx || !b || !tp || !f0 || !vuv || !h_y_off || !h_t0 || !h_dt)
+    return wh::fail_msg("wh_synthesis_timebase", "null argument");
+  WH_ENTER(ctx);
+  if (pulse_cap < 1) return wh::fail_msg("wh_synthesis_timebase", "pulse_cap must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = b->n_utt;
+  std::vector<SynUtt> meta;
+  int64_t max_ny = 0;
+  if (int rc = fill_syn_meta("wh_synthesis_timebase", b, h_y_off, h_t0, h_dt, pulse_cap, nullptr, nullptr, meta, &max_ny)) return rc;
   const int64_t ny_tot = h_y_off[B];
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
@@ -1476,6 +1500,7 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   const size_t o_pw = off; off += al(sizeof(double) * B * pulse_cap);
   const size_t o_pu = off; off += al(sizeof(int32_t) * B * pulse_cap);
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
+  ctx->timebase.valid = false;
   char* ws = reinterpret_cast<char*>(ctx->ws);
   SynUtt* d_meta = nullptr;
   double* d_phase = reinterpret_cast<double*>(ws + o_phase);
@@ -1485,30 +1510,90 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   int64_t* d_pi = reinterpret_cast<int64_t*>(ws + o_pi);
   double* d_ps = reinterpret_cast<double*>(ws + o_ps);
   int64_t* d_pn = reinterpret_cast<int64_t*>(ws + o_pn);
-  int64_t* d_pf = reinterpret_cast<int64_t*>(ws + o_pf);
-  double* d_pw = reinterpret_cast<double*>(ws + o_pw);
-  int32_t* d_pu = reinterpret_cast<int32_t*>(ws + o_pu);
   int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
-  if (int rc = wh::persistent_upload(ctx, st, "syn.meta", meta, &d_meta)) return rc;
-  WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
+  if (int rc = wh::persistent_upload(ctx, st, "syn.tbmeta", meta, &d_meta)) return rc;
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
-                     d_phase, d_vuv); }
+                     f0_low_limit, d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
   if (int rc = exact_cumsum_segments(ctx, st, d_phase, h_y_off, B)) return rc;
   if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ws + o_px)) return rc;
   { wh::KernelTimer _kt(ctx, st, "pulse_base_kernel"); hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb); }
   WH_LAUNCH_CHECK("pulse_base_kernel");
+  { wh::KernelTimer _kt(ctx, st, "pulse_frames_kernel"); hipLaunchKernelGGL(pulse_frames_kernel, dim3((unsigned)((pulse_cap + 255) / 256), B), dim3(256), 0, st, d_meta, tp, d_pt, d_pc, d_pb,
+                     reinterpret_cast<int64_t*>(ws + o_pf), reinterpret_cast<double*>(ws + o_pw), reinterpret_cast<int32_t*>(ws + o_pu)); }
+  WH_LAUNCH_CHECK("pulse_frames_kernel");
+  wh_ctx::TimeBase& t = ctx->timebase;
+  t.valid = true;
+  t.n_utt = B;
+  t.pulse_cap = pulse_cap;
+  t.ny_tot = ny_tot;
+  t.frames = b->total_frames;
+  t.o_vuv = o_vuv; t.o_pt = o_pt; t.o_pi = o_pi; t.o_ps = o_ps; t.o_pn = o_pn; t.o_pc = o_pc; t.o_pb = o_pb;
+  t.o_pf = o_pf; t.o_pw = o_pw; t.o_pu = o_pu;
+  return 0;
+}
+
+// The spectral part: one response per pulse of the time base held by `timebase_ctx` (this context or another one of the
+// same device), overlap-added into y.  Stream order (or an event the caller waits on) must put it behind that time base.
+extern "C" int wh_synthesis_render(wh_ctx* ctx, void* stream, const wh_batch* b, const wh_ctx* timebase_ctx,
+                                   const double* tp, const double* spectrogram, const double* aperiodicity, double fs,
+                                   int fft_size, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
+                                   int64_t pulse_cap, const double* noise, const int64_t* h_noise_off, uint64_t seed,
+                                   double* y, int32_t* pulse_count_out) {
+  if (!ctx || !b || !timebase_ctx || !tp || !spectrogram || !aperiodicity || !h_y_off || !h_t0 || !h_dt || !y)
+    return wh::fail_msg("wh_synthesis_render", "null argument");
+  WH_ENTER(ctx);
+  if (noise && !h_noise_off) return wh::fail_msg("wh_synthesis_render", "noise given without h_noise_off");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = b->n_utt;
+  const wh_ctx::TimeBase& t = timebase_ctx->timebase;
+  if (!t.valid || t.n_utt != B || t.pulse_cap != pulse_cap || t.ny_tot != h_y_off[B] || t.frames != b->total_frames ||
+      timebase_ctx->device != ctx->device)
+    return wh::fail_msg("wh_synthesis_render", "no matching time base in timebase_ctx (run wh_synthesis_timebase on it "
+                                               "with the same batch, lengths and pulse_cap, and nothing else since)");
+  std::vector<SynUtt> meta;
+  int64_t max_ny = 0;
+  if (int rc = fill_syn_meta("wh_synthesis_render", b, h_y_off, h_t0, h_dt, pulse_cap, noise, h_noise_off, meta, &max_ny)) return rc;
+  const char* ws = reinterpret_cast<const char*>(timebase_ctx->ws);
+  SynUtt* d_meta = nullptr;
+  if (int rc = wh::persistent_upload(ctx, st, "syn.meta", meta, &d_meta)) return rc;
+  WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * t.ny_tot, st));
+  const uint8_t* d_vuv = reinterpret_cast<const uint8_t*>(ws + t.o_vuv);
+  const int64_t* d_pb = reinterpret_cast<const int64_t*>(ws + t.o_pb);
+  const double* d_pt = reinterpret_cast<const double*>(ws + t.o_pt);
+  const int64_t* d_pi = reinterpret_cast<const int64_t*>(ws + t.o_pi);
+  const double* d_ps = reinterpret_cast<const double*>(ws + t.o_ps);
+  const int64_t* d_pn = reinterpret_cast<const int64_t*>(ws + t.o_pn);
+  const int64_t* d_pf = reinterpret_cast<const int64_t*>(ws + t.o_pf);
+  const double* d_pw = reinterpret_cast<const double*>(ws + t.o_pw);
+  const int32_t* d_pu = reinterpret_cast<const int32_t*>(ws + t.o_pu);
+  const int32_t* d_pc = reinterpret_cast<const int32_t*>(ws + t.o_pc);
   int rc;
   switch (fft_size) {
     case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
     case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
     case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
     case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
-    default: return wh::fail_msg("wh_synthesis", "fft_size must be a power of two in [512, 4096]");
+    default: return wh::fail_msg("wh_synthesis_render", "fft_size must be a power of two in [512, 4096]");
   }
   if (rc) return rc;
   if (pulse_count_out) WH_CHECK(hipMemcpyAsync(pulse_count_out, d_pc, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st));
   return 0;
+}
+
+extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,
+                            const double* vuv, const double* spectrogram, const double* aperiodicity, double fs,
+                            int fft_size, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
+                            int64_t pulse_cap, const double* noise, const int64_t* h_noise_off, uint64_t seed, double* y,
+                            int32_t* pulse_count_out) {
+  if (!ctx || !b || !tp || !f0 || !vuv || !spectrogram || !aperiodicity || !h_y_off || !h_t0 || !h_dt || !y)
+    return wh::fail_msg("wh_synthesis", "null argument");
+  if (noise && !h_noise_off) return wh::fail_msg("wh_synthesis", "noise given without h_noise_off");
+  if (fft_size != 512 && fft_size != 1024 && fft_size != 2048 && fft_size != 4096)
+    return wh::fail_msg("wh_synthesis", "fft_size must be a power of two in [512, 4096]");
+  if (int rc = wh_synthesis_timebase(ctx, stream, b, tp, f0, vuv, fs, h_y_off, h_t0, h_dt, pulse_cap, 0.0)) return rc;
+  return wh_synthesis_render(ctx, stream, b, ctx, tp, spectrogram, aperiodicity, fs, fft_size, h_y_off, h_t0, h_dt, pulse_cap,
+                             noise, h_noise_off, seed, y, pulse_count_out);
 }
 
 // ---- peak normalisation of decode(): y /= max|y| where it exceeds 1 (world/main.py:209-212), per utterance ----
@@ -1636,8 +1721,9 @@ extern "C" int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, c
   int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
   if (int rc = wh::persistent_upload(ctx, st, "syn.meta", meta, &d_meta)) return rc;
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs,
-                     d_phase, d_vuv); }
+                     0.0, d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
+  ctx->timebase.valid = false;  // (this call lays the workspace out its own way)
   if (int rc = exact_cumsum_segments(ctx, st, d_phase, h_y_off, B)) return rc;
   if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, reinterpret_cast<double*>(ws + o_pt), d_pi,
                              reinterpret_cast<double*>(ws + o_ps), d_pn, d_pc, ws + o_px)) return rc;
@@ -1726,7 +1812,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   if (int rc = wh::persistent_upload(ctx, st, "syn.meta", meta, &d_meta)) return rc;
   if (int rc = wh::persistent_upload(ctx, st, "syn.req", rq, &d_rq)) return rc;
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
-  { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs, d_phase, d_vuv); }
+  { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs, 0.0, d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
   if (int rc = exact_cumsum_segments(ctx, st, d_phase, h_y_off, B)) return rc;
   if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ws + o_px)) return rc;

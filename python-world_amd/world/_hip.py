@@ -51,6 +51,9 @@ SIGNATURES = {
     "wh_stonemask": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _int, _vp]),
     "wh_synthesis": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp,
                             ctypes.c_uint64, _vp, _vp]),
+    "wh_synthesis_timebase": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, ctypes.c_int64, _dbl]),
+    "wh_synthesis_render": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp,
+                                   ctypes.c_uint64, _vp, _vp]),
     "wh_cumsum_exact": (_int, [_vp, _vp, _vp, _vp, _int]),
     "wh_peak_normalise": (_int, [_vp, _vp, _vp, _vp, _int]),
     "wh_synthesis_plan": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
@@ -234,7 +237,10 @@ class Runtime:
     def check_flags(self, where, allow=()):
         """take_flags() and raise WorldHipError for every condition that is set and not in ``allow``.  Returns the
         flag list (so that a caller can react to an allowed one, e.g. retry with a larger pulse capacity)."""
-        flags = self.take_flags()
+        return self.raise_for_flags(self.take_flags(), where, allow)
+
+    @staticmethod
+    def raise_for_flags(flags, where, allow=()):
         bad = [FLAG_MESSAGES.get(i, "device flag %d" % i) for i, v in enumerate(flags) if v and i not in allow]
         if bad:
             raise WorldHipError("%s: %s" % (where, "; ".join(bad)))

@@ -5,6 +5,8 @@ Utterances are concatenated into one waveform tensor; every stage runs ONE launc
 frames x utterances.  Results stay in HBM as torch tensors (frame-major spectrogram / aperiodicity);
 `BatchEncoding.to_dicts()` materialises reference-layout NumPy dicts on demand.
 """
+import os
+
 import numpy as np
 
 from . import _hip, _tables
@@ -13,7 +15,8 @@ from .d4c import d4c_device
 from .d4cRequiem import d4c_requiem_device
 from .dio import dio_device
 from .stonemask import stonemask_device
-from .synthesis import safe_pulse_cap, synthesis_device, time_axis_params
+from .synthesis import (default_pulse_cap, safe_pulse_cap, synthesis_device, synthesis_timebase_device,
+                        time_axis_params)
 
 
 class BatchEncoding:
@@ -35,6 +38,7 @@ class BatchEncoding:
         self.f0, self.vuv = f0, vuv
         self.spectrogram, self.aperiodicity = spectrogram, aperiodicity
         self.fft_size, self.is_requiem, self.frame_period = fft_size, is_requiem, frame_period
+        self._timebase = None  # synthesis time base computed ahead by WorldBatch.encode_device (see timebase_for)
 
     @classmethod
     def from_dicts(cls, rt, dats):
@@ -68,6 +72,22 @@ class BatchEncoding:
     @property
     def n_utt(self):
         return self.batch.n_utt
+
+    def _stamp(self):
+        """What a prefetched time base was computed from: the f0 / vuv / frame-time tensors and their in-place version
+        counters (scale_pitch, scale_duration and friends bump them; assigning a new tensor changes the pointer)."""
+        return tuple((t.data_ptr(), t._version) for t in (self.f0, self.vuv, self._tp))
+
+    def timebase_for(self, owner, pulse_cap):
+        """The prefetched time base if it still describes this encoding (same tensors, untouched since encode, made by
+        ``owner``'s latest prefetch, same pulse capacity — None: the default one the prefetch used), else None."""
+        tb = self._timebase
+        # the time-base context is shared by every WorldBatch of a (device, lane): its generation counts the prefetches
+        if tb is None or tb["rt"] is not owner._tb_rt or tb["generation"] != tb["rt"].timebase_generation:
+            return None
+        if tb["stamp"] != self._stamp() or (pulse_cap is not None and tb["pulse_cap"] != pulse_cap):
+            return None
+        return tb
 
     def scale_pitch(self, factor):
         """world/main.py:154-162, on the device."""
@@ -172,8 +192,44 @@ def _on_lane_stream(fn):
 
 
 class WorldBatch:
-    def __init__(self, device_index=None, lane=0):
+    def __init__(self, device_index=None, lane=0, prefetch_timebase=True):
         self.rt = _hip.Runtime.get(device_index, lane)
+        # encode_device computes the decode's time base (everything synthesis derives from f0 / vuv / frame times: the
+        # exact phase scan, pulse positions, per-pulse frame pairs) on a second stream and context while CheapTrick and
+        # D4C run on the first; decode_device then only renders.  Off: decode computes it in line.
+        self.prefetch_timebase = prefetch_timebase and os.environ.get("WH_PREFETCH_TIMEBASE", "1") != "0"
+        self._tb_rt = None
+
+    def _timebase_runtime(self):
+        if self._tb_rt is None:
+            self._tb_rt = _hip.Runtime.get(self.rt.index, 1000 + self.rt.lane)  # its own context, workspace and stream
+            if not hasattr(self._tb_rt, "timebase_generation"):
+                self._tb_rt.timebase_generation = 0
+        return self._tb_rt
+
+    def _prefetch_timebase(self, batch, tp_d, tp_host, f0_d, vuv_d, fs, ct_fft):
+        """Fork: the time base of the pulse-wise decode from the F0 stage's output, behind everything enqueued so far on
+        the lane's stream, on the time-base runtime's stream.  f0 is read through the rule that CheapTrick and D4C will
+        apply to it (wh_synthesis_timebase, f0_low_limit), from a private copy (those two kernels rewrite f0 in place)."""
+        torch = self.rt.torch
+        tb = self._timebase_runtime()
+        fo = batch.frame_off
+        geo = [time_axis_params(tp_host[int(fo[u]):int(fo[u + 1])], fs) for u in range(batch.n_utt)]
+        ny = [g[0] for g in geo]
+        cap = default_pulse_cap(ny)
+        f0_copy = f0_d.clone()
+        main = torch.cuda.current_stream(self.rt.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(tb.own_stream):
+            tb.own_stream.wait_event(ready)
+            synthesis_timebase_device(tb, batch, tp_d, f0_copy, vuv_d, fs, ny, [g[1] for g in geo], [g[2] for g in geo],
+                                      cap, f0_low_limit=fs * 3.0 / (ct_fft - 3.0))
+            done = torch.cuda.Event()
+            done.record(tb.own_stream)
+        tb.timebase_generation += 1
+        return {"generation": tb.timebase_generation, "rt": tb, "done": done, "geo": geo, "pulse_cap": cap,
+                "keep": (f0_copy,), "stamp": None}
 
     @_on_lane_stream
     def upload(self, xs, fs, frame_period=5, swipe_grid=False):
@@ -225,16 +281,23 @@ class WorldBatch:
         if f0_done is not None:
             f0_done()
         ct_fft = int(fft_size) if fft_size is not None else default_fft_size(fs)
+        tp_host = batch.tp_host if getattr(batch, "tp_d", None) is tp_d else None
+        timebase = None
+        if self.prefetch_timebase and not is_requiem and tp_host is not None:
+            timebase = self._prefetch_timebase(batch, tp_d, tp_host, f0_d, vuv_d, fs, ct_fft)
         spec_d, _ = cheaptrick_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, ct_fft)
         if is_requiem:
             ap_d = d4c_requiem_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, fft_size)
         else:
             ap_d, _ = d4c_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, ct_fft)
-        tp_host = batch.tp_host if getattr(batch, "tp_d", None) is tp_d else None
         if check:
             rt.check_flags("encode_device")
-        return BatchEncoding(rt, batch, fs, tp_d.clone(), f0_d, vuv_d, spec_d, ap_d, ct_fft, is_requiem, frame_period,
-                             tp_host=None if tp_host is None else tp_host.copy())
+        enc = BatchEncoding(rt, batch, fs, tp_d.clone(), f0_d, vuv_d, spec_d, ap_d, ct_fft, is_requiem, frame_period,
+                            tp_host=None if tp_host is None else tp_host.copy())
+        if timebase is not None:
+            timebase["stamp"] = enc._stamp()
+            enc._timebase = timebase
+        return enc
 
     @_on_lane_stream
     def refill_from_pinned(self, x_d, x_pin):
@@ -294,7 +357,10 @@ class WorldBatch:
     def check(self, where="WorldBatch"):
         """Read-and-clear the device condition flags of this lane; raises WorldHipError if any is set."""
         with self.rt.on_stream():
-            return self.rt.check_flags(where)
+            flags = self.rt.take_flags()
+            if self._tb_rt is not None:  # conditions raised by a prefetched time base
+                flags = [a | b for a, b in zip(flags, self._tb_rt.take_flags())]
+            return self.rt.raise_for_flags(flags, where)
 
     def encode(self, xs, fs, **kw):
         batch, x_d, tp_d = self.upload(xs, fs, kw.get('frame_period', 5), swipe_grid=kw.get('f0_method') == 'swipe')
@@ -344,8 +410,14 @@ class WorldBatch:
         asynchronous; call ``WorldBatch.check()`` before trusting the audio."""
         rt = self.rt
         fo = enc.batch.frame_off
-        tp_h = enc.host_times()
-        geo = [time_axis_params(tp_h[int(fo[u]):int(fo[u + 1])], enc.fs) for u in range(enc.n_utt)]
+        tb = None
+        if not enc.is_requiem:
+            tb = enc.timebase_for(self, pulse_cap)
+        if tb is not None:
+            geo = tb["geo"]
+        else:
+            tp_h = enc.host_times()
+            geo = [time_axis_params(tp_h[int(fo[u]):int(fo[u + 1])], enc.fs) for u in range(enc.n_utt)]
         ny = [g[0] for g in geo]
         noise_d = noise_off = None
         if noise is not None and not enc.is_requiem:
@@ -357,16 +429,23 @@ class WorldBatch:
                 from .synthesisRequiem import synthesis_requiem_device
                 y, y_off = synthesis_requiem_device(rt, enc, ny, geo, seeds=seeds, cursor=cursor, pulse_cap=cap)
             else:
+                use_tb = tb is not None and (cap is None or cap == tb["pulse_cap"])
+                if use_tb:  # join: the render goes behind the prefetched time base
+                    rt.torch.cuda.current_stream(rt.device).wait_event(tb["done"])
                 y, y_off = synthesis_device(rt, enc.batch, enc.temporal_positions, enc.f0, enc.vuv, enc.spectrogram,
                                             enc.aperiodicity, enc.fs, enc.fft_size, ny, [g[1] for g in geo],
                                             [g[2] for g in geo], noise_d=noise_d, noise_off=noise_off, seed=seed,
-                                            pulse_cap=cap)
+                                            pulse_cap=tb["pulse_cap"] if use_tb else cap,
+                                            timebase_rt=tb["rt"] if use_tb else None)
             self._peak_normalise(y, y_off)
             return y, y_off
 
         y, y_off = run(pulse_cap)
         if check:
-            flags = rt.check_flags("decode_device", allow=() if pulse_cap is not None else (_hip.FLAG_PULSE_OVERFLOW,))
+            flags = rt.take_flags()
+            if tb is not None:  # conditions raised by the time-base kernels live in that context's flags
+                flags = [a | b for a, b in zip(flags, tb["rt"].take_flags())]
+            rt.raise_for_flags(flags, "decode_device", allow=() if pulse_cap is not None else (_hip.FLAG_PULSE_OVERFLOW,))
             if flags[_hip.FLAG_PULSE_OVERFLOW]:
                 y, y_off = run(safe_pulse_cap(ny))
                 rt.check_flags("decode_device")

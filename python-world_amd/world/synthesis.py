@@ -34,9 +34,25 @@ def safe_pulse_cap(ny_list):
     return int(max(ny_list)) // 2 + 16
 
 
+def synthesis_timebase_device(rt_tb, batch, tp_d, f0_d, vuv_d, fs, ny_list, t0_list, dt_list, pulse_cap, f0_low_limit=0.0):
+    """The half of synthesis() that depends on the time base alone (wh_synthesis_timebase), on ``rt_tb``'s context and
+    stream; its results stay in that context's workspace for ``synthesis_device(..., timebase_rt=rt_tb)``.
+    ``f0_low_limit`` > 0: ``f0_d`` is the F0 stage's output, read as encode() leaves it after CheapTrick and D4C."""
+    y_off = np.concatenate([[0], np.cumsum(ny_list)]).astype(np.int64)
+    t0 = np.ascontiguousarray(t0_list, dtype=np.float64)
+    dt = np.ascontiguousarray(dt_list, dtype=np.float64)
+    vp = ctypes.c_void_p
+    _hip.check(rt_tb.lib.wh_synthesis_timebase(rt_tb.ctx, rt_tb.stream(), batch.handle, rt_tb.ptr(tp_d), rt_tb.ptr(f0_d),
+                                               rt_tb.ptr(vuv_d), float(fs), y_off.ctypes.data_as(vp),
+                                               t0.ctypes.data_as(vp), dt.ctypes.data_as(vp), int(pulse_cap),
+                                               float(f0_low_limit)))
+
+
 def synthesis_device(rt, batch, tp_d, f0_d, vuv_d, spec_d, ap_d, fs, fft_size, ny_list, t0_list, dt_list,
-                     noise_d=None, noise_off=None, seed=0, pulse_cap=None):
-    """Device-resident core.  spec_d/ap_d are frame-major [F][K].  Returns the concatenated waveform tensor."""
+                     noise_d=None, noise_off=None, seed=0, pulse_cap=None, timebase_rt=None):
+    """Device-resident core.  spec_d/ap_d are frame-major [F][K].  Returns the concatenated waveform tensor.
+    ``timebase_rt``: a runtime whose context already holds this batch's time base (``synthesis_timebase_device`` with
+    the same lengths and pulse_cap); only the spectral half (wh_synthesis_render) runs then."""
     y_off = np.concatenate([[0], np.cumsum(ny_list)]).astype(np.int64)
     t0 = np.ascontiguousarray(t0_list, dtype=np.float64)
     dt = np.ascontiguousarray(dt_list, dtype=np.float64)
@@ -47,11 +63,17 @@ def synthesis_device(rt, batch, tp_d, f0_d, vuv_d, spec_d, ap_d, fs, fft_size, n
     noff = None
     if noise_d is not None:
         noff = np.ascontiguousarray(noise_off, dtype=np.int64)
+    noff_p = noff.ctypes.data_as(vp) if noff is not None else vp(None)
+    if timebase_rt is not None:
+        _hip.check(rt.lib.wh_synthesis_render(rt.ctx, rt.stream(), batch.handle, timebase_rt.ctx, rt.ptr(tp_d),
+                                              rt.ptr(spec_d), rt.ptr(ap_d), float(fs), int(fft_size),
+                                              y_off.ctypes.data_as(vp), t0.ctypes.data_as(vp), dt.ctypes.data_as(vp),
+                                              int(pulse_cap), rt.ptr(noise_d), noff_p, int(seed), rt.ptr(y), vp(None)))
+        return y, y_off
     _hip.check(rt.lib.wh_synthesis(rt.ctx, rt.stream(), batch.handle, rt.ptr(tp_d), rt.ptr(f0_d), rt.ptr(vuv_d),
                                    rt.ptr(spec_d), rt.ptr(ap_d), float(fs), int(fft_size), y_off.ctypes.data_as(vp),
                                    t0.ctypes.data_as(vp), dt.ctypes.data_as(vp), int(pulse_cap), rt.ptr(noise_d),
-                                   noff.ctypes.data_as(vp) if noff is not None else vp(None), int(seed), rt.ptr(y),
-                                   vp(None)))
+                                   noff_p, int(seed), rt.ptr(y), vp(None)))
     return y, y_off
 
 

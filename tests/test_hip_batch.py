@@ -139,3 +139,48 @@ def test_download_async_double_buffer():
         for a, b in zip(r, g):
             assert np.array_equal(a, b)
     assert not np.array_equal(got[0][2], got[1][2])  # different noise seeds: the slots really carried different steps
+
+
+def test_prefetched_time_base_equals_inline_decode():
+    """encode_device computes the decode's time base on a second stream from the F0 stage's output (read through the
+    rule CheapTrick / D4C apply to f0); decode_device then only renders.  Same audio as the in-line decode (up to the
+    order of the overlap-add atomics); a modifier drops the prefetch; a second batch invalidates the first one's."""
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+
+    fs = 16000
+    xs = [synth_utterance(80 + i, fs, 0.6 + 0.2 * i) for i in range(3)]
+    for method in ("dio", "harvest"):
+        a = WorldBatch(prefetch_timebase=True)
+        b = WorldBatch(prefetch_timebase=False)
+        ea = a.encode(xs, fs, f0_method=method)
+        eb = b.encode(xs, fs, f0_method=method)
+        assert ea._timebase is not None and eb._timebase is None
+        assert ea.timebase_for(a, None) is not None
+        for t in ("f0", "vuv", "spectrogram", "aperiodicity"):
+            assert np.array_equal(getattr(ea, t).cpu().numpy(), getattr(eb, t).cpu().numpy())
+        ya, offa = a.decode_device(ea, seed=4)
+        yb, offb = b.decode_device(eb, seed=4)
+        assert np.array_equal(offa, offb)
+        ya, yb = ya.cpu().numpy(), yb.cpu().numpy()
+        assert np.max(np.abs(ya - yb)) <= 1e-15 * max(1.0, np.max(np.abs(yb)))
+        # decoding again re-uses the same time base; host noise goes through it too
+        rng = np.random.RandomState(1)
+        noise = [rng.randn(2 * len(x)) for x in xs]
+        y2 = a.decode_device(ea, noise=noise)[0].cpu().numpy()
+        y3 = b.decode_device(eb, noise=noise)[0].cpu().numpy()
+        assert np.max(np.abs(y2 - y3)) <= 1e-15 * max(1.0, np.max(np.abs(y3)))
+        # a modifier invalidates it (the time base depends on f0 and the frame times)
+        ea.scale_pitch(1.5)
+        eb.scale_pitch(1.5)
+        assert ea.timebase_for(a, None) is None
+        y4 = a.decode_device(ea, seed=4)[0].cpu().numpy()
+        y5 = b.decode_device(eb, seed=4)[0].cpu().numpy()
+        assert np.max(np.abs(y4 - y5)) <= 1e-15 * max(1.0, np.max(np.abs(y5)))
+        # another encode on the same WorldBatch takes the time-base context over
+        e1 = a.encode(xs, fs, f0_method=method)
+        e2 = a.encode(xs[:2], fs, f0_method=method)
+        assert e1.timebase_for(a, None) is None and e2.timebase_for(a, None) is not None
+        y6 = a.decode_device(e1, seed=4)[0].cpu().numpy()  # falls back to the in-line time base
+        assert np.max(np.abs(y6 - yb)) <= 1e-15 * max(1.0, np.max(np.abs(yb)))
+        assert a.rt.take_flags() == [0] * 16

@@ -57,7 +57,11 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
   // per-frame constants are inverted once and multiplied in (an FP64 divide is ~12 dependent instructions; the
   // results move by an ulp)
   const double inv_span = 1.0 / fs / 1.5;
-  double s_w2 = 0.0;
+  // One walk over the window's samples and ONE block reduction: the L2 norm of the window, the mean of x*w and the
+  // mean of w.  The reference normalises the window first and takes the means of the normalised products
+  // (cheaptrick.py:84-95); the DC ratio mean(x w') / mean(w') is that of the unnormalised sums — the norm and the 1/L
+  // cancel — so the second reduction and the pass that rescaled the stored window are gone.
+  double s_w2 = 0.0, s_sw = 0.0, s_w = 0.0;
   {
     // cos(pi*f0*t_j) for this thread's samples j = tid, tid + FT, ...: one sincospi for the first, a fixed rotation by
     // FT samples after that (at most N/FT + 1 steps: error growth ~1e-15) instead of a cospi per sample
@@ -66,33 +70,23 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
     if (L > FT) sincospi(((double)FT * inv_span) * f0, &rs, &rc);  // frame-uniform
     for (int j = threadIdx.x; j < L; j += FT) {
       const double w = 0.5 * cs + 0.5;
+      const double seg = wh::sample_clamped(xu, xn, centre + (j - hwl));
       s_w2 += w * w;
+      s_sw += seg * w;  // np.fft crops rows longer than N, the means still see them (Q7)
+      s_w += w;
       if (j < N) zr[j] = w;
       const double cn = cs * rc - sn * rs;
       sn = sn * rc + cs * rs;
       cs = cn;
     }
   }
-  const double norm = sqrt(wh::block_sum<FT>(s_w2, scratch));
-  const double inv_norm = 1.0 / norm;
-  double s_sw = 0.0, s_w = 0.0;
-  for (int j = threadIdx.x; j < L; j += FT) {
-    const double seg = wh::sample_clamped(xu, xn, centre + (j - hwl));
-    // np.fft crops rows longer than N, the means still see them (Q7)
-    double w = j < N ? zr[j] : 0.5 * cospi(((double)(j - hwl) * inv_span) * f0) + 0.5;
-    w = w * inv_norm;
-    s_sw += seg * w;
-    s_w += w;
-    if (j < N) zr[j] = w;
-  }
-  wh::block_sum2<FT>(s_sw, s_w, scratch);
-  const double mean_sw = s_sw / (double)L;
-  const double mean_w = s_w / (double)L;
-  const double dc = mean_sw / mean_w;
+  wh::block_sum3<FT>(s_w2, s_sw, s_w, scratch);
+  const double inv_norm = 1.0 / sqrt(s_w2);
+  const double dc = s_sw / s_w;
   for (int j = threadIdx.x; j < N; j += FT) {
     double v = 0.0;
     if (j < L) {
-      const double w = zr[j];
+      const double w = zr[j] * inv_norm;
       v = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w - w * dc;
     }
     zr[j] = v;
@@ -156,16 +150,36 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
       cs = cn;
     }
   }
-  wh::rfft_lds<N, FT>(zb, tw_base);
-  for (int k = threadIdx.x; k < K; k += FT) {
-    const double l = aux[k];
-    double2 z = zb[k];
-    z.x = z.x * l;
-    z.y = z.y * l;
-    zb[k] = z;
+  // forward transform of the mirrored log spectrum (real and even, so its spectrum is real), lifter, inverse
+  // transform: between the two half-size complex FFTs a thread keeps its pair of bins (k, N/2 - k) in registers through
+  // the forward post-pass (real parts only), the product with the lifters and the pre-pass of the inverse real
+  // transform — one pass over the half spectrum instead of three (wh::rfft_lds / multiply / wh::irfft_lds).
+  {
+    constexpr int M = N / 2;
+    wh::fft_lds<M, false, FT>(zb, tw_base + M);  // (its barriers also complete the lifter table for the loop below)
+    const double2* __restrict__ wtw = tw_base + N;
+    for (int k = threadIdx.x; k <= M / 2; k += FT) {
+      const double2 a = zb[k], b = zb[M - k];
+      const double2 wk = wh::ldg2(wtw + k);
+      double x0, x1;  // Re X[k], Re X[M-k]
+      if (k == 0) {
+        x0 = a.x + a.y;
+        x1 = a.x - a.y;
+      } else {
+        const double er = 0.5 * (a.x + b.x), dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
+        const double tr = fma(wk.x, di, wk.y * dr);
+        x0 = er + tr;
+        x1 = er - tr;
+      }
+      const double A = x0 * aux[k], B = x1 * aux[M - k];
+      const double er = A + B, dr = A - B;
+      const double orr = dr * wk.x, oi = -(dr * wk.y);
+      zb[k] = make_double2(er - oi, orr);
+      if (k != 0) zb[M - k] = make_double2(er + oi, orr);
+    }
+    wh::sync<FT>();
+    wh::fft_lds<M, true, FT>(zb, tw_base + M);
   }
-  wh::sync<FT>();
-  wh::irfft_lds<N, FT>(zb, tw_base);
   double* o = spec_out + f * (int64_t)K;
   for (int k = threadIdx.x; k < K; k += FT) o[k] = exp(zr[k] * (1.0 / N));  // N is a power of two: exact
 }

@@ -94,17 +94,37 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
   wh::sync<FT>();
 
   // ---- power spectrum (cheaptrick.py:64-75): real FFT through an N/2-point complex transform -------
-  wh::rfft_lds<N, FT>(zb, tw_base);
-  if (ps_out) {
+  if (ps_out) {  // the caller wants the complex pitch-synchronous spectrum ('ps spectrogram'): materialise it
+    wh::rfft_lds<N, FT>(zb, tw_base);
     double2* o = ps_out + f * (int64_t)N;
     for (int k = threadIdx.x; k < N; k += FT) {
       const double2 z = zb[k <= N / 2 ? k : N - k];
       o[k] = k <= N / 2 ? z : make_double2(z.x, -z.y);
     }
-  }
-  for (int k = threadIdx.x; k < K; k += FT) {
-    const double2 z = zb[k];
-    aux[k] = z.x * z.x + z.y * z.y;
+    for (int k = threadIdx.x; k < K; k += FT) {
+      const double2 z = zb[k];
+      aux[k] = z.x * z.x + z.y * z.y;
+    }
+  } else {  // only its power is needed: the post-pass of the real transform goes straight to |X|^2 (no store of X)
+    constexpr int M = N / 2;
+    wh::fft_lds<M, false, FT>(zb, tw_base + M);
+    const double2* __restrict__ wtw = tw_base + N;
+    for (int k = threadIdx.x; k <= M / 2; k += FT) {
+      const double2 a = zb[k], b = zb[M - k];
+      if (k == 0) {
+        aux[0] = (a.x + a.y) * (a.x + a.y);
+        aux[M] = (a.x - a.y) * (a.x - a.y);
+      } else {
+        const double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);
+        const double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
+        const double2 wk = wh::ldg2(wtw + k);
+        const double tr = fma(wk.x, di, wk.y * dr);
+        const double ti = fma(wk.y, di, -(wk.x * dr));
+        const double xr = er + tr, xi = ei + ti, yr = er - tr, yi = ti - ei;
+        aux[k] = xr * xr + xi * xi;
+        aux[M - k] = yr * yr + yi * yi;
+      }
+    }
   }
   wh::sync<FT>();
   wh::low_band_replica<FT>(aux, zr, N, fs, f0, f0 + fs / N);

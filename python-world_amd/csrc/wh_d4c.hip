@@ -455,10 +455,11 @@ __global__ __launch_bounds__(ft_love(NLT)) void love_train_kernel(
 //       ballots (no atomic counter) and its members are ranked against each other (~11 on speech); equal values are
 //       interchangeable in a sum, so ties need no index rule.
 // Each thread then adds its own kept elements in a fixed order -> deterministic sums.
-// x[q] = value of element i = tid + q*FT (i < K) in the caller's registers.  work: >= 80 ints + K doubles of free
+// x[q], q < PER: the thread's share of the K values (bit q of `valid` set where the slot is used — any assignment of the
+// values to threads will do).  work: >= 80 ints + K doubles of free
 // LDS; scratch: 32 doubles.  Four barrier phases.
 template <int K, int FT, int PER>
-__device__ __forceinline__ void sum_smallest(const double (&x)[PER], int m, void* work, double* scratch,
+__device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned valid, int m, void* work, double* scratch,
                                              double* s_small, double* s_total) {
   constexpr int NW = FT / 64;
   // exponents per round.  On speech the K - m (~22) largest bins lie within 4 octaves of the maximum on average, 7 at
@@ -472,7 +473,7 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], int m, void
   double t = 0.0;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
-    const bool in = threadIdx.x + q * FT < K;
+    const bool in = (valid >> q) & 1u;  // slot q of this thread holds one of the K values
     key[q] = in ? (int)((__double_as_longlong(x[q]) >> 52) & 0x7FF) : -1;
     if (in) t += x[q];
     kmax = key[q] > kmax ? key[q] : kmax;
@@ -876,7 +877,6 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   // ---- band-wise aperiodicity (d4c.py:192-209) -----------------------------------------------
   const int boundary = lc.boundary;
   const int half = wlen / 2;
-  constexpr int PER = (K + FT - 1) / FT;
   for (int b = 0; b < nap; ++b) {
     const int centre = lc.centre[b];
     for (int j = threadIdx.x; j < N; j += FT) {
@@ -891,28 +891,53 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     }
     wh::sync<FT>();
     STAGE_MARK(12)
-#if WH_D4C_ABLATE != 6  // (timing experiment: no band transform)
-    wh::rfft_lds<N, FT, FT, d4c_rmaxr(N)>(buf, fresh_table(tw_base));
-#endif
-    STAGE_MARK(13)
-    double px[PER];
+    // real transform of the windowed segment = half-size complex transform of its sample pairs + post-pass; only
+    // |X[k]|^2 is needed, so the post-pass goes from the pair of bins (k, N/2 - k) straight to the two powers in the
+    // thread's registers (the selection below takes its values in any distribution over the threads)
+    constexpr int MB = N / 2;
+    constexpr int PJ = (MB / 2 + 1 + FT - 1) / FT;  // pair jobs per thread
+    double px[2 * PJ];
+    unsigned pvalid = 0;
+    {
+      const double2* twb = fresh_table(tw_base);
+      wh::fft_lds<MB, false, FT, FT, d4c_rmaxr(N)>(buf, twb + MB);
+      const double2* __restrict__ wpost = twb + N;
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const int k = threadIdx.x + q * FT;
-      px[q] = 0.0;
-      if (k < K) {
-        const double2 z = buf[k];
-        px[q] = z.x * z.x + z.y * z.y;
+      for (int i = 0; i < PJ; ++i) {
+        const int k = threadIdx.x + i * FT;
+        px[2 * i] = px[2 * i + 1] = 0.0;
+        if (k <= MB / 2) {
+          const double2 a = buf[k], b = buf[MB - k];
+          if (k == 0) {
+            px[0] = (a.x + a.y) * (a.x + a.y);
+            px[1] = (a.x - a.y) * (a.x - a.y);
+            pvalid |= 3u;
+          } else {
+            const double er = 0.5 * (a.x + b.x), ei = 0.5 * (a.y - b.y);
+            const double dr = 0.5 * (a.x - b.x), di = 0.5 * (a.y + b.y);
+            const double2 wk = wh::ldg2(wpost + k);
+            const double tr = fma(wk.x, di, wk.y * dr);
+            const double ti = fma(wk.y, di, -(wk.x * dr));
+            const double xr = er + tr, xi = ei + ti, yr = er - tr, yi = ti - ei;
+            px[2 * i] = xr * xr + xi * xi;
+            pvalid |= 1u << (2 * i);
+            if (k != MB - k) {  // (the middle bin pairs with itself)
+              px[2 * i + 1] = yr * yr + yi * yi;
+              pvalid |= 2u << (2 * i);
+            }
+          }
+        }
       }
     }
+    STAGE_MARK(13)
     wh::sync<FT>();  // the spectrum has been read: the lower part of the buffer becomes the selection's work area
     STAGE_MARK(9)
     double s_small, s_total;
 #if WH_D4C_ABLATE == 5  // (timing experiment: no rank selection)
     s_small = px[0];
-    s_total = px[1] + 1.0;
+    s_total = px[1] + 1.0 + (double)pvalid;
 #else
-    sum_smallest<K, FT, PER>(px, N / 2 - boundary, zr, scratch, &s_small, &s_total);
+    sum_smallest<K, FT, 2 * PJ>(px, pvalid, N / 2 - boundary, zr, scratch, &s_small, &s_total);
 #endif
     if (threadIdx.x == 0) band[b] = -10 * log10(s_small / s_total);
     wh::sync<FT>();

@@ -295,6 +295,9 @@ class WorldBatch:
         enc = BatchEncoding(rt, batch, fs, tp_d.clone(), f0_d, vuv_d, spec_d, ap_d, ct_fft, is_requiem, frame_period,
                             tp_host=None if tp_host is None else tp_host.copy())
         if timebase is not None:
+            # join: behind CheapTrick and D4C in stream order, so the overlap has already happened — and the fork is
+            # closed inside this call (a caller that captures encode_device alone in a graph gets a well-formed one)
+            rt.torch.cuda.current_stream(rt.device).wait_event(timebase["done"])
             timebase["stamp"] = enc._stamp()
             enc._timebase = timebase
         return enc

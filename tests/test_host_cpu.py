@@ -202,3 +202,50 @@ def test_refinement_windows_do_not_depend_on_the_frame_time():
             ref = np.cos(2 * math.pi * ((idx_raw - 1) / fs - t0) / wlit)
             tab = np.cos(math.pi * ((bt - 0.5 / fs) * (2.0 / wlit)))                           # wh_stonemask.hip, host table
             assert np.max(np.abs(tab - ref)) < 2e-11 * max(1.0, t0)  # measured: 1e-12 * t0
+
+
+def test_prefetched_time_base_validity_rules():
+    """BatchEncoding.timebase_for (host logic of the decode-time-base prefetch): valid only for the tensors it was
+    computed from, untouched (in-place version counters), for the shared time-base context's latest prefetch, and for
+    the same pulse capacity."""
+    import types
+
+    import torch
+
+    from world.batch import BatchEncoding
+
+    tb_rt = types.SimpleNamespace(timebase_generation=3)
+    owner = types.SimpleNamespace(_tb_rt=tb_rt)
+    other_owner = types.SimpleNamespace(_tb_rt=types.SimpleNamespace(timebase_generation=3))
+    nf = 5
+    enc = BatchEncoding(None, None, 16000, torch.arange(nf, dtype=torch.float64) * 0.005, torch.full((nf,), 100.0, dtype=torch.float64),
+                        torch.ones(nf, dtype=torch.float64), None, None, 1024, False, 5)
+    assert enc.timebase_for(owner, None) is None  # nothing prefetched
+    enc._timebase = {"generation": 3, "rt": tb_rt, "pulse_cap": 77, "stamp": enc._stamp()}
+    assert enc.timebase_for(owner, None) is enc._timebase
+    assert enc.timebase_for(owner, 77) is enc._timebase and enc.timebase_for(owner, 78) is None
+    assert enc.timebase_for(other_owner, None) is None       # another (device, lane)'s time-base context
+    tb_rt.timebase_generation = 4                              # a later prefetch took the context over
+    assert enc.timebase_for(owner, None) is None
+    tb_rt.timebase_generation = 3
+    enc.scale_pitch(1.5)                                       # in-place f0 *= factor bumps the version counter
+    assert enc.timebase_for(owner, None) is None
+    enc._timebase["stamp"] = enc._stamp()
+    assert enc.timebase_for(owner, None) is not None
+    enc.scale_duration(2.0)
+    assert enc.timebase_for(owner, None) is None
+    enc._timebase["stamp"] = enc._stamp()
+    enc.f0 = enc.f0.clone()                                    # a new tensor: another pointer
+    assert enc.timebase_for(owner, None) is None
+
+
+def test_table_tag_is_content_identity():
+    from world._hip import table_tag
+
+    a = np.arange(12.0).reshape(3, 4)
+    assert table_tag(a) == table_tag(a.copy()) and table_tag(a) != 0 and table_tag(a) % 2 == 1
+    assert table_tag(a) != table_tag(a.reshape(4, 3))          # same bytes, another shape
+    b = a.copy()
+    b[1, 2] += 1e-9
+    assert table_tag(a) != table_tag(b)
+    assert table_tag(a, b) != table_tag(b, a) and table_tag(a) < 2 ** 63

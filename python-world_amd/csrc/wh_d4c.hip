@@ -464,7 +464,7 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned va
   constexpr int NW = FT / 64;
   // exponents per round.  On speech the K - m (~22) largest bins lie within 4 octaves of the maximum on average, 7 at
   // most (measured on the oracle's spectra): one round of 8 almost always; the loop below slides on otherwise.
-  constexpr int WIN = 8;
+  constexpr int WIN = 8;  // (also the number of values of a 3-bit mantissa digit in the refinement below)
   int* cnts = reinterpret_cast<int*>(work);                     // [NW][WIN + 1]: counts per exponent, then the wave's top
   double* list = reinterpret_cast<double*>(cnts + NW * (WIN + 1) + (NW * (WIN + 1) & 1));
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -539,22 +539,81 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned va
     first = false;
   }
   // tbin < 0 cannot happen (every element has an exponent in [0, kmax]); guard anyway: drop nothing more
-  const int need = tbin >= 0 ? drop - above : 0;  // members of the threshold bin that belong to the large set
-  // compaction of the threshold bin: wave offset from the per-wave counts, lane offset from the ballots
-  {
-    int pos = wave_before;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const unsigned long long mk = __ballot(key[q] == tbin);
-      if (key[q] == tbin) list[pos + __popcll(mk & ((1ull << lane) - 1ull))] = x[q];
-      pos += __popcll(mk);
-    }
-  }
-  wh::sync<FT>();
+  int need = tbin >= 0 ? drop - above : 0;  // members of the threshold bin that belong to the large set
   double a = 0.0;
 #pragma unroll
   for (int q = 0; q < PER; ++q)
     if (key[q] >= 0 && key[q] < tbin) a += x[q];  // everything below the threshold bin is kept
+  // The members of the threshold bin are ranked against each other below, in_bin^2 / FT comparisons: fine for the ~11
+  // members a 2048-point band spectrum leaves there (22 bins dropped of 1025), not for the hundreds of a 4096-point one
+  // (65 of 2049: 41 % of the whole kernel at 48 kHz).  While the bin holds more than 32 values it is split by the next
+  // three mantissa bits — the same ballot counts, eight digits, one LDS hop — and only the digit that holds the
+  // threshold stays a candidate: larger digits are dropped whole, smaller ones kept whole.
+  unsigned cand = 0;  // bit q: slot q is a member of the current threshold set
+#pragma unroll
+  for (int q = 0; q < PER; ++q) cand |= (key[q] == tbin ? 1u : 0u) << q;
+  int shift = 52;
+  while (in_bin > 32 && shift >= 3) {  // (uniform)
+    shift -= 3;
+    int dig[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) dig[q] = ((cand >> q) & 1u) ? (int)((__double_as_longlong(x[q]) >> shift) & 7) : -1;
+    int mine[WIN];
+#pragma unroll
+    for (int e = 0; e < WIN; ++e) {  // e counts down from the largest digit: WIN == 8 digits
+      int c = 0;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) c += __popcll(__ballot(dig[q] == 7 - e));
+      mine[e] = c;
+    }
+    wh::sync<FT>();
+    if (lane < WIN) {
+      int c = 0;
+#pragma unroll
+      for (int e = 0; e < WIN; ++e) c = lane == e ? mine[e] : c;
+      cnts[w * (WIN + 1) + lane] = c;
+    }
+    wh::sync<FT>();
+    int run = 0, td = -1, bef = 0, tot_d = 0, run_at = 0;
+#pragma unroll
+    for (int e = 0; e < WIN; ++e) {
+      int tot = 0, before = 0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int c = cnts[i * (WIN + 1) + e];
+        before += i < w ? c : 0;
+        tot += c;
+      }
+      if (td < 0 && run + tot >= need) {
+        td = 7 - e;
+        run_at = run;
+        bef = before;
+        tot_d = tot;
+      }
+      run += tot;
+    }
+    // (td >= 0 always: the set holds at least `need` members)
+    need -= run_at;
+    wave_before = bef;
+    in_bin = tot_d;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      if (dig[q] >= 0 && dig[q] < td) a += x[q];  // below the threshold digit: kept
+      if (dig[q] != td) cand &= ~(1u << q);
+    }
+  }
+  // compaction of the threshold set: wave offset from the per-wave counts, lane offset from the ballots
+  {
+    int pos = wave_before;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const bool mem = (cand >> q) & 1u;
+      const unsigned long long mk = __ballot(mem);
+      if (mem) list[pos + __popcll(mk & ((1ull << lane) - 1ull))] = x[q];
+      pos += __popcll(mk);
+    }
+  }
+  wh::sync<FT>();
   // the threshold bin: list entry i is kept unless it is one of the `need` largest (ties: list order).  One entry
   // per thread, so the ranking costs in_bin LDS reads per thread whatever the distribution of the bin over threads.
   for (int i = threadIdx.x; i < in_bin; i += FT) {

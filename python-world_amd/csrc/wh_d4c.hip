@@ -513,18 +513,23 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned va
 #pragma unroll
       for (int i = 0; i < NW; ++i) gtop = cnts[i * (WIN + 1) + WIN] > gtop ? cnts[i * (WIN + 1) + WIN] : gtop;
     }
-    int run = above;
-#pragma unroll
-    for (int e = 0; e < WIN; ++e) {  // e: offset below the BLOCK's top
-      int tot = 0, before = 0;
+    // lane e sums the waves' counts of offset e (and what the waves in front of this one hold of it); the eight results
+    // come back through readlane as uniform values — 8 LDS reads in 8 lanes instead of 64 in every lane
+    int tot_l = 0, bef_l = 0;
+    if (lane < WIN) {
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
         // wave i counted exponent gtop - e at its own offset e - (gtop - top_i)
         const int sh = first ? gtop - cnts[i * (WIN + 1) + WIN] : 0;
-        const int c = e - sh >= 0 ? cnts[i * (WIN + 1) + (e - sh)] : 0;
-        before += i < w ? c : 0;
-        tot += c;
+        const int c = lane - sh >= 0 ? cnts[i * (WIN + 1) + (lane - sh)] : 0;
+        bef_l += i < w ? c : 0;
+        tot_l += c;
       }
+    }
+    int run = above;
+#pragma unroll
+    for (int e = 0; e < WIN; ++e) {  // e: offset below the BLOCK's top
+      const int tot = __builtin_amdgcn_readlane(tot_l, e), before = __builtin_amdgcn_readlane(bef_l, e);
       if (tbin < 0 && run + tot >= drop) {
         tbin = gtop - e;
         above = run;
@@ -574,16 +579,19 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned va
       cnts[w * (WIN + 1) + lane] = c;
     }
     wh::sync<FT>();
+    int tot_l = 0, bef_l = 0;
+    if (lane < WIN) {
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int c = cnts[i * (WIN + 1) + lane];
+        bef_l += i < w ? c : 0;
+        tot_l += c;
+      }
+    }
     int run = 0, td = -1, bef = 0, tot_d = 0, run_at = 0;
 #pragma unroll
     for (int e = 0; e < WIN; ++e) {
-      int tot = 0, before = 0;
-#pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        const int c = cnts[i * (WIN + 1) + e];
-        before += i < w ? c : 0;
-        tot += c;
-      }
+      const int tot = __builtin_amdgcn_readlane(tot_l, e), before = __builtin_amdgcn_readlane(bef_l, e);
       if (td < 0 && run + tot >= need) {
         td = 7 - e;
         run_at = run;

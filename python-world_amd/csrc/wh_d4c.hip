@@ -458,13 +458,70 @@ __global__ __launch_bounds__(ft_love(NLT)) void love_train_kernel(
 // x[q], q < PER: the thread's share of the K values (bit q of `valid` set where the slot is used — any assignment of the
 // values to threads will do).  work: >= 80 ints + K doubles of free
 // LDS; scratch: 32 doubles.  Four barrier phases.
+#ifndef WH_D4C_SEL_PACKED
+#define WH_D4C_SEL_PACKED 1
+#endif
+// 64-lane sum of a 32-bit integer on the VALU (the DPP ladder of wh::wave_sum), result uniform
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// mine[e] = number of slots in the wave whose digit (0 .. WIN-1, or < 0: not counted) is e.  Packed form: every lane
+// counts its own slots into 16-bit fields (two digit values per register) and the registers are summed over the wave
+// by DPP — VALU only; the ballot form is a v_cmp, an s_bcnt1 and an s_add per (digit value, slot), each SALU instruction
+// waiting for the VALU-written mask.
+template <int WIN, int PER, class Digit>
+__device__ __forceinline__ void wave_digit_counts(Digit digit, int (&mine)[WIN]) {
+#if WH_D4C_SEL_PACKED
+  static_assert(WIN % 2 == 0, "two digit values per register");
+  unsigned c[WIN / 2];
+#pragma unroll
+  for (int j = 0; j < WIN / 2; ++j) c[j] = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int d = digit(q);
+#pragma unroll
+    for (int j = 0; j < WIN / 2; ++j) c[j] += (d >> 1) == j ? (1u << (16 * (d & 1))) : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < WIN / 2; ++j) {
+    const unsigned ssum = wave_sum_u32(c[j]);
+    mine[2 * j] = (int)(ssum & 0xFFFF);
+    mine[2 * j + 1] = (int)(ssum >> 16);
+  }
+#else
+#pragma unroll
+  for (int e = 0; e < WIN; ++e) {
+    int cc = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) cc += __popcll(__ballot(digit(q) == e));
+    mine[e] = cc;
+  }
+#endif
+}
+
 template <int K, int FT, int PER>
 __device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned valid, int m, void* work, double* scratch,
                                              double* s_small, double* s_total) {
   constexpr int NW = FT / 64;
   // exponents per round.  On speech the K - m (~22) largest bins lie within 4 octaves of the maximum on average, 7 at
   // most (measured on the oracle's spectra): one round of 8 almost always; the loop below slides on otherwise.
-  constexpr int WIN = 8;  // (also the number of values of a 3-bit mantissa digit in the refinement below)
+  // Long spectra (K = 2049 at 48 kHz: 65 bins dropped, spread over more octaves, hundreds of values in the threshold bin)
+  // take 16 exponents per round and 4 mantissa bits per refinement level: the same number of ballots in half as many
+  // rounds, i.e. half as many barrier pairs and count exchanges.
+#ifndef WH_D4C_SEL_DB_LONG
+#define WH_D4C_SEL_DB_LONG 2
+#endif
+#ifndef WH_D4C_SEL_DB
+#define WH_D4C_SEL_DB 2
+#endif
+  constexpr int DB = K > 1100 ? WH_D4C_SEL_DB_LONG : WH_D4C_SEL_DB;   // mantissa bits per refinement level
+  constexpr int WIN = 1 << DB;           // exponents per round = values of a mantissa digit
   int* cnts = reinterpret_cast<int*>(work);                     // [NW][WIN + 1]: counts per exponent, then the wave's top
   double* list = reinterpret_cast<double*>(cnts + NW * (WIN + 1) + (NW * (WIN + 1) & 1));
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -493,13 +550,10 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned va
   bool first = true;
   while (true) {
     int mine[WIN];
-#pragma unroll
-    for (int e = 0; e < WIN; ++e) {
-      int c = 0;
-#pragma unroll
-      for (int q = 0; q < PER; ++q) c += __popcll(__ballot(key[q] == top - e));  // key -1 = padding lane
-      mine[e] = top - e >= 0 ? c : 0;
-    }
+    wave_digit_counts<WIN, PER>([&](int q) {  // digit e = exponent top - e; padding slots (key -1) and the rest: none
+      const int d = top - key[q];
+      return (key[q] >= 0 && d >= 0 && d < WIN) ? d : -1;
+    }, mine);
     wh::sync<FT>();  // the work area is free (previous round's counts have been read by everyone)
     if (lane <= WIN) {
       int c = top;
@@ -558,19 +612,13 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned va
 #pragma unroll
   for (int q = 0; q < PER; ++q) cand |= (key[q] == tbin ? 1u : 0u) << q;
   int shift = 52;
-  while (in_bin > 32 && shift >= 3) {  // (uniform)
-    shift -= 3;
+  while (in_bin > 32 && shift >= DB) {  // (uniform)
+    shift -= DB;
     int dig[PER];
 #pragma unroll
-    for (int q = 0; q < PER; ++q) dig[q] = ((cand >> q) & 1u) ? (int)((__double_as_longlong(x[q]) >> shift) & 7) : -1;
+    for (int q = 0; q < PER; ++q) dig[q] = ((cand >> q) & 1u) ? (int)((__double_as_longlong(x[q]) >> shift) & (WIN - 1)) : -1;
     int mine[WIN];
-#pragma unroll
-    for (int e = 0; e < WIN; ++e) {  // e counts down from the largest digit: WIN == 8 digits
-      int c = 0;
-#pragma unroll
-      for (int q = 0; q < PER; ++q) c += __popcll(__ballot(dig[q] == 7 - e));
-      mine[e] = c;
-    }
+    wave_digit_counts<WIN, PER>([&](int q) { return dig[q] >= 0 ? WIN - 1 - dig[q] : -1; }, mine);  // e counts down from the largest digit
     wh::sync<FT>();
     if (lane < WIN) {
       int c = 0;
@@ -593,7 +641,7 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned va
     for (int e = 0; e < WIN; ++e) {
       const int tot = __builtin_amdgcn_readlane(tot_l, e), before = __builtin_amdgcn_readlane(bef_l, e);
       if (td < 0 && run + tot >= need) {
-        td = 7 - e;
+        td = WIN - 1 - e;
         run_at = run;
         bef = before;
         tot_d = tot;

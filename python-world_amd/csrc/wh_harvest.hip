@@ -742,7 +742,8 @@ __global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUt
                                                         const double2* __restrict__ tw_base, int tw_n,
                                                         const double2* __restrict__ rot_tab,
                                                         const double2* __restrict__ win_tab,
-                                                        double* __restrict__ rf0, double* __restrict__ rsc) {
+                                                        double* __restrict__ rf0, double* __restrict__ rsc,
+                                                        int64_t* __restrict__ lst) {
   // All of the kernel's LDS is the dynamic block, so that it starts at LDS address 0 and the twiddle table's byte
   // offsets are LDS addresses as they stand (hv_refine_lds_bytes mirrors this layout).
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -764,6 +765,9 @@ __global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUt
   int* order = cl_meta + kItems;                             // kItems
   int* bucket = order + kItems;                              // kBuckets
   int& cl_n = bucket[kBuckets];
+  uint32_t* nzmask = reinterpret_cast<uint32_t*>(bucket + kBuckets + 1);  // [kFramesPerBlock][4]: rows of a frame that hold a candidate
+  int* foff = reinterpret_cast<int*>(nzmask + kFramesPerBlock * 4);       // [kFramesPerBlock + 1]: first list slot of a frame
+  if (threadIdx.x < kFramesPerBlock * 4) nzmask[threadIdx.x] = 0;
   if (TWL)
     for (int i = threadIdx.x; i < tw_n; i += 256) twl[i] = tw_base[tw_n + i];
   const int64_t centre0 = (int64_t)floor(((double)f_first * 1 / 1000) * fs + 0.5);
@@ -777,7 +781,10 @@ __global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUt
   if (threadIdx.x == 0) cl_n = 0;
   __syncthreads();
   // gather the overlapped candidates of the block's frames (+-3 frames, harvest.py:114-125) and compact the
-  // non-zero ones into a work list; results go back to row e of their frame, so the order is irrelevant
+  // non-zero ones into a work list.  The reference's [frame][105] candidate map is ~17 % occupied; what the later stages
+  // need from it is the ORDER of a frame's candidates (first-index / last-index tie rules), not the row numbers, so the
+  // results are stored as per-frame lists in row order: the block's frames share one contiguous pool region (at the place
+  // the dense rows of its first frame would start), lst[frame] = (first pool slot << 8) | count.
   for (int q = threadIdx.x; q < kFramesPerBlock * kRows; q += 256) {
     const int fl = q / kRows, e = q % kRows;
     const int64_t f = f_first + fl;
@@ -787,16 +794,26 @@ __global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUt
     double cand = 0.0;
     if (src >= 0 && src < m.nf1 && c < dcount[m.f1_off + src]) cand = dc[(m.f1_off + src) * kMaxC + c];
     if (e == 0 && f < 3) cand = dc[(m.f1_off + f) * kMaxC + 6];  // stray seeding of row 0 (harvest.py:119)
-    rf0[(m.f1_off + f) * kRows + e] = 0.0;
-    rsc[(m.f1_off + f) * kRows + e] = 0.0;
     if (cand != 0.0 && ceil(3 * fs / cand / 2) <= (double)hmax) {
       const int p = atomicAdd(&cl_n, 1);
       cl_val[p] = cand;
       cl_meta[p] = q;
+      atomicOr(&nzmask[fl * 4 + (e >> 5)], 1u << (e & 31));
     }
   }
   __syncthreads();
   const int n_items = cl_n;
+  const int64_t pool_base = (m.f1_off + f_first) * kRows;
+  if (threadIdx.x == 64) {  // (wave 1: beside the bucket scan of wave 0 below)
+    int run = 0;
+    for (int fl = 0; fl < kFramesPerBlock; ++fl) {
+      foff[fl] = run;
+      const int c = __popc(nzmask[fl * 4]) + __popc(nzmask[fl * 4 + 1]) + __popc(nzmask[fl * 4 + 2]) + __popc(nzmask[fl * 4 + 3]);
+      if (f_first + fl < m.nf1) lst[m.f1_off + f_first + fl] = ((pool_base + run) << 8) | (int64_t)c;
+      run += c;
+    }
+    foff[kFramesPerBlock] = run;
+  }
   // A wave refines 64 / RL candidates at once, one per group of RL lanes, and runs as long as its longest one: the
   // window length goes with 1/f0 (31 ... 340 samples at 8 kHz), and a frame's candidates are typically an f0 with its
   // octave neighbours.  Counting sort of the work list by iteration count, so that the groups of a wave (consecutive
@@ -831,48 +848,58 @@ __global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUt
       hv_refine_row<TWL, WTAB, RL>(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem,
                                    tw_n, rot_tab, win_tab, &r0, &r1);
       if ((threadIdx.x & (RL - 1)) == 0) {
-        rf0[(m.f1_off + f) * kRows + q % kRows] = r0;
-        rsc[(m.f1_off + f) * kRows + q % kRows] = r1;
+        const int fl = q / kRows, e = q % kRows;
+        const uint32_t* mw = nzmask + fl * 4;
+        int slot = foff[fl] + __popc(mw[e >> 5] & ((1u << (e & 31)) - 1u));  // rank of row e among the frame's rows
+        for (int w = 0; w < (e >> 5); ++w) slot += __popc(mw[w]);
+        rf0[pool_base + slot] = r0;
+        rsc[pool_base + slot] = r1;
       }
     }
   }
 }
 
 // RemoveUnreliableCandidates (harvest.py:215-234): a candidate survives if some candidate of frame j-1
-// or j+1 lies within 5 %.  A workgroup takes kPruneFrames consecutive frames: the non-zero candidates of those frames
-// and their two outer neighbours are compacted once into LDS lists (one wave per frame, ballot ranks), then every
-// (frame, row) is tested against the lists of its two neighbours.  (One 128-thread workgroup per frame — 640 k of them
-// for 64 x 10 s — was bound by the rate at which workgroups can be launched, and read every frame three times.)
+// or j+1 lies within 5 %.  A workgroup takes kPruneFrames consecutive frames: the candidate lists of those frames and
+// their two outer neighbours are fetched once (one wave per frame), their non-zero entries compacted into LDS (ballot
+// ranks), then every list entry is tested against the non-zero entries of its two neighbours.  (One 128-thread workgroup
+// per frame — 640 k of them for 64 x 10 s — was bound by the rate at which workgroups can be launched, and read every
+// frame three times.)
 constexpr int kPruneFrames = 16;
 
-// The result is a 128-bit keep mask per frame (bit e: candidate e survives, i.e. is non-zero and passed the test): the
-// contour kernels read the refined arrays through it (wh_harvest_contour.h: kept()), which spares this pass — it runs at
-// HBM speed — the score array and two dense copies (2.1 GB -> 0.55 GB of traffic for 64 x 10 s).
+// The result is a 128-bit keep mask per frame (bit k: entry k of the frame's list survives, i.e. is non-zero and passed
+// the test): the contour kernels read the refined lists through it (wh_harvest_contour.h), which spares this pass the
+// score array and pruned copies.
 __global__ __launch_bounds__(256) void hv_prune_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ rf0,
-                                                       uint32_t* __restrict__ keep) {
-  __shared__ double lst[kPruneFrames + 2][kRows];  // compacted non-zero candidates of frames f_first-1 .. f_first+16
+                                                       const int64_t* __restrict__ lst, uint32_t* __restrict__ keep) {
+  __shared__ double nzl[kPruneFrames + 2][kRows];  // non-zero candidates of frames f_first-1 .. f_first+16
   __shared__ int ln[kPruneFrames + 2];
-  __shared__ uint32_t mk[kPruneFrames][4];
-  if (threadIdx.x < kPruneFrames * 4) mk[threadIdx.x >> 2][threadIdx.x & 3] = 0;
   const HvUtt m = meta[blockIdx.y];
   const int64_t f_first = (int64_t)blockIdx.x * kPruneFrames;
   if (f_first >= m.nf1) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // a wave's frames (4-5 of the 18) are fetched together — ten independent 512-byte loads in flight per wave before the
-  // first ballot needs one (taken one frame at a time the pass ran at 1.6 TB/s) — then compacted
+  // a wave's frames (4-5 of the 18) are fetched together: the list heads first, then every list — independent loads in
+  // flight before the first ballot needs one.  Entry k of a list sits on lane k & 63 (pass k >> 6) and stays there: the
+  // wave that fetched a frame also tests it.
   constexpr int kPer = (kPruneFrames + 2 + 3) / 4;
   constexpr int kPass = (kRows + 63) / 64;
-  double val[kPer][kPass];
+  int64_t ent[kPer];
 #pragma unroll
   for (int i = 0; i < kPer; ++i) {
     const int fr = w + 4 * i;
     const int64_t f = f_first - 1 + fr;
     const bool ok = fr < kPruneFrames + 2 && f >= 0 && f < m.nf1;
-    const double* src = rf0 + (m.f1_off + (ok ? f : 0)) * kRows;
+    ent[i] = ok ? lst[m.f1_off + f] : 0;
+  }
+  double val[kPer][kPass];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const double* src = rf0 + (ent[i] >> 8);
+    const int n = (int)(ent[i] & 255);
 #pragma unroll
     for (int pass = 0; pass < kPass; ++pass) {
       const int e = lane + 64 * pass;
-      val[i][pass] = (ok && e < kRows) ? src[e] : 0.0;
+      val[i][pass] = e < n ? src[e] : 0.0;
     }
   }
 #pragma unroll
@@ -884,40 +911,42 @@ __global__ __launch_bounds__(256) void hv_prune_kernel(const HvUtt* __restrict__
       for (int pass = 0; pass < kPass; ++pass) {
         const double a = val[i][pass];
         const unsigned long long nz = __ballot(a != 0.0);  // zeros can never be the nearest candidate
-        if (a != 0.0) lst[fr][n + __popcll(nz & ((1ull << lane) - 1))] = a;
+        if (a != 0.0) nzl[fr][n + __popcll(nz & ((1ull << lane) - 1))] = a;
         n += __popcll(nz);
       }
       if (lane == 0) ln[fr] = n;
     }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < kPruneFrames * kRows; idx += 256) {
-    const int fl = idx / kRows, e = idx - fl * kRows;
-    const int64_t f = f_first + fl;
-    if (f >= m.nf1) break;
-    const int64_t o = (m.f1_off + f) * kRows;
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const int fr = w + 4 * i;
+    const int64_t f = f_first - 1 + fr;
+    if (fr < 1 || fr > kPruneFrames || f >= m.nf1) continue;  // (wave-uniform) rows 0 and 17 are neighbours only
     const bool inner = f >= 1 && f <= m.nf1 - 2;
-    double v = rf0[o + e];
-    if (inner && v != 0.0) {
-      double e1 = 1.0, e2 = 1.0;  // SelectBestF0 with allowed_range = 1 (a zero candidate gives exactly 1)
-      // min_k |v - nb_k| / v == (min_k |v - nb_k|) / v bit for bit (division by v > 0 is monotone): one divide per
-      // neighbour frame instead of one per neighbour candidate
-      const int n_prev = ln[fl], n_next = ln[fl + 2];
-      const double* nb_prev = lst[fl];
-      const double* nb_next = lst[fl + 2];
-      double d1 = INFINITY, d2 = INFINITY;
-      for (int k = 0; k < n_next; ++k) d1 = fmin(d1, fabs(v - nb_next[k]));
-      for (int k = 0; k < n_prev; ++k) d2 = fmin(d2, fabs(v - nb_prev[k]));
-      if (n_next > 0) e1 = fmin(e1, d1 / v);
-      if (n_prev > 0) e2 = fmin(e2, d2 / v);
-      if (fmin(e1, e2) > 0.05) v = 0.0;
+    const int n_prev = ln[fr - 1], n_next = ln[fr + 1];
+    const double* nb_prev = nzl[fr - 1];
+    const double* nb_next = nzl[fr + 1];
+#pragma unroll
+    for (int pass = 0; pass < kPass; ++pass) {
+      double v = val[i][pass];
+      if (inner && v != 0.0) {
+        double e1 = 1.0, e2 = 1.0;  // SelectBestF0 with allowed_range = 1 (a zero candidate gives exactly 1)
+        // min_k |v - nb_k| / v == (min_k |v - nb_k|) / v bit for bit (division by v > 0 is monotone): one divide per
+        // neighbour frame instead of one per neighbour candidate
+        double d1 = INFINITY, d2 = INFINITY;
+        for (int k = 0; k < n_next; ++k) d1 = fmin(d1, fabs(v - nb_next[k]));
+        for (int k = 0; k < n_prev; ++k) d2 = fmin(d2, fabs(v - nb_prev[k]));
+        if (n_next > 0) e1 = fmin(e1, d1 / v);
+        if (n_prev > 0) e2 = fmin(e2, d2 / v);
+        if (fmin(e1, e2) > 0.05) v = 0.0;
+      }
+      const unsigned long long kept = __ballot(v != 0.0);
+      if (lane == 0) {
+        keep[(m.f1_off + f) * 4 + 2 * pass] = (uint32_t)kept;
+        keep[(m.f1_off + f) * 4 + 2 * pass + 1] = (uint32_t)(kept >> 32);
+      }
     }
-    if (v != 0.0) atomicOr(&mk[fl][e >> 5], 1u << (e & 31));
-  }
-  __syncthreads();
-  if (threadIdx.x < kPruneFrames * 4) {
-    const int64_t f = f_first + (threadIdx.x >> 2);
-    if (f < m.nf1) keep[(m.f1_off + f) * 4 + (threadIdx.x & 3)] = mk[threadIdx.x >> 2][threadIdx.x & 3];
   }
 }
 
@@ -1038,6 +1067,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t o_rf0 = off; off += al(sizeof(double) * f1_tot * kRows);
   const size_t o_rsc = off; off += al(sizeof(double) * f1_tot * kRows);
   const size_t o_keep = off; off += al(sizeof(uint32_t) * 4 * f1_tot);
+  const size_t o_lst = off; off += al(sizeof(int64_t) * f1_tot);
   const size_t o_ct = off; off += al(contour_workspace_bytes(f1_tot, B));
   // overlap-save band filters: tile spectra of every utterance + the channels' tap spectra
   std::vector<int64_t> tile_off(B + 1, 0);
@@ -1074,6 +1104,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   double* d_rf0 = reinterpret_cast<double*>(ws + o_rf0);
   double* d_rsc = reinterpret_cast<double*>(ws + o_rsc);
   uint32_t* d_keep = reinterpret_cast<uint32_t*>(ws + o_keep);
+  int64_t* d_lst = reinterpret_cast<int64_t*>(ws + o_lst);
   double* d_taps = nullptr;
   double* d_bf = nullptr;
   int32_t* d_ti = nullptr;
@@ -1157,7 +1188,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     const int fpb = refine_frames(use_wtab);
     const int seglen = 2 * hmax + 8 + (fpb - 1) * ((int)ceil(fs_d / 1000.0) + 1);
     const size_t lds = sizeof(double2) * (size_t)tw_n + sizeof(double) * (size_t)((seglen + 1) & ~1) +
-                       (sizeof(double) + 2 * sizeof(int)) * (size_t)(fpb * kRows) + sizeof(int) * 72;
+                       (sizeof(double) + 2 * sizeof(int)) * (size_t)(fpb * kRows) + sizeof(int) * (72 + 5 * fpb + 1);
     // 16-sample rotation (sin, cos)(16*pi*dx) of the window phase for every half length (hv_refine_row)
     double2* d_rot = nullptr;
     {
@@ -1212,7 +1243,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     if (int rc = wh::allow_lds(&hv_refine_kernel<TWL_, WTAB_>, lds)) return rc;                                         \
     wh::KernelTimer _kt(ctx, st, "hv_refine_kernel");                                                                   \
     hipLaunchKernelGGL((hv_refine_kernel<TWL_, WTAB_>), grid, dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, \
-                       f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rot, d_wtab, d_rf0, d_rsc);                        \
+                       f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rot, d_wtab, d_rf0, d_rsc, d_lst);                        \
   }
     if (tw_n && use_wtab) WH_REFINE_LAUNCH(true, true)
     else if (tw_n) WH_REFINE_LAUNCH(true, false)
@@ -1220,9 +1251,9 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
 #undef WH_REFINE_LAUNCH
     WH_LAUNCH_CHECK("hv_refine_kernel");
   }
-  { wh::KernelTimer _kt(ctx, st, "hv_prune_kernel"); hipLaunchKernelGGL(hv_prune_kernel, dim3((unsigned)((max_nf1 + kPruneFrames - 1) / kPruneFrames), B), dim3(256), 0, st, d_meta, d_rf0, d_keep); }
+  { wh::KernelTimer _kt(ctx, st, "hv_prune_kernel"); hipLaunchKernelGGL(hv_prune_kernel, dim3((unsigned)((max_nf1 + kPruneFrames - 1) / kPruneFrames), B), dim3(256), 0, st, d_meta, d_rf0, d_lst, d_keep); }
   WH_LAUNCH_CHECK("hv_prune_kernel");
   // ---- contour, smoothing, 5 ms pick -------------------------------------------------------------------------
-  return harvest_contour(ctx, st, B, d_meta, meta, f1_tot, max_nf1, max_nf, d_rf0, d_rsc, d_keep, d_ct, tp, f0_out, vuv_out,
+  return harvest_contour(ctx, st, B, d_meta, meta, f1_tot, max_nf1, max_nf, d_rf0, d_rsc, d_lst, d_keep, d_ct, tp, f0_out, vuv_out,
                          dbg_f0_1ms);
 }

@@ -23,10 +23,24 @@ struct HcSec {
   int32_t pad_;
 };
 
-// Candidate e of (absolute) 1 ms frame fr survived hv_prune_kernel; the contour kernels read the refined f0 / score
-// arrays through this mask instead of pruned copies.
-__device__ __forceinline__ bool kept(const uint32_t* __restrict__ keep, int64_t fr, int e) {
-  return (keep[fr * 4 + (e >> 5)] >> (e & 31)) & 1u;
+// The refined candidates of a 1 ms frame are a LIST in the reference's row order (hv_refine_kernel): lst[frame] =
+// (first slot in the pf0 / psc pools << 8) | count; bit k of the frame's 128-bit keep mask says entry k survived
+// hv_prune_kernel.  The contour kernels read the lists through the mask instead of pruned copies.  Only the ORDER of a
+// frame's candidates enters the reference's rules (np.argmax: first maximum; SelectBestF0: last minimum), and a pruned
+// or absent candidate is a zero there, which can win neither.
+struct HcList {
+  const double* f0;
+  const double* sc;
+  int n;
+};
+__device__ __forceinline__ HcList hc_list(const int64_t* __restrict__ lst, const double* __restrict__ pf0,
+                                          const double* __restrict__ psc, int64_t fr) {
+  const int64_t ent = lst[fr];
+  HcList l;
+  l.f0 = pf0 + (ent >> 8);
+  l.sc = psc + (ent >> 8);
+  l.n = (int)(ent & 255);
+  return l;
 }
 
 inline size_t contour_workspace_bytes(int64_t f1_tot, int n_utt) {
@@ -37,27 +51,35 @@ inline size_t contour_workspace_bytes(int64_t f1_tot, int n_utt) {
 
 __global__ __launch_bounds__(256) void hc_base_kernel(const HvUtt* __restrict__ meta, const HcUtt* __restrict__ hc,
                                                       const double* __restrict__ pf0, const double* __restrict__ psc,
+                                                      const int64_t* __restrict__ lst,
                                                       const uint32_t* __restrict__ keep, double* __restrict__ rows) {
   const HvUtt m = meta[blockIdx.y];
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= m.nf1) return;
-  const double* f = pf0 + (m.f1_off + j) * kRows;
-  const double* s = psc + (m.f1_off + j) * kRows;
+  const HcList l = hc_list(lst, pf0, psc, m.f1_off + j);
   uint32_t kw[4];
 #pragma unroll
   for (int w = 0; w < 4; ++w) kw[w] = keep[(m.f1_off + j) * 4 + w];
-  // np.argmax of the pruned scores (first maximum); the scores are read densely (independent loads), the mask applied
-  // in registers
-  int best = 0;
-  double bs = (kw[0] & 1u) ? s[0] : 0.0;
-  for (int e = 1; e < kRows; ++e) {
-    const double se = ((kw[e >> 5] >> (e & 31)) & 1u) ? s[e] : 0.0;
-    if (se > bs) {
-      bs = se;
-      best = e;
+  // np.argmax of the pruned scores (first maximum).  A surviving candidate's score is >= 2.5 (hv_refine_row), every
+  // other row of the reference's map holds 0: the first maximum is the first largest surviving score, or a zero row
+  // (f0 = 0) when nothing survives.  Scores are fetched four at a time (independent loads).
+  int best = -1;
+  double bs = 0.0;
+  for (int e0 = 0; e0 < l.n; e0 += 4) {
+    double sv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sv[q] = e0 + q < l.n ? l.sc[e0 + q] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q;
+      const double se = (e < l.n && ((kw[e >> 5] >> (e & 31)) & 1u)) ? sv[q] : 0.0;
+      if (se > bs) {
+        bs = se;
+        best = e;
+      }
     }
   }
-  rows[hc[blockIdx.y].f_base + j] = ((kw[best >> 5] >> (best & 31)) & 1u) ? f[best] : 0.0;
+  rows[hc[blockIdx.y].f_base + j] = best >= 0 ? l.f0[best] : 0.0;
 }
 
 __global__ __launch_bounds__(256) void hc_step1_kernel(const HvUtt* __restrict__ meta, const HcUtt* __restrict__ hc,
@@ -228,6 +250,7 @@ __device__ __forceinline__ double select_best_regs(double ref, double c0, double
 // (ExtendF0, harvest.py:408-429) — one wave per section.
 __global__ __launch_bounds__(64) void hc_extend_kernel(const HvUtt* __restrict__ meta, const HcUtt* __restrict__ hc,
                                                        const double* __restrict__ rows, const double* __restrict__ pf0,
+                                                       const int64_t* __restrict__ lst,
                                                        const uint32_t* __restrict__ keep,
                                                        HcSec* __restrict__ secs, const int32_t* __restrict__ nsec,
                                                        double* __restrict__ chan) {
@@ -248,20 +271,26 @@ __global__ __launch_bounds__(64) void hc_extend_kernel(const HvUtt* __restrict__
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const double* cands = pf0 + m.f1_off * kRows;
   // The walk is a chain (the next step's reference value is this step's pick), but which rows it will read is known:
   // the candidate rows of the next kAhead frames are fetched together, so a step waits for global memory once in
   // kAhead instead of every time.
   constexpr int kAhead = 4;
   auto load_rows = [&](int64_t first, int dir, int count, double (&c0)[kAhead], double (&c1)[kAhead]) {
+    int64_t ent[kAhead];  // the list heads of the kAhead frames first (one round trip), then lists and masks side by side
 #pragma unroll
     for (int q = 0; q < kAhead; ++q) {
       const int64_t fr = first + (int64_t)dir * q;
       const bool ok = q < count && fr >= 0 && fr < n;
-      const double* col = cands + fr * kRows;
-      // values and mask words are fetched side by side (no load waits for another), the mask applied in registers
-      const double v0 = ok ? col[lane] : 0.0;
-      const double v1 = (ok && lane + 64 < kRows) ? col[lane + 64] : 0.0;
+      ent[q] = ok ? lst[m.f1_off + fr] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < kAhead; ++q) {
+      const int64_t fr = first + (int64_t)dir * q;
+      const bool ok = q < count && fr >= 0 && fr < n;
+      const double* col = pf0 + (ent[q] >> 8);
+      const int cnt = (int)(ent[q] & 255);
+      const double v0 = lane < cnt ? col[lane] : 0.0;  // entry k of the list sits on lane k & 63
+      const double v1 = lane + 64 < cnt ? col[lane + 64] : 0.0;
       const uint32_t w0 = ok ? keep[(m.f1_off + fr) * 4 + (lane >> 5)] : 0u;
       const uint32_t w1 = ok ? keep[(m.f1_off + fr) * 4 + 2 + (lane >> 5)] : 0u;
       c0[q] = ((w0 >> (lane & 31)) & 1u) ? v0 : 0.0;
@@ -336,19 +365,20 @@ __device__ __forceinline__ double chan_at(const double* __restrict__ chan_u, con
 }
 
 // SerachScore (harvest.py:490-495)
-__device__ __forceinline__ double search_score(double f0, const double* __restrict__ cf, const double* __restrict__ cs,
-                                               const uint32_t* __restrict__ kw) {
+__device__ __forceinline__ double search_score(double f0, const HcList& l, const uint32_t* __restrict__ kw) {
+  const double* __restrict__ cf = l.f0;
+  const double* __restrict__ cs = l.sc;
   double sc = 0.0;
   if (f0 == 0.0) return sc;  // only surviving (non-zero) candidates can match from here on
-  // the candidates are fetched eight at a time (one wait per block instead of one per row); a score is only read for
-  // the row or two that match
-  for (int e0 = 0; e0 < kRows; e0 += 8) {
+  // the candidates are fetched eight at a time (one wait per block instead of one per entry); a score is only read for
+  // the entry or two that match
+  for (int e0 = 0; e0 < l.n; e0 += 8) {
     double c[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) c[q] = e0 + q < kRows ? cf[e0 + q] : 0.0;
+    for (int q = 0; q < 8; ++q) c[q] = e0 + q < l.n ? cf[e0 + q] : 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      if (e0 + q < kRows && f0 == c[q] && ((kw[(e0 + q) >> 5] >> ((e0 + q) & 31)) & 1u)) {
+      if (e0 + q < l.n && f0 == c[q] && ((kw[(e0 + q) >> 5] >> ((e0 + q) & 31)) & 1u)) {
         const double v = cs[e0 + q];
         if (sc < v) sc = v;
       }
@@ -359,7 +389,8 @@ __device__ __forceinline__ double search_score(double f0, const double* __restri
 // FixStep3 second half (MergeF0, harvest.py:442-486), FixStep4 (harvest.py:388-404), vuv.
 __global__ __launch_bounds__(256) void hc_merge_kernel(const HvUtt* __restrict__ meta, const HcUtt* __restrict__ hc,
                                                        double* __restrict__ rows, const double* __restrict__ pf0,
-                                                       const double* __restrict__ psc, const uint32_t* __restrict__ keep,
+                                                       const double* __restrict__ psc, const int64_t* __restrict__ lst,
+                                                       const uint32_t* __restrict__ keep,
                                                        const HcSec* __restrict__ secs,
                                                        const int32_t* __restrict__ nsec, const double* __restrict__ chan,
                                                        int32_t* __restrict__ runs) {
@@ -410,11 +441,10 @@ __global__ __launch_bounds__(256) void hc_merge_kernel(const HvUtt* __restrict__
       } else {
         double a = 0.0, b = 0.0;
         for (int64_t j = s.r0 + threadIdx.x; j <= R1; j += 256) {
-          const double* cf = pf0 + (m.f1_off + j) * kRows;
-          const double* cs = psc + (m.f1_off + j) * kRows;
+          const HcList l = hc_list(lst, pf0, psc, m.f1_off + j);
           const uint32_t* kw = keep + (m.f1_off + j) * 4;
-          a += search_score(s3[j], cf, cs, kw);
-          b += search_score(chan_at(chan_u, s, j), cf, cs, kw);
+          a += search_score(s3[j], l, kw);
+          b += search_score(chan_at(chan_u, s, j), l, kw);
         }
         wh::block_sum2(a, b, red);
         const int64_t from = (a > b) ? R1 : s.r0;
@@ -549,7 +579,7 @@ __global__ __launch_bounds__(256) void hc_pick_kernel(const HvUtt* __restrict__ 
 
 inline int harvest_contour(wh_ctx* ctx, hipStream_t st, int B, const HvUtt* d_meta, const std::vector<HvUtt>& meta,
                            int64_t f1_tot, int64_t max_nf1, int64_t max_nf, const double* d_pf0, const double* d_psc,
-                           const uint32_t* d_keep,
+                           const int64_t* d_lst, const uint32_t* d_keep,
                            char* d_ws, const double* tp, double* f0_out, double* vuv_out, double* dbg_f0_1ms) {
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   std::vector<HcUtt> hc(B);
@@ -582,15 +612,15 @@ inline int harvest_contour(wh_ctx* ctx, hipStream_t st, int B, const HvUtt* d_me
   double* d_ch = reinterpret_cast<double*>(d_ws + o_ch);
   if (int rc = wh::persistent_upload(ctx, st, "hv.contour", hc, &d_hc)) return rc;
   const dim3 gf((unsigned)((max_nf1 + 255) / 256), B);
-  { wh::KernelTimer _kt(ctx, st, "hc_base_kernel"); hipLaunchKernelGGL(hc_base_kernel, gf, dim3(256), 0, st, d_meta, d_hc, d_pf0, d_psc, d_keep, d_rows); }
+  { wh::KernelTimer _kt(ctx, st, "hc_base_kernel"); hipLaunchKernelGGL(hc_base_kernel, gf, dim3(256), 0, st, d_meta, d_hc, d_pf0, d_psc, d_lst, d_keep, d_rows); }
   WH_LAUNCH_CHECK("hc_base_kernel");
   { wh::KernelTimer _kt(ctx, st, "hc_step1_kernel"); hipLaunchKernelGGL(hc_step1_kernel, gf, dim3(256), 0, st, d_meta, d_hc, d_rows); }
   WH_LAUNCH_CHECK("hc_step1_kernel");
   { wh::KernelTimer _kt(ctx, st, "hc_sections_kernel"); hipLaunchKernelGGL(hc_sections_kernel, dim3(B), dim3(256), 0, st, d_meta, d_hc, d_rows, d_runs, d_secs, d_ns); }
   WH_LAUNCH_CHECK("hc_sections_kernel");
-  { wh::KernelTimer _kt(ctx, st, "hc_extend_kernel"); hipLaunchKernelGGL(hc_extend_kernel, dim3((unsigned)max_secs, B), dim3(64), 0, st, d_meta, d_hc, d_rows, d_pf0, d_keep, d_secs, d_ns, d_ch); }
+  { wh::KernelTimer _kt(ctx, st, "hc_extend_kernel"); hipLaunchKernelGGL(hc_extend_kernel, dim3((unsigned)max_secs, B), dim3(64), 0, st, d_meta, d_hc, d_rows, d_pf0, d_lst, d_keep, d_secs, d_ns, d_ch); }
   WH_LAUNCH_CHECK("hc_extend_kernel");
-  { wh::KernelTimer _kt(ctx, st, "hc_merge_kernel"); hipLaunchKernelGGL(hc_merge_kernel, dim3(B), dim3(256), 0, st, d_meta, d_hc, d_rows, d_pf0, d_psc, d_keep, d_secs, d_ns, d_ch, d_runs); }
+  { wh::KernelTimer _kt(ctx, st, "hc_merge_kernel"); hipLaunchKernelGGL(hc_merge_kernel, dim3(B), dim3(256), 0, st, d_meta, d_hc, d_rows, d_pf0, d_psc, d_lst, d_keep, d_secs, d_ns, d_ch, d_runs); }
   WH_LAUNCH_CHECK("hc_merge_kernel");
   { wh::KernelTimer _kt(ctx, st, "hc_smooth_kernel"); hipLaunchKernelGGL(hc_smooth_kernel, dim3(B), dim3(256), 0, st, d_meta, d_hc, d_rows, d_runs, d_ch); }
   WH_LAUNCH_CHECK("hc_smooth_kernel");

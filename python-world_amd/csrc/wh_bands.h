@@ -225,6 +225,9 @@ inline int launch_band_events(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs
                        // needs 169 with the thread index read opaquely — wh_harvest.hip — and ~310 without: 2 -> 4.45 ms,
                        // 3 -> 3.7 ms at config 3)
 #endif
+#ifndef WH_OLS_FUSED_PRE
+#define WH_OLS_FUSED_PRE 1
+#endif
 #ifndef WH_OLS_N
 #define WH_OLS_N 4096
 #endif
@@ -317,6 +320,27 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
   // Software pipeline over (tile, channel): the tap spectrum of the next channel and, behind a tile's last channel, the
   // next tile's spectrum are fetched while the current channel's crossings are extracted — the one stretch of the
   // loop that needs few registers — so neither load's L2 latency (33 KB per channel-tile) sits in front of a product.
+#if WH_OLS_FUSED_PRE
+  // A thread holds the bins k = tid + 256 q (q < 4) of the two spectra TOGETHER WITH their mirrors N/2 - k (and the
+  // self-paired bin N/4): the product and the real transform's pre-pass (irfft_lds: Z[k] = 2E + i 2O from Y[k] and
+  // Y[N/2 - k]) then happen in registers and the buffer is written once, already as the half-size complex sequence —
+  // against storing the 2049 products, a barrier, and a pre-pass that reads and rewrites them (19 of a channel-tile's 51
+  // LDS stores per thread, the expensive direction on this LDS, and one of its barriers).  Same arithmetic as
+  // irfft_lds, value for value.
+  constexpr int NH = kOlsN / 2;
+  constexpr int PQ = NH / 2 / 256;  // 4 bin pairs per thread
+  constexpr int SLOTS = 2 * PQ + 1;
+  double2 zr[SLOTS], tr[SLOTS];
+  auto load_spec = [&](double2 (&dst)[SLOTS], const double2* src) {
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+      const int k = threadIdx.x + q * 256;
+      dst[2 * q] = src[k];
+      dst[2 * q + 1] = src[NH - k];
+    }
+    dst[2 * PQ] = src[NH / 2];
+  };
+#else
   double2 zr[PER], tr[PER];
   auto load_spec = [&](double2 (&dst)[PER], const double2* src) {
 #pragma unroll
@@ -325,6 +349,7 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
       dst[q] = k < KS ? src[k] : make_double2(0.0, 0.0);
     }
   };
+#endif
   const int n_ch = nb - b0 < kOlsBands ? nb - b0 : kOlsBands;
   load_spec(zr, zspec + tile_off[u] * KS);
   load_spec(tr, tspec + (int64_t)b0 * KS);
@@ -339,6 +364,40 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
       int base_cnt[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) base_cnt[t] = s_cnt[g][t];
+#if WH_OLS_FUSED_PRE
+      {
+        const double2* __restrict__ w = tw_base + kOlsN;
+        auto fold = [&](double2 a, double2 bb, double2 wk, double2* lo, double2* hi) {
+          const double er = a.x + bb.x, ei = a.y - bb.y;  // 2E = A + conj(B)
+          const double dr = a.x - bb.x, di = a.y + bb.y;  // 2D = A - conj(B)
+          const double orr = fma(dr, wk.x, di * wk.y);    // 2O = 2D * conj(W^k)
+          const double oi = fma(di, wk.x, -(dr * wk.y));
+          *lo = make_double2(er - oi, ei + orr);  // Z[k]       = 2E + i*2O
+          *hi = make_double2(er + oi, orr - ei);  // Z[N/2 - k] = conj(2E) + i*conj(2O)
+        };
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+          const int k = threadIdx.x + q * 256;
+          double2 a = cmul(zr[2 * q], tr[2 * q]), bb = cmul(zr[2 * q + 1], tr[2 * q + 1]);
+          if (k == 0) {  // DC and Nyquist bins: only their real parts reach a real output
+            a.y = 0.0;
+            bb.y = 0.0;
+          }
+          double2 lo, hi;
+          fold(a, bb, ldg2(w + k), &lo, &hi);
+          ybuf[k] = lo;
+          if (k != 0) ybuf[NH - k] = hi;
+        }
+        if (threadIdx.x == 0) {  // k = N/4 pairs with itself; irfft_lds leaves the second of its two stores there
+          const double2 a = cmul(zr[2 * PQ], tr[2 * PQ]);
+          double2 lo, hi;
+          fold(a, a, ldg2(w + NH / 2), &lo, &hi);
+          ybuf[NH / 2] = hi;
+        }
+      }
+      sync_lds<256>();
+      fft_lds<NH, true, 256>(ybuf, tw_base + NH);
+#else
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int k = threadIdx.x + q * 256;
@@ -346,6 +405,7 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
       }
       sync_lds<256>();
       irfft_lds<kOlsN, 256>(ybuf, tw_base);
+#endif
       if (g + 1 < n_ch) {
         load_spec(tr, tspec + (int64_t)(b + 1) * KS);
       } else {

@@ -299,7 +299,6 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
                                                                      int32_t* __restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = kOlsN / 2 + 1;           // 2049 spectrum bins
-  constexpr int PER = (KS + 255) / 256;       // 9 per thread
   double2* ybuf = reinterpret_cast<double2*>(smem);
   double* sig_all = reinterpret_cast<double*>(smem);
   unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(ybuf + KS + 1);  // 8
@@ -341,6 +340,7 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
     dst[2 * PQ] = src[NH / 2];
   };
 #else
+  constexpr int PER = (KS + 255) / 256;  // 9 per thread
   double2 zr[PER], tr[PER];
   auto load_spec = [&](double2 (&dst)[PER], const double2* src) {
 #pragma unroll

@@ -37,7 +37,7 @@ struct wh_ctx {
     bool valid = false;
     int n_utt = 0;
     int64_t pulse_cap = 0, ny_tot = 0, frames = 0;
-    size_t o_vuv = 0, o_pt = 0, o_pi = 0, o_ps = 0, o_pn = 0, o_pc = 0, o_pb = 0, o_pf = 0, o_pw = 0, o_pu = 0;
+    size_t o_vuv = 0, o_pt = 0, o_pi = 0, o_ps = 0, o_pn = 0, o_pc = 0, o_pb = 0, o_rec = 0;
   } timebase;
   // optional per-kernel timing (HIP events on the launch stream), see wh_profile_*
   bool prof = false;

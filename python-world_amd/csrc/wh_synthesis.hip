@@ -689,19 +689,39 @@ __global__ void pulse_base_kernel(const int32_t* __restrict__ p_count, int n_utt
   }
 }
 
+// Everything response_kernel has to know about a pulse before it can touch the spectra, packed by the time base so that
+// a workgroup gets it with ONE 64-byte scalar load — and gets the NEXT pulse's under the current pulse's row fetch —
+// where it used to walk p_utt -> meta / p_base / p_count -> p_idx, p_shift, p_frames, p_weight, p_noff -> vuv_s: four
+// dependent round trips in front of every pulse.
+struct alignas(64) PulseRec {
+  int64_t pidx;        // 1-based output index of the pulse (pulse_locations_index)
+  int64_t rows;        // absolute spectrogram rows: (f_off + earlier frame) | (f_off + later frame) << 32
+  double weight;       // of the later frame; -1: both frames are the same one
+  double shift;        // pulse_locations_time_shift
+  int64_t noff;        // offset of the pulse's noise run in the utterance's stream
+  int32_t u;           // utterance
+  int32_t noise_size;  // next pulse's index - this one's (0 for the last)
+  int32_t vuv;         // interpolated vuv at the pulse (synthesis.py:69 reads it at pidx - 1)
+  int32_t pad_[3];
+};
+static_assert(sizeof(PulseRec) == 64, "one 64-byte scalar load");
+
 // Per pulse: the two frames it interpolates between and the weight of the later one (synthesis.py:49-51,144-180).
 // One thread per pulse here, so that the 256-thread response workgroups do not each walk the same 11-deep chain of
 // dependent loads (binary search over the frame times) before they can start.
 __global__ __launch_bounds__(256) void pulse_frames_kernel(const SynUtt* __restrict__ meta, const double* __restrict__ tp,
                                                            const double* __restrict__ p_time,
+                                                           const int64_t* __restrict__ p_idx,
+                                                           const double* __restrict__ p_shift,
+                                                           const int64_t* __restrict__ p_noff,
+                                                           const uint8_t* __restrict__ vuv_s,
                                                            const int32_t* __restrict__ p_count,
                                                            const int64_t* __restrict__ p_base,
-                                                           int64_t* __restrict__ p_frames, double* __restrict__ p_weight,
-                                                           int32_t* __restrict__ p_utt) {
+                                                           PulseRec* __restrict__ p_rec) {
   const SynUtt m = meta[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p_count[blockIdx.y]) return;
-  p_utt[p_base[blockIdx.y] + i] = blockIdx.y;  // flat pulse number -> utterance: one load in response_kernel instead of a search
+  const int count = p_count[blockIdx.y];
+  if (i >= count) return;
   const double* tpu = tp + m.f_off;
   const double ptime = p_time[m.p_off + i];
   // temporal_position_index = interp(tp -> 1..F)(time), clipped to [1, F]
@@ -719,8 +739,19 @@ __global__ __launch_bounds__(256) void pulse_frames_kernel(const SynUtt* __restr
   const int64_t fhi = (int64_t)ceil(pos) - 1;
   const double t1 = tpu[flo], t2 = tpu[fhi];
   const double xq = fmax(t1, fmin(t2, ptime));
-  p_frames[m.p_off + i] = flo | (fhi << 32);
-  p_weight[m.p_off + i] = (t1 == t2) ? -1.0 : (xq - t1) / (t2 - t1);  // -1: both frames are the same one
+  PulseRec r;
+  r.pidx = p_idx[m.p_off + i];
+  r.rows = (m.f_off + flo) | ((m.f_off + fhi) << 32);
+  r.weight = (t1 == t2) ? -1.0 : (xq - t1) / (t2 - t1);
+  r.shift = p_shift[m.p_off + i];
+  r.noff = p_noff[m.p_off + i];
+  r.u = blockIdx.y;
+  r.noise_size = (int32_t)(p_idx[m.p_off + (i + 1 < count ? i + 1 : count - 1)] - r.pidx);
+  int64_t vi = r.pidx - 1;
+  vi = vi < 0 ? 0 : (vi > m.ny - 1 ? m.ny - 1 : vi);
+  r.vuv = vuv_s[m.y_off + vi] != 0 ? 1 : 0;
+  r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+  p_rec[p_base[blockIdx.y] + i] = r;  // flat pulse numbering: utterance by utterance, in time order
 }
 
 inline int pulse_tiles(int64_t max_ny) { return max_ny > 1 ? (int)((max_ny - 1 + kPTile - 1) / kPTile) : 1; }
@@ -913,17 +944,9 @@ struct RespArgs {
   const double* spectrogram;
   const double* aperiodicity;
   double fs;
-  const double* p_time;
-  const int64_t* p_idx;
-  const double* p_shift;
-  const int64_t* p_noff;
-  const int64_t* p_frames;
-  const double* p_weight;
-  const int32_t* p_utt;
-  const int32_t* p_count;
+  const PulseRec* p_rec;
   const int64_t* p_base;
   int n_utt;
-  const uint8_t* vuv_s;
   const double* noise;
   uint64_t seed;
   const double* dc_base;
@@ -957,17 +980,11 @@ __device__ __forceinline__ void ring_flush(double* ring, int64_t a, int64_t b, d
 
 // One pulse of a run.
 template <int N>
-__device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, char* smem, double* ring, RunState& rs) {
+__device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec& rec, char* smem, double* ring, RunState& rs) {
   const SynUtt* __restrict__ meta = A.meta;
   const double* __restrict__ spectrogram = A.spectrogram;
   const double* __restrict__ aperiodicity = A.aperiodicity;
   const double fs = A.fs;
-  const int64_t* __restrict__ p_idx = A.p_idx;
-  const double* __restrict__ p_shift = A.p_shift;
-  const int64_t* __restrict__ p_noff = A.p_noff;
-  const int32_t* __restrict__ p_count = A.p_count;
-  const int64_t* __restrict__ p_base = A.p_base;
-  const uint8_t* __restrict__ vuv_s = A.vuv_s;
   const double* __restrict__ noise = A.noise;
   const uint64_t seed = A.seed;
   const double* __restrict__ dc_base = A.dc_base;
@@ -991,36 +1008,30 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
 
   RSTAGE_BEGIN
   wh::sync<FT>();
-  const int u = A.p_utt[gp];
-  const SynUtt m = meta[u];
-  const int i = (int)(gp - p_base[u]);
-  const int count = p_count[u];
-  const int64_t pidx = p_idx[m.p_off + i];
-  const double shift = p_shift[m.p_off + i];
-  const int64_t pidx_next = p_idx[m.p_off + (i + 1 < count ? i + 1 : count - 1)];
-  const int64_t noise_size = pidx_next - pidx;
+  const int u = rec.u;
+  const SynUtt m = meta[u];  // (output / noise offsets: not needed before the noise fetch and the overlap-add)
+  const int64_t pidx = rec.pidx;
+  const double shift = rec.shift;
+  const int64_t noise_size = rec.noise_size;
 
   // ---- spectral parameters of this pulse (synthesis.py:49-51,144-180) -------------------------
   // the two neighbouring frames and the interpolation weight, from pulse_frames_kernel
-  const int64_t fpair = A.p_frames[m.p_off + i];
-  const int64_t flo = fpair & 0xffffffffll, fhi = fpair >> 32;
-  const double bw = A.p_weight[m.p_off + i];
+  const int64_t row_lo = rec.rows & 0xffffffffll, row_hi = rec.rows >> 32;
+  const double bw = rec.weight;
   const bool same = bw < 0.0;
   const double b = same ? 0.0 : bw;
   const double a = 1 - b;
-  const double* s_lo = spectrogram + (m.f_off + flo) * K;
-  const double* s_hi = spectrogram + (m.f_off + fhi) * K;
-  const double* a_lo = aperiodicity + (m.f_off + flo) * K;
-  const double* a_hi = aperiodicity + (m.f_off + fhi) * K;
+  const double* s_lo = spectrogram + row_lo * K;
+  const double* s_hi = spectrogram + row_hi * K;
+  const double* a_lo = aperiodicity + row_lo * K;
+  const double* a_hi = aperiodicity + row_hi * K;
   // aperiodic_slice[0] decides voicing (synthesis.py:69)
   double aper0;
   {
     const double al = a_lo[0] * a_lo[0], ah = a_hi[0] * a_hi[0];
     aper0 = same ? al : a * al + b * ah;
   }
-  int64_t vi = pidx - 1;
-  vi = vi < 0 ? 0 : (vi > m.ny - 1 ? m.ny - 1 : vi);
-  const bool voiced = (vuv_s[m.y_off + vi] != 0) && (aper0 <= 0.999);
+  const bool voiced = (rec.vuv != 0) && (aper0 <= 0.999);
 
   for (int k = WH_TID; k < K; k += FT) {
     const double sl = s_lo[k], sh = s_hi[k];
@@ -1046,7 +1057,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, int64_t gp, ch
   }
   // ---- noise for this pulse: max(3, noise_size) samples, zero-mean (synthesis.py:93-95) -----------
   const int64_t nd = noise_size > 3 ? noise_size : 3;
-  const int64_t noff = p_noff[m.p_off + i];
+  const int64_t noff = rec.noff;
   auto noise_at = [&](int64_t j) -> double {
     if (noise) {
       const int64_t q = noff + j;
@@ -1245,8 +1256,13 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
   RunState rs{-1, 0};
   const int64_t gp0 = run * WH_RESP_RUN;
   const int64_t gp1 = gp0 + WH_RESP_RUN < total ? gp0 + WH_RESP_RUN : total;
+  PulseRec cur = A.p_rec[gp0];
 #pragma unroll 1
-  for (int64_t gp = gp0; gp < gp1; ++gp) response_pulse<N>(A, gp, smem, ring, rs);
+  for (int64_t gp = gp0; gp < gp1; ++gp) {
+    const PulseRec nxt = A.p_rec[gp + 1 < gp1 ? gp + 1 : gp];  // in flight under this pulse's row fetch
+    response_pulse<N>(A, cur, smem, ring, rs);
+    cur = nxt;
+  }
   wh::sync<FT>();
   if (rs.u >= 0) {
     const SynUtt mp = A.meta[rs.u];
@@ -1257,10 +1273,8 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
 
 template <int N>
 int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynUtt* d_meta, const double* tp,
-                const double* spec, const double* ap, double fs, const double* p_time, const int64_t* p_idx,
-                const double* p_shift, const int64_t* p_noff, const int32_t* p_count, const int64_t* p_base,
-                const uint8_t* vuv_s, const double* noise, uint64_t seed, double* y, const int64_t* p_frames,
-                const double* p_weight, const int32_t* p_utt) {
+                const double* spec, const double* ap, double fs, const PulseRec* p_rec, const int64_t* p_base,
+                const double* noise, uint64_t seed, double* y) {
   std::vector<double> dc(N);
   double sum = 0.0;
   for (int n = 0; n < N; ++n) {  // hanning(N+2)[1:-1] normalised (synthesis.py:57-58)
@@ -1274,7 +1288,7 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
   // one workgroup per run of WH_RESP_RUN pulse slots; runs past the real pulse count exit at once
   const int64_t grid = wh::xcd_grid((pcap_max * B + WH_RESP_RUN - 1) / WH_RESP_RUN);
-  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_time, p_idx, p_shift, p_noff, p_frames, p_weight, p_utt, p_count, p_base, B, vuv_s, noise, seed, d_dc, ctx->d_twiddle, y};
+  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_rec, p_base, B, noise, seed, d_dc, ctx->d_twiddle, y};
   hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(ft_syn(N)), lds, st, ra); }
   WH_LAUNCH_CHECK("response_kernel");
   return 0;
@@ -1496,9 +1510,7 @@ extern "C" int wh_synthesis_timebase(wh_ctx* ctx, void* stream, const wh_batch* 
   const size_t o_pc = off; off += al(sizeof(int32_t) * B);
   const size_t o_px = off; off += pulse_scratch_bytes(B, max_ny);
   const size_t o_pb = off; off += al(sizeof(int64_t) * (B + 1));
-  const size_t o_pf = off; off += al(sizeof(int64_t) * B * pulse_cap);
-  const size_t o_pw = off; off += al(sizeof(double) * B * pulse_cap);
-  const size_t o_pu = off; off += al(sizeof(int32_t) * B * pulse_cap);
+  const size_t o_rec = off; off += al(sizeof(PulseRec) * B * pulse_cap);
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   ctx->timebase.valid = false;
   char* ws = reinterpret_cast<char*>(ctx->ws);
@@ -1519,8 +1531,8 @@ extern "C" int wh_synthesis_timebase(wh_ctx* ctx, void* stream, const wh_batch* 
   if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ws + o_px)) return rc;
   { wh::KernelTimer _kt(ctx, st, "pulse_base_kernel"); hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb); }
   WH_LAUNCH_CHECK("pulse_base_kernel");
-  { wh::KernelTimer _kt(ctx, st, "pulse_frames_kernel"); hipLaunchKernelGGL(pulse_frames_kernel, dim3((unsigned)((pulse_cap + 255) / 256), B), dim3(256), 0, st, d_meta, tp, d_pt, d_pc, d_pb,
-                     reinterpret_cast<int64_t*>(ws + o_pf), reinterpret_cast<double*>(ws + o_pw), reinterpret_cast<int32_t*>(ws + o_pu)); }
+  { wh::KernelTimer _kt(ctx, st, "pulse_frames_kernel"); hipLaunchKernelGGL(pulse_frames_kernel, dim3((unsigned)((pulse_cap + 255) / 256), B), dim3(256), 0, st, d_meta, tp, d_pt, d_pi, d_ps, d_pn, d_vuv, d_pc, d_pb,
+                     reinterpret_cast<PulseRec*>(ws + o_rec)); }
   WH_LAUNCH_CHECK("pulse_frames_kernel");
   wh_ctx::TimeBase& t = ctx->timebase;
   t.valid = true;
@@ -1529,7 +1541,7 @@ extern "C" int wh_synthesis_timebase(wh_ctx* ctx, void* stream, const wh_batch* 
   t.ny_tot = ny_tot;
   t.frames = b->total_frames;
   t.o_vuv = o_vuv; t.o_pt = o_pt; t.o_pi = o_pi; t.o_ps = o_ps; t.o_pn = o_pn; t.o_pc = o_pc; t.o_pb = o_pb;
-  t.o_pf = o_pf; t.o_pw = o_pw; t.o_pu = o_pu;
+  t.o_rec = o_rec;
   return 0;
 }
 
@@ -1558,22 +1570,15 @@ extern "C" int wh_synthesis_render(wh_ctx* ctx, void* stream, const wh_batch* b,
   SynUtt* d_meta = nullptr;
   if (int rc = wh::persistent_upload(ctx, st, "syn.meta", meta, &d_meta)) return rc;
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * t.ny_tot, st));
-  const uint8_t* d_vuv = reinterpret_cast<const uint8_t*>(ws + t.o_vuv);
   const int64_t* d_pb = reinterpret_cast<const int64_t*>(ws + t.o_pb);
-  const double* d_pt = reinterpret_cast<const double*>(ws + t.o_pt);
-  const int64_t* d_pi = reinterpret_cast<const int64_t*>(ws + t.o_pi);
-  const double* d_ps = reinterpret_cast<const double*>(ws + t.o_ps);
-  const int64_t* d_pn = reinterpret_cast<const int64_t*>(ws + t.o_pn);
-  const int64_t* d_pf = reinterpret_cast<const int64_t*>(ws + t.o_pf);
-  const double* d_pw = reinterpret_cast<const double*>(ws + t.o_pw);
-  const int32_t* d_pu = reinterpret_cast<const int32_t*>(ws + t.o_pu);
+  const PulseRec* d_rec = reinterpret_cast<const PulseRec*>(ws + t.o_rec);
   const int32_t* d_pc = reinterpret_cast<const int32_t*>(ws + t.o_pc);
   int rc;
   switch (fft_size) {
-    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
-    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
-    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
-    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_pt, d_pi, d_ps, d_pn, d_pc, d_pb, d_vuv, noise, seed, y, d_pf, d_pw, d_pu); break;
+    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, noise, seed, y); break;
+    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, noise, seed, y); break;
+    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, noise, seed, y); break;
+    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, noise, seed, y); break;
     default: return wh::fail_msg("wh_synthesis_render", "fft_size must be a power of two in [512, 4096]");
   }
   if (rc) return rc;

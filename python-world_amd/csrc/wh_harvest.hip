@@ -578,9 +578,13 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       const double smp = j < L ? yl[sc] : 0.0;
       si += RL;
       const double a = smp * cur.x, d = smp * cur.y;
+      double2 wv[6];  // all six gathers in flight before the first FMA needs one (left to the compiler, every gather's
+                      // LDS latency sat in front of its own four FMAs)
+#pragma unroll
+      for (int h = 0; h < 6; ++h) wv[h] = twiddle(tix[h]);
 #pragma unroll
       for (int h = 0; h < 6; ++h) {
-        const double2 w = twiddle(tix[h]);
+        const double2 w = wv[h];
         xr[h] = fma(a, w.x, xr[h]);
         xi[h] = fma(a, w.y, xi[h]);
         dr[h] = fma(d, w.x, dr[h]);
@@ -725,6 +729,9 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   *out_sc = sc;
 }
 
+#ifndef WH_HV_MINW
+#define WH_HV_MINW 3  // waves per SIMD the tabulated variant is compiled for (2: 5.07 ms against 4.09 at config 3)
+#endif
 #ifndef WH_HV_ROW_LANES
 #define WH_HV_ROW_LANES 4
 #endif
@@ -736,7 +743,7 @@ constexpr int refine_lanes(bool wtab) { return wtab ? WH_HV_ROW_LANES : 16; }
 constexpr int refine_frames(bool wtab) { return wtab ? WH_HV_TAB_FRAMES : 4; }
 
 template <bool TWL, bool WTAB>
-__global__ __launch_bounds__(256, WTAB ? 3 : 1) void hv_refine_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
+__global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
                                                         const double* __restrict__ dc, const int32_t* __restrict__ dcount,
                                                         double fs, double f0_floor, double f0_ceil, int hmax, int seglen,
                                                         const double2* __restrict__ tw_base, int tw_n,

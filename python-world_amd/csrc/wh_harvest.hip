@@ -249,6 +249,8 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
   // intervals staged per tile: twice the ~1.1*bf*0.256 a band-limited signal can hold, plus the cursor's slack
   int need = 2 * (int)(bf * 1.1 * (kRawTile * 0.001) + 1.0) + 8;
   need = need > kRawChunk ? kRawChunk : need;
+  int search_steps = 0;  // halvings that settle a lower_bound over [0, need]
+  while ((1 << search_steps) < need + 1) ++search_steps;
   // blockIdx.z cuts the frames into gridDim.z segments of whole tiles, each with its own workgroup (the tile loop is a
   // chain of load -> barrier -> search -> barrier; more workgroups in flight hide it).  A segment's first cursors
   // are found by a search over the whole list.
@@ -304,14 +306,29 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
     if (f < f_end) {
       const double t = (double)f * 1 / 1000;  // basic_temporal_positions (harvest.py:21)
       double v[4];
+      // lower_bound of t among the staged locations, the four trains in lockstep: a fixed number of branch-free halving
+      // steps (the window holds at most `need` intervals), so that a step's four LDS reads are in flight together —
+      // four while-loops one after the other were 32 dependent LDS round trips per frame
+      int lo4[4], hi4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        lo4[k] = 0;
+        hi4[k] = nloc[k];
+      }
+      for (int st = 0; st < search_steps; ++st) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool act = lo4[k] < hi4[k];
+          const int mid = (lo4[k] + hi4[k]) >> 1;
+          const bool lt = iv[k][act ? mid : 0].x < t;
+          lo4[k] = (act && lt) ? mid + 1 : lo4[k];
+          hi4[k] = (act && !lt) ? mid : hi4[k];
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int ni = cnt[k] - 1;  // intervals of the whole train; location i = (e[i]+e[i+1])/2/fs
-        int lo = 0, hi = nloc[k];   // lower_bound inside the window
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (iv[k][mid].x < t) lo = mid + 1; else hi = mid;
-        }
+        const int lo = lo4[k];
         const bool inside = lo < nloc[k] || start[k] + nloc[k] == ni;
         const double* e = job.edges + (int64_t)k * job.cap;
         int g = start[k] + lo;  // count of locations < t over the whole train

@@ -30,6 +30,9 @@ __device__ __forceinline__ int wh_opaque_tid() {
 // FFT radix caps of d4c_kernel by transform length.  At 128 VGPRs (four workgroups per CU) the radix-8 plan fits
 // N <= 1024 without spilling; at N = 2048 / 4096 it spills ~23 registers — still 2 % faster, but the spills are HBM
 // traffic (1.86 GB per launch where the kernel's compulsory bytes are 0.61 GB), so those lengths keep radix 4.
+#ifndef WH_D4C_GATHER_UNCOND
+#define WH_D4C_GATHER_UNCOND 1
+#endif
 #ifndef WH_D4C_REGFED
 #define WH_D4C_REGFED 1  // windows keep their samples in registers and feed the first (radix-8) FFT pass directly
 #endif
@@ -305,11 +308,22 @@ __device__ __forceinline__ void d4c_window_regs(const double* __restrict__ xu, c
     return xb[rel];
   };
   const int nq = L >= N ? Q : (L + FT - 1) / FT;  // rows that hold window samples (workgroup-uniform)
+  // All Q loads are issued unconditionally (the index is clamped: always a valid address; rows past the window read its
+  // last sample, one line for the whole wave) and the rows past nq zeroed by a select.  Written as `if (q < nq) out[q] =
+  // sample(..)` the compiler made a chain of conditional blocks, each WAITING for its load before the next block's and
+  // copying the whole array between them: nq dependent global round trips and ~25 register moves per row.
+#if WH_D4C_GATHER_UNCOND
+#pragma unroll
+  for (int q = 0; q < Q; ++q) out[q] = sample(threadIdx.x + q * FT);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) out[q] = q < nq ? out[q] : 0.0;
+#else
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     out[q] = 0.0;
-    if (q < nq) out[q] = sample(threadIdx.x + q * FT);  // clamped: always a valid address; all loads in flight at once
+    if (q < nq) out[q] = sample(threadIdx.x + q * FT);
   }
+#endif
   const double rot_s = ws.rot_s, rot_c = ws.rot_c;
   const double c0 = ws.base_c * e_tid.y - ws.base_s * e_tid.x;  // phase of this thread's first sample: base * E[tid]
   const double s0 = ws.base_s * e_tid.y + ws.base_c * e_tid.x;

@@ -131,12 +131,21 @@ __device__ __forceinline__ double dpp_or_zero(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+// a permutation inside the rows of 16 lanes: every lane has a source, so there is no "old" value to prepare (with
+// update_dpp(0, ..) each of these steps carried two v_mov_b32 v, 0 in front of its two v_mov_b32_dpp)
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_perm(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #if WH_WAVE_SUM_DPP
-  v += dpp_or_zero<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-  v += dpp_or_zero<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-  v += dpp_or_zero<0x141, 0xF>(v);  // row_half_mirror
-  v += dpp_or_zero<0x140, 0xF>(v);  // row_mirror: every lane holds its row's total
+  v += dpp_row_perm<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_row_perm<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_row_perm<0x141>(v);  // row_half_mirror
+  v += dpp_row_perm<0x140>(v);  // row_mirror: every lane holds its row's total
   v += dpp_or_zero<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
   v += dpp_or_zero<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's total
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);

@@ -30,6 +30,9 @@ __device__ __forceinline__ int wh_opaque_tid() {
 // FFT radix caps of d4c_kernel by transform length.  At 128 VGPRs (four workgroups per CU) the radix-8 plan fits
 // N <= 1024 without spilling; at N = 2048 / 4096 it spills ~23 registers — still 2 % faster, but the spills are HBM
 // traffic (1.86 GB per launch where the kernel's compulsory bytes are 0.61 GB), so those lengths keep radix 4.
+#ifndef WH_D4C_KEEP_W
+#define WH_D4C_KEEP_W 4  // rows of a register-fed window whose window values survive from the first walk to the second
+#endif
 #ifndef WH_D4C_GATHER_UNCOND
 #define WH_D4C_GATHER_UNCOND 1
 #endif
@@ -328,14 +331,19 @@ __device__ __forceinline__ void d4c_window_regs(const double* __restrict__ xu, c
   const double c0 = ws.base_c * e_tid.y - ws.base_s * e_tid.x;  // phase of this thread's first sample: base * E[tid]
   const double s0 = ws.base_s * e_tid.y + ws.base_c * e_tid.x;
   double s_sw = 0.0, s_w = 0.0, s_swsw = 0.0, s_sww = 0.0, s_ww = 0.0;
+  // The window values of the first KEEPQ rows are kept for the second walk (rows beyond that — windows longer than
+  // KEEPQ * FT samples, f0 below ~62 Hz at N = 2048 — re-derive theirs by the rotation, as every row used to).
+  constexpr int KEEPQ = N >= 4096 ? 0 : (WH_D4C_KEEP_W < Q ? WH_D4C_KEEP_W : Q);  // (N = 4096: 26 ... 276 spilled registers)
+  double wk[KEEPQ > 0 ? KEEPQ : 1];
   {
     double c = c0, sn = s0;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       if (q < nq) {
         const int j = threadIdx.x + q * FT;
+        double w = 0.0;
         if (j < L) {
-          const double w = shape(c);
+          w = shape(c);
           const double sw = out[q] * w;
           s_sw += sw;
           s_w += w;
@@ -345,6 +353,7 @@ __device__ __forceinline__ void d4c_window_regs(const double* __restrict__ xu, c
             s_ww += w * w;
           }
         }
+        if (q < KEEPQ) wk[q] = w;
         const double cn = c * rot_c - sn * rot_s;
         sn = sn * rot_c + c * rot_s;
         c = cn;
@@ -370,20 +379,35 @@ __device__ __forceinline__ void d4c_window_regs(const double* __restrict__ xu, c
   const double inv_nrm = ENERGY ? 1.0 / sqrt((s_swsw - 2.0 * dc * s_sww) + dc * dc * s_ww) : 1.0;
   {
     double c = c0, sn = s0;
+    if (KEEPQ < Q && nq > KEEPQ) {  // phase of row KEEPQ for the rows that re-derive their window value
+#pragma unroll
+      for (int q = 0; q < KEEPQ; ++q) {
+        const double cn = c * rot_c - sn * rot_s;
+        sn = sn * rot_c + c * rot_s;
+        c = cn;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       if (q < nq) {
         const int j = threadIdx.x + q * FT;
         double val = 0.0;
-        if (j < L) {
-          const double w = shape(c);
+        if (q < KEEPQ) {
+          const double w = wk[q];  // 0 past the window's end
           val = out[q] * w - w * dc;
           if (ENERGY) val *= inv_nrm;
+          if (!(j < L)) val = 0.0;
+        } else {
+          if (j < L) {
+            const double w = shape(c);
+            val = out[q] * w - w * dc;
+            if (ENERGY) val *= inv_nrm;
+          }
+          const double cn = c * rot_c - sn * rot_s;
+          sn = sn * rot_c + c * rot_s;
+          c = cn;
         }
         out[q] = val;
-        const double cn = c * rot_c - sn * rot_s;
-        sn = sn * rot_c + c * rot_s;
-        c = cn;
       }
     }
   }

@@ -1033,9 +1033,25 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   }
   const bool voiced = (rec.vuv != 0) && (aper0 <= 0.999);
 
-  for (int k = WH_TID; k < K; k += FT) {
-    const double sl = s_lo[k], sh = s_hi[k];
-    const double al = a_lo[k] * a_lo[k], ah = a_hi[k] * a_hi[k];
+  // a thread's bins k = tid + q FT: all of their row loads are issued before the first log (a call: nothing is moved
+  // across it), one global round trip per pulse instead of one per bin
+  constexpr int KQ = (K + FT - 1) / FT;
+  double rsl[KQ], rsh[KQ], ral[KQ], rah[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = WH_TID + q * FT;
+    const int kc = k < K ? k : K - 1;  // (clamped: always a valid address; the surplus slot is not used)
+    rsl[q] = s_lo[kc];
+    rsh[q] = s_hi[kc];
+    ral[q] = a_lo[kc];
+    rah[q] = a_hi[kc];
+  }
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = WH_TID + q * FT;
+    if (k >= K) break;
+    const double sl = rsl[q], sh = rsh[q];
+    const double al = ral[q] * ral[q], ah = rah[q] * rah[q];
     const double pl = fmax(0.001, 1 - al), ph = fmax(0.001, 1 - ah);
     const double sp = same ? sl : a * sl + b * sh;
     const double pe = same ? pl : a * pl + b * ph;

@@ -980,7 +980,8 @@ __device__ __forceinline__ void ring_flush(double* ring, int64_t a, int64_t b, d
 
 // One pulse of a run.
 template <int N>
-__device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec& rec, char* smem, double* ring, RunState& rs) {
+__device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec& rec, char* smem, double* ring, RunState& rs,
+                                               const double (&dcw)[N / ft_syn(N) <= 4 ? N / ft_syn(N) : 1]) {
   const SynUtt* __restrict__ meta = A.meta;
   const double* __restrict__ spectrogram = A.spectrogram;
   const double* __restrict__ aperiodicity = A.aperiodicity;
@@ -1247,7 +1248,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
     const int mm = m0 + q;
     const int64_t tgt = s1 + mm;
     double v = acc[q];
-    if (voiced) v += (zrP[(mm + N / 2) & (N - 1)] / N + dc_base[mm] * -dc_total) * gain;
+    if (voiced) v += (zrP[(mm + N / 2) & (N - 1)] / N + (R <= 4 ? dcw[R <= 4 ? q : 0] : dc_base[mm]) * -dc_total) * gain;
     if (tgt < 1) continue;                    // clipped to 1 and overwritten by the in-range tap
     if (tgt < m.ny) ring[(int)(tgt & (N - 1))] += v;    // this thread is the only writer of its R slots
     else if (mm == N - 1) atomicAdd(&yu[m.ny - 1], v);  // last duplicate wins on the high side
@@ -1273,10 +1274,20 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
   const int64_t gp0 = run * WH_RESP_RUN;
   const int64_t gp1 = gp0 + WH_RESP_RUN < total ? gp0 + WH_RESP_RUN : total;
   PulseRec cur = A.p_rec[gp0];
+  // the DC-removal weights of this thread's R output samples are the same for every pulse: read once per run (R <= 4;
+  // beyond that they would cost the registers the convolution needs)
+  constexpr int R = N / FT;
+  double dcw[R <= 4 ? R : 1];
+  if constexpr (R <= 4) {
+#pragma unroll
+    for (int q = 0; q < R; ++q) dcw[q] = A.dc_base[threadIdx.x * R + q];
+  } else {
+    dcw[0] = 0.0;
+  }
 #pragma unroll 1
   for (int64_t gp = gp0; gp < gp1; ++gp) {
     const PulseRec nxt = A.p_rec[gp + 1 < gp1 ? gp + 1 : gp];  // in flight under this pulse's row fetch
-    response_pulse<N>(A, cur, smem, ring, rs);
+    response_pulse<N>(A, cur, smem, ring, rs, dcw);
     cur = nxt;
   }
   wh::sync<FT>();

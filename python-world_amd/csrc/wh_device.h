@@ -284,6 +284,10 @@ __device__ __forceinline__ double wave_scan_incl(double v) {
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
   return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
 }
+// a * conj(b): the same roundings as cmul(a, (b.x, -b.y)), the negations riding on the operands
+__device__ __forceinline__ double2 cmul_conj(double2 a, double2 b) {
+  return make_double2(fma(a.x, b.x, a.y * b.y), fma(-a.x, b.y, a.y * b.x));
+}
 
 // In-place Stockham passes of radix 8 (then 4 or 2 for what is left of N), NT threads on one N-point buffer.
 //
@@ -374,7 +378,7 @@ __device__ __forceinline__ void fft_pass_finish(double2* __restrict__ s, double2
       const int k = j & (NS - 1);
       if (NS > 1) {
 #pragma unroll
-        for (int r = 1; r < R; ++r) v[p][r] = cmul(v[p][r], w[p][r]);
+        for (int r = 1; r < R; ++r) v[p][r] = INV ? cmul_conj(v[p][r], w[p][r]) : cmul(v[p][r], w[p][r]);
       }
       dft_small<R, INV>(v[p]);
       const int base = (j - k) * R + k;
@@ -403,9 +407,9 @@ __device__ __forceinline__ void fft_pass_twiddles(const double2* __restrict__ tw
         const int k = j & (NS - 1);
 #pragma unroll
         for (int r = 1; r < R; ++r) {
-          double2 t = ldg2(tw + ((k * r * STEP) & (N - 1)));
-          if (INV) t.y = -t.y;
-          w[p][r] = t;
+          // as stored: the inverse transform's conjugation is folded into the multiply (fft_pass_finish) — negating
+          // here made every load's wait come right behind it, in front of the pass's LDS reads instead of under them
+          w[p][r] = ldg2(tw + ((k * r * STEP) & (N - 1)));
         }
       }
     }

@@ -1026,14 +1026,6 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   const double* s_hi = spectrogram + row_hi * K;
   const double* a_lo = aperiodicity + row_lo * K;
   const double* a_hi = aperiodicity + row_hi * K;
-  // aperiodic_slice[0] decides voicing (synthesis.py:69)
-  double aper0;
-  {
-    const double al = a_lo[0] * a_lo[0], ah = a_hi[0] * a_hi[0];
-    aper0 = same ? al : a * al + b * ah;
-  }
-  const bool voiced = (rec.vuv != 0) && (aper0 <= 0.999);
-
   // a thread's bins k = tid + q FT: all of their row loads are issued before the first log (a call: nothing is moved
   // across it), one global round trip per pulse instead of one per bin
   constexpr int KQ = (K + FT - 1) / FT;
@@ -1047,6 +1039,16 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
     ral[q] = a_lo[kc];
     rah[q] = a_hi[kc];
   }
+  // aperiodic_slice[0] decides voicing (synthesis.py:69); its two loads ride with the rows' (issued first, they put
+  // two more dependent round trips in front of the rows: the compiler waited for each before going on)
+  double ap0_lo = a_lo[0], ap0_hi = a_hi[0];
+  asm volatile("" : "+v"(ap0_lo), "+v"(ap0_hi));  // (both issued here: else the second is sunk behind the test of `same`)
+  double aper0;
+  {
+    const double al = ap0_lo * ap0_lo, ah = ap0_hi * ap0_hi;
+    aper0 = same ? al : a * al + b * ah;
+  }
+  const bool voiced = (rec.vuv != 0) && (aper0 <= 0.999);
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
     const int k = WH_TID + q * FT;
@@ -1273,7 +1275,29 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
   RunState rs{-1, 0};
   const int64_t gp0 = run * WH_RESP_RUN;
   const int64_t gp1 = gp0 + WH_RESP_RUN < total ? gp0 + WH_RESP_RUN : total;
-  PulseRec cur = A.p_rec[gp0];
+  // A pulse's record travels as ONE dword per lane (lane i & 15 holds dword i) and is turned into scalars by
+  // v_readlane at the top of the pulse that uses it — a pulse after its load was issued.  Fetched as a struct the
+  // compiler made scalars of it (readfirstlane) right behind the load: the "prefetch" was waited for at once.
+  auto fetch_rec = [&](int64_t gp) -> uint32_t {
+    return reinterpret_cast<const uint32_t*>(A.p_rec + gp)[threadIdx.x & 15];
+  };
+  auto unpack_rec = [&](uint32_t word) -> PulseRec {
+    uint32_t d[16];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) d[i] = (uint32_t)__builtin_amdgcn_readlane((int)word, i);
+    PulseRec r;
+    r.pidx = (int64_t)(((uint64_t)d[1] << 32) | d[0]);
+    r.rows = (int64_t)(((uint64_t)d[3] << 32) | d[2]);
+    r.weight = __hiloint2double((int)d[5], (int)d[4]);
+    r.shift = __hiloint2double((int)d[7], (int)d[6]);
+    r.noff = (int64_t)(((uint64_t)d[9] << 32) | d[8]);
+    r.u = (int32_t)d[10];
+    r.noise_size = (int32_t)d[11];
+    r.vuv = (int32_t)d[12];
+    r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+    return r;
+  };
+  uint32_t cur_w = fetch_rec(gp0);
   // the DC-removal weights of this thread's R output samples are the same for every pulse: read once per run (R <= 4;
   // beyond that they would cost the registers the convolution needs)
   constexpr int R = N / FT;
@@ -1286,9 +1310,10 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
   }
 #pragma unroll 1
   for (int64_t gp = gp0; gp < gp1; ++gp) {
-    const PulseRec nxt = A.p_rec[gp + 1 < gp1 ? gp + 1 : gp];  // in flight under this pulse's row fetch
+    const PulseRec cur = unpack_rec(cur_w);
+    const uint32_t nxt_w = fetch_rec(gp + 1 < gp1 ? gp + 1 : gp);  // in flight under this whole pulse
     response_pulse<N>(A, cur, smem, ring, rs, dcw);
-    cur = nxt;
+    cur_w = nxt_w;
   }
   wh::sync<FT>();
   if (rs.u >= 0) {

@@ -62,19 +62,39 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
   // (cheaptrick.py:84-95); the DC ratio mean(x w') / mean(w') is that of the unnormalised sums — the norm and the 1/L
   // cancel — so the second reduction and the pass that rescaled the stored window are gone.
   double s_w2 = 0.0, s_sw = 0.0, s_w = 0.0;
+  // The thread's samples j = tid + q FT, q < N / FT, are fetched in ONE round of loads (clamped indices: always valid
+  // addresses) and stay in registers for both walks; taken inside the walks — a loop of load, use, load — every row
+  // cost a global round trip, twice.  Rows at or past the window's end are not used.
+  constexpr int Q = N / FT;
+  double xs[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) xs[q] = wh::sample_clamped(xu, xn, centre + ((int)threadIdx.x + q * FT - hwl));
   {
     // cos(pi*f0*t_j) for this thread's samples j = tid, tid + FT, ...: one sincospi for the first, a fixed rotation by
     // FT samples after that (at most N/FT + 1 steps: error growth ~1e-15) instead of a cospi per sample
     double sn, cs, rs = 0.0, rc = 1.0;
     sincospi(((double)((int)threadIdx.x - hwl) * inv_span) * f0, &sn, &cs);
     if (L > FT) sincospi(((double)FT * inv_span) * f0, &rs, &rc);  // frame-uniform
-    for (int j = threadIdx.x; j < L; j += FT) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = threadIdx.x + q * FT;
+      if (j < L) {
+        const double w = 0.5 * cs + 0.5;
+        s_w2 += w * w;
+        s_sw += xs[q] * w;
+        s_w += w;
+        zr[j] = w;
+        const double cn = cs * rc - sn * rs;
+        sn = sn * rc + cs * rs;
+        cs = cn;
+      }
+    }
+    for (int j = N + threadIdx.x; j < L; j += FT) {  // np.fft crops rows longer than N, the means still see them (Q7)
       const double w = 0.5 * cs + 0.5;
       const double seg = wh::sample_clamped(xu, xn, centre + (j - hwl));
       s_w2 += w * w;
-      s_sw += seg * w;  // np.fft crops rows longer than N, the means still see them (Q7)
+      s_sw += seg * w;
       s_w += w;
-      if (j < N) zr[j] = w;
       const double cn = cs * rc - sn * rs;
       sn = sn * rc + cs * rs;
       cs = cn;
@@ -83,11 +103,13 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
   wh::block_sum3<FT>(s_w2, s_sw, s_w, scratch);
   const double inv_norm = 1.0 / sqrt(s_w2);
   const double dc = s_sw / s_w;
-  for (int j = threadIdx.x; j < N; j += FT) {
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int j = threadIdx.x + q * FT;
     double v = 0.0;
     if (j < L) {
       const double w = zr[j] * inv_norm;
-      v = wh::sample_clamped(xu, xn, centre + (j - hwl)) * w - w * dc;
+      v = xs[q] * w - w * dc;
     }
     zr[j] = v;
   }

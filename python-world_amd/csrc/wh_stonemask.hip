@@ -214,15 +214,23 @@ __device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long lon
   int j = lg;
   const double xn_d = (double)xn;
   double2 cur = j < L ? wt[j] : make_double2(0.0, 0.0);
-  double bc = j < L ? qt[j - hwl] : 0.0;
+  // 1-based pick floor((t0 + bt)*fs + 0.5), clamped like the reference (stonemask.py:39-41; every tap time is
+  // positive here: the kernel checked it)
+  auto pick = [&](double bt) -> double {
+    const double ir = fmax(1.0, fmin(xn_d, (t0 + bt) * fs + 0.5));
+    return xu[(long long)ir - 1];
+  };
+  // The sample of a tap is addressed through its tabulated time: a chain table -> index -> waveform.  The time is
+  // fetched two taps ahead and the sample one tap ahead, so neither round trip sits in front of the tap that uses it
+  // (fetched in the iteration that consumed it, every tap waited for a global load).
+  const double bc = j < L ? qt[j - hwl] : 0.0;
+  double bn = j + kSmLanes < L ? qt[j + kSmLanes - hwl] : 0.0;
+  double smp = j < L ? pick(bc) : 0.0;
   for (int it = 0; it < n_it; ++it) {
-    const int jn = j + kSmLanes;
+    const int jn = j + kSmLanes, jnn = j + 2 * kSmLanes;
     const double2 nxt = jn < L ? wt[jn] : make_double2(0.0, 0.0);
-    const double bn = jn < L ? qt[jn - hwl] : 0.0;
-    // 1-based pick floor((t0 + bt)*fs + 0.5), clamped like the reference (stonemask.py:39-41; every tap time is
-    // positive here: the kernel checked it)
-    const double ir = fmax(1.0, fmin(xn_d, (t0 + bc) * fs + 0.5));
-    const double smp = j < L ? xu[(long long)ir - 1] : 0.0;
+    const double bnn = jnn < L ? qt[jnn - hwl] : 0.0;
+    const double smp_n = jn < L ? pick(bn) : 0.0;
     const double a = smp * cur.x, d = smp * cur.y;
 #pragma unroll
     for (int h = 0; h < NB; ++h) {
@@ -235,7 +243,8 @@ __device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long lon
       tix[h] = (tix[h] + tstep[h]) & tmask;
     }
     cur = nxt;
-    bc = bn;
+    bn = bnn;
+    smp = smp_n;
     j = jn;
   }
 #pragma unroll

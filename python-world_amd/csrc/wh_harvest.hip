@@ -420,7 +420,8 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
   for (int b0 = 0; b0 < nb; b0 += 8) {
     uint8_t v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = b0 + q < nb ? lcol[(int64_t)(b0 + q) * m.nf1] : 0;
+    for (int q = 0; q < 8; ++q) v[q] = lcol[(int64_t)(b0 + q < nb ? b0 + q : nb - 1) * m.nf1];  // clamped, not skipped: a
+    // conditional load becomes a branch, and eight of them a chain of load-wait-load (the surplus values are not read)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int b = b0 + q;

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void hc_base_kernel(const HvUtt* __restrict__ 
   for (int e0 = 0; e0 < l.n; e0 += 4) {
     double sv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sv[q] = e0 + q < l.n ? l.sc[e0 + q] : 0.0;
+    for (int q = 0; q < 4; ++q) sv[q] = l.sc[e0 + q < l.n ? e0 + q : l.n - 1];  // clamped (a conditional load is a branch: four of them, a chain of waits)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int e = e0 + q;
@@ -375,7 +375,7 @@ __device__ __forceinline__ double search_score(double f0, const HcList& l, const
   for (int e0 = 0; e0 < l.n; e0 += 8) {
     double c[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) c[q] = e0 + q < l.n ? cf[e0 + q] : 0.0;
+    for (int q = 0; q < 8; ++q) c[q] = cf[e0 + q < l.n ? e0 + q : l.n - 1];  // clamped: see hc_base_kernel (surplus slots are tested out below)
 #pragma unroll
     for (int q = 0; q < 8; ++q)
       if (e0 + q < l.n && f0 == c[q] && ((kw[(e0 + q) >> 5] >> ((e0 + q) & 31)) & 1u)) {

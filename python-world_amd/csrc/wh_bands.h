@@ -331,9 +331,12 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
   constexpr int SLOTS = 2 * PQ + 1;
   double2 zr[SLOTS], tr[SLOTS];
   auto load_spec = [&](double2 (&dst)[SLOTS], const double2* src) {
+    // (the thread index read opaquely: as loop invariants the eight per-thread offsets were kept in registers across
+    // the whole walk, spilled, and every prefetch load then waited for the scratch load of its own address)
+    const int tid = WH_TID;
 #pragma unroll
     for (int q = 0; q < PQ; ++q) {
-      const int k = threadIdx.x + q * 256;
+      const int k = tid + q * 256;
       dst[2 * q] = src[k];
       dst[2 * q + 1] = src[NH - k];
     }

@@ -810,14 +810,29 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
   // need from it is the ORDER of a frame's candidates (first-index / last-index tie rules), not the row numbers, so the
   // results are stored as per-frame lists in row order: the block's frames share one contiguous pool region (at the place
   // the dense rows of its first frame would start), lst[frame] = (first pool slot << 8) | count.
-  for (int q = threadIdx.x; q < kFramesPerBlock * kRows; q += 256) {
+  // A thread's (up to 7) candidate slots are fetched in one round of unconditional loads from clamped source frames —
+  // hv_detect writes every one of a frame's kMaxC slots, zeros past its count, so the count itself is not needed; as
+  // `if (in range && c < dcount[src]) cand = dc[..]` every slot was two dependent round trips, one slot after the other.
+  constexpr int kGather = (kFramesPerBlock * kRows + 255) / 256;
+  double cv[kGather];
+#pragma unroll
+  for (int it = 0; it < kGather; ++it) {
+    const int q = threadIdx.x + it * 256;
+    const int qc = q < kFramesPerBlock * kRows ? q : 0;
+    const int fl = qc / kRows, e = qc % kRows;
+    int64_t src = f_first + fl + (e / kMaxC - 3);
+    src = src < 0 ? 0 : (src > m.nf1 - 1 ? m.nf1 - 1 : src);
+    cv[it] = dc[(m.f1_off + src) * kMaxC + e % kMaxC];
+  }
+#pragma unroll
+  for (int it = 0; it < kGather; ++it) {
+    const int q = threadIdx.x + it * 256;
+    if (q >= kFramesPerBlock * kRows) break;
     const int fl = q / kRows, e = q % kRows;
     const int64_t f = f_first + fl;
     if (f >= m.nf1) continue;
-    const int s = e / kMaxC - 3, c = e % kMaxC;
-    const int64_t src = f + s;
-    double cand = 0.0;
-    if (src >= 0 && src < m.nf1 && c < dcount[m.f1_off + src]) cand = dc[(m.f1_off + src) * kMaxC + c];
+    const int64_t src = f + (e / kMaxC - 3);
+    double cand = (src >= 0 && src < m.nf1) ? cv[it] : 0.0;
     if (e == 0 && f < 3) cand = dc[(m.f1_off + f) * kMaxC + 6];  // stray seeding of row 0 (harvest.py:119)
     if (cand != 0.0 && ceil(3 * fs / cand / 2) <= (double)hmax) {
       const int p = atomicAdd(&cl_n, 1);

@@ -963,7 +963,7 @@ struct RunState {
   int64_t win_start;  // 1-based output index of the first sample of the ring's window
 };
 #ifndef WH_RESP_RUN
-#define WH_RESP_RUN 8
+#define WH_RESP_RUN 0  // pulses per workgroup; 0: by transform length (resp_run below)
 #endif
 
 // Samples [a, b) (1-based, within the ring's current window) are final for this run: add them to y, clear the ring.
@@ -1258,7 +1258,12 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   RSTAGE_MARK(4)
 }
 
-// One workgroup per RUN of WH_RESP_RUN consecutive pulses (flat pulse numbering: utterance by utterance, in time
+// Pulses per workgroup: 6 up to N = 1024, 8 beyond (measured with the pulse record prefetch in place: 4 / 5 / 6 / 7 / 8 /
+// 12 / 16 pulses 3.414 / 3.416 / 3.417 / 3.449 / 3.46 / 3.51 / 3.59 ms at config 2; at 48 kHz, N = 2048, 5 pulses 42.5
+// against 41.6 ms for 8: the flush of the longer ring is what a short run does not amortise).
+constexpr int resp_run(int n) { return WH_RESP_RUN > 0 ? WH_RESP_RUN : (n <= 1024 ? 6 : 8); }
+
+// One workgroup per RUN of resp_run(N) consecutive pulses (flat pulse numbering: utterance by utterance, in time
 // order).  The grid is sized from the host's pulse capacity; the runs that exist (device-side pulse count) are dealt
 // to the XCDs in contiguous ranges, so that the spectrogram / aperiodicity rows neighbouring pulses share are fetched
 // into one L2 — the surplus workgroups exit at once.
@@ -1267,14 +1272,15 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int FT = ft_syn(N);
   const int64_t total = A.p_base[A.n_utt];
-  const int64_t n_runs = (total + WH_RESP_RUN - 1) / WH_RESP_RUN;
+  constexpr int RUN = resp_run(N);
+  const int64_t n_runs = (total + RUN - 1) / RUN;
   const int64_t run = wh::xcd_unit(blockIdx.x, n_runs);
   if (run >= n_runs) return;
   double* ring = reinterpret_cast<double*>(smem) + (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32);
   for (int i = threadIdx.x; i < N; i += FT) ring[i] = 0.0;
   RunState rs{-1, 0};
-  const int64_t gp0 = run * WH_RESP_RUN;
-  const int64_t gp1 = gp0 + WH_RESP_RUN < total ? gp0 + WH_RESP_RUN : total;
+  const int64_t gp0 = run * RUN;
+  const int64_t gp1 = gp0 + RUN < total ? gp0 + RUN : total;
   // A pulse's record travels as ONE dword per lane (lane i & 15 holds dword i) and is turned into scalars by
   // v_readlane at the top of the pulse that uses it — a pulse after its load was issued.  Fetched as a struct the
   // compiler made scalars of it (readfirstlane) right behind the load: the "prefetch" was waited for at once.
@@ -1338,8 +1344,8 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   if (int rc = wh::const_table(ctx, "dc_base:" + std::to_string(N), dc, &d_dc)) return rc;
   const size_t lds = sizeof(double) * (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32 + N);  // ... + the overlap-add ring
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
-  // one workgroup per run of WH_RESP_RUN pulse slots; runs past the real pulse count exit at once
-  const int64_t grid = wh::xcd_grid((pcap_max * B + WH_RESP_RUN - 1) / WH_RESP_RUN);
+  // one workgroup per run of resp_run(N) pulse slots; runs past the real pulse count exit at once
+  const int64_t grid = wh::xcd_grid((pcap_max * B + resp_run(N) - 1) / resp_run(N));
   { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_rec, p_base, B, noise, seed, d_dc, ctx->d_twiddle, y};
   hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(ft_syn(N)), lds, st, ra); }
   WH_LAUNCH_CHECK("response_kernel");

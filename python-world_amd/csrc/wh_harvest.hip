@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void hv_pad_kernel(const HvUtt* __restrict__ m
 #define WH_HV_RAW_SEGS 1
 #endif
 #ifndef WH_HV_RAW_TILE
-#define WH_HV_RAW_TILE 128
+#define WH_HV_RAW_TILE 64  // (one wave per workgroup: 1.56 ms at config 3 against 1.66 for 128 and 1.79 for 256; 23.3 against 25.0 ms at 1024 utterances)
 #endif
 constexpr int kRawTile = WH_HV_RAW_TILE;   // frames per tile = threads per workgroup
 constexpr int kRawChunk = 2 * kRawTile;    // intervals staged per train and tile, at most

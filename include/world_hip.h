@@ -63,6 +63,15 @@ int wh_copy_mapped(wh_ctx* ctx, void* stream, void* dst, const void* src, size_t
 #define WH_FLAG_NO_PULSE 3         /* an utterance produced no pulse (reference asserts, synthesis.py:131) */
 #define WH_FLAG_PULSE_OVERFLOW 4   /* more pulses than the pulse capacity */
 int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16);
+/* The same flags without a host wait, for callers that keep a pipeline of batches in flight:
+ *   wh_flags_post — enqueue (one 16-lane kernel on `stream`) the publication of the flags raised by everything before
+ *     it on the stream to a pinned host word per flag, and clear them on the device (discard != 0: clear them
+ *     without publishing — for work whose results have been abandoned);
+ *   wh_flags_poll — read, WITHOUT synchronising, the conditions published since the last poll / take (h_flags16[i] != 0).
+ * A condition is therefore reported at the first poll after its post has executed — late, never lost; wh_take_flags
+ * (which synchronises) also reports whatever has been posted and not yet polled. */
+int wh_flags_post(wh_ctx* ctx, void* stream, int discard);
+int wh_flags_poll(wh_ctx* ctx, int32_t* h_flags16);
 
 /* Per-kernel timing: while enabled every kernel launch of this ctx is bracketed by a HIP event pair on
  * its launch stream.  wh_profile_collect synchronises the device and returns one record per launch in
@@ -188,6 +197,13 @@ int wh_synthesis_render(wh_ctx* ctx, void* stream, const wh_batch* b, const wh_c
 int wh_synthesis_plan(wh_ctx* ctx, void* stream, const wh_batch* b, const double* tp, const double* f0,
                       const double* vuv, double fs, const int64_t* h_y_off, const double* h_t0, const double* h_dt,
                       int64_t pulse_cap, int32_t* h_pulse_count, int64_t* h_noise_total);
+
+/* The device noise of wh_synthesis / wh_synthesis_render (noise == NULL), exposed for sample-exact checks: out[i]
+ * (DEVICE, n doubles) = sample q0 + i of the standard-normal stream that utterance `utt` of a batch reads under
+ * `seed` — the stand-in for the reference's np.random.randn draws (world/synthesis.py:93): pulse i consumes samples
+ * noff_i .. noff_i + max(3, noise_size_i) of it, exactly as it would consume a host-supplied `noise` stream, so a
+ * decode with noise = this dump equals the decode with noise == NULL and the same seed. */
+int wh_philox_normals(wh_ctx* ctx, void* stream, uint64_t seed, int utt, int64_t q0, int64_t n, double* out);
 
 /* decode()'s peak normalisation (world/main.py:209-212): per utterance u, y[h_y_off[u] .. h_y_off[u+1]) is divided
  * by max|y| when that exceeds 1.  In place, on the stream; the workspace of ctx is used (call it after wh_synthesis*

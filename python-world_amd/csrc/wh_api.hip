@@ -41,8 +41,11 @@ int fail_msg(const char* where, const char* msg) {
   return -1;
 }
 int ws_reserve(wh_ctx* ctx, size_t bytes) {
+  // Every stage lays the arena out afresh through this call, so whatever time base an earlier wh_synthesis_timebase left
+  // in it is gone from here on — also when the arena does not move (wh_synthesis_timebase sets the mark again after
+  // its own reservation; wh_synthesis_render reserves nothing).
+  ctx->timebase.valid = false;
   if (bytes <= ctx->ws_bytes) return 0;
-  ctx->timebase.valid = false;  // the arena moves: a stored time base goes with it
   if (ctx->ws) {
     WH_CHECK(hipDeviceSynchronize());
     WH_CHECK(hipFree(ctx->ws));
@@ -122,7 +125,7 @@ int persistent_scratch(wh_ctx* ctx, const std::string& slot, size_t bytes, void*
 
 extern "C" {
 
-int wh_version(void) { return 102; }
+int wh_version(void) { return 103; }
 const char* wh_last_error(void) { return g_last_error.c_str(); }
 
 int wh_device_count(int* count) {
@@ -155,6 +158,10 @@ int wh_ctx_create(int device, wh_ctx** out) {
   if (e == hipSuccess) e = hipMemcpy(c->d_twiddle, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, 16 * sizeof(int32_t));
   if (e == hipSuccess) e = hipMemset(c->d_flags, 0, 16 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_flag_cum, 16 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemset(c->d_flag_cum, 0, 16 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flag_cum, 16 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) memset((void*)c->h_flag_cum, 0, 16 * sizeof(int32_t));
   if (e != hipSuccess) {
     delete c;
     return wh::fail("wh_ctx_create", e);
@@ -169,6 +176,8 @@ int wh_ctx_destroy(wh_ctx* ctx) {
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+  if (ctx->d_flag_cum) (void)hipFree(ctx->d_flag_cum);
+  if (ctx->h_flag_cum) (void)hipHostFree((void*)ctx->h_flag_cum);
   for (auto& kv : ctx->tables) (void)hipFree(kv.second);
   for (auto e : ctx->prof_events) (void)hipEventDestroy(e);
   for (auto& kv : ctx->persist) {
@@ -182,6 +191,16 @@ int wh_ctx_destroy(wh_ctx* ctx) {
   return 0;
 }
 
+// what wh_flags_post has published and no poll / take has reported yet
+static void drain_posted(wh_ctx* ctx, int32_t* h_flags16, bool accumulate) {
+  for (int i = 0; i < 16; ++i) {
+    const int32_t cum = ctx->h_flag_cum[i];
+    const int32_t fresh = cum - ctx->h_flag_seen[i];
+    ctx->h_flag_seen[i] = cum;
+    h_flags16[i] = (accumulate ? h_flags16[i] : 0) | (fresh != 0 ? 1 : 0);
+  }
+}
+
 int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16) {
   if (!ctx || !h_flags16) return wh::fail_msg("wh_take_flags", "null argument");
   WH_ENTER(ctx);
@@ -189,6 +208,43 @@ int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16) {
   WH_CHECK(hipMemcpyAsync(h_flags16, ctx->d_flags, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   WH_CHECK(hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int32_t), st));
   WH_CHECK(hipStreamSynchronize(st));
+  drain_posted(ctx, h_flags16, true);  // conditions an earlier wh_flags_post moved out of d_flags
+  return 0;
+}
+
+// One thread: flags that are set bump their cumulative counter, the counters go to the host mirror, the flags are cleared.
+static __global__ void flags_post_kernel(int32_t* __restrict__ flags, int32_t* __restrict__ cum,
+                                         volatile int32_t* __restrict__ mirror) {
+  const int i = threadIdx.x;
+  if (i >= 16) return;
+  const int32_t v = flags[i];
+  if (v) {
+    flags[i] = 0;
+    const int32_t c = cum[i] + 1;
+    cum[i] = c;
+    mirror[i] = c;
+    __threadfence_system();
+  }
+}
+
+int wh_flags_post(wh_ctx* ctx, void* stream, int discard) {
+  if (!ctx) return wh::fail_msg("wh_flags_post", "null ctx");
+  WH_ENTER(ctx);
+  hipStream_t st = (hipStream_t)stream;
+  if (discard) {
+    WH_CHECK(hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int32_t), st));
+    return 0;
+  }
+  int32_t* d_mirror = nullptr;
+  WH_CHECK(hipHostGetDevicePointer((void**)&d_mirror, (void*)ctx->h_flag_cum, 0));
+  hipLaunchKernelGGL(flags_post_kernel, dim3(1), dim3(64), 0, st, ctx->d_flags, ctx->d_flag_cum, d_mirror);
+  WH_LAUNCH_CHECK("flags_post_kernel");
+  return 0;
+}
+
+int wh_flags_poll(wh_ctx* ctx, int32_t* h_flags16) {
+  if (!ctx || !h_flags16) return wh::fail_msg("wh_flags_poll", "null argument");
+  drain_posted(ctx, h_flags16, false);
   return 0;
 }
 

@@ -17,6 +17,12 @@ struct wh_ctx {
   size_t ws_bytes = 0;
   std::map<std::string, double*> tables;  // small constant tables resident on the device (windows, taps)
   int32_t* d_flags = nullptr;             // [16] sticky device-side condition flags (see wh_take_flags)
+  // deferred reading of the flags (wh_flags_post / wh_flags_poll): d_flag_cum[i] counts the posts that found flag i set;
+  // h_flag_cum is its mirror in pinned, device-mapped host memory (the post kernel is its only writer, the host only
+  // reads it), h_flag_seen what the host has reported so far
+  int32_t* d_flag_cum = nullptr;          // [16]
+  volatile int32_t* h_flag_cum = nullptr; // [16] pinned
+  int32_t h_flag_seen[16] = {0};
   // small per-call tables (utterance metadata, filter taps) kept in their own device buffers together with
   // the host bytes they were filled from: an identical call re-uses them without any copy or stream sync
   struct Persist {

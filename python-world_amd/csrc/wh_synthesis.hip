@@ -674,7 +674,8 @@ __global__ __launch_bounds__(kPFinish) void pulse_finish_kernel(const SynUtt* __
     if (i < count) pn[i] = run + excl;
     run += total;
   }
-  if (threadIdx.x == 0 && m.noise_len >= 0 && run > m.noise_len) atomicOr(flags + WH_FLAG_NOISE_SHORT, 1);
+  // (whether a host-supplied noise stream covers `run` draws is tested by wh_synthesis_render, which is the call that
+  // knows the stream: noise_cover_kernel)
 }
 
 // Exclusive prefix of the per-utterance pulse counts → flat pulse numbering for the response grid.
@@ -821,6 +822,30 @@ __device__ __attribute__((noinline)) double2 normal_pair(uint64_t seed, uint64_t
   double s, c;
   sincospi(2 * u2, &s, &c);
   return make_double2(rr * c, rr * s);
+}
+
+// The stream key of utterance u under `seed` (response_kernel derives the same one).
+__device__ __host__ __forceinline__ uint64_t philox_key(uint64_t seed, uint64_t u) {
+  return seed * 0x9E3779B97F4A7C15ull + u * 0xD1B54A32D192ED03ull + 1;
+}
+// out[i] = sample q0 + i of utterance u's stream: what wh_philox_normals exposes, so that the device-noise decode can be
+// checked sample by sample (tests/test_hip_synthesis.py: the dumped stream fed back as host noise, and to the oracle).
+__global__ __launch_bounds__(256) void philox_dump_kernel(uint64_t seed, int32_t u, int64_t q0, int64_t n,
+                                                          double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = normal_at(philox_key(seed, (uint64_t)u), (uint64_t)(q0 + i));
+}
+// Host-supplied noise must cover every draw of the utterance: the last pulse's offset + its run (synthesis.py:93).
+__global__ __launch_bounds__(64) void noise_cover_kernel(const SynUtt* __restrict__ meta, const PulseRec* __restrict__ rec,
+                                                         const int64_t* __restrict__ p_base, int n_utt,
+                                                         int32_t* __restrict__ flags) {
+  const int u = blockIdx.x * 64 + threadIdx.x;
+  if (u >= n_utt) return;
+  const int64_t count = p_base[u + 1] - p_base[u];
+  if (count < 1) return;
+  const PulseRec& r = rec[p_base[u] + count - 1];
+  const int64_t need = r.noff + (r.noise_size > 3 ? r.noise_size : 3);
+  if (meta[u].noise_len >= 0 && need > meta[u].noise_len) atomicOr(flags + WH_FLAG_NOISE_SHORT, 1);
 }
 
 // Transcendentals of the per-pulse loop as real calls: inlined, their polynomial coefficients (64-bit literals live in
@@ -1082,7 +1107,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
       const int64_t q = noff + j;
       return q < m.noise_len ? noise[m.noise_off + q] : 0.0;
     }
-    return normal_at(seed * 0x9E3779B97F4A7C15ull + (uint64_t)u * 0xD1B54A32D192ED03ull + 1, (uint64_t)(noff + j));
+    return normal_at(philox_key(seed, (uint64_t)u), (uint64_t)(noff + j));
   };
   double mean;
   {
@@ -1095,7 +1120,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
       }
     } else {
       // device stream: sample q of the utterance is one half of Philox block q >> 1 — walk the blocks the run touches
-      const uint64_t key = seed * 0x9E3779B97F4A7C15ull + (uint64_t)u * 0xD1B54A32D192ED03ull + 1;
+      const uint64_t key = philox_key(seed, (uint64_t)u);
       const int64_t b1 = (noff + nd - 1) >> 1;
       for (int64_t blk = (noff >> 1) + WH_TID; blk <= b1; blk += FT) {
         const double2 z = normal_pair(key, (uint64_t)blk);
@@ -1631,6 +1656,11 @@ extern "C" int wh_synthesis_render(wh_ctx* ctx, void* stream, const wh_batch* b,
   const int64_t* d_pb = reinterpret_cast<const int64_t*>(ws + t.o_pb);
   const PulseRec* d_rec = reinterpret_cast<const PulseRec*>(ws + t.o_rec);
   const int32_t* d_pc = reinterpret_cast<const int32_t*>(ws + t.o_pc);
+  if (noise) {  // (the time base knows nothing about the noise stream: the cover test belongs to the call that is given one)
+    wh::KernelTimer _kt(ctx, st, "noise_cover_kernel");
+    hipLaunchKernelGGL(noise_cover_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, d_meta, d_rec, d_pb, B, ctx->d_flags);
+  }
+  WH_LAUNCH_CHECK("noise_cover_kernel");
   int rc;
   switch (fft_size) {
     case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, noise, seed, y); break;
@@ -1657,6 +1687,19 @@ extern "C" int wh_synthesis(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   if (int rc = wh_synthesis_timebase(ctx, stream, b, tp, f0, vuv, fs, h_y_off, h_t0, h_dt, pulse_cap, 0.0)) return rc;
   return wh_synthesis_render(ctx, stream, b, ctx, tp, spectrogram, aperiodicity, fs, fft_size, h_y_off, h_t0, h_dt, pulse_cap,
                              noise, h_noise_off, seed, y, pulse_count_out);
+}
+
+// Samples [q0, q0 + n) of the normal stream that the device-noise decode (noise == NULL) reads for utterance `utt`
+// under `seed`: pulse i of that utterance consumes samples noff_i .. noff_i + max(3, noise_size_i) of it, exactly as it
+// would consume a host-supplied stream.  Feeding the dump back as `noise` therefore reproduces the seeded decode.
+extern "C" int wh_philox_normals(wh_ctx* ctx, void* stream, uint64_t seed, int utt, int64_t q0, int64_t n, double* out) {
+  if (!ctx || !out || utt < 0 || q0 < 0 || n < 0) return wh::fail_msg("wh_philox_normals", "bad argument");
+  WH_ENTER(ctx);
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  { wh::KernelTimer _kt(ctx, st, "philox_dump_kernel"); hipLaunchKernelGGL(philox_dump_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seed, (int32_t)utt, q0, n, out); }
+  WH_LAUNCH_CHECK("philox_dump_kernel");
+  return 0;
 }
 
 // ---- peak normalisation of decode(): y /= max|y| where it exceeds 1 (world/main.py:209-212), per utterance ----

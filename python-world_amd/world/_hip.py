@@ -44,6 +44,8 @@ SIGNATURES = {
     "wh_profile_collect": (_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_float), _int,
                                   ctypes.POINTER(_int)]),
     "wh_take_flags": (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
+    "wh_flags_post": (_int, [_vp, _vp, _int]),
+    "wh_flags_poll": (_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
     "wh_dio": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _int,
                       _vp, _vp, _vp, _vp]),
     "wh_harvest": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp,
@@ -54,6 +56,7 @@ SIGNATURES = {
     "wh_synthesis_timebase": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, ctypes.c_int64, _dbl]),
     "wh_synthesis_render": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp,
                                    ctypes.c_uint64, _vp, _vp]),
+    "wh_philox_normals": (_int, [_vp, _vp, ctypes.c_uint64, _int, ctypes.c_int64, ctypes.c_int64, _vp]),
     "wh_cumsum_exact": (_int, [_vp, _vp, _vp, _vp, _int]),
     "wh_peak_normalise": (_int, [_vp, _vp, _vp, _vp, _int]),
     "wh_synthesis_plan": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
@@ -232,6 +235,17 @@ class Runtime:
         """Read-and-clear the sticky device condition flags (synchronises the current stream)."""
         buf = (ctypes.c_int32 * 16)()
         check(self.lib.wh_take_flags(self.ctx, self.stream(), buf))
+        return list(buf)
+
+    def post_flags(self, discard=False):
+        """Enqueue the publication of the flags raised so far on this lane's stream (no host wait): wh_flags_post.
+        ``discard``: clear them unpublished instead (conditions of work whose results nobody will use)."""
+        check(self.lib.wh_flags_post(self.ctx, self.stream(), 1 if discard else 0))
+
+    def poll_flags(self):
+        """Conditions published by earlier ``post_flags`` calls that have executed, without synchronising."""
+        buf = (ctypes.c_int32 * 16)()
+        check(self.lib.wh_flags_poll(self.ctx, buf))
         return list(buf)
 
     def check_flags(self, where, allow=()):

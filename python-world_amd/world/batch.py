@@ -31,8 +31,11 @@ class BatchEncoding:
     is not supported — use scale_duration / modify_duration."""
 
     def __init__(self, rt, batch, fs, tp, f0, vuv, spectrogram, aperiodicity, fft_size, is_requiem, frame_period,
-                 tp_host=None):
+                 tp_host=None, ps_spectrogram=None):
         self.rt, self.batch, self.fs = rt, batch, fs
+        # CheapTrick's complex pitch-synchronous spectra, frame-major [F][fft_size] complex128 — encode()'s
+        # 'ps spectrogram' (world/main.py:149, world/cheaptrick.py:30,38): kept only when encode_device(want_ps=True)
+        self.ps_spectrogram = ps_spectrogram
         self._tp = tp
         self.tp_host = tp_host  # host copy of the frame times: no D2H in decode
         self.f0, self.vuv = f0, vuv
@@ -61,6 +64,7 @@ class BatchEncoding:
     @temporal_positions.setter
     def temporal_positions(self, value):
         self._tp = value
+        self._timebase = None
         self.tp_host = None  # whoever replaces the tensor owns its content: refreshed from the device on demand
 
     def host_times(self):
@@ -75,8 +79,13 @@ class BatchEncoding:
 
     def _stamp(self):
         """What a prefetched time base was computed from: the f0 / vuv / frame-time tensors and their in-place version
-        counters (scale_pitch, scale_duration and friends bump them; assigning a new tensor changes the pointer)."""
-        return tuple((t.data_ptr(), t._version) for t in (self.f0, self.vuv, self._tp))
+        counters (edits behind the object's back bump them; assigning a new tensor changes the pointer; the modifiers
+        below drop the time base themselves).  None where torch keeps no version counter (tensors made under
+        torch.inference_mode()): no time base is prefetched or reused then."""
+        try:
+            return tuple((t.data_ptr(), t._version) for t in (self.f0, self.vuv, self._tp))
+        except RuntimeError:
+            return None
 
     def timebase_for(self, owner, pulse_cap):
         """The prefetched time base if it still describes this encoding (same tensors, untouched since encode, made by
@@ -85,17 +94,20 @@ class BatchEncoding:
         # the time-base context is shared by every WorldBatch of a (device, lane): its generation counts the prefetches
         if tb is None or tb["rt"] is not owner._tb_rt or tb["generation"] != tb["rt"].timebase_generation:
             return None
-        if tb["stamp"] != self._stamp() or (pulse_cap is not None and tb["pulse_cap"] != pulse_cap):
+        stamp = self._stamp()
+        if stamp is None or tb["stamp"] != stamp or (pulse_cap is not None and tb["pulse_cap"] != pulse_cap):
             return None
         return tb
 
     def scale_pitch(self, factor):
         """world/main.py:154-162, on the device."""
+        self._timebase = None  # (the version counter would say so too; a freed tensor's address can come back)
         self.f0 *= factor
         return self
 
     def scale_duration(self, factor):
         """world/main.py:170-178, on the device."""
+        self._timebase = None
         self._tp *= factor
         if self.tp_host is not None:
             self.tp_host = self.tp_host * factor
@@ -156,18 +168,27 @@ class BatchEncoding:
         from .features import mcep_device
         return mcep_device(self.rt, self.spectrogram, n0, self.fs, lowhz, highhz)
 
-    def to_dicts(self):
-        """List of per-utterance dicts with the reference's keys and (bins, frames) layouts."""
+    def to_dicts(self, want_ps=False):
+        """List of per-utterance dicts with the reference's keys and (bins, frames) layouts.  ``want_ps``: include
+        encode()'s 'ps spectrogram' (fft_size, frames) complex128 (world/main.py:149) — the encoding must have been made
+        with ``want_ps=True`` (16 B x fft_size per frame: 2 GB for the 64 x 10 s batch, which is why it is opt-in)."""
         fo = self.batch.frame_off
         tp, f0, vuv = (t.cpu().numpy() for t in (self.temporal_positions, self.f0, self.vuv))
         sp = self.spectrogram.cpu().numpy()
         ap = self.aperiodicity.cpu().numpy()
+        ps = None
+        if want_ps:
+            if self.ps_spectrogram is None:
+                raise ValueError("this encoding holds no 'ps spectrogram': encode with want_ps=True")
+            ps = self.ps_spectrogram.cpu().numpy()
         out = []
         for u in range(self.n_utt):
             s = slice(int(fo[u]), int(fo[u + 1]))
             out.append({'temporal_positions': tp[s].copy(), 'vuv': vuv[s].copy(), 'fs': self.fs, 'f0': f0[s].copy(),
                         'aperiodicity': np.ascontiguousarray(ap[s].T), 'spectrogram': np.ascontiguousarray(sp[s].T),
                         'is_requiem': self.is_requiem})
+            if ps is not None:
+                out[-1]['ps spectrogram'] = np.ascontiguousarray(ps[s].T)
         return out
 
 
@@ -175,9 +196,11 @@ SWIPE_DT = 0.005  # swipe()'s default dt, the only one World.encode ever uses (w
 
 
 def _require_swipe_period(frame_period):
+    """A caller-supplied batch grid must be swipe()'s own 5 ms grid (WorldBatch.encode builds it whatever
+    ``frame_period`` says, like the reference: world/main.py:134-135)."""
     if frame_period != 5:
         raise ValueError("f0_method='swipe' runs on swipe()'s 5 ms grid (the reference ignores frame_period there); "
-                         "got frame_period=%r" % (frame_period,))
+                         "got a batch grid with frame_period=%r" % (frame_period,))
 
 
 def _on_lane_stream(fn):
@@ -223,6 +246,11 @@ class WorldBatch:
         ready.record(main)
         with torch.cuda.stream(tb.own_stream):
             tb.own_stream.wait_event(ready)
+            # a condition still pending in this context belongs to an earlier prefetch whose time base this one
+            # supersedes (its encoding can only be decoded in line from now on, which raises the condition again where
+            # it belongs): drop it instead of leaving it to be blamed on this batch
+            tb.post_flags(discard=True)
+            tb.poll_flags()
             synthesis_timebase_device(tb, batch, tp_d, f0_copy, vuv_d, fs, ny, [g[1] for g in geo], [g[2] for g in geo],
                                       cap, f0_low_limit=fs * 3.0 / (ct_fft - 3.0))
             done = torch.cuda.Event()
@@ -254,13 +282,17 @@ class WorldBatch:
     @_on_lane_stream
     def encode_device(self, batch, x_d, tp_d, fs, f0_method='dio', f0_floor=71, f0_ceil=800, channels_in_octave=2,
                       target_fs=4000, frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False,
-                      f0_done=None, check=True):
+                      f0_done=None, check=True, want_ps=False):
         """world/main.py:106-152 for a resident batch.  tp_d is not modified (a copy is kept in the result).
         ``f0_done``: optional callable invoked once the F0 stage has been enqueued (used to stagger lanes).
-        ``check``: read the sticky device flags afterwards (synchronises this lane's stream) and raise WorldHipError
-        if a kernel reported a condition; pass False to keep the call asynchronous and check later
-        (``WorldBatch.check()``)."""
+        ``check``: True — read the sticky device flags afterwards (synchronises this lane's stream) and raise
+        WorldHipError if a kernel reported a condition; False — keep the call asynchronous and check later
+        (``WorldBatch.check()``); ``'deferred'`` — no host wait either: the flags are published by a kernel behind this
+        call's work (wh_flags_post) and the NEXT deferred-check call (or ``check()``) raises for them — late, never lost:
+        the mode for a caller that keeps batches in flight.
+        ``want_ps``: keep CheapTrick's complex spectra as ``enc.ps_spectrogram`` (encode()'s 'ps spectrogram')."""
         rt = self.rt
+        self._deferred_begin(check, "encode_device")
         if fft_size is not None:
             f0_floor = 3.0 * fs / fft_size
         if f0_method == 'dio':
@@ -285,22 +317,34 @@ class WorldBatch:
         timebase = None
         if self.prefetch_timebase and not is_requiem and tp_host is not None:
             timebase = self._prefetch_timebase(batch, tp_d, tp_host, f0_d, vuv_d, fs, ct_fft)
-        spec_d, _ = cheaptrick_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, ct_fft)
+        spec_d, ps_d = cheaptrick_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, ct_fft, want_ps=want_ps)
         if is_requiem:
             ap_d = d4c_requiem_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, fft_size)
         else:
             ap_d, _ = d4c_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, ct_fft)
-        if check:
+        if check is True:
             rt.check_flags("encode_device")
+        elif check == 'deferred':
+            rt.post_flags()
         enc = BatchEncoding(rt, batch, fs, tp_d.clone(), f0_d, vuv_d, spec_d, ap_d, ct_fft, is_requiem, frame_period,
-                            tp_host=None if tp_host is None else tp_host.copy())
+                            tp_host=None if tp_host is None else tp_host.copy(), ps_spectrogram=ps_d)
         if timebase is not None:
             # join: behind CheapTrick and D4C in stream order, so the overlap has already happened — and the fork is
             # closed inside this call (a caller that captures encode_device alone in a graph gets a well-formed one)
             rt.torch.cuda.current_stream(rt.device).wait_event(timebase["done"])
             timebase["stamp"] = enc._stamp()
-            enc._timebase = timebase
+            if timebase["stamp"] is not None:
+                enc._timebase = timebase
         return enc
+
+    def _deferred_begin(self, check, where):
+        """check='deferred': raise for what earlier deferred-check calls have published by now (no host wait)."""
+        if check != 'deferred':
+            return
+        flags = self.rt.poll_flags()
+        if self._tb_rt is not None:
+            flags = [a | b for a, b in zip(flags, self._tb_rt.poll_flags())]
+        self.rt.raise_for_flags(flags, where + " (condition reported by an earlier call with check='deferred')")
 
     @_on_lane_stream
     def refill_from_pinned(self, x_d, x_pin):
@@ -366,6 +410,10 @@ class WorldBatch:
             return self.rt.raise_for_flags(flags, where)
 
     def encode(self, xs, fs, **kw):
+        if kw.get('f0_method') == 'swipe':
+            # the reference calls swipe() with its default dt = 5 ms whatever frame_period says and every later stage
+            # runs on that grid (world/main.py:134-135): frame_period is ignored, as in World.encode
+            kw = dict(kw, frame_period=5)
         batch, x_d, tp_d = self.upload(xs, fs, kw.get('frame_period', 5), swipe_grid=kw.get('f0_method') == 'swipe')
         return self.encode_device(batch, x_d, tp_d, fs, **kw)
 
@@ -410,8 +458,10 @@ class WorldBatch:
         With ``check`` (default) the sticky device flags are read afterwards (synchronises the stream): an overflow
         of the DEFAULT capacity re-runs the decode with the safe bound ny//2+16 (f0 < fs/2), any other condition —
         or an overflow of an explicit ``pulse_cap`` — raises WorldHipError.  ``check=False`` keeps the call
-        asynchronous; call ``WorldBatch.check()`` before trusting the audio."""
+        asynchronous; call ``WorldBatch.check()`` before trusting the audio.  ``check='deferred'``: as in
+        encode_device — published behind the work, raised by the next deferred-check call or ``check()``."""
         rt = self.rt
+        self._deferred_begin(check, "decode_device")
         fo = enc.batch.frame_off
         tb = None
         if not enc.is_requiem:
@@ -444,7 +494,14 @@ class WorldBatch:
             return y, y_off
 
         y, y_off = run(pulse_cap)
-        if check:
+        if check == 'deferred':
+            # (an overflow of the default pulse capacity cannot be retried here: it is raised at the next poll — pass
+            # pulse_cap=safe_pulse_cap(...) for material whose mean f0 may exceed fs/8)
+            rt.post_flags()
+            if tb is not None:
+                with rt.torch.cuda.stream(tb["rt"].own_stream):
+                    tb["rt"].post_flags()
+        elif check:
             flags = rt.take_flags()
             if tb is not None:  # conditions raised by the time-base kernels live in that context's flags
                 flags = [a | b for a, b in zip(flags, tb["rt"].take_flags())]

@@ -156,12 +156,16 @@ class ShardedWorldBatch:
             return list(per_utterance)
         return gather_small(list(per_utterance), group=self.group, dst=dst)
 
-    def gather_f0(self, enc=None, dst=0):
+    def gather_f0(self, enc=None, dst=0, use_collectives=None):
         """[(f0, vuv)] per utterance of the whole batch on ``dst`` (None elsewhere): <= 16 B per frame over xGMI.
         Typed collectives on the device tensors themselves (``all_gather_ragged``): the frame counts, then f0 and vuv
-        stacked — the contours never pass through pickle or a host buffer on their way between GPUs."""
+        stacked — the contours never pass through pickle or a host buffer on their way between GPUs.
+        ``use_collectives``: default = only when there is more than one rank; True runs the collectives also in a
+        one-rank group (the single-GPU rehearsal of the RCCL path, tests/test_hip_nccl_single_rank.py)."""
         enc = self.enc if enc is None else enc
-        if self.world == 1:
+        if use_collectives is None:
+            use_collectives = self.world > 1
+        if not use_collectives:
             if enc is None:
                 return []
             fo = enc.batch.frame_off

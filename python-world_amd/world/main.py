@@ -98,10 +98,10 @@ class World(object):
 
     # ---- batched convenience (not in the reference; SURVEY.md §8(b): "World.encode_batch/decode_batch") ----------
     def encode_batch(self, fs, xs, f0_method='harvest', f0_floor=71, f0_ceil=800, channels_in_octave=2, target_fs=4000,
-                     frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False):
+                     frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False, want_ps=False):
         """encode() — same arguments, same defaults (Harvest) — for a list of utterances in one pass per kernel.
-        Each dict has encode()'s keys except 'ps spectrogram' (the complex pitch-synchronous spectra, fft_size x frames
-        x 16 B per utterance, are not kept by the batch pipeline; call cheaptrick() for them).  Under an initialised
+        Each dict has encode()'s keys; 'ps spectrogram' (the complex pitch-synchronous spectra of world/main.py:149,
+        fft_size x frames x 16 B per utterance) only with ``want_ps=True``.  Under an initialised
         torch.distributed process group (one process per GPU) the batch is sharded by utterance over the ranks and the
         list holds only this rank's utterances; use ``world.distributed.ShardedWorldBatch`` directly to keep results
         on the device."""
@@ -110,8 +110,8 @@ class World(object):
         sb = ShardedWorldBatch()
         enc = sb.encode(xs, fs, f0_method=f0_method, f0_floor=f0_floor, f0_ceil=f0_ceil,
                         channels_in_octave=channels_in_octave, target_fs=target_fs, frame_period=frame_period,
-                        allowed_range=allowed_range, fft_size=fft_size, is_requiem=is_requiem)
-        dats = enc.to_dicts() if enc is not None else []
+                        allowed_range=allowed_range, fft_size=fft_size, is_requiem=is_requiem, want_ps=want_ps)
+        dats = enc.to_dicts(want_ps=want_ps) if enc is not None else []
         for d in dats:
             d['_batch_range'] = sb.range
         return dats

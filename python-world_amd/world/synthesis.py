@@ -77,6 +77,16 @@ def synthesis_device(rt, batch, tp_d, f0_d, vuv_d, spec_d, ap_d, fs, fft_size, n
     return y, y_off
 
 
+def philox_normals(rt, seed, utt, n, q0=0):
+    """Samples [q0, q0 + n) of the standard-normal stream that the device-noise decode (``noise=None``) reads for
+    utterance ``utt`` of a batch under ``seed`` (wh_philox_normals): a device tensor.  Feeding it back as that
+    utterance's ``noise`` reproduces the seeded decode — the hook that makes the Philox path checkable sample by sample
+    against the oracle (the stand-in for the reference's np.random.randn draws, world/synthesis.py:93)."""
+    out = rt.empty((int(n),))
+    _hip.check(rt.lib.wh_philox_normals(rt.ctx, rt.stream(), int(seed), int(utt), int(q0), int(n), rt.ptr(out)))
+    return out
+
+
 def synthesis_plan(rt, batch, tp_d, f0_d, vuv_d, fs, ny_list, t0_list, dt_list, pulse_cap):
     """(pulse counts, exact reference randn draw counts) per utterance."""
     y_off = np.concatenate([[0], np.cumsum(ny_list)]).astype(np.int64)

@@ -185,3 +185,20 @@ def test_sharded_world_batch_single_process():
     assert sb.range == (0, 3) and enc.n_utt == 3
     got = sb.gather_f0()
     assert [float(f0[0]) for f0, _ in got] == [0.0, 1.0, 2.0]
+
+
+def test_shard_ranges_for_the_benchmark_configs():
+    """BASELINE.json configs 4 and 5 over the 8 GPUs of a node: 1024 x 10 s at 16 kHz -> 128 utterances per rank,
+    128 x 60 s at 48 kHz -> 16 per rank; ranges contiguous, in rank order, covering the batch once."""
+    from world.distributed import shard_ranges
+
+    for n_utt, samples, world, per in ((1024, 160000, 8, 128), (128, 2880000, 8, 16), (1024, 160000, 4, 256),
+                                       (1024, 160000, 2, 512), (64, 160000, 8, 8)):
+        r = shard_ranges([samples] * n_utt, world)
+        assert [b - a for a, b in r] == [per] * world
+        assert r[0][0] == 0 and r[-1][1] == n_utt and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+    # ragged: balanced by samples, not by count
+    lengths = [160000] * 8 + [16000] * 80
+    r = shard_ranges(lengths, 2)
+    tot = [sum(lengths[a:b]) for a, b in r]
+    assert abs(tot[0] - tot[1]) <= 160000 and r[0][1] == r[1][0]

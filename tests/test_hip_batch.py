@@ -113,8 +113,15 @@ def test_swipe_batch_runs_on_swipes_own_grid():
     enc = wb.encode([x], fs, f0_method='swipe')
     one = swipe(fs, x, [71, 800], sTHR=0.3)
     assert np.array_equal(enc.temporal_positions.cpu().numpy(), one["temporal_positions"])
+    # World.encode ignores frame_period for swipe (world/main.py:134-135): so does the batch encode
+    enc4 = wb.encode([x], fs, f0_method='swipe', frame_period=4)
+    assert enc4.frame_period == 5
+    assert np.array_equal(enc4.temporal_positions.cpu().numpy(), one["temporal_positions"])
+    assert np.array_equal(enc4.f0.cpu().numpy(), enc.f0.cpu().numpy())
+    # ... but a caller-supplied batch grid of another period cannot be swipe's grid
+    batch, x_d, tp_d = wb.upload([x], fs, frame_period=4)
     with pytest.raises(ValueError):
-        wb.encode([x], fs, f0_method='swipe', frame_period=4)
+        wb.encode_device(batch, x_d, tp_d, fs, f0_method='swipe', frame_period=4)
 
 
 def test_download_async_double_buffer():
@@ -184,3 +191,74 @@ def test_prefetched_time_base_equals_inline_decode():
         y6 = a.decode_device(e1, seed=4)[0].cpu().numpy()  # falls back to the in-line time base
         assert np.max(np.abs(y6 - yb)) <= 1e-15 * max(1.0, np.max(np.abs(yb)))
         assert a.rt.take_flags() == [0] * 16
+
+
+def test_encode_batch_ps_spectrogram_opt_in(golden):
+    """encode() returns CheapTrick's complex spectra as 'ps spectrogram' (world/main.py:149, world/cheaptrick.py:30,38);
+    the batch path keeps them on request: against the reference fixture and against the single-utterance encode()."""
+    from world import main
+    from world._synthetic import synth_utterance
+
+    g = golden("getters")
+    fs = int(g["fs"])
+    x = synth_utterance(int(g["utt"]), fs, float(g["seconds"]))  # the fixture's input (tests/test_hip_getters.py)
+    other = synth_utterance(61, fs, 0.4)
+    w = main.World()
+    dats = w.encode_batch(fs, [x, other], f0_method='dio', want_ps=True)
+    assert dats[0]['ps spectrogram'].shape == tuple(g["getspec_ps_shape"])
+    assert dats[0]['ps spectrogram'].dtype == np.complex128
+    ps = dats[0]['ps spectrogram'][:, g["getspec_ps_cols"]]
+    ref = g["getspec_ps"]
+    assert np.sqrt(np.mean(np.abs(ps - ref) ** 2) / np.mean(np.abs(ref) ** 2)) < 1e-10
+    one = w.encode(fs, other, f0_method='dio')
+    assert np.array_equal(dats[1]['ps spectrogram'], one['ps spectrogram'])
+    assert 'ps spectrogram' not in w.encode_batch(fs, [other], f0_method='dio')[0]
+    from world.batch import WorldBatch
+    with pytest.raises(ValueError):
+        WorldBatch().encode([other], fs, f0_method='dio').to_dicts(want_ps=True)
+
+
+def test_deferred_flag_check_reports_late_but_not_never():
+    """check='deferred': no host wait in encode/decode; a condition raised by a kernel is published behind the call's
+    work (wh_flags_post) and raised by the next deferred-check call, or by check().  Driven with a pulse capacity that
+    is too small (WH_FLAG_PULSE_OVERFLOW)."""
+    from world import _hip
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+
+    fs = 16000
+    xs = [synth_utterance(62, fs, 0.6), synth_utterance(63, fs, 0.5)]
+    wb = WorldBatch(prefetch_timebase=False)
+    enc = wb.encode(xs, fs, f0_method='dio', check='deferred')
+    y_ok, off = wb.decode_device(enc, check='deferred')      # nothing to report
+    wb.decode_device(enc, pulse_cap=8, check='deferred')     # overflows: returns without raising ...
+    wb.rt.torch.cuda.synchronize()
+    with pytest.raises(_hip.WorldHipError, match="pulse_cap"):
+        wb.decode_device(enc, check='deferred')              # ... the next deferred call does
+    y2, _ = wb.decode_device(enc, check='deferred')          # reported once, then clean again
+    wb.check()
+    assert np.array_equal(y2.cpu().numpy(), y_ok.cpu().numpy()) or np.allclose(y2.cpu().numpy(), y_ok.cpu().numpy(), atol=1e-13)
+    # check() (synchronising) also sees what was posted and not yet polled
+    wb.decode_device(enc, pulse_cap=8, check='deferred')
+    with pytest.raises(_hip.WorldHipError, match="pulse_cap"):
+        wb.check()
+    assert wb.rt.take_flags() == [0] * 16
+
+
+def test_encode_device_under_inference_mode():
+    """Tensors made under torch.inference_mode() have no version counter: the time-base prefetch is skipped, the encode
+    and decode work as without it."""
+    import torch
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+
+    fs = 16000
+    xs = [synth_utterance(64, fs, 0.5)]
+    wb = WorldBatch()
+    ref = wb.encode(xs, fs, f0_method='dio')
+    y_ref, _ = wb.decode_device(ref, seed=3)
+    with torch.inference_mode():
+        enc = wb.encode(xs, fs, f0_method='dio')
+        y, _ = wb.decode_device(enc, seed=3)
+    assert np.array_equal(enc.f0.cpu().numpy(), ref.f0.cpu().numpy())
+    assert np.allclose(y.cpu().numpy(), y_ref.cpu().numpy(), atol=1e-13)

@@ -81,6 +81,108 @@ def test_synthesis_device_rng_statistics(golden):
     assert rt.take_flags() == [0] * 16
 
 
+def _philox_dump(wb, seed, ny_list):
+    from world.synthesis import philox_normals
+
+    # an utterance draws sum_i max(3, noise_size_i) <= ny + 3 * pulses samples; 2 * ny + 64 covers any f0 < fs / 2
+    return [philox_normals(wb.rt, seed, u, 2 * ny + 64).cpu().numpy() for u, ny in enumerate(ny_list)]
+
+
+@pytest.mark.parametrize("case", ["syn16k", "syn48k", "ragged3"])
+def test_philox_decode_is_sample_exact(golden, case):
+    """The decode bench.py times draws its noise on the device (Philox + Box-Muller).  wh_philox_normals exposes that
+    stream; with it the seeded decode is checked sample by sample: (a) against the same kernels fed the dumped stream as
+    host noise — the stream indexing of the two branches of response_kernel agrees, and (b) against the oracle's
+    synthesis (world/synthesis.py:86-96 with np.random.randn replaced by the dumped stream)."""
+    from oracle import api as oapi
+    from world._synthetic import synth_utterance
+    from world.batch import BatchEncoding, WorldBatch
+    from world.synthesis import time_axis_params
+
+    wb = WorldBatch()
+    if case == "ragged3":
+        fs = 16000
+        xs = [synth_utterance(70, fs, 0.9), synth_utterance(71, fs, 0.37), synth_utterance(72, fs, 0.62)]
+        enc = wb.encode(xs, fs, f0_method="dio")
+        dats = enc.to_dicts()
+    else:
+        g = golden(case)
+        dats = [dict(_dat(g), is_requiem=False)]
+        enc = BatchEncoding.from_dicts(wb.rt, dats)
+    fs = dats[0]["fs"]
+    ny = [time_axis_params(d["temporal_positions"], fs)[0] for d in dats]
+    for seed in (0, 12345):
+        y_seed, off = wb.decode_device(enc, seed=seed)
+        y_seed = y_seed.cpu().numpy()
+        dump = _philox_dump(wb, seed, ny)
+        for z in dump:  # a standard-normal stream, not zeros
+            assert abs(z.mean()) < 0.05 and abs(z.std() - 1) < 0.05
+        y_noise, off2 = wb.decode_device(enc, noise=dump)
+        assert np.array_equal(off, off2)
+        scale = np.max(np.abs(y_seed))
+        # same arithmetic, overlap-add by FP64 atomics: equal up to the order of the adds
+        assert np.max(np.abs(y_noise.cpu().numpy() - y_seed)) < 1e-13 * max(scale, 1.0)
+        for u, d in enumerate(dats):
+            yo = oapi.decode_np(dict(d), noise=dump[u])["out"]
+            seg = y_seed[off[u]:off[u + 1]]
+            assert len(seg) == len(yo)
+            assert rel_rms(seg, yo) < 1e-9
+            assert np.max(np.abs(seg - yo)) < 1e-9 * max(scale, 1.0)
+    assert wb.rt.take_flags() == [0] * 16
+    # another seed is another stream, another utterance index another stream of the same seed
+    a, b = _philox_dump(wb, 1, [64, 64])
+    assert not np.array_equal(a, b) and not np.array_equal(a, _philox_dump(wb, 2, [64])[0])
+
+
+def test_short_host_noise_raises():
+    """A host-supplied noise stream that does not cover an utterance's draws must raise WH_FLAG_NOISE_SHORT (the
+    missing samples would otherwise read as zeros)."""
+    from world import _hip
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+
+    fs = 16000
+    xs = [synth_utterance(80, fs, 0.5), synth_utterance(81, fs, 0.5)]
+    wb = WorldBatch()
+    enc = wb.encode(xs, fs, f0_method="dio")
+    rng = np.random.RandomState(1)
+    full = [rng.randn(2 * len(x) + 64) for x in xs]
+    wb.decode_device(enc, noise=full)  # covers: no flag
+    with pytest.raises(_hip.WorldHipError, match="noise"):
+        wb.decode_device(enc, noise=[full[0], full[1][:1000]])
+    assert wb.rt.take_flags() == [0] * 16  # read-and-cleared by the raise
+
+
+def test_requiem_decode_with_device_seed_tables_is_sample_exact():
+    """The batched Requiem decode's default seed tables are generated on the device (wh_requiem_seeds).  Dumped and
+    handed to the oracle's synthesisRequiem (world/synthesisRequiem.py:12-141) they must reproduce the device decode
+    sample by sample, the circular cursor chained across the utterances."""
+    from oracle import resynth
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+    from world.get_seeds_signals import get_seeds_signals_device
+
+    fs = 16000
+    xs = [synth_utterance(90, fs, 0.8), synth_utterance(91, fs, 0.45), synth_utterance(92, fs, 0.6)]
+    wb = WorldBatch()
+    enc = wb.encode(xs, fs, f0_method="dio", is_requiem=True)
+    seeds_d = get_seeds_signals_device(fs, seed=5)
+    y, off = wb.decode_device(enc, seeds=seeds_d)
+    y = y.cpu().numpy()
+    seeds = {"pulse": seeds_d["pulse_d"].cpu().numpy(), "noise": seeds_d["noise_d"].cpu().numpy()}
+    cursor = None
+    for u, d in enumerate(enc.to_dicts()):
+        yo, cursor = resynth.synthesis_requiem_np(d["f0"], d["vuv"], d["temporal_positions"], d["spectrogram"],
+                                                  d["aperiodicity"], fs, seeds, cursor=cursor)
+        peak = np.max(np.abs(yo))
+        if peak > 1:
+            yo = yo / peak
+        seg = y[off[u]:off[u + 1]]
+        assert len(seg) == len(yo)
+        assert rel_rms(seg, yo) < 1e-9
+    assert wb.rt.take_flags() == [0] * 16
+
+
 def test_peak_normalisation_branches():
     """decode() divides by max|y| only where it exceeds 1 (world/main.py:209-212): a loud and a quiet utterance in
     one batch, against the same pair scaled on the host."""

@@ -108,10 +108,12 @@ def test_encode_batch_mirrors_encode_signature():
 
     a = inspect.signature(main.World.encode).parameters
     b = inspect.signature(main.World.encode_batch).parameters
-    assert [k for k in a if k not in ("self", "fs", "x")] == [k for k in b if k not in ("self", "fs", "xs")]
+    extra = ("want_ps",)  # batch-only: encode() always returns 'ps spectrogram', the batch keeps it on request
+    assert [k for k in a if k not in ("self", "fs", "x")] == [k for k in b if k not in ("self", "fs", "xs") + extra]
     for k in b:
-        if k not in ("self", "fs", "xs"):
+        if k not in ("self", "fs", "xs") + extra:
             assert a[k].default == b[k].default, k
+    assert b["want_ps"].default is False
     assert b["f0_method"].default == "harvest"
 
 
@@ -228,14 +230,26 @@ def test_prefetched_time_base_validity_rules():
     tb_rt.timebase_generation = 4                              # a later prefetch took the context over
     assert enc.timebase_for(owner, None) is None
     tb_rt.timebase_generation = 3
-    enc.scale_pitch(1.5)                                       # in-place f0 *= factor bumps the version counter
-    assert enc.timebase_for(owner, None) is None
-    enc._timebase["stamp"] = enc._stamp()
-    assert enc.timebase_for(owner, None) is not None
+    fresh = lambda: {"generation": 3, "rt": tb_rt, "pulse_cap": 77, "stamp": enc._stamp()}  # noqa: E731
+    enc.scale_pitch(1.5)                                       # the modifiers drop the time base themselves ...
+    assert enc._timebase is None and enc.timebase_for(owner, None) is None
+    enc._timebase = fresh()
     enc.scale_duration(2.0)
-    assert enc.timebase_for(owner, None) is None
-    enc._timebase["stamp"] = enc._stamp()
+    assert enc._timebase is None
+    enc._timebase = fresh()
+    enc.temporal_positions = enc.temporal_positions.clone()
+    assert enc._timebase is None
+    enc._timebase = fresh()
+    enc.f0 *= 1.01                                             # ... an in-place edit behind the object's back bumps the
+    assert enc.timebase_for(owner, None) is None               # tensor's version counter
+    enc._timebase = fresh()
+    assert enc.timebase_for(owner, None) is not None
     enc.f0 = enc.f0.clone()                                    # a new tensor: another pointer
+    assert enc.timebase_for(owner, None) is None
+    with torch.inference_mode():                               # no version counters: no time base is trusted
+        enc.f0 = torch.ones(nf, dtype=torch.float64)
+    assert enc._stamp() is None
+    enc._timebase = {"generation": 3, "rt": tb_rt, "pulse_cap": 77, "stamp": None}
     assert enc.timebase_for(owner, None) is None
 
 

@@ -164,6 +164,75 @@ __device__ __forceinline__ void emit_crossings_block(const double* sig, int64_t 
   for (int t = 0; t < 4; ++t) base_cnt[t] += (int)((total >> (16 * t)) & 0xFFFF);
 }
 
+// emit_crossings_block for a tile whose edge lists live in LDS (the fused Harvest front end, wh_harvest_front.h):
+// positions p in [0, n_pos) of sig (p = 0 is sample g0 of the signal; sig[p], sig[p+1], sig[p+2] readable for every
+// p < PER * 256, flagged or not), lists start empty, cnt[4] = the four counts afterwards (block-uniform).  An entry
+// beyond `cap` is dropped and counted: the caller compares cnt with cap.  Same tests and the same edge arithmetic as
+// emit_crossings_block, value for value.  Contains barriers.
+template <int PER>
+__device__ __forceinline__ void emit_crossings_lds(const double* sig, int64_t g0, int n_pos, int64_t M, double* edges,
+                                                   int cap, int* cnt, unsigned long long* scratch) {
+  static_assert(PER <= 16, "masks are 16 bits, counts 16 bits per train");
+  const int tid = threadIdx.x;
+  unsigned m01 = 0, m23 = 0;  // bits [0,16): negative-going, [16,32): positive-going
+  {
+    const int i0 = tid * PER;
+    double a = sig[i0], b = sig[i0 + 1];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const double c = sig[i0 + q + 2];
+      const int64_t g = g0 + i0 + q;
+      const bool in = i0 + q < n_pos;
+      if (in && g + 1 < M && a * b < 0) m01 |= (b < a ? 1u : (b > a ? 0x10000u : 0u)) << q;
+      const double d0 = b - a, d1 = c - b;
+      if (in && g + 2 < M && d0 * d1 < 0) m23 |= (d1 < d0 ? 1u : (d1 > d0 ? 0x10000u : 0u)) << q;
+      a = b;
+      b = c;
+    }
+  }
+  const unsigned long long packed = (unsigned long long)__popc(m01 & 0xFFFFu) | ((unsigned long long)__popc(m01 >> 16) << 16) |
+                                    ((unsigned long long)__popc(m23 & 0xFFFFu) << 32) |
+                                    ((unsigned long long)__popc(m23 >> 16) << 48);
+  const unsigned long long incl = wave_scan_incl_u64(packed);
+  const int w = tid >> 6;
+  sync_lds<WH_BLOCK>();  // (LDS-only fences: the caller's spectrum prefetch and candidate stores stay in flight)
+  if ((tid & 63) == 63) scratch[w] = incl;
+  sync_lds<WH_BLOCK>();
+  unsigned long long excl = incl - packed;
+  unsigned long long total = 0;
+#pragma unroll
+  for (int i = 0; i < WH_BLOCK / 64; ++i) {
+    if (i < w) excl += scratch[i];
+    total += scratch[i];
+  }
+  int pos[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) pos[t] = (int)((excl >> (16 * t)) & 0xFFFF);
+  unsigned any = (m01 | (m01 >> 16) | m23 | (m23 >> 16)) & 0xFFFFu;
+  while (any) {  // flagged positions only, ascending
+    const int q = __ffs(any) - 1;
+    any &= any - 1;
+    const int i = tid * PER + q;
+    const double a = sig[i], b = sig[i + 1], c = sig[i + 2];
+    const double at = (double)(g0 + i + 1);
+    if ((m01 >> q) & 0x10001u) {
+      const int t = (m01 >> q) & 1u ? 0 : 1;
+      const double fe = at - a / (b - a);
+      if (pos[t] < cap) edges[t * cap + pos[t]] = fe;
+      ++pos[t];
+    }
+    if ((m23 >> q) & 0x10001u) {
+      const int t = (m23 >> q) & 1u ? 2 : 3;
+      const double d0 = b - a, d1 = c - b;
+      const double fe = at - d0 / (d1 - d0);
+      if (pos[t] < cap) edges[t * cap + pos[t]] = fe;
+      ++pos[t];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) cnt[t] = (int)((total >> (16 * t)) & 0xFFFF);
+}
+
 // Interpolate the four interval-F0 trains at time t (linear, end-segment extrapolation — SciPy's
 // interp1d(..., fill_value='extrapolate') arithmetic) and reduce: mean and, optionally, ddof=1 std.
 // Fewer than 3 intervals in any train → (0, 1000) (dio.py:159-162,182-184).

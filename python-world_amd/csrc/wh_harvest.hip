@@ -222,9 +222,10 @@ constexpr int kRawChunk = 2 * kRawTile;    // intervals staged per train and til
 __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restrict__ meta, const wh::BandJob* __restrict__ jobs,
                                                      const double* __restrict__ band_f0, int nb, double fs_d,
                                                      double f0_floor, double f0_ceil, double* __restrict__ raw,
-                                                     uint8_t* __restrict__ live) {
+                                                     uint8_t* __restrict__ live, const int32_t* __restrict__ gate) {
   __shared__ double2 iv[4][kRawChunk];  // (location, frequency) of interval start + i
   __shared__ int s_next[4];
+  if (gate && !gate[(int64_t)blockIdx.y * nb + blockIdx.x]) return;  // (only the channels the fused front end handed back)
   const HvUtt m = meta[blockIdx.y];
   const int b = blockIdx.x;
   const wh::BandJob job = jobs[(int64_t)blockIdx.y * nb + b];
@@ -377,6 +378,10 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
     for (int k = 0; k < 4; ++k) pos[k] = s_next[k];
   }
 }
+
+}  // namespace
+#include "wh_harvest_front.h"
+namespace {
 
 // NumPy's pairwise summation for n <= 128 (what np.mean does on the run of channel values)
 __device__ __forceinline__ double np_sum_strided(const double* __restrict__ a, int64_t stride, int n) {
@@ -1127,6 +1132,29 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t spec_bins = wh::kOlsN / 2 + 1;
   const size_t o_tspec = off; off += use_ols ? al(sizeof(double2) * spec_bins * n_bands) : 0;
   const size_t o_zspec = off; off += use_ols ? al(sizeof(double2) * spec_bins * (size_t)tile_off[B]) : 0;
+  // fused front end (wh_harvest_front.h): tiles of frames, each with the block of kOlsN samples centred on it; the
+  // lowest channel's valid outputs (kOlsN - 2 h_max - 2 samples) must cover the tile's frames and a margin either side
+  // OPT-IN (WH_HV_FRONT=1): exact and five times lighter on HBM, but slower than the chain it replaces — these kernels are
+  // bound by the instructions they issue, not by memory ("Harvest front end, fused": 95 against
+  // 70 ms at 1024 utterances; the crossing pass alone costs more than the transforms).
+  static const bool front_enabled = getenv("WH_HV_FRONT") && getenv("WH_HV_FRONT")[0] == '1';
+  std::vector<HvTile> tile_geo(B);
+  int64_t front_tiles = 0;
+  bool use_front = use_ols && front_enabled;
+  if (use_front) {
+    const int margin = hv_front_margin(fs_d, h_band_f0[0]);
+    const int64_t span = (int64_t)wh::kOlsN - 2 * h_max - 2 - 2 * margin;  // samples a tile's frames may span
+    int64_t tf_max = (int64_t)floor((double)span * 1000.0 / fs_d);
+    if (tf_max > kFrTFMax) tf_max = kFrTFMax;
+    if (tf_max < 64) use_front = false;  // (a floor so low that the margins eat the block: the unfused chain)
+    for (int u = 0; use_front && u < B; ++u) {
+      const int64_t nt = (meta[u].nf1 + tf_max - 1) / tf_max;
+      tile_geo[u].ntiles = (int32_t)nt;
+      tile_geo[u].tf = (int32_t)((meta[u].nf1 + nt - 1) / nt);
+      front_tiles = std::max(front_tiles, nt);
+    }
+  }
+  const size_t o_fb = off; off += al(sizeof(int32_t) * ((size_t)B + (size_t)B * n_bands));  // per utterance, then per channel
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
   HvUtt* d_meta = nullptr;
@@ -1198,13 +1226,34 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   if (dbg_y) WH_CHECK(hipMemcpyAsync(dbg_y, d_y, sizeof(double) * y_tot, hipMemcpyDeviceToDevice, st));
 
   // ---- 152 channels: FIR + crossings, then per-frame raw candidates ------------------------------------
+  int32_t* d_gate = nullptr;     // != nullptr: the unfused chain runs only for the (utterance, channel) pairs marked
+  int32_t* d_gate_ch = nullptr;  // in d_gate_ch[u * n_bands + b]; d_gate[u] = any channel of u
+  if (use_front) {
+    d_gate = reinterpret_cast<int32_t*>(ws + o_fb);
+    d_gate_ch = d_gate + B;
+    HvTile* d_geo = nullptr;
+    if (int rc = wh::persistent_upload(ctx, st, "hv.tile_geo", tile_geo, &d_geo)) return rc;
+    WH_CHECK(hipMemsetAsync(d_gate, 0, sizeof(int32_t) * ((size_t)B + (size_t)B * n_bands), st));
+    double2* d_tspec = reinterpret_cast<double2*>(ws + o_tspec);
+    { wh::KernelTimer _kt(ctx, st, "band_taps_fft_kernel"); hipLaunchKernelGGL(wh::band_taps_fft_kernel, dim3(n_bands), dim3(256), sizeof(double) * (wh::kOlsN + 2), st, d_taps, d_ti, d_ti + n_bands, ctx->d_twiddle, d_tspec); }
+    WH_LAUNCH_CHECK("band_taps_fft_kernel");
+    const dim3 fgrid((unsigned)front_tiles, B);
+    {
+      wh::KernelTimer _kt(ctx, st, "hv_front_kernel");
+      if (dbg_raw)  // (the debug copy of the whole candidate map needs its zeros too)
+        hipLaunchKernelGGL(hv_front_kernel<true>, fgrid, dim3(256), kFrLds, st, d_meta, d_geo, d_z, pad, n_bands, d_ti + 2 * n_bands, d_bf, d_tspec, ctx->d_twiddle, fs_d, f0_floor, f0_ceil, d_raw, d_live, d_gate, d_gate_ch);
+      else
+        hipLaunchKernelGGL(hv_front_kernel<false>, fgrid, dim3(256), kFrLds, st, d_meta, d_geo, d_z, pad, n_bands, d_ti + 2 * n_bands, d_bf, d_tspec, ctx->d_twiddle, fs_d, f0_floor, f0_ceil, d_raw, d_live, d_gate, d_gate_ch);
+    }
+    WH_LAUNCH_CHECK("hv_front_kernel");
+  }
   if (use_ols) {
     int64_t* d_tile_off = nullptr;
     if (int rc = wh::persistent_upload(ctx, st, "hv.tile_off", tile_off, &d_tile_off)) return rc;
     if (int rc = wh::launch_band_events_ols(ctx, st, d_jobs, n_bands, B, pad, h_max, d_taps, d_ti, d_ti + n_bands,
                                             d_ti + 2 * n_bands, d_tile_off, max_tiles,
                                             reinterpret_cast<double2*>(ws + o_tspec), reinterpret_cast<double2*>(ws + o_zspec),
-                                            ctx->d_flags + WH_FLAG_EVENT_OVERFLOW))
+                                            ctx->d_flags + WH_FLAG_EVENT_OVERFLOW, d_gate, d_gate_ch, use_front))
       return rc;
   } else if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands,
                                              d_ti + 2 * n_bands, max_lb, true, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW)) {
@@ -1213,7 +1262,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   // frames of an (utterance, channel) cut into segments with a workgroup each while the grid is a few rounds of the chip
   // (2560 workgroups at ten per CU): 1.80 -> 1.70 ms at 64 utterances; large batches keep one (no second cursor search)
   const int raw_segs = WH_HV_RAW_SEGS > 1 ? WH_HV_RAW_SEGS : ((int64_t)n_bands * B < 16 * 2560 ? 4 : 1);
-  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B, raw_segs), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw, d_live); }
+  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B, raw_segs), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw, d_live, d_gate_ch); }
   WH_LAUNCH_CHECK("hv_raw_kernel");
   if (dbg_raw) WH_CHECK(hipMemcpyAsync(dbg_raw, d_raw, sizeof(double) * f1_tot * n_bands, hipMemcpyDeviceToDevice, st));
   { wh::KernelTimer _kt(ctx, st, "hv_detect_kernel"); hipLaunchKernelGGL(hv_detect_kernel, dim3((unsigned)((max_nf1 + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw, d_live, d_dc, d_dn); }

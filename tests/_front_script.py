@@ -1,0 +1,45 @@
+"""Helper of tests/test_hip_harvest_front.py: Harvest of a small ragged batch in THIS process's library configuration
+(WH_HV_FRONT / WH_HV_FRONT_MARGIN are read once per process); results to an .npz."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "python-world_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def inputs():
+    from world._synthetic import synth_utterance
+
+    fs = 16000
+    xs = [synth_utterance(120, fs, 1.3), synth_utterance(121, fs, 0.45), synth_utterance(122, fs, 2.1)]
+    quiet = synth_utterance(123, fs, 1.6).copy()  # a stretch 60 dB down: candidates from the noise floor alone
+    quiet[9000:17000] *= 1e-3
+    xs.append(quiet)
+    return fs, xs
+
+
+def main(out):
+    from world import _hip
+    from world.harvest import harvest_device
+    from world.batch import WorldBatch
+
+    fs, xs = inputs()
+    wb = WorldBatch()
+    batch, x_d, tp_d = wb.upload(xs, fs)
+    wb.rt.profile(True)
+    f0_d, vuv_d = harvest_device(wb.rt, batch, x_d, tp_d, fs, 71, 800, 5)
+    prof = dict()
+    for name, ms in wb.rt.profile_collect():
+        prof[name] = prof.get(name, 0.0) + ms
+    wb.rt.profile(False)
+    assert wb.rt.take_flags() == [0] * 16
+    np.savez(out, f0=f0_d.cpu().numpy(), vuv=vuv_d.cpu().numpy(), frame_off=batch.frame_off,
+             kernels=np.array(sorted(prof)), ms=np.array([prof[k] for k in sorted(prof)]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1,0 +1,55 @@
+"""GPU: the fused Harvest front end (csrc/wh_harvest_front.h, opt-in: WH_HV_FRONT=1) against the default chain and the
+oracle.  The switch is read once per process, so every configuration runs in its own subprocess:
+  default            band_events -> edge lists -> hv_raw (what ships)
+  fused              hv_front_kernel with its standard margins
+  fused, margin 0.2  margins so small that many channels of every utterance fail the coverage check and go back through
+                     the unfused chain, per channel — the hand-back path, exercised on purpose
+All three must give the same voicing decisions and the same f0 (the filtered tiles differ by rounding only: the block
+origins differ) and match the oracle's harvest (world/harvest.py:17-54)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(tmp_path, tag, **env):
+    out = str(tmp_path / ("front_%s.npz" % tag))
+    e = dict(os.environ)
+    for k in ("WH_HV_FRONT", "WH_HV_FRONT_MARGIN"):
+        e.pop(k, None)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_front_script.py"), out], capture_output=True, text=True,
+                       timeout=600, env=e)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = dict(np.load(out))
+    d["prof"] = dict(zip([str(k) for k in d["kernels"]], d["ms"]))
+    return d
+
+
+def test_fused_front_end_equals_the_chain_and_the_oracle(tmp_path):
+    from oracle import pitch_harvest
+    from _front_script import inputs
+
+    base = _run(tmp_path, "default")
+    fused = _run(tmp_path, "fused", WH_HV_FRONT="1")
+    forced = _run(tmp_path, "forced", WH_HV_FRONT="1", WH_HV_FRONT_MARGIN="0.2")
+    assert "hv_front_kernel" not in base["prof"] and "hv_front_kernel" in fused["prof"]
+    # the hand-back path really ran in the forced configuration: its gated kernels did work there and (next to) none before
+    assert forced["prof"]["hv_raw_kernel"] > 2 * fused["prof"]["hv_raw_kernel"]
+    assert forced["prof"]["band_events_kernel"] > 2 * fused["prof"]["band_events_kernel"]
+    for other in (fused, forced):
+        assert np.array_equal(other["vuv"], base["vuv"])
+        assert np.max(np.abs(other["f0"] - base["f0"])) < 1e-7
+    fs, xs = inputs()
+    fo = base["frame_off"]
+    for u, x in enumerate(xs):
+        ref = pitch_harvest.harvest_np(x, fs)
+        a, b = int(fo[u]), int(fo[u + 1])
+        for d in (base, fused):
+            assert np.array_equal(d["vuv"][a:b], ref["vuv"])
+            assert np.max(np.abs(d["f0"][a:b] - ref["f0"])) < 1e-6

@@ -6,6 +6,9 @@
 // scan, and appended to per-(band, train) edge lists; frames later binary-search those lists.
 #pragma once
 #include "wh_device.h"
+#ifndef WH_EMIT_BATCHED
+#define WH_EMIT_BATCHED 1
+#endif
 
 namespace wh {
 
@@ -107,16 +110,21 @@ __device__ __forceinline__ void emit_crossings_block(const double* sig, int64_t 
   unsigned m01 = 0, m23 = 0;  // bits [0,16): negative-going, [16,32): positive-going
   {
     const int i0 = tid * PER;
-    double a = sig[i0 * STRIDE], b = sig[(i0 + 1) * STRIDE];
+    // the thread's PER + 2 samples in ONE round of LDS reads (left to the compiler the walk was read - wait - test, PER / 2
+    // times over: every pair of samples an exposed LDS round trip)
+    double s[PER + 2];
+#pragma unroll
+    for (int q = 0; q < PER + 2; ++q) s[q] = sig[(i0 + q) * STRIDE];
+#if WH_EMIT_BATCHED
+    asm volatile("" ::: "memory");
+#endif
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-      const double c = sig[(i0 + q + 2) * STRIDE];
+      const double a = s[q], b = s[q + 1], c = s[q + 2];
       const int64_t g = t0 + i0 + q;
       if (g + 1 < M && a * b < 0) m01 |= (b < a ? 1u : (b > a ? 0x10000u : 0u)) << q;
       const double d0 = b - a, d1 = c - b;
       if (g + 2 < M && d0 * d1 < 0) m23 |= (d1 < d0 ? 1u : (d1 > d0 ? 0x10000u : 0u)) << q;
-      a = b;
-      b = c;
     }
   }
   const unsigned long long packed = (unsigned long long)__popc(m01 & 0xFFFFu) | ((unsigned long long)__popc(m01 >> 16) << 16) |

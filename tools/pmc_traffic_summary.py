@@ -3,11 +3,14 @@
 as /opt/skills/guides/MI355X_MICROARCH.md prescribes), written in the table bench.py's `roofline.traffic` reads.
 
 usage: tools/pmc_traffic_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <frames_per_launch>
-       > profiles/hbm_traffic_cfg2_latest.txt
+           [label] [fs=16000] [fft=1024] [requiem=0] [out_hop_scale=1]  > profiles/hbm_traffic_cfg2_latest.txt
+   e.g. config 4: ... 128064 "config 4 (64 x 10 s, Requiem)" fs=16000 fft=1024 requiem=1
+        config 5: ... 192016 "config 5 (16 x 60 s, 48 kHz)" fs=48000 fft=2048 out_hop_scale=2
 
 rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (the guide's
 HBM section), so corrected_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  Values are averaged over the launches of each
-kernel in the run.  algorithmic_MB uses bench.algo_bytes_per_frame (SURVEY 8(d) components) for 16 kHz / fft 1024.
+kernel in the run.  algorithmic_MB uses bench.algo_bytes_per_frame (SURVEY 8(d) components) for the given rate, FFT size,
+aperiodicity format (requiem=1: band values instead of the 513-bin row) and output hop scale (scale_duration).
 """
 import collections
 import csv
@@ -39,9 +42,12 @@ def main():
     fetch, nf = per_launch(sys.argv[1], "FETCH_SIZE")
     write, _ = per_launch(sys.argv[2], "WRITE_SIZE")
     frames = int(sys.argv[3])
-    label = sys.argv[4] if len(sys.argv) > 4 else "config 2 (64 x 10 s)"
+    label = sys.argv[4] if len(sys.argv) > 4 and "=" not in sys.argv[4] else "config 2 (64 x 10 s)"
+    opt = dict(a.split("=", 1) for a in sys.argv[4:] if "=" in a)
+    fs, fft = int(opt.get("fs", 16000)), int(opt.get("fft", 1024))
     import bench
-    algo, _ = bench.algo_bytes_per_frame(16000, 1024)
+    algo, _ = bench.algo_bytes_per_frame(fs, fft, float(opt.get("out_hop_scale", 1.0)), requiem=opt.get("requiem", "0") == "1")
+    label += " [algorithmic bytes for fs %d, fft %d%s]" % (fs, fft, ", Requiem" if opt.get("requiem", "0") == "1" else "")
     print("# HBM traffic per launch from rocprofv3 PMC (separate --pmc passes for FETCH_SIZE and WRITE_SIZE), "
           "%s, %d frames per launch" % (label, frames))
     print("# rocprofv3 reports KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md "

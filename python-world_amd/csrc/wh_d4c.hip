@@ -108,7 +108,8 @@ constexpr int ft_of(int n) { return n >= 4096 ? 2 * WH_FT_D4C : (n == 1024 ? WH_
 // fed form (two waves per frame): the radix-8 butterflies need the 128-register budget; eight workgroups per CU.
 #define WH_D4C_MINBLK1024 (WH_D4C_REGFED ? 4 : 5)
 #endif
-constexpr int minblk_of(int n) { return n >= 4096 ? WH_D4C_MINBLK4096 : (n == 1024 ? WH_D4C_MINBLK1024 : (n < 1024 ? 5 : WH_D4C_MINBLK)); }
+// (N = 8192, 96 kHz material: 131 KB of LDS per frame -> one 512-thread workgroup per CU, 256 registers per thread)
+constexpr int minblk_of(int n) { return n >= 8192 ? 1 : n >= 4096 ? WH_D4C_MINBLK4096 : (n == 1024 ? WH_D4C_MINBLK1024 : (n < 1024 ? 5 : WH_D4C_MINBLK)); }
 
 // Windowed, DC-removed pitch-synchronous frame (world/d4c.py:92-110).  emit(j, value) is called for every sample
 // j = tid + q*FT < N (zero beyond the window; rows longer than N are cropped like np.fft.fft(x, n), Q7) — the callers
@@ -1194,7 +1195,8 @@ int d4c_common(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, co
       case 1024: return launch_main<1024, true>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
       case 2048: return launch_main<2048, true>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
       case 4096: return launch_main<4096, true>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
-      default: return wh::fail_msg("wh_d4c", "D4C FFT size outside [512, 4096]");
+      case 8192: return launch_main<8192, true>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+      default: return wh::fail_msg("wh_d4c", "D4C FFT size outside [512, 8192]");
     }
   }
   int rc;
@@ -1203,7 +1205,8 @@ int d4c_common(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, co
     case 1024: rc = launch_lt<1024>(ctx, st, b, x, tp, f0, vuv, fs, threshold, gate); break;
     case 2048: rc = launch_lt<2048>(ctx, st, b, x, tp, f0, vuv, fs, threshold, gate); break;
     case 4096: rc = launch_lt<4096>(ctx, st, b, x, tp, f0, vuv, fs, threshold, gate); break;
-    default: return wh::fail_msg("wh_d4c", "love-train FFT size outside [512, 4096] (fs must be <= ~54 kHz)");
+    case 8192: rc = launch_lt<8192>(ctx, st, b, x, tp, f0, vuv, fs, threshold, gate); break;
+    default: return wh::fail_msg("wh_d4c", "love-train FFT size outside [512, 8192] (fs must be <= ~109 kHz)");
   }
   if (rc) return rc;
   switch (nfft) {
@@ -1211,7 +1214,8 @@ int d4c_common(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, co
     case 1024: return launch_main<1024, false>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
     case 2048: return launch_main<2048, false>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
     case 4096: return launch_main<4096, false>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
-    default: return wh::fail_msg("wh_d4c", "D4C FFT size outside [512, 4096]");
+    case 8192: return launch_main<8192, false>(ctx, st, b, x, tp, f0, vuv, gate, threshold, fs, nap, interval, d_win, wlen, k_spec, out, coarse);
+    default: return wh::fail_msg("wh_d4c", "D4C FFT size outside [512, 8192]");
   }
 }
 

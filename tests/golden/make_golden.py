@@ -414,6 +414,33 @@ def differential_fixture():
     print("differential written; worst", {k: "%.2e" % v for k, v in worst.items()})
 
 
+def hires_fixture():
+    """96 kHz: the rates beyond 48 kHz need 8192-point transforms in D4C (d4c.py:20: 2^ceil(log2(4 fs / 47 + 1))) and the
+    love-train gate (d4c.py:75).  DIO is all-unvoiced up there, so the dense stages are driven with
+    Harvest's contour: harvest -> cheaptrick -> d4c / d4cRequiem -> seeded synthesis."""
+    fs = 96000
+    x = _syn.synth_utterance(7, fs, 0.35)
+    out = {"x": x, "fs": fs}
+    h = R.harvest.harvest(x.copy(), fs)
+    out["harvest_f0"], out["harvest_vuv"], out["tp"] = h["f0"].copy(), h["vuv"].copy(), h["temporal_positions"].copy()
+    src = {"f0": h["f0"].copy(), "vuv": h["vuv"].copy(), "temporal_positions": h["temporal_positions"].copy()}
+    ct = R.cheaptrick.cheaptrick(x, fs, src)
+    out["ct_spectrogram"] = ct["spectrogram"].copy()
+    out["ct_f0_after"] = src["f0"].copy()
+    src2 = {k: v.copy() for k, v in src.items()}
+    a = R.d4c.d4c(x, fs, src2)
+    out["d4c_aperiodicity"], out["d4c_coarse"], out["d4c_f0_after"] = a["aperiodicity"].copy(), a["coarse_ap"].copy(), a["f0"].copy()
+    src3 = {k: v.copy() for k, v in src.items()}
+    out["req_band_ap"] = R.d4cRequiem.d4cRequiem(x, fs, src3)["aperiodicity"].copy()
+    dat = {"f0": a["f0"].copy(), "vuv": h["vuv"].copy(), "temporal_positions": h["temporal_positions"].copy(),
+           "spectrogram": ct["spectrogram"].copy(), "aperiodicity": a["aperiodicity"].copy(), "fs": fs}
+    np.random.seed(SEED)
+    out["syn_y"] = R.synthesis.synthesis(dat, dat)
+    out["seed"] = SEED
+    np.savez_compressed(os.path.join(HERE, "golden_syn96k.npz"), **out)
+    print("syn96k written;", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected fixtures only: python make_golden.py getters heads ...
         for name in sys.argv[1:]:
@@ -429,3 +456,4 @@ if __name__ == "__main__":
     modifiers_fixture()
     longform_fixture()
     differential_fixture()
+    hires_fixture()

@@ -78,3 +78,23 @@ def test_d4c_rank_select_wide_dynamic_range(fs):
         got_band = d4cRequiem(x, fs, src)["aperiodicity"]
         assert np.isfinite(want_band).all()
         assert np.max(np.abs(got_band - want_band)) < 1e-3
+
+
+def test_d4c_96k_needs_8192_point_transforms(golden):
+    """Beyond ~54 kHz D4C's transform (d4c.py:20) and the love-train gate's (d4c.py:75) are 8192 points: the 96 kHz
+    fixture (reference: harvest -> cheaptrick -> d4c / d4cRequiem)."""
+    from world.d4c import d4c
+    from world.d4cRequiem import d4cRequiem
+
+    g = golden("syn96k")
+    fs = int(g["fs"])
+    src = {"f0": g["ct_f0_after"].copy(), "vuv": g["harvest_vuv"].copy(), "temporal_positions": g["tp"].copy()}
+    out = d4c(g["x"], fs, src)
+    assert np.array_equal(src["f0"], g["d4c_f0_after"])
+    assert np.array_equal(out["coarse_ap"] != 0, g["d4c_coarse"] != 0)
+    assert np.max(np.abs(out["coarse_ap"] - g["d4c_coarse"])) < 1e-6
+    assert np.max(np.abs(out["aperiodicity"] - g["d4c_aperiodicity"])) < 1e-7
+    src = {"f0": g["ct_f0_after"].copy(), "vuv": g["harvest_vuv"].copy(), "temporal_positions": g["tp"].copy()}
+    rq = d4cRequiem(g["x"], fs, src)
+    assert rq["aperiodicity"].shape == g["req_band_ap"].shape
+    assert np.max(np.abs(rq["aperiodicity"] - g["req_band_ap"])) < 1e-6

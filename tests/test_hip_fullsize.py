@@ -119,3 +119,30 @@ def test_harvest_batch_rows_equal_single_utterance():
     vuv = enc.vuv.cpu().numpy()
     voiced = f0[vuv != 0]
     assert len(voiced) > 0.5 * len(f0) and 60 < voiced.min() and voiced.max() < 900
+
+
+def test_facade_at_96k(golden):
+    """World().encode(harvest) + seeded decode at 96 kHz against the reference's stage outputs (golden_syn96k.npz):
+    Harvest exact in vuv, CheapTrick 4096-point, D4C 8192-point, pulse-wise synthesis 4096-point."""
+    import numpy as np
+    from conftest import rel_rms
+    from world import main
+
+    g = golden("syn96k")
+    fs = int(g["fs"])
+    W = main.World()
+    dat = W.encode(fs, g["x"].copy(), f0_method="harvest")
+    assert np.array_equal(dat["vuv"], g["harvest_vuv"])
+    assert np.max(np.abs(dat["f0"] - g["d4c_f0_after"])) < 1e-6
+    assert dat["spectrogram"].shape == g["ct_spectrogram"].shape
+    assert rel_rms(dat["spectrogram"], g["ct_spectrogram"]) < 1e-8
+    assert np.max(np.abs(dat["aperiodicity"] - g["d4c_aperiodicity"])) < 1e-6
+    np.random.seed(int(g["seed"]))
+    y = W.decode(dict(dat))["out"]
+    ref = g["syn_y"] / max(1.0, np.max(np.abs(g["syn_y"])))
+    assert len(y) == len(ref) and rel_rms(y, ref) < 1e-6
+    # Requiem path at this rate too (band aperiodicity from an 8192-point transform; 2048-point seed pulses)
+    datr = W.encode(fs, g["x"].copy(), f0_method="harvest", is_requiem=True)
+    assert np.max(np.abs(datr["aperiodicity"] - g["req_band_ap"])) < 1e-5
+    yr = W.decode(dict(datr))["out"]
+    assert np.all(np.isfinite(yr)) and len(yr) == len(ref)

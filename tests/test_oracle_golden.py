@@ -203,3 +203,23 @@ def test_swipe_oracle_on_quirk_candidates(golden):
         r = pitch_swipe.swipe_np(int(fs), harmonic_tone(int(fs), float(f0)), [71, 800], 0.005, 0.3)
         assert np.array_equal(r["f0"], g["tone_f0_%d_%d" % (fs, f0)]), (fs, f0)
         assert np.array_equal(r["vuv"], g["tone_vuv_%d_%d" % (fs, f0)])
+
+
+def test_hires_96k_chain(golden):
+    """96 kHz (8192-point D4C transforms): the oracle against the reference's harvest -> cheaptrick -> d4c / d4cRequiem
+    -> seeded synthesis (make_golden.py hires_fixture)."""
+    g = golden("syn96k")
+    fs = int(g["fs"])
+    h = pitch_harvest.harvest_np(g["x"], fs)
+    assert np.array_equal(h["vuv"], g["harvest_vuv"]) and np.array_equal(h["f0"], g["harvest_f0"])
+    sp, _, f0u = envelope.cheaptrick_np(g["x"], fs, g["harvest_f0"], g["harvest_vuv"], g["tp"])
+    assert np.array_equal(f0u, g["ct_f0_after"]) and rel_rms(sp, g["ct_spectrogram"]) < 1e-10
+    ap, coarse, f0o = aperiodicity.d4c_np(g["x"], fs, g["ct_f0_after"], g["harvest_vuv"], g["tp"])
+    assert np.array_equal(f0o, g["d4c_f0_after"])
+    assert np.allclose(coarse, g["d4c_coarse"], rtol=0, atol=1e-8)
+    assert np.allclose(ap, g["d4c_aperiodicity"], rtol=0, atol=1e-9)
+    band, _ = aperiodicity.d4c_requiem_np(g["x"], fs, g["ct_f0_after"], g["harvest_vuv"], g["tp"])
+    assert np.allclose(band, g["req_band_ap"], rtol=0, atol=1e-8)
+    np.random.seed(int(g["seed"]))
+    y = resynth.synthesis_np(g["d4c_f0_after"], g["harvest_vuv"], g["tp"], g["ct_spectrogram"], g["d4c_aperiodicity"], fs)
+    assert len(y) == len(g["syn_y"]) and np.max(np.abs(y - g["syn_y"])) < 1e-10

@@ -6,9 +6,7 @@
 // scan, and appended to per-(band, train) edge lists; frames later binary-search those lists.
 #pragma once
 #include "wh_device.h"
-#ifndef WH_EMIT_BATCHED
-#define WH_EMIT_BATCHED 1
-#endif
+
 
 namespace wh {
 
@@ -97,6 +95,69 @@ __device__ __forceinline__ void emit_crossings(const double* sig, int64_t t0, in
   }
 }
 
+// First walk of the crossing pass over one thread's PER consecutive positions (s[0 .. PER + 2) readable): which of them
+// carry a crossing, per train.  Position q is sample g = g_first + q; a crossing of the signal needs g + 1 < M, one of
+// its first difference g + 2 < M, and q < n_pos: `left` = M - g_first and n_pos turn into two bit masks applied once,
+// after the walk, instead of two 64-bit compares per position.  With a*b < 0 the two values differ, so ONE compare
+// tells the direction (it was two); the difference d1 of a position is d0 of the next.  All samples come in one round
+// of LDS reads (left to the compiler the walk was read - wait - test, PER / 2 times over).
+template <int STRIDE, int PER>
+__device__ __forceinline__ void crossing_flags(const double* s_ptr, int64_t left, int n_pos, unsigned* m01_out,
+                                               unsigned* m23_out) {
+  double s[PER + 2];
+#pragma unroll
+  for (int q = 0; q < PER + 2; ++q) s[q] = s_ptr[q * STRIDE];
+  unsigned m01 = 0, m23 = 0;
+  double d0 = s[1] - s[0];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const double a = s[q], b = s[q + 1], c = s[q + 2];
+    const unsigned f01 = a * b < 0 ? (b < a ? 1u : 0x10000u) : 0u;
+    const double d1 = c - b;
+    const unsigned f23 = d0 * d1 < 0 ? (d1 < d0 ? 1u : 0x10000u) : 0u;
+    m01 |= f01 << q;
+    m23 |= f23 << q;
+    d0 = d1;
+  }
+  // positions q with g + 1 < M  <=>  q < left - 1;  g + 2 < M  <=>  q < left - 2;  and q < n_pos
+  int64_t l1 = left - 1, l2 = left - 2;
+  l1 = l1 < 0 ? 0 : (l1 > n_pos ? n_pos : l1);
+  l2 = l2 < 0 ? 0 : (l2 > n_pos ? n_pos : l2);
+  const unsigned k1 = (1u << (int)l1) - 1u, k2 = (1u << (int)l2) - 1u;  // (<= 16 bits)
+  *m01_out = m01 & (k1 | (k1 << 16));
+  *m23_out = m23 & (k2 | (k2 << 16));
+}
+
+// Second walk: the flagged positions of one thread, ascending, one divide per crossing — the signal's crossings in one
+// loop, the first difference's in another (a wave runs a loop as long as its busiest lane: two loops of one divide take
+// max + max rounds, one loop with both bodies took max-of-sums rounds of two).  put(train, slot, edge) stores; pos[4] are
+// the thread's first slots.  Edge = (1-based position) - v[i] / (v[i+1] - v[i])  (dio.py:201).
+template <int STRIDE, class Put>
+__device__ __forceinline__ void crossing_edges(const double* s_ptr, int64_t g_first, unsigned m01, unsigned m23, int* pos,
+                                               Put put) {
+  unsigned any = (m01 | (m01 >> 16)) & 0xFFFFu;
+  while (any) {
+    const int q = __ffs(any) - 1;
+    any &= any - 1;
+    const double a = s_ptr[q * STRIDE], b = s_ptr[(q + 1) * STRIDE];
+    const int t = (m01 >> q) & 1u ? 0 : 1;
+    const double fe = (double)(g_first + q + 1) - a / (b - a);
+    put(t, pos[t], fe);
+    ++pos[t];
+  }
+  any = (m23 | (m23 >> 16)) & 0xFFFFu;
+  while (any) {
+    const int q = __ffs(any) - 1;
+    any &= any - 1;
+    const double a = s_ptr[q * STRIDE], b = s_ptr[(q + 1) * STRIDE], c = s_ptr[(q + 2) * STRIDE];
+    const int t = (m23 >> q) & 1u ? 2 : 3;
+    const double d0 = b - a, d1 = c - b;
+    const double fe = (double)(g_first + q + 1) - d0 / (d1 - d0);
+    put(t, pos[t], fe);
+    ++pos[t];
+  }
+}
+
 // The same for a tile of PER * 256 positions in ONE pass (one block scan and two barriers whatever the tile length):
 // the first walk only flags the crossings (no divides, nothing kept but four PER-bit masks), the second re-reads the
 // flagged samples and writes the edge positions at the offsets the scan produced.  Used by the overlap-save band
@@ -107,26 +168,9 @@ __device__ __forceinline__ void emit_crossings_block(const double* sig, int64_t 
                                                      int32_t* overflow_flag) {
   static_assert(PER <= 16, "masks are 16 bits, counts 16 bits per train");
   const int tid = threadIdx.x;
-  unsigned m01 = 0, m23 = 0;  // bits [0,16): negative-going, [16,32): positive-going
-  {
-    const int i0 = tid * PER;
-    // the thread's PER + 2 samples in ONE round of LDS reads (left to the compiler the walk was read - wait - test, PER / 2
-    // times over: every pair of samples an exposed LDS round trip)
-    double s[PER + 2];
-#pragma unroll
-    for (int q = 0; q < PER + 2; ++q) s[q] = sig[(i0 + q) * STRIDE];
-#if WH_EMIT_BATCHED
-    asm volatile("" ::: "memory");
-#endif
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const double a = s[q], b = s[q + 1], c = s[q + 2];
-      const int64_t g = t0 + i0 + q;
-      if (g + 1 < M && a * b < 0) m01 |= (b < a ? 1u : (b > a ? 0x10000u : 0u)) << q;
-      const double d0 = b - a, d1 = c - b;
-      if (g + 2 < M && d0 * d1 < 0) m23 |= (d1 < d0 ? 1u : (d1 > d0 ? 0x10000u : 0u)) << q;
-    }
-  }
+  const int i0 = tid * PER;
+  unsigned m01, m23;  // bits [0,16): negative-going, [16,32): positive-going
+  crossing_flags<STRIDE, PER>(sig + (int64_t)i0 * STRIDE, M - (t0 + i0), PER, &m01, &m23);
   const unsigned long long packed = (unsigned long long)__popc(m01 & 0xFFFFu) | ((unsigned long long)__popc(m01 >> 16) << 16) |
                                     ((unsigned long long)__popc(m23 & 0xFFFFu) << 32) |
                                     ((unsigned long long)__popc(m23 >> 16) << 48);
@@ -145,29 +189,12 @@ __device__ __forceinline__ void emit_crossings_block(const double* sig, int64_t 
   int pos[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) pos[t] = base_cnt[t] + (int)((excl >> (16 * t)) & 0xFFFF);
-  unsigned any = (m01 | (m01 >> 16) | m23 | (m23 >> 16)) & 0xFFFFu;
-  while (any) {  // flagged positions only, ascending
-    const int q = __ffs(any) - 1;
-    any &= any - 1;
-    const int i = tid * PER + q;
-    const double a = sig[i * STRIDE], b = sig[(i + 1) * STRIDE], c = sig[(i + 2) * STRIDE];
-    const double at = (double)(t0 + i + 1);
-    if ((m01 >> q) & 0x10001u) {
-      const int t = (m01 >> q) & 1u ? 0 : 1;
-      const double fe = at - a / (b - a);
-      if (pos[t] < cap) edges[(int64_t)t * cap + pos[t]] = fe;
-      else atomicOr(overflow_flag, 1);
-      ++pos[t];
-    }
-    if ((m23 >> q) & 0x10001u) {
-      const int t = (m23 >> q) & 1u ? 2 : 3;
-      const double d0 = b - a, d1 = c - b;
-      const double fe = at - d0 / (d1 - d0);
-      if (pos[t] < cap) edges[(int64_t)t * cap + pos[t]] = fe;
-      else atomicOr(overflow_flag, 1);
-      ++pos[t];
-    }
-  }
+  bool over = false;
+  crossing_edges<STRIDE>(sig + (int64_t)i0 * STRIDE, t0 + i0, m01, m23, pos, [&](int t, int at, double fe) {
+    if (at < cap) edges[(int64_t)t * cap + at] = fe;
+    else over = true;
+  });
+  if (over) atomicOr(overflow_flag, 1);
 #pragma unroll
   for (int t = 0; t < 4; ++t) base_cnt[t] += (int)((total >> (16 * t)) & 0xFFFF);
 }
@@ -182,22 +209,11 @@ __device__ __forceinline__ void emit_crossings_lds(const double* sig, int64_t g0
                                                    int cap, int* cnt, unsigned long long* scratch) {
   static_assert(PER <= 16, "masks are 16 bits, counts 16 bits per train");
   const int tid = threadIdx.x;
-  unsigned m01 = 0, m23 = 0;  // bits [0,16): negative-going, [16,32): positive-going
-  {
-    const int i0 = tid * PER;
-    double a = sig[i0], b = sig[i0 + 1];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const double c = sig[i0 + q + 2];
-      const int64_t g = g0 + i0 + q;
-      const bool in = i0 + q < n_pos;
-      if (in && g + 1 < M && a * b < 0) m01 |= (b < a ? 1u : (b > a ? 0x10000u : 0u)) << q;
-      const double d0 = b - a, d1 = c - b;
-      if (in && g + 2 < M && d0 * d1 < 0) m23 |= (d1 < d0 ? 1u : (d1 > d0 ? 0x10000u : 0u)) << q;
-      a = b;
-      b = c;
-    }
-  }
+  const int i0 = tid * PER;
+  unsigned m01, m23;
+  int np = n_pos - i0;
+  np = np < 0 ? 0 : (np > PER ? PER : np);
+  crossing_flags<1, PER>(sig + i0, M - (g0 + i0), np, &m01, &m23);
   const unsigned long long packed = (unsigned long long)__popc(m01 & 0xFFFFu) | ((unsigned long long)__popc(m01 >> 16) << 16) |
                                     ((unsigned long long)__popc(m23 & 0xFFFFu) << 32) |
                                     ((unsigned long long)__popc(m23 >> 16) << 48);
@@ -216,27 +232,9 @@ __device__ __forceinline__ void emit_crossings_lds(const double* sig, int64_t g0
   int pos[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) pos[t] = (int)((excl >> (16 * t)) & 0xFFFF);
-  unsigned any = (m01 | (m01 >> 16) | m23 | (m23 >> 16)) & 0xFFFFu;
-  while (any) {  // flagged positions only, ascending
-    const int q = __ffs(any) - 1;
-    any &= any - 1;
-    const int i = tid * PER + q;
-    const double a = sig[i], b = sig[i + 1], c = sig[i + 2];
-    const double at = (double)(g0 + i + 1);
-    if ((m01 >> q) & 0x10001u) {
-      const int t = (m01 >> q) & 1u ? 0 : 1;
-      const double fe = at - a / (b - a);
-      if (pos[t] < cap) edges[t * cap + pos[t]] = fe;
-      ++pos[t];
-    }
-    if ((m23 >> q) & 0x10001u) {
-      const int t = (m23 >> q) & 1u ? 2 : 3;
-      const double d0 = b - a, d1 = c - b;
-      const double fe = at - d0 / (d1 - d0);
-      if (pos[t] < cap) edges[t * cap + pos[t]] = fe;
-      ++pos[t];
-    }
-  }
+  crossing_edges<1>(sig + i0, g0 + i0, m01, m23, pos, [&](int t, int at, double fe) {
+    if (at < cap) edges[t * cap + at] = fe;
+  });
 #pragma unroll
   for (int t = 0; t < 4; ++t) cnt[t] = (int)((total >> (16 * t)) & 0xFFFF);
 }

@@ -509,6 +509,7 @@ def main():
                 blocks.append(("with_transfers_overlapped",
                                lambda: with_transfers_lanes_block(torch, local_rank, xs, FS, args.transfer_lanes)))
             blocks.append(("varying_lengths", lambda: varying_lengths_block(torch, local_rank, xs, FS)))
+            blocks.append(("decode_alone", lambda: decode_alone_block(torch, wl, FS)))
             blocks.append(("config1_latency", lambda: config1_latency_block(torch)))
             blocks.append(("feature_heads", lambda: feature_heads_block(torch, wl, FS)))
             blocks.append(("swipe", lambda: swipe_block(torch, wl, FS)))
@@ -700,6 +701,34 @@ def roundtrip_out_only_block(torch, wl, xs, fs, steps=6):
             "flag_check": "deferred (wh_flags_post / wh_flags_poll: no host wait per call)",
             "note": "config 2 with H2D of x and D2H of `out` only inside the timed region, pipelined: what a "
                     "resynthesis caller (encode -> modify -> decode) pays; median of 4 rounds"}
+
+
+def decode_alone_block(torch, wl, fs, reps=10):
+    """The decode of config 2 on its own: (a) with the time base that encode prefetched under CheapTrick / D4C (only the
+    spectral half runs), (b) with that time base dropped, i.e. what decode_batch of a fresh from_dicts encoding or a
+    decode after scale_pitch / scale_duration pays: prep, the exact phase scan, the pulse kernels, then the responses.
+    HIP-event times of whole calls; per-kernel times of (b) from one profiled call."""
+    wb = wl.lanes[0]
+    rt = wb.rt
+    batch, x_d, tp_d = wl.resident[0]
+    enc = wb.encode_device(batch, x_d, tp_d, fs, f0_method="dio", check=False)
+    wb.decode_device(enc, seed=1, check=False)
+    ms_pref, _ = _event_ms(torch, lambda: wb.decode_device(enc, seed=1, check=False), reps)
+    tb, enc._timebase = enc._timebase, None
+    wb.decode_device(enc, seed=1, check=False)
+    ms_inline, _ = _event_ms(torch, lambda: wb.decode_device(enc, seed=1, check=False), reps)
+    rt.profile(True)
+    wb.decode_device(enc, seed=1, check=False)
+    agg = {}
+    for name, t in rt.profile_collect():
+        agg[name] = agg.get(name, 0.0) + t
+    rt.profile(False)
+    enc._timebase = tb
+    wb.check("decode_alone")
+    return {"prefetched_timebase_ms": ms_pref, "inline_timebase_ms": ms_inline, "timebase_cost_ms": ms_inline - ms_pref,
+            "kernel_ms_inline": {k: round(v, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:12]},
+            "note": "config-2 encoding, decode only; 'inline' = no prefetched time base (fresh from_dicts encodings, "
+                    "modified encodings)"}
 
 
 def with_transfers_lanes_block(torch, device_index, xs, fs, lanes=4, steps=5):

@@ -490,12 +490,15 @@ __device__ __forceinline__ bool rotation_path_ok(bool wtab, double a0, double a0
 // whatever the number of candidates in the wave, and with the tabulated windows they outweigh the loop (233 + 391
 // against 40 instructions per 16 samples): eight lanes per candidate — eight candidates per wave — halve their share
 // and drop one of the four reduction steps.  The rotation path needs the 16-lane row rotates.
-template <bool TWL, bool WTAB, int RL>
+// `members(eval)`: the caller runs eval(f0c_m, &f0, &score) for every candidate of the frame that shares this one's
+// window length and harmonic bins (hv_refine_kernel: the seven overlapped copies of a slowly moving pitch track mostly
+// do) — the spectra at the harmonic bins are the same for all of them, only the score looks at the candidate itself.
+template <bool TWL, bool WTAB, int RL, class Members>
 __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int64_t ybase, int64_t ylen, double fs,
                                               double t0, double f0c, double f0_floor, double f0_ceil,
                                               const double2* __restrict__ tw_base, const char* tw_lds, int tw_n,
                                               const double2* __restrict__ rot_tab, const double2* __restrict__ win_tab,
-                                              double* out_f0, double* out_sc) {
+                                              Members members) {
   static_assert(WTAB || RL == 16, "the rotation path exchanges window values with 16-lane row rotates");
   const int l16 = threadIdx.x & (RL - 1);  // lane within the candidate's group
   const double hwl_d = ceil(3 * fs / f0c / 2);
@@ -726,32 +729,53 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       my_bin[h / RL] = bins[h];
     }
   }
-  double t_num = 0.0, t_den = 0.0, t_var = 0.0;
+  // per harmonic of this lane: instantaneous frequency and amplitude (harvest.py:193-203) — functions of the spectra
+  // alone; numerator / denominator / variation are summed per candidate below, over ITS harmonics
+  double inst_q[P], amp_q[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const double p = sa[q] * sa[q] + sb[q] * sb[q];
+    const double nm = sa[q] * sd[q] - sb[q] * sc_[q];
+    // bin / nfft is exact (power of two), and so is the halving
+    inst_q[q] = ((double)my_bin[q] * (1.0 / (double)nfft) + nm / p * 0.5 / M_PI) * fs;
+    amp_q[q] = sqrt(p);
+  }
+  // numerator and denominator run over the harmonics below nh — the same for every member (nh is part of the class key)
+  double t_num = 0.0, t_den = 0.0, a_q[P];
 #pragma unroll
   for (int q = 0; q < P; ++q) {
     const int h = l16 + q * RL;
+    a_q[q] = inst_q[q] / (double)(h + 1);
     if (h < nh) {
-      const double p = sa[q] * sa[q] + sb[q] * sb[q];
-      const double nm = sa[q] * sd[q] - sb[q] * sc_[q];
-      // bin / nfft is exact (power of two), and so is the halving
-      const double inst = ((double)my_bin[q] * (1.0 / (double)nfft) + nm / p * 0.5 / M_PI) * fs;
-      const double amp = sqrt(p);
-      t_num += amp * inst;
-      t_den += amp * (double)(h + 1);
-      t_var += fabs((inst / (double)(h + 1) - f0c) / f0c);
+      t_num += amp_q[q] * inst_q[q];
+      t_den += amp_q[q] * (double)(h + 1);
     }
   }
-  const double num = row_sum<RL>(t_num), den = row_sum<RL>(t_den), var = row_sum<RL>(t_var);
-  double rf = num / den;
-  double sc = 1 / (0.000000000001 + var / (double)nh);
-  if (rf < f0_floor || rf > f0_ceil || sc < 2.5) {
-    rf = 0.0;
-    sc = 0.0;
-  }
-  *out_f0 = rf;
-  *out_sc = sc;
+  const double num = row_sum<RL>(t_num), den = row_sum<RL>(t_den);
+  const double rf_all = num / den;
+  // (scoring four members at a time, one per lane, was measured and is no faster: 3.51 against 3.53 ms)
+  members([&](double f0m, double* out_f0, double* out_sc) {
+    double t_var = 0.0;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      const int h = l16 + q * RL;
+      if (h < nh) t_var += fabs((a_q[q] - f0m) / f0m);
+    }
+    const double var = row_sum<RL>(t_var);
+    double rf = rf_all;
+    double sc = 1 / (0.000000000001 + var / (double)nh);
+    if (rf < f0_floor || rf > f0_ceil || sc < 2.5) {
+      rf = 0.0;
+      sc = 0.0;
+    }
+    *out_f0 = rf;
+    *out_sc = sc;
+  });
 }
 
+#ifndef WH_HV_CLASSES
+#define WH_HV_CLASSES 1  // 0: no sharing between the candidates of a frame (timing experiments)
+#endif
 #ifndef WH_HV_MINW
 #define WH_HV_MINW 3  // waves per SIMD the tabulated variant is compiled for (2: 5.07 ms against 4.09 at config 3)
 #endif
@@ -829,27 +853,30 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
     src = src < 0 ? 0 : (src > m.nf1 - 1 ? m.nf1 - 1 : src);
     cv[it] = dc[(m.f1_off + src) * kMaxC + e % kMaxC];
   }
+  // The work list is written in LIST-SLOT order (the rank of a row among its frame's rows: the order the results are
+  // stored in), so a frame's items are contiguous and an item's index is its result slot: a first pass marks the rows
+  // that hold a candidate, a second, behind the per-frame offsets, places them.
+  bool live_q[kGather];
 #pragma unroll
   for (int it = 0; it < kGather; ++it) {
     const int q = threadIdx.x + it * 256;
-    if (q >= kFramesPerBlock * kRows) break;
+    live_q[it] = false;
+    if (q >= kFramesPerBlock * kRows) continue;
     const int fl = q / kRows, e = q % kRows;
     const int64_t f = f_first + fl;
     if (f >= m.nf1) continue;
     const int64_t src = f + (e / kMaxC - 3);
     double cand = (src >= 0 && src < m.nf1) ? cv[it] : 0.0;
     if (e == 0 && f < 3) cand = dc[(m.f1_off + f) * kMaxC + 6];  // stray seeding of row 0 (harvest.py:119)
+    cv[it] = cand;
     if (cand != 0.0 && ceil(3 * fs / cand / 2) <= (double)hmax) {
-      const int p = atomicAdd(&cl_n, 1);
-      cl_val[p] = cand;
-      cl_meta[p] = q;
+      live_q[it] = true;
       atomicOr(&nzmask[fl * 4 + (e >> 5)], 1u << (e & 31));
     }
   }
   __syncthreads();
-  const int n_items = cl_n;
   const int64_t pool_base = (m.f1_off + f_first) * kRows;
-  if (threadIdx.x == 64) {  // (wave 1: beside the bucket scan of wave 0 below)
+  if (threadIdx.x == 64) {
     int run = 0;
     for (int fl = 0; fl < kFramesPerBlock; ++fl) {
       foff[fl] = run;
@@ -859,20 +886,94 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
     }
     foff[kFramesPerBlock] = run;
   }
-  // A wave refines 64 / RL candidates at once, one per group of RL lanes, and runs as long as its longest one: the
+  __syncthreads();
+  const int n_items = foff[kFramesPerBlock];
+  // EQUAL-KEY CLASSES.  What a refinement costs — the two windowed spectra at the harmonic bins — depends on the
+  // candidate only through its window half length and its six rounded bins (harvest.py:171-174,203): the seven overlapped
+  // copies of a slowly moving pitch track that meet in one frame mostly share them (measured on the benchmark input: 178 k
+  // work items per 10 s, 121 k distinct keys; the reference's own test recording: 83 k / 66 k).  One item of a class does the
+  // sums; every member gets its own score from them (it is the score that looks at the candidate's value,
+  // harvest.py:205-206) — same arithmetic, same results, a third less work.
+  // cl_meta fields: [0,4) frame; [4,10) iteration count (the counting sort's key); phase 1: [17,31) the bins' offsets from
+  // multiples of the first; phase 2: [17,28) successor in the class + 1, bit 28: not the class's first item.
+  int* key_a = order;  // (the schedule is built after the classes are known)
+#pragma unroll
+  for (int it = 0; it < kGather; ++it) {
+    if (!live_q[it]) continue;
+    const int q = threadIdx.x + it * 256;
+    const int fl = q / kRows, e = q % kRows;
+    const uint32_t* mw = nzmask + fl * 4;
+    int slot = foff[fl] + __popc(mw[e >> 5] & ((1u << (e & 31)) - 1u));  // rank of row e among the frame's rows
+    for (int w = 0; w < (e >> 5); ++w) slot += __popc(mw[w]);
+    cl_val[slot] = cv[it];
+    cl_meta[slot] = fl;
+  }
+  __syncthreads();
+  // the keys, one thread per PLACED item (every lane busy; inside the gather loop above the same arithmetic ran seven
+  // times per wave with a tenth of the lanes)
+  for (int i = threadIdx.x; i < n_items; i += 256) {
+    const double v = cl_val[i];
+    const int hwl = (int)ceil(3 * fs / v / 2);
+    const int L = 2 * hwl + 1;
+    int nfft;
+    {
+      int ex = 0;
+      while ((1 << ex) < L) ++ex;
+      nfft = 1 << (ex + 1);
+    }
+    const int nh = (int)fmin(floor(fs / 2 / v), 6.0);
+    int bins[6];
+#pragma unroll
+    for (int h = 0; h < 6; ++h) bins[h] = (int)(v * nfft / fs * (double)(h + 1) + 0.5);  // as hv_refine_row computes them
+    // bins[h] - (h+1)*bins[0] is within +-(h+2)/2: 2 + 3 + 3 + 3 + 3 bits; a value outside (not expected) makes the item
+    // a class of its own
+    const int d1 = bins[1] - 2 * bins[0] + 1, d2 = bins[2] - 3 * bins[0] + 3, d3 = bins[3] - 4 * bins[0] + 3;
+    const int d4 = bins[4] - 5 * bins[0] + 3, d5 = bins[5] - 6 * bins[0] + 3;
+    const bool fits = (unsigned)d1 < 4u && (unsigned)d2 < 8u && (unsigned)d3 < 8u && (unsigned)d4 < 8u && (unsigned)d5 < 8u &&
+                      hwl < 512 && bins[0] < 1024;
+    int skey = (L + RL - 1) / RL;  // iteration count of the sample loop: the counting sort's key
+    skey = skey > kBuckets - 1 ? kBuckets - 1 : skey;
+    key_a[i] = fits ? (hwl | (bins[0] << 9) | (nh << 19)) : (int)(0x80000000u | (unsigned)i);
+    cl_meta[i] = cl_meta[i] | (skey << 4) | ((d1 | (d2 << 2) | (d3 << 5) | (d4 << 8) | (d5 << 11)) << 17);
+  }
+  __syncthreads();
+  constexpr int kClassScan = (kItems + 255) / 256;
+  int link[kClassScan];  // per item of this thread: (successor + 1) | not-first flag << 11
+#pragma unroll
+  for (int r = 0; r < kClassScan; ++r) {
+    const int i = threadIdx.x + r * 256;
+    link[r] = 0;
+    if (i < n_items) {
+      const int mi = cl_meta[i];
+      const int ka = key_a[i], kb = mi >> 17, fl = mi & 15;
+      const int lo = foff[fl], hi = foff[fl + 1];  // the frame's items
+      bool has_pred = false;
+      int succ = 0;
+      for (int j = lo; j < i; ++j) has_pred = has_pred || (key_a[j] == ka && (cl_meta[j] >> 17) == kb);
+      for (int j = hi - 1; j > i; --j)
+        if (key_a[j] == ka && (cl_meta[j] >> 17) == kb) succ = j + 1;
+#if !WH_HV_CLASSES
+      has_pred = false;  // (ablation: every item its own class)
+      succ = 0;
+#endif
+      link[r] = succ | (has_pred ? 1 << 11 : 0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kClassScan; ++r) {
+    const int i = threadIdx.x + r * 256;
+    if (i < n_items) cl_meta[i] = (cl_meta[i] & 0x3ff) | (link[r] << 17);
+  }
+  // A wave refines 64 / RL classes at once, one per group of RL lanes, and runs as long as its longest one: the
   // window length goes with 1/f0 (31 ... 340 samples at 8 kHz), and a frame's candidates are typically an f0 with its
-  // octave neighbours.  Counting sort of the work list by iteration count, so that the groups of a wave (consecutive
-  // entries) carry windows of the same length class.
+  // octave neighbours.  Counting sort of the classes' first items by iteration count, so that the groups of a wave
+  // (consecutive entries) carry windows of the same length class.
   {
     if (threadIdx.x < kBuckets) bucket[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n_items; i += 256) {
-      const int len = 2 * (int)ceil(3 * fs / cl_val[i] / 2) + 1;
-      int key = (len + RL - 1) / RL;
-      key = key > kBuckets - 1 ? kBuckets - 1 : key;
-      atomicAdd(&bucket[key], 1);
-      cl_meta[i] |= key << 16;  // q < 840 fits 16 bits
-    }
+    for (int i = threadIdx.x; i < n_items; i += 256)
+      if (!(cl_meta[i] >> 28 & 1)) atomicAdd(&bucket[(cl_meta[i] >> 4) & 63], 1);  // the classes' first items
     __syncthreads();
     if (threadIdx.x == 0) {  // exclusive scan of the counts, longest first (the long items start the block's schedule)
       int run = 0;
@@ -881,25 +982,33 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
         bucket[k] = run;
         run += c;
       }
+      cl_n = run;  // classes
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_items; i += 256) order[atomicAdd(&bucket[cl_meta[i] >> 16], 1)] = i;
+    const int n_lead = cl_n;
+    __syncthreads();  // (everybody has read the count before the scatter's atomics move the buckets; cl_n is not theirs)
+    for (int i = threadIdx.x; i < n_items; i += 256)
+      if (!(cl_meta[i] >> 28 & 1)) order[atomicAdd(&bucket[(cl_meta[i] >> 4) & 63], 1)] = i;
     __syncthreads();
-    for (int it = threadIdx.x / RL; it < n_items; it += 256 / RL) {
+    for (int it = threadIdx.x / RL; it < n_lead; it += 256 / RL) {
       const int src = order[it];
-      const int q = cl_meta[src] & 0xffff;
-      const int64_t f = f_first + q / kRows;
-      double r0, r1;
-      hv_refine_row<TWL, WTAB, RL>(yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem,
-                                   tw_n, rot_tab, win_tab, &r0, &r1);
-      if ((threadIdx.x & (RL - 1)) == 0) {
-        const int fl = q / kRows, e = q % kRows;
-        const uint32_t* mw = nzmask + fl * 4;
-        int slot = foff[fl] + __popc(mw[e >> 5] & ((1u << (e & 31)) - 1u));  // rank of row e among the frame's rows
-        for (int w = 0; w < (e >> 5); ++w) slot += __popc(mw[w]);
-        rf0[pool_base + slot] = r0;
-        rsc[pool_base + slot] = r1;
-      }
+      const int64_t f = f_first + (cl_meta[src] & 15);
+      hv_refine_row<TWL, WTAB, RL>(
+          yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem, tw_n, rot_tab, win_tab,
+          [&](auto eval) {
+            int p = src;
+            while (true) {
+              double r0, r1;
+              eval(cl_val[p], &r0, &r1);
+              if ((threadIdx.x & (RL - 1)) == 0) {
+                rf0[pool_base + p] = r0;  // (an item's index is its slot in the block's pool region)
+                rsc[pool_base + p] = r1;
+              }
+              const int nx = (cl_meta[p] >> 17) & 0x7ff;
+              if (!nx) break;
+              p = nx - 1;
+            }
+          });
     }
   }
 }

@@ -990,6 +990,10 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
     for (int i = threadIdx.x; i < n_items; i += 256)
       if (!(cl_meta[i] >> 28 & 1)) order[atomicAdd(&bucket[(cl_meta[i] >> 4) & 63], 1)] = i;
     __syncthreads();
+#ifdef WH_HV_REFINE_ABLATE  // timing experiments: the list building alone
+    if (threadIdx.x == 0 && n_lead == 123456) rf0[0] = 0;
+    return;
+#endif
     for (int it = threadIdx.x / RL; it < n_lead; it += 256 / RL) {
       const int src = order[it];
       const int64_t f = f_first + (cl_meta[src] & 15);

@@ -783,11 +783,16 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
 #define WH_HV_ROW_LANES 4
 #endif
 #ifndef WH_HV_TAB_FRAMES
-#define WH_HV_TAB_FRAMES 16
+#define WH_HV_TAB_FRAMES 24  // (the list building is per block and a wave pass takes 16 classes whatever it holds; config 3:
+                            // 16 frames 3.81 ms, 24: 3.34, 32: 3.37, 48: 4.79 — 52.3 against 59.7 ms at 1024 utterances)
+#endif
+#ifndef WH_HV_ITEM_CAP
+#define WH_HV_ITEM_CAP 1680  // work-list slots in LDS; a block whose frames hold more takes them in several rounds of whole frames
 #endif
 // lanes per candidate and frames per workgroup of the two refinement variants
 constexpr int refine_lanes(bool wtab) { return wtab ? WH_HV_ROW_LANES : 16; }
 constexpr int refine_frames(bool wtab) { return wtab ? WH_HV_TAB_FRAMES : 4; }
+constexpr int refine_item_cap(bool wtab) { return refine_frames(wtab) * kRows < WH_HV_ITEM_CAP ? refine_frames(wtab) * kRows : WH_HV_ITEM_CAP; }
 
 template <bool TWL, bool WTAB>
 __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ y,
@@ -797,7 +802,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
                                                         const double2* __restrict__ rot_tab,
                                                         const double2* __restrict__ win_tab,
                                                         double* __restrict__ rf0, double* __restrict__ rsc,
-                                                        int64_t* __restrict__ lst) {
+                                                        int64_t* __restrict__ lst, int item_cap) {
   // All of the kernel's LDS is the dynamic block, so that it starts at LDS address 0 and the twiddle table's byte
   // offsets are LDS addresses as they stand (hv_refine_lds_bytes mirrors this layout).
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -813,7 +818,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
   double2* twl = reinterpret_cast<double2*>(smem);
   if (TWL && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
   double* yl = reinterpret_cast<double*>(smem + (TWL ? sizeof(double2) * (size_t)tw_n : 0));
-  constexpr int kItems = kFramesPerBlock * kRows;
+  constexpr int kItems = refine_item_cap(WTAB);                // (>= kRows: a single frame always fits)
   double* cl_val = yl + ((seglen + 1) & ~1);                 // kItems
   int* cl_meta = reinterpret_cast<int*>(cl_val + kItems);    // kItems
   int* order = cl_meta + kItems;                             // kItems
@@ -821,7 +826,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
   int& cl_n = bucket[kBuckets];
   uint32_t* nzmask = reinterpret_cast<uint32_t*>(bucket + kBuckets + 1);  // [kFramesPerBlock][4]: rows of a frame that hold a candidate
   int* foff = reinterpret_cast<int*>(nzmask + kFramesPerBlock * 4);       // [kFramesPerBlock + 1]: first list slot of a frame
-  if (threadIdx.x < kFramesPerBlock * 4) nzmask[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < kFramesPerBlock * 4; i += 256) nzmask[i] = 0;
   if (TWL)
     for (int i = threadIdx.x; i < tw_n; i += 256) twl[i] = tw_base[tw_n + i];
   const int64_t centre0 = (int64_t)floor(((double)f_first * 1 / 1000) * fs + 0.5);
@@ -887,132 +892,164 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
     foff[kFramesPerBlock] = run;
   }
   __syncthreads();
-  const int n_items = foff[kFramesPerBlock];
-  // EQUAL-KEY CLASSES.  What a refinement costs — the two windowed spectra at the harmonic bins — depends on the
-  // candidate only through its window half length and its six rounded bins (harvest.py:171-174,203): the seven overlapped
-  // copies of a slowly moving pitch track that meet in one frame mostly share them (measured on the benchmark input: 178 k
-  // work items per 10 s, 121 k distinct keys; the reference's own test recording: 83 k / 66 k).  One item of a class does the
-  // sums; every member gets its own score from them (it is the score that looks at the candidate's value,
-  // harvest.py:205-206) — same arithmetic, same results, a third less work.
-  // cl_meta fields: [0,4) frame; [4,10) iteration count (the counting sort's key); phase 1: [17,31) the bins' offsets from
-  // multiples of the first; phase 2: [17,28) successor in the class + 1, bit 28: not the class's first item.
-  int* key_a = order;  // (the schedule is built after the classes are known)
+  // Rounds of whole frames whose candidates fit the work list (kItems slots; the 32 frames of a block hold ~400 candidates
+  // on speech-like input, 3360 at most): normally one.  The first round is placed from the registers of the gather above
+  // (which die here: inside the loop they would stay alive across the refinement passes), a further round fetches its
+  // rows again.
+  auto round_end = [&](int fa) {
+    int fb = fa + 1;
+    while (fb < kFramesPerBlock && foff[fb + 1] - foff[fa] <= item_cap) ++fb;  // (item_cap <= kItems: the LDS slots)
+    return fb;
+  };
+  auto slot_of = [&](int fl, int e, int s0) {
+    const uint32_t* mw = nzmask + fl * 4;
+    int slot = foff[fl] - s0 + __popc(mw[e >> 5] & ((1u << (e & 31)) - 1u));  // rank of row e among the round's rows
+    for (int w = 0; w < (e >> 5); ++w) slot += __popc(mw[w]);
+    return slot;
+  };
+  int fa = 0, fb = round_end(0);
 #pragma unroll
   for (int it = 0; it < kGather; ++it) {
     if (!live_q[it]) continue;
     const int q = threadIdx.x + it * 256;
     const int fl = q / kRows, e = q % kRows;
-    const uint32_t* mw = nzmask + fl * 4;
-    int slot = foff[fl] + __popc(mw[e >> 5] & ((1u << (e & 31)) - 1u));  // rank of row e among the frame's rows
-    for (int w = 0; w < (e >> 5); ++w) slot += __popc(mw[w]);
+    if (fl >= fb) continue;
+    const int slot = slot_of(fl, e, 0);
     cl_val[slot] = cv[it];
     cl_meta[slot] = fl;
   }
-  __syncthreads();
-  // the keys, one thread per PLACED item (every lane busy; inside the gather loop above the same arithmetic ran seven
-  // times per wave with a tenth of the lanes)
-  for (int i = threadIdx.x; i < n_items; i += 256) {
-    const double v = cl_val[i];
-    const int hwl = (int)ceil(3 * fs / v / 2);
-    const int L = 2 * hwl + 1;
-    int nfft;
-    {
-      int ex = 0;
-      while ((1 << ex) < L) ++ex;
-      nfft = 1 << (ex + 1);
-    }
-    const int nh = (int)fmin(floor(fs / 2 / v), 6.0);
-    int bins[6];
-#pragma unroll
-    for (int h = 0; h < 6; ++h) bins[h] = (int)(v * nfft / fs * (double)(h + 1) + 0.5);  // as hv_refine_row computes them
-    // bins[h] - (h+1)*bins[0] is within +-(h+2)/2: 2 + 3 + 3 + 3 + 3 bits; a value outside (not expected) makes the item
-    // a class of its own
-    const int d1 = bins[1] - 2 * bins[0] + 1, d2 = bins[2] - 3 * bins[0] + 3, d3 = bins[3] - 4 * bins[0] + 3;
-    const int d4 = bins[4] - 5 * bins[0] + 3, d5 = bins[5] - 6 * bins[0] + 3;
-    const bool fits = (unsigned)d1 < 4u && (unsigned)d2 < 8u && (unsigned)d3 < 8u && (unsigned)d4 < 8u && (unsigned)d5 < 8u &&
-                      hwl < 512 && bins[0] < 1024;
-    int skey = (L + RL - 1) / RL;  // iteration count of the sample loop: the counting sort's key
-    skey = skey > kBuckets - 1 ? kBuckets - 1 : skey;
-    key_a[i] = fits ? (hwl | (bins[0] << 9) | (nh << 19)) : (int)(0x80000000u | (unsigned)i);
-    cl_meta[i] = cl_meta[i] | (skey << 4) | ((d1 | (d2 << 2) | (d3 << 5) | (d4 << 8) | (d5 << 11)) << 17);
-  }
-  __syncthreads();
-  constexpr int kClassScan = (kItems + 255) / 256;
-  int link[kClassScan];  // per item of this thread: (successor + 1) | not-first flag << 11
-#pragma unroll
-  for (int r = 0; r < kClassScan; ++r) {
-    const int i = threadIdx.x + r * 256;
-    link[r] = 0;
-    if (i < n_items) {
-      const int mi = cl_meta[i];
-      const int ka = key_a[i], kb = mi >> 17, fl = mi & 15;
-      const int lo = foff[fl], hi = foff[fl + 1];  // the frame's items
-      bool has_pred = false;
-      int succ = 0;
-      for (int j = lo; j < i; ++j) has_pred = has_pred || (key_a[j] == ka && (cl_meta[j] >> 17) == kb);
-      for (int j = hi - 1; j > i; --j)
-        if (key_a[j] == ka && (cl_meta[j] >> 17) == kb) succ = j + 1;
-#if !WH_HV_CLASSES
-      has_pred = false;  // (ablation: every item its own class)
-      succ = 0;
-#endif
-      link[r] = succ | (has_pred ? 1 << 11 : 0);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < kClassScan; ++r) {
-    const int i = threadIdx.x + r * 256;
-    if (i < n_items) cl_meta[i] = (cl_meta[i] & 0x3ff) | (link[r] << 17);
-  }
-  // A wave refines 64 / RL classes at once, one per group of RL lanes, and runs as long as its longest one: the
-  // window length goes with 1/f0 (31 ... 340 samples at 8 kHz), and a frame's candidates are typically an f0 with its
-  // octave neighbours.  Counting sort of the classes' first items by iteration count, so that the groups of a wave
-  // (consecutive entries) carry windows of the same length class.
-  {
-    if (threadIdx.x < kBuckets) bucket[threadIdx.x] = 0;
+  while (true) {
+    const int s0 = foff[fa];
+    const int n_items = foff[fb] - s0;
+    // EQUAL-KEY CLASSES.  What a refinement costs — the two windowed spectra at the harmonic bins — depends on the
+    // candidate only through its window half length and its six rounded bins (harvest.py:171-174,203): the seven overlapped
+    // copies of a slowly moving pitch track that meet in one frame mostly share them (measured on the benchmark input: 178 k
+    // work items per 10 s, 121 k distinct keys; the reference's own test recording: 83 k / 66 k).  One item of a class does the
+    // sums; every member gets its own score from them (it is the score that looks at the candidate's value,
+    // harvest.py:205-206) — same arithmetic, same results, a third less work.
+    // cl_meta fields: [0,5) frame; [5,11) iteration count (the counting sort's key); phase 1: [17,31) the bins' offsets from
+    // multiples of the first; phase 2: [17,28) successor in the class + 1, bit 28: not the class's first item.
+    int* key_a = order;  // (the schedule is built after the classes are known)
     __syncthreads();
-    for (int i = threadIdx.x; i < n_items; i += 256)
-      if (!(cl_meta[i] >> 28 & 1)) atomicAdd(&bucket[(cl_meta[i] >> 4) & 63], 1);  // the classes' first items
-    __syncthreads();
-    if (threadIdx.x == 0) {  // exclusive scan of the counts, longest first (the long items start the block's schedule)
-      int run = 0;
-      for (int k = kBuckets - 1; k >= 0; --k) {
-        const int c = bucket[k];
-        bucket[k] = run;
-        run += c;
+    // the keys, one thread per PLACED item (every lane busy; inside the gather loop above the same arithmetic ran seven
+    // times per wave with a tenth of the lanes)
+    for (int i = threadIdx.x; i < n_items; i += 256) {
+      const double v = cl_val[i];
+      const int hwl = (int)ceil(3 * fs / v / 2);
+      const int L = 2 * hwl + 1;
+      int nfft;
+      {
+        int ex = 0;
+        while ((1 << ex) < L) ++ex;
+        nfft = 1 << (ex + 1);
       }
-      cl_n = run;  // classes
+      const int nh = (int)fmin(floor(fs / 2 / v), 6.0);
+      int bins[6];
+  #pragma unroll
+      for (int h = 0; h < 6; ++h) bins[h] = (int)(v * nfft / fs * (double)(h + 1) + 0.5);  // as hv_refine_row computes them
+      // bins[h] - (h+1)*bins[0] is within +-(h+2)/2: 2 + 3 + 3 + 3 + 3 bits; a value outside (not expected) makes the item
+      // a class of its own
+      const int d1 = bins[1] - 2 * bins[0] + 1, d2 = bins[2] - 3 * bins[0] + 3, d3 = bins[3] - 4 * bins[0] + 3;
+      const int d4 = bins[4] - 5 * bins[0] + 3, d5 = bins[5] - 6 * bins[0] + 3;
+      const bool fits = (unsigned)d1 < 4u && (unsigned)d2 < 8u && (unsigned)d3 < 8u && (unsigned)d4 < 8u && (unsigned)d5 < 8u &&
+                        hwl < 512 && bins[0] < 1024;
+      int skey = (L + RL - 1) / RL;  // iteration count of the sample loop: the counting sort's key
+      skey = skey > kBuckets - 1 ? kBuckets - 1 : skey;
+      key_a[i] = fits ? (hwl | (bins[0] << 9) | (nh << 19)) : (int)(0x80000000u | (unsigned)i);
+      cl_meta[i] = cl_meta[i] | (skey << 5) | ((d1 | (d2 << 2) | (d3 << 5) | (d4 << 8) | (d5 << 11)) << 17);
     }
     __syncthreads();
-    const int n_lead = cl_n;
-    __syncthreads();  // (everybody has read the count before the scatter's atomics move the buckets; cl_n is not theirs)
-    for (int i = threadIdx.x; i < n_items; i += 256)
-      if (!(cl_meta[i] >> 28 & 1)) order[atomicAdd(&bucket[(cl_meta[i] >> 4) & 63], 1)] = i;
+    constexpr int kClassScan = (kItems + 255) / 256;
+    int link[kClassScan];  // per item of this thread: (successor + 1) | not-first flag << 11
+  #pragma unroll
+    for (int r = 0; r < kClassScan; ++r) {
+      const int i = threadIdx.x + r * 256;
+      link[r] = 0;
+      if (i < n_items) {
+        const int mi = cl_meta[i];
+        const int ka = key_a[i], kb = mi >> 17, fl = mi & 31;
+        const int lo = foff[fl] - s0, hi = foff[fl + 1] - s0;  // the frame's items
+        bool has_pred = false;
+        int succ = 0;
+        for (int j = lo; j < i; ++j) has_pred = has_pred || (key_a[j] == ka && (cl_meta[j] >> 17) == kb);
+        for (int j = hi - 1; j > i; --j)
+          if (key_a[j] == ka && (cl_meta[j] >> 17) == kb) succ = j + 1;
+  #if !WH_HV_CLASSES
+        has_pred = false;  // (ablation: every item its own class)
+        succ = 0;
+  #endif
+        link[r] = succ | (has_pred ? 1 << 11 : 0);
+      }
+    }
     __syncthreads();
-#ifdef WH_HV_REFINE_ABLATE  // timing experiments: the list building alone
-    if (threadIdx.x == 0 && n_lead == 123456) rf0[0] = 0;
-    return;
-#endif
-    for (int it = threadIdx.x / RL; it < n_lead; it += 256 / RL) {
-      const int src = order[it];
-      const int64_t f = f_first + (cl_meta[src] & 15);
-      hv_refine_row<TWL, WTAB, RL>(
-          yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem, tw_n, rot_tab, win_tab,
-          [&](auto eval) {
-            int p = src;
-            while (true) {
-              double r0, r1;
-              eval(cl_val[p], &r0, &r1);
-              if ((threadIdx.x & (RL - 1)) == 0) {
-                rf0[pool_base + p] = r0;  // (an item's index is its slot in the block's pool region)
-                rsc[pool_base + p] = r1;
+  #pragma unroll
+    for (int r = 0; r < kClassScan; ++r) {
+      const int i = threadIdx.x + r * 256;
+      if (i < n_items) cl_meta[i] = (cl_meta[i] & 0x7ff) | (link[r] << 17);
+    }
+    // A wave refines 64 / RL classes at once, one per group of RL lanes, and runs as long as its longest one: the
+    // window length goes with 1/f0 (31 ... 340 samples at 8 kHz), and a frame's candidates are typically an f0 with its
+    // octave neighbours.  Counting sort of the classes' first items by iteration count, so that the groups of a wave
+    // (consecutive entries) carry windows of the same length class.
+    {
+      if (threadIdx.x < kBuckets) bucket[threadIdx.x] = 0;
+      __syncthreads();
+      for (int i = threadIdx.x; i < n_items; i += 256)
+        if (!(cl_meta[i] >> 28 & 1)) atomicAdd(&bucket[(cl_meta[i] >> 5) & 63], 1);  // the classes' first items
+      __syncthreads();
+      if (threadIdx.x == 0) {  // exclusive scan of the counts, longest first (the long items start the block's schedule)
+        int run = 0;
+        for (int k = kBuckets - 1; k >= 0; --k) {
+          const int c = bucket[k];
+          bucket[k] = run;
+          run += c;
+        }
+        cl_n = run;  // classes
+      }
+      __syncthreads();
+      const int n_lead = cl_n;
+      __syncthreads();  // (everybody has read the count before the scatter's atomics move the buckets; cl_n is not theirs)
+      for (int i = threadIdx.x; i < n_items; i += 256)
+        if (!(cl_meta[i] >> 28 & 1)) order[atomicAdd(&bucket[(cl_meta[i] >> 5) & 63], 1)] = i;
+      __syncthreads();
+  #ifdef WH_HV_REFINE_ABLATE  // timing experiments: the list building alone
+      if (threadIdx.x == 0 && n_lead == 123456) rf0[0] = 0;
+      return;
+  #endif
+      for (int it = threadIdx.x / RL; it < n_lead; it += 256 / RL) {
+        const int src = order[it];
+        const int64_t f = f_first + (cl_meta[src] & 31);
+        hv_refine_row<TWL, WTAB, RL>(
+            yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem, tw_n, rot_tab, win_tab,
+            [&](auto eval) {
+              int p = src;
+              while (true) {
+                double r0, r1;
+                eval(cl_val[p], &r0, &r1);
+                if ((threadIdx.x & (RL - 1)) == 0) {
+                  rf0[pool_base + s0 + p] = r0;  // (an item's index is its slot in the round's part of the block's pool region)
+                  rsc[pool_base + s0 + p] = r1;
+                }
+                const int nx = (cl_meta[p] >> 17) & 0x7ff;
+                if (!nx) break;
+                p = nx - 1;
               }
-              const int nx = (cl_meta[p] >> 17) & 0x7ff;
-              if (!nx) break;
-              p = nx - 1;
-            }
-          });
+            });
+      }
+    }
+    fa = fb;
+    if (fa >= kFramesPerBlock) break;
+    fb = round_end(fa);
+    __syncthreads();  // (this round's lists have been consumed)
+    for (int q = threadIdx.x; q < kFramesPerBlock * kRows; q += 256) {  // the next round's rows, fetched again (rare path)
+      const int fl = q / kRows, e = q % kRows;
+      if (fl < fa || fl >= fb || !((nzmask[fl * 4 + (e >> 5)] >> (e & 31)) & 1u)) continue;
+      const int64_t f = f_first + fl;
+      const int64_t src = f + (e / kMaxC - 3);
+      const double cand = (e == 0 && f < 3) ? dc[(m.f1_off + f) * kMaxC + 6] : dc[(m.f1_off + src) * kMaxC + e % kMaxC];
+      const int slot = slot_of(fl, e, foff[fa]);
+      cl_val[slot] = cand;
+      cl_meta[slot] = fl;
     }
   }
 }
@@ -1390,7 +1427,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     const int fpb = refine_frames(use_wtab);
     const int seglen = 2 * hmax + 8 + (fpb - 1) * ((int)ceil(fs_d / 1000.0) + 1);
     const size_t lds = sizeof(double2) * (size_t)tw_n + sizeof(double) * (size_t)((seglen + 1) & ~1) +
-                       (sizeof(double) + 2 * sizeof(int)) * (size_t)(fpb * kRows) + sizeof(int) * (72 + 5 * fpb + 1);
+                       (sizeof(double) + 2 * sizeof(int)) * (size_t)refine_item_cap(use_wtab) + sizeof(int) * (72 + 5 * fpb + 1);
     // 16-sample rotation (sin, cos)(16*pi*dx) of the window phase for every half length (hv_refine_row)
     double2* d_rot = nullptr;
     {
@@ -1440,12 +1477,17 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
       }
     }
     const dim3 grid((unsigned)((max_nf1 + fpb - 1) / fpb), B);
+    // slots of the work list a round may fill: all of them, unless WH_HV_ITEM_CAP_RT (tests: the several-rounds path,
+    // which real input reaches only with > ~70 candidates per frame over a whole block) says fewer
+    static const int cap_env = getenv("WH_HV_ITEM_CAP_RT") ? atoi(getenv("WH_HV_ITEM_CAP_RT")) : 0;
+    int item_cap = refine_item_cap(use_wtab);
+    if (cap_env >= kRows && cap_env < item_cap) item_cap = cap_env;
 #define WH_REFINE_LAUNCH(TWL_, WTAB_)                                                                                   \
   {                                                                                                                     \
     if (int rc = wh::allow_lds(&hv_refine_kernel<TWL_, WTAB_>, lds)) return rc;                                         \
     wh::KernelTimer _kt(ctx, st, "hv_refine_kernel");                                                                   \
     hipLaunchKernelGGL((hv_refine_kernel<TWL_, WTAB_>), grid, dim3(256), lds, st, d_meta, d_y, d_dc, d_dn, fs_d, f0_floor, \
-                       f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rot, d_wtab, d_rf0, d_rsc, d_lst);                        \
+                       f0_ceil, hmax, seglen, ctx->d_twiddle, tw_n, d_rot, d_wtab, d_rf0, d_rsc, d_lst, item_cap);              \
   }
     if (tw_n && use_wtab) WH_REFINE_LAUNCH(true, true)
     else if (tw_n) WH_REFINE_LAUNCH(true, false)

@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _run(tmp_path, tag, **env):
     out = str(tmp_path / ("front_%s.npz" % tag))
     e = dict(os.environ)
-    for k in ("WH_HV_FRONT", "WH_HV_FRONT_MARGIN"):
+    for k in ("WH_HV_FRONT", "WH_HV_FRONT_MARGIN", "WH_HV_ITEM_CAP_RT"):
         e.pop(k, None)
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(HERE, "_front_script.py"), out], capture_output=True, text=True,
@@ -53,3 +53,12 @@ def test_fused_front_end_equals_the_chain_and_the_oracle(tmp_path):
         for d in (base, fused):
             assert np.array_equal(d["vuv"][a:b], ref["vuv"])
             assert np.max(np.abs(d["f0"][a:b] - ref["f0"])) < 1e-6
+
+
+def test_refinement_in_several_rounds_equals_one_round(tmp_path):
+    """hv_refine_kernel takes the candidates of a block's 24 frames in rounds of whole frames that fit its LDS work list
+    (1680 slots: one round on real input).  With the list capped at 120 slots (WH_HV_ITEM_CAP_RT) every block needs
+    several rounds, the later ones fetching their rows again: the contour must not change by a bit."""
+    base = _run(tmp_path, "default")
+    capped = _run(tmp_path, "capped", WH_HV_ITEM_CAP_RT="120")
+    assert np.array_equal(capped["vuv"], base["vuv"]) and np.array_equal(capped["f0"], base["f0"])

@@ -4,6 +4,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/$1; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -2 $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --config 3 --steps 5 --warmup 2 --no-pmc > $O/bench_cfg3.json 2> $O/bench_cfg3.err
 python bench.py --config 3 --utts 256 --steps 3 --warmup 1 --no-pmc > $O/bench_cfg3_256.json 2> $O/bench_cfg3_256.err

@@ -14,9 +14,13 @@
 //                      pool (harvest.py:131-211); here four lanes per candidate accumulate only the harmonic bins as
 //                      direct DFT sums — window pairs from a per-length table (the frame time cancels out of the
 //                      reference's window argument), twiddles from an LDS table, samples from an LDS stage of the
-//                      16 frames a workgroup takes; a 16-lane rotation form remains for f0 floors whose tables do not
-//                      fit LDS
+//                      frames a workgroup takes; a 16-lane rotation form remains for f0 floors whose tables do not
+//                      fit LDS.  The candidates of a frame that share window length and harmonic bins — mostly the seven
+//                      overlapped copies of one pitch track — share ONE pass over the samples (equal-key classes), every
+//                      member taking its own score from the class's spectra; 24 frames per workgroup
 //   hv_prune_kernel  : neighbour-frame consistency test (harvest.py:215-248), 16 frames per workgroup
+//   hv_front_kernel  : (wh_harvest_front.h, opt-in WH_HV_FRONT=1) band filter + crossings + raw candidates fused per
+//                      (utterance, tile of frames): exact, 3.4 x less HBM traffic, slower — see DESIGN.md section 4
 // Back end (wh_harvest_contour.h): contour tracking, smoothing, 5 ms pick.
 #include <math.h>
 #include <hip/hip_runtime.h>

@@ -174,21 +174,21 @@ class BatchEncoding:
         with ``want_ps=True`` (16 B x fft_size per frame: 2 GB for the 64 x 10 s batch, which is why it is opt-in)."""
         fo = self.batch.frame_off
         tp, f0, vuv = (t.cpu().numpy() for t in (self.temporal_positions, self.f0, self.vuv))
-        sp = self.spectrogram.cpu().numpy()
-        ap = self.aperiodicity.cpu().numpy()
-        ps = None
-        if want_ps:
-            if self.ps_spectrogram is None:
-                raise ValueError("this encoding holds no 'ps spectrogram': encode with want_ps=True")
-            ps = self.ps_spectrogram.cpu().numpy()
+        if want_ps and self.ps_spectrogram is None:
+            raise ValueError("this encoding holds no 'ps spectrogram': encode with want_ps=True")
+        # the dense tensors are frame-major on the device; the reference's layout is (bins, frames): every utterance's slice
+        # is transposed ON THE DEVICE and lands in pinned host memory (Runtime.to_host) — a pageable download of the whole
+        # batch followed by strided host copies took 0.43 s for the 64 x 10 s batch (1.05 GB), this 0.03 - 0.16 s
+        to_rows = lambda t, s: self.rt.to_host(t[s], transpose=True)  # noqa: E731
         out = []
-        for u in range(self.n_utt):
-            s = slice(int(fo[u]), int(fo[u + 1]))
-            out.append({'temporal_positions': tp[s].copy(), 'vuv': vuv[s].copy(), 'fs': self.fs, 'f0': f0[s].copy(),
-                        'aperiodicity': np.ascontiguousarray(ap[s].T), 'spectrogram': np.ascontiguousarray(sp[s].T),
-                        'is_requiem': self.is_requiem})
-            if ps is not None:
-                out[-1]['ps spectrogram'] = np.ascontiguousarray(ps[s].T)
+        with self.rt.on_stream():
+            for u in range(self.n_utt):
+                s = slice(int(fo[u]), int(fo[u + 1]))
+                out.append({'temporal_positions': tp[s].copy(), 'vuv': vuv[s].copy(), 'fs': self.fs, 'f0': f0[s].copy(),
+                            'aperiodicity': to_rows(self.aperiodicity, s), 'spectrogram': to_rows(self.spectrogram, s),
+                            'is_requiem': self.is_requiem})
+                if want_ps:
+                    out[-1]['ps spectrogram'] = to_rows(self.ps_spectrogram, s)
         return out
 
 
@@ -322,10 +322,10 @@ class WorldBatch:
             ap_d = d4c_requiem_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, fft_size)
         else:
             ap_d, _ = d4c_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, 0.85, ct_fft)
-        if check is True:
-            rt.check_flags("encode_device")
-        elif check == 'deferred':
+        if check == 'deferred':
             rt.post_flags()
+        elif check:
+            rt.check_flags("encode_device")
         enc = BatchEncoding(rt, batch, fs, tp_d.clone(), f0_d, vuv_d, spec_d, ap_d, ct_fft, is_requiem, frame_period,
                             tp_host=None if tp_host is None else tp_host.copy(), ps_spectrogram=ps_d)
         if timebase is not None:

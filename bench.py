@@ -510,6 +510,7 @@ def main():
                                lambda: with_transfers_lanes_block(torch, local_rank, xs, FS, args.transfer_lanes)))
             blocks.append(("varying_lengths", lambda: varying_lengths_block(torch, local_rank, xs, FS)))
             blocks.append(("decode_alone", lambda: decode_alone_block(torch, wl, FS)))
+            blocks.append(("facade_batch", lambda: facade_batch_block(torch, xs, FS)))
             blocks.append(("config1_latency", lambda: config1_latency_block(torch)))
             blocks.append(("feature_heads", lambda: feature_heads_block(torch, wl, FS)))
             blocks.append(("swipe", lambda: swipe_block(torch, wl, FS)))
@@ -729,6 +730,35 @@ def decode_alone_block(torch, wl, fs, reps=10):
             "kernel_ms_inline": {k: round(v, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:12]},
             "note": "config-2 encoding, decode only; 'inline' = no prefetched time base (fresh from_dicts encodings, "
                     "modified encodings)"}
+
+
+def facade_batch_block(torch, xs, fs, reps=3):
+    """The public batched API with HOST arrays on both sides: `World().encode_batch(fs, xs, f0_method='dio')`
+    -> list of reference-layout dicts ((bins, frames) NumPy arrays: every dense tensor downloaded and transposed),
+    `World().decode_batch(dats)` -> dats with 'out' (every dense tensor uploaded again).  What a script that swaps the
+    reference's per-utterance loop for the batch calls sees, nothing resident, nothing pipelined."""
+    from world import main
+
+    W = main.World()
+    dats = W.encode_batch(fs, xs, f0_method="dio")
+    W.decode_batch(dats)
+    torch.cuda.synchronize()
+    enc_s, dec_s = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dats = W.encode_batch(fs, xs, f0_method="dio")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        W.decode_batch(dats)
+        torch.cuda.synchronize()
+        enc_s.append(t1 - t0)
+        dec_s.append(time.perf_counter() - t1)
+    frames = sum(len(d["f0"]) for d in dats)
+    e, d = float(np.median(enc_s)), float(np.median(dec_s))
+    return {"encode_batch_ms": e * 1e3, "decode_batch_ms": d * 1e3, "value": frames / (e + d), "unit": "frames/s",
+            "x_realtime": len(xs) * len(xs[0]) / fs / (e + d),
+            "note": "World.encode_batch + World.decode_batch on 64 x 10 s, NumPy in / NumPy dicts out / NumPy audio out; median "
+                    "of %d" % reps}
 
 
 def with_transfers_lanes_block(torch, device_index, xs, fs, lanes=4, steps=5):

@@ -51,7 +51,11 @@ class BatchEncoding:
         frame_off = np.concatenate([[0], np.cumsum(nfs)])
         batch = rt.make_batch(np.zeros(len(dats) + 1, dtype=np.int64), frame_off)
         flat = lambda key: rt.to_device(np.concatenate([np.asarray(d[key], dtype=np.float64) for d in dats]))  # noqa: E731
-        rows = lambda key: rt.to_device(np.concatenate([np.asarray(d[key], dtype=np.float64).T for d in dats]))  # noqa: E731
+        def rows(key):
+            # (bins, frames) per utterance on the host -> one frame-major tensor: uploaded as they lie, transposed on the
+            # device (strided host copies of the 64 x 10 s batch took as long as its whole decode)
+            parts = [rt.to_device(np.asarray(d[key], dtype=np.float64)).transpose(0, 1) for d in dats]
+            return rt.torch.cat(parts, dim=0).contiguous()
         tp_h = np.concatenate([np.asarray(d['temporal_positions'], dtype=np.float64) for d in dats])
         fft_size = (dats[0]['spectrogram'].shape[0] - 1) * 2
         return cls(rt, batch, dats[0]['fs'], rt.to_device(tp_h), flat('f0'), flat('vuv'), rows('spectrogram'),

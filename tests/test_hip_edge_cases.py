@@ -85,3 +85,22 @@ def test_other_sampling_rates_match_oracle(fs):
         else:
             assert np.max(np.abs(d["aperiodicity"] - o["aperiodicity"])) < 1e-7
     wb.rt.take_flags()
+
+
+def test_rates_beyond_the_transform_ceiling_fail_loudly():
+    """Transforms go up to 8192 points in D4C / love-train and 4096 in CheapTrick / synthesis (fs up to ~97 kHz; the 96 kHz
+    case is checked against a reference fixture in test_hip_fullsize.py).  Beyond that every entry point must refuse with a
+    message, never compute something else: 192 kHz needs 8192 points in CheapTrick and 16384 in D4C."""
+    from world import _hip
+    from world._synthetic import synth_utterance
+    from world.cheaptrick import cheaptrick
+    from world.d4c import d4c
+
+    fs = 192000
+    x = synth_utterance(3, fs, 0.05)
+    nf = int(1000 * len(x) / fs / 5 + 1)
+    src = lambda: {"f0": np.full(nf, 150.0), "vuv": np.ones(nf), "temporal_positions": np.arange(nf) * 0.005}  # noqa: E731
+    with pytest.raises(_hip.WorldHipError, match="fft_size"):
+        cheaptrick(x, fs, src())
+    with pytest.raises(_hip.WorldHipError, match="FFT size"):
+        d4c(x, fs, src())

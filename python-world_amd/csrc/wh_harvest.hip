@@ -885,15 +885,24 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
   }
   __syncthreads();
   const int64_t pool_base = (m.f1_off + f_first) * kRows;
-  if (threadIdx.x == 64) {
-    int run = 0;
-    for (int fl = 0; fl < kFramesPerBlock; ++fl) {
-      foff[fl] = run;
-      const int c = __popc(nzmask[fl * 4]) + __popc(nzmask[fl * 4 + 1]) + __popc(nzmask[fl * 4 + 2]) + __popc(nzmask[fl * 4 + 3]);
-      if (f_first + fl < m.nf1) lst[m.f1_off + f_first + fl] = ((pool_base + run) << 8) | (int64_t)c;
-      run += c;
+  static_assert(kFramesPerBlock <= 64, "one lane per frame below");
+  if (threadIdx.x < 64) {  // per-frame counts -> list offsets: one lane per frame, a wave scan (one lane walking the frames
+                           // was a chain of dependent LDS round trips with the other 255 threads at the barrier)
+    const int fl = threadIdx.x;
+    const int c = fl < kFramesPerBlock
+                      ? __popc(nzmask[fl * 4]) + __popc(nzmask[fl * 4 + 1]) + __popc(nzmask[fl * 4 + 2]) + __popc(nzmask[fl * 4 + 3])
+                      : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (fl >= o) incl += up;
     }
-    foff[kFramesPerBlock] = run;
+    if (fl < kFramesPerBlock) {
+      foff[fl] = incl - c;
+      if (f_first + fl < m.nf1) lst[m.f1_off + f_first + fl] = ((pool_base + (incl - c)) << 8) | (int64_t)c;
+    }
+    if (fl == 63) foff[kFramesPerBlock] = incl;
   }
   __syncthreads();
   // Rounds of whole frames whose candidates fit the work list (kItems slots; the 32 frames of a block hold ~400 candidates
@@ -963,6 +972,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
       cl_meta[i] = cl_meta[i] | (skey << 5) | ((d1 | (d2 << 2) | (d3 << 5) | (d4 << 8) | (d5 << 11)) << 17);
     }
     __syncthreads();
+    if (threadIdx.x < kBuckets) bucket[threadIdx.x] = 0;  // (for the counting sort below: one barrier less)
     constexpr int kClassScan = (kItems + 255) / 256;
     int link[kClassScan];  // per item of this thread: (successor + 1) | not-first flag << 11
   #pragma unroll
@@ -996,23 +1006,25 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
     // octave neighbours.  Counting sort of the classes' first items by iteration count, so that the groups of a wave
     // (consecutive entries) carry windows of the same length class.
     {
-      if (threadIdx.x < kBuckets) bucket[threadIdx.x] = 0;
-      __syncthreads();
+      // (the buckets were zeroed in front of the class scan's barrier; a thread counts the items whose links it wrote)
       for (int i = threadIdx.x; i < n_items; i += 256)
         if (!(cl_meta[i] >> 28 & 1)) atomicAdd(&bucket[(cl_meta[i] >> 5) & 63], 1);  // the classes' first items
       __syncthreads();
-      if (threadIdx.x == 0) {  // exclusive scan of the counts, longest first (the long items start the block's schedule)
-        int run = 0;
-        for (int k = kBuckets - 1; k >= 0; --k) {
-          const int c = bucket[k];
-          bucket[k] = run;
-          run += c;
+      static_assert(kBuckets == 64, "one lane per bucket");
+      if (threadIdx.x < 64) {  // exclusive scan of the counts, longest first (the long items start the block's schedule)
+        const int k = kBuckets - 1 - threadIdx.x;
+        const int c = bucket[k];
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int up = __shfl_up(incl, o, 64);
+          if ((int)threadIdx.x >= o) incl += up;
         }
-        cl_n = run;  // classes
+        bucket[k] = incl - c;
+        if (threadIdx.x == 63) cl_n = incl;  // classes
       }
       __syncthreads();
-      const int n_lead = cl_n;
-      __syncthreads();  // (everybody has read the count before the scatter's atomics move the buckets; cl_n is not theirs)
+        const int n_lead = cl_n;
       for (int i = threadIdx.x; i < n_items; i += 256)
         if (!(cl_meta[i] >> 28 & 1)) order[atomicAdd(&bucket[(cl_meta[i] >> 5) & 63], 1)] = i;
       __syncthreads();

@@ -2,7 +2,7 @@
 oracle.  The switch is read once per process, so every configuration runs in its own subprocess:
   default            band_events -> edge lists -> hv_raw (what ships)
   fused              hv_front_kernel with its standard margins
-  fused, margin 0.2  margins so small that many channels of every utterance fail the coverage check and go back through
+  fused, margin 0.05 margins so small that most channels of every utterance fail the coverage check and go back through
                      the unfused chain, per channel — the hand-back path, exercised on purpose
 All three must give the same voicing decisions and the same f0 (the filtered tiles differ by rounding only: the block
 origins differ) and match the oracle's harvest (world/harvest.py:17-54)."""
@@ -37,9 +37,10 @@ def test_fused_front_end_equals_the_chain_and_the_oracle(tmp_path):
 
     base = _run(tmp_path, "default")
     fused = _run(tmp_path, "fused", WH_HV_FRONT="1")
-    forced = _run(tmp_path, "forced", WH_HV_FRONT="1", WH_HV_FRONT_MARGIN="0.2")
+    forced = _run(tmp_path, "forced", WH_HV_FRONT="1", WH_HV_FRONT_MARGIN="0.05")
     assert "hv_front_kernel" not in base["prof"] and "hv_front_kernel" in fused["prof"]
     # the hand-back path really ran in the forced configuration: its gated kernels did work there and (next to) none before
+    # (a gated kernel with nothing to do is a few microseconds of launch; with work it is tens)
     assert forced["prof"]["hv_raw_kernel"] > 2 * fused["prof"]["hv_raw_kernel"]
     assert forced["prof"]["band_events_kernel"] > 2 * fused["prof"]["band_events_kernel"]
     for other in (fused, forced):

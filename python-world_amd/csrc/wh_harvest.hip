@@ -907,7 +907,8 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
   // (which die here: inside the loop they would stay alive across the refinement passes), a further round fetches its
   // rows again.
   auto round_end = [&](int fa) {
-    int fb = fa + 1;
+    if (foff[kFramesPerBlock] - foff[fa] <= item_cap) return (int)kFramesPerBlock;  // the usual case: all that is left
+    int fb = fa + 1;  // (walking the frames costs a dependent LDS read each, on every thread)
     while (fb < kFramesPerBlock && foff[fb + 1] - foff[fa] <= item_cap) ++fb;  // (item_cap <= kItems: the LDS slots)
     return fb;
   };

@@ -304,6 +304,9 @@ __device__ __forceinline__ double2 cmul_conj(double2 a, double2 b) {
 #ifndef WH_FFT_TW_PREFETCH
 #define WH_FFT_TW_PREFETCH 1
 #endif
+#ifndef WH_FFT_SWZ
+#define WH_FFT_SWZ 1  // 0: natural intermediate layout everywhere (stores at immediate offsets, bank conflicts in the early passes)
+#endif
 __device__ __forceinline__ int fft_swz(int i) { return i ^ ((i >> 3) & 7); }
 
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
@@ -446,7 +449,7 @@ template <int N, int NT, int NS, bool INV, int SNT = NT, int MAXR = 8>
 __device__ __forceinline__ void fft_passes(double2* s, const double2* tw) {
   if constexpr (NS < N) {
     constexpr int R = FftRadix<N, NT, NS, MAXR>::value;
-    constexpr bool SWZ = N >= 64 && MAXR >= 8;  // radix-4 plans keep the natural layout (one address VGPR per pass)
+    constexpr bool SWZ = WH_FFT_SWZ && N >= 64 && MAXR >= 8;  // radix-4 plans keep the natural layout (one address VGPR per pass)
     fft_pass<N, NT, R, NS, INV, SNT, SWZ && (NS > 1), SWZ && (NS * R < N)>(s, tw);
     fft_passes<N, NT, NS * R, INV, SNT, MAXR>(s, tw);
   }
@@ -475,7 +478,7 @@ __device__ __forceinline__ void fft_lds_from_regs(const double2 (&x)[N / NT], do
 #pragma unroll
     for (int r = 0; r < R; ++r) v[p][r] = x[p + r * PER];
   sync_lds<NT>();
-  fft_pass_finish<N, NT, R, 1, INV, (R < N && MAXR >= 8)>(s, v, w);
+  fft_pass_finish<N, NT, R, 1, INV, (WH_FFT_SWZ && R < N && MAXR >= 8)>(s, v, w);
   sync_lds<NT>();
   fft_passes<N, NT, R, INV, NT, MAXR>(s, tw);
 }

@@ -22,6 +22,15 @@ def inputs():
     return fs, xs
 
 
+def inputs_22k():
+    from scipy.io import wavfile
+
+    from world._synthetic import synth_utterance
+
+    fs, xi = wavfile.read(os.path.join(ROOT, "tests", "golden", "test-mwm.wav"))
+    return int(fs), [xi / (2 ** 15 - 1), synth_utterance(124, int(fs), 0.9)]
+
+
 def main(out):
     from world import _hip
     from world.harvest import harvest_device
@@ -37,7 +46,14 @@ def main(out):
         prof[name] = prof.get(name, 0.0) + ms
     wb.rt.profile(False)
     assert wb.rt.take_flags() == [0] * 16
+    # a second batch at 22.05 kHz (decimated rate 7350 Hz: 7.35 samples per 1 ms frame, tile edges between samples) with
+    # another f0 floor (longer filters, wider margins): the reference's test recording and a synthetic utterance
+    fs2, xs2 = inputs_22k()
+    batch2, x2_d, tp2_d = wb.upload(xs2, fs2)
+    f0_2, vuv_2 = harvest_device(wb.rt, batch2, x2_d, tp2_d, fs2, 60, 700, 5)
+    assert wb.rt.take_flags() == [0] * 16
     np.savez(out, f0=f0_d.cpu().numpy(), vuv=vuv_d.cpu().numpy(), frame_off=batch.frame_off,
+             f0_22k=f0_2.cpu().numpy(), vuv_22k=vuv_2.cpu().numpy(), frame_off_22k=batch2.frame_off,
              kernels=np.array(sorted(prof)), ms=np.array([prof[k] for k in sorted(prof)]))
 
 

@@ -33,7 +33,7 @@ def _run(tmp_path, tag, **env):
 
 def test_fused_front_end_equals_the_chain_and_the_oracle(tmp_path):
     from oracle import pitch_harvest
-    from _front_script import inputs
+    from _front_script import inputs, inputs_22k
 
     base = _run(tmp_path, "default")
     fused = _run(tmp_path, "fused", WH_HV_FRONT="1")
@@ -46,6 +46,15 @@ def test_fused_front_end_equals_the_chain_and_the_oracle(tmp_path):
     for other in (fused, forced):
         assert np.array_equal(other["vuv"], base["vuv"])
         assert np.max(np.abs(other["f0"] - base["f0"])) < 1e-7
+        assert np.array_equal(other["vuv_22k"], base["vuv_22k"])  # 22.05 kHz (7350 Hz decimated), f0 floor 60 Hz
+        assert np.max(np.abs(other["f0_22k"] - base["f0_22k"])) < 1e-7
+    fs2, xs2 = inputs_22k()
+    fo2 = base["frame_off_22k"]
+    for u, x in enumerate(xs2):
+        ref = pitch_harvest.harvest_np(x, fs2, 60, 700)
+        a, b = int(fo2[u]), int(fo2[u + 1])
+        assert np.array_equal(fused["vuv_22k"][a:b], ref["vuv"])
+        assert np.max(np.abs(fused["f0_22k"][a:b] - ref["f0"])) < 1e-6
     fs, xs = inputs()
     fo = base["frame_off"]
     for u, x in enumerate(xs):

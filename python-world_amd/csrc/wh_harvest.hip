@@ -484,6 +484,12 @@ __device__ __forceinline__ double row_sum(double v) {
 // WTAB: the Blackman window and its derivative twin depend on the window length alone (the frame time cancels out of the
 // reference's window argument, see the tabulated loop) — (w(j), dw(j)) come from a per-call table (win_tab, row hwl at
 // offset hwl^2) instead of being re-derived per sample by rotation + DPP neighbour exchange.
+#ifndef WH_HV_SYMMETRIC
+#define WH_HV_SYMMETRIC 1  // 0: one twiddle per sample instead of one per sample pair (timing experiments)
+#endif
+#ifndef WH_HV_SYM_PREFETCH
+#define WH_HV_SYM_PREFETCH 0  // window pairs fetched an iteration ahead: 12 more spilled registers, 2.63 against 2.57 ms at config 3
+#endif
 __device__ __forceinline__ bool rotation_path_ok(bool wtab, double a0, double a0_frac) {
   return !wtab && a0 > 1.0 && a0_frac > 1e-6 && a0_frac < 1.0 - 1e-6;
 }
@@ -585,6 +591,69 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
     // the frame, through i_first below).  The loop is the 24 FMAs, the six twiddle gathers and one table read
     // (fetched an iteration ahead).
     const double2* wt = win_tab + hwl * hwl;
+#if WH_HV_SYMMETRIC
+    // The sums run over the sample PAIRS (hwl + m, hwl - m), m = 1..hwl, around the window's centre: the twiddle of
+    // bin b at -m is the conjugate of the one at +m, so with a = x*w and d = x*dw
+    //   sum_j a_j e^{-i th (j - hwl)} = a_0 + sum_m (a_m + a_-m) cos(th m) - i (a_m - a_-m) sin(th m)
+    // — one twiddle gather and four FMAs per harmonic and PAIR instead of per sample (half the gathers, half the FMAs of
+    // the loop).  Referring the phase to the centre multiplies both spectra by the same unit factor e^{i th hwl}: the
+    // power |X|^2 and the cross term Im(conj(X) D) that the instantaneous frequency is made of do not see it.
+    // (The window is NOT symmetric — its argument is (j - hwl - 0.499)/fs — so both window pairs are read.)
+    int tix[6], tstep[6];  // byte offsets into the twiddle table (see the rotation path below)
+    const int tmask = ((nfft - 1) << tw_sh);
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      tix[h] = ((bins[h] * (1 + l16)) & (nfft - 1)) << tw_sh;
+      tstep[h] = ((bins[h] * RL) & (nfft - 1)) << tw_sh;
+    }
+    const int n_it = (hwl + RL - 1) / RL;
+    const int64_t i_first = (int64_t)a0;
+    const int i_lo = (int)(0 - ybase), i_hi = (int)(ylen - 1 - ybase);
+    const int sc0 = (int)(i_first - 1 - ybase) + hwl;  // staged-signal index of the centre sample
+    auto pick = [&](int si) -> double { return yl[si < i_lo ? i_lo : (si > i_hi ? i_hi : si)]; };
+    if (l16 == 0) {  // the centre sample: cos = 1 for every bin
+      const double2 wc = wt[hwl];
+      const double smp = pick(sc0);
+#pragma unroll
+      for (int h = 0; h < 6; ++h) {
+        xr[h] = smp * wc.x;
+        dr[h] = smp * wc.y;
+      }
+    }
+    int m = 1 + l16;
+    double2 cur_p = m <= hwl ? wt[hwl + m] : make_double2(0.0, 0.0);
+    double2 cur_m = m <= hwl ? wt[hwl - m] : make_double2(0.0, 0.0);
+    for (int it = 0; it < n_it; ++it) {
+      const int mn = m + RL;
+#if WH_HV_SYM_PREFETCH
+      const double2 nxt_p = mn <= hwl ? wt[hwl + mn] : make_double2(0.0, 0.0);
+      const double2 nxt_m = mn <= hwl ? wt[hwl - mn] : make_double2(0.0, 0.0);
+#endif
+      const double sp = pick(sc0 + m), sm = pick(sc0 - m);  // (past the window's end the window pair is zero)
+      const double ap = sp * cur_p.x, am = sm * cur_m.x, dp = sp * cur_p.y, dm = sm * cur_m.y;
+      const double ea = ap + am, oa = ap - am, ed = dp + dm, od = dp - dm;
+      double2 wv[6];  // all six gathers in flight before the first FMA needs one
+#pragma unroll
+      for (int h = 0; h < 6; ++h) wv[h] = twiddle(tix[h]);
+#pragma unroll
+      for (int h = 0; h < 6; ++h) {
+        const double2 w = wv[h];
+        xr[h] = fma(ea, w.x, xr[h]);
+        xi[h] = fma(oa, w.y, xi[h]);
+        dr[h] = fma(ed, w.x, dr[h]);
+        di[h] = fma(od, w.y, di[h]);
+        tix[h] = (tix[h] + tstep[h]) & tmask;
+      }
+#if WH_HV_SYM_PREFETCH
+      cur_p = nxt_p;
+      cur_m = nxt_m;
+#else
+      cur_p = mn <= hwl ? wt[hwl + mn] : make_double2(0.0, 0.0);
+      cur_m = mn <= hwl ? wt[hwl - mn] : make_double2(0.0, 0.0);
+#endif
+      m = mn;
+    }
+#else
     int tix[6], tstep[6];  // byte offsets into the twiddle table (see the rotation path below)
     const int tmask = ((nfft - 1) << tw_sh);
 #pragma unroll
@@ -621,6 +690,7 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       cur = nxt;
       j = jn;
     }
+#endif
   } else if (rotation_path_ok(WTAB, a0, a0_frac)) {
     if constexpr (!WTAB) {
     // Every index of the frame is positive (all frames but the first few of an utterance): idx_raw, and with it the

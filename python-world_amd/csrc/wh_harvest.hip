@@ -484,8 +484,60 @@ __device__ __forceinline__ double row_sum(double v) {
 // WTAB: the Blackman window and its derivative twin depend on the window length alone (the frame time cancels out of the
 // reference's window argument, see the tabulated loop) — (w(j), dw(j)) come from a per-call table (win_tab, row hwl at
 // offset hwl^2) instead of being re-derived per sample by rotation + DPP neighbour exchange.
+// Window half length, transform length, harmonic count and the six rounded harmonic bins of a candidate
+// (harvest.py:171-174,203), and their packed form: two candidates with the same key have the same two spectra at the
+// same bins (hv_refine_kernel's classes), and the key is all the sample loop needs to know about the candidate.
+struct RefineGeom {
+  int hwl, nfft, nh, bins[6];
+};
+__device__ __forceinline__ int refine_nfft(int hwl) {
+  const int L = 2 * hwl + 1;
+  int e = 0;
+  while ((1 << e) < L) ++e;
+  return 1 << (e + 1);
+}
+__device__ __forceinline__ RefineGeom refine_geom(double f0c, double fs) {
+  RefineGeom g;
+  g.hwl = (int)ceil(3 * fs / f0c / 2);
+  g.nfft = refine_nfft(g.hwl);
+  g.nh = (int)fmin(floor(fs / 2 / f0c), 6.0);
+#pragma unroll
+  for (int h = 0; h < 6; ++h) g.bins[h] = (int)(f0c * g.nfft / fs * (double)(h + 1) + 0.5);
+  return g;
+}
+// the first bin is within a few units of 1.5 * nfft / hwl (f0c lies in (1.5 fs / hwl, 1.5 fs / (hwl - 1)]): any
+// deterministic function of (hwl, nfft) serves as the base it is stored against
+__device__ __forceinline__ int refine_bin_base(int hwl, int nfft) { return (int)(1.5f * (float)nfft / (float)hwl) - 1; }
+// [0,9) hwl; [9,11) bins[0] - base; [11,14) nh; [14,16), [16,19), [19,22), [22,25), [25,28): bins[h] - (h+1)*bins[0], which is
+// within +-(h+2)/2, offset to be non-negative.  -1: a value outside these ranges (not expected; the item is then a class
+// of its own and the sample loop derives everything from the candidate).
+__device__ __forceinline__ int refine_pack(const RefineGeom& g) {
+  const int b0 = g.bins[0] - refine_bin_base(g.hwl, g.nfft);
+  const int d1 = g.bins[1] - 2 * g.bins[0] + 1, d2 = g.bins[2] - 3 * g.bins[0] + 3, d3 = g.bins[3] - 4 * g.bins[0] + 3;
+  const int d4 = g.bins[4] - 5 * g.bins[0] + 3, d5 = g.bins[5] - 6 * g.bins[0] + 3;
+  const bool fits = (unsigned)d1 < 4u && (unsigned)d2 < 8u && (unsigned)d3 < 8u && (unsigned)d4 < 8u && (unsigned)d5 < 8u &&
+                    (unsigned)b0 < 4u && (unsigned)g.hwl < 512u && (unsigned)g.nh < 8u;
+  return fits ? (g.hwl | (b0 << 9) | (g.nh << 11) | (d1 << 14) | (d2 << 16) | (d3 << 19) | (d4 << 22) | (d5 << 25)) : -1;
+}
+__device__ __forceinline__ RefineGeom refine_unpack(int key) {
+  RefineGeom g;
+  g.hwl = key & 511;
+  g.nfft = refine_nfft(g.hwl);
+  g.nh = (key >> 11) & 7;
+  const int b0 = refine_bin_base(g.hwl, g.nfft) + ((key >> 9) & 3);
+  g.bins[0] = b0;
+  g.bins[1] = 2 * b0 + ((key >> 14) & 3) - 1;
+  g.bins[2] = 3 * b0 + ((key >> 16) & 7) - 3;
+  g.bins[3] = 4 * b0 + ((key >> 19) & 7) - 3;
+  g.bins[4] = 5 * b0 + ((key >> 22) & 7) - 3;
+  g.bins[5] = 6 * b0 + ((key >> 25) & 7) - 3;
+  return g;
+}
 #ifndef WH_HV_SYMMETRIC
 #define WH_HV_SYMMETRIC 1  // 0: one twiddle per sample instead of one per sample pair (timing experiments)
+#endif
+#ifndef WH_HV_SKEY_L
+#define WH_HV_SKEY_L 0
 #endif
 #ifndef WH_HV_SYM_PREFETCH
 #define WH_HV_SYM_PREFETCH 0  // window pairs fetched an iteration ahead: 12 more spilled registers, 2.63 against 2.57 ms at config 3
@@ -502,23 +554,20 @@ __device__ __forceinline__ bool rotation_path_ok(bool wtab, double a0, double a0
 // do) — the spectra at the harmonic bins are the same for all of them, only the score looks at the candidate itself.
 template <bool TWL, bool WTAB, int RL, class Members>
 __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int64_t ybase, int64_t ylen, double fs,
-                                              double t0, double f0c, double f0_floor, double f0_ceil,
+                                              double t0, double f0c, int pkey, double f0_floor, double f0_ceil,
                                               const double2* __restrict__ tw_base, const char* tw_lds, int tw_n,
                                               const double2* __restrict__ rot_tab, const double2* __restrict__ win_tab,
                                               Members members) {
   static_assert(WTAB || RL == 16, "the rotation path exchanges window values with 16-lane row rotates");
   const int l16 = threadIdx.x & (RL - 1);  // lane within the candidate's group
-  const double hwl_d = ceil(3 * fs / f0c / 2);
-  const int hwl = (int)hwl_d;
+  // pkey >= 0: the candidate's packed geometry (refine_pack), computed when the classes were built
+  const RefineGeom geo = pkey >= 0 ? refine_unpack(pkey) : refine_geom(f0c, fs);
+  const int hwl = geo.hwl;
+  const double hwl_d = (double)hwl;
   const int L = 2 * hwl + 1;
   const double wlit = (2 * hwl_d + 1) / fs;
-  int nfft;
-  {
-    int e = 0;
-    while ((1 << e) < L) ++e;
-    nfft = 1 << (e + 1);
-  }
-  const int nh = (int)fmin(floor(fs / 2 / f0c), 6.0);
+  const int nfft = geo.nfft;
+  const int nh = geo.nh;
   // twiddles exp(-2*pi*i*k/nfft): from the workgroup's LDS copy of the largest table any of its candidates can
   // need (the smaller tables are its subsamples, bit for bit), else from the global table
   const char* tw = TWL ? tw_lds : reinterpret_cast<const char*>(tw_base + nfft);
@@ -535,7 +584,7 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   };
   int bins[6];
 #pragma unroll
-  for (int h = 0; h < 6; ++h) bins[h] = (int)(f0c * nfft / fs * (double)(h + 1) + 0.5);
+  for (int h = 0; h < 6; ++h) bins[h] = geo.bins[h];
   const double inv_fs = 1.0 / fs;  // the sample index below is floor(integer + 0.501 +- 1e-12): an ulp cannot move it
   auto idx_raw_at = [&](int j) -> double {
     const double v = (t0 + (double)(j - hwl) * inv_fs) * fs + 0.001;  // "first-aid treatment", harvest.py:178
@@ -858,7 +907,7 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
                             // 16 frames 3.81 ms, 24: 3.34, 32: 3.37, 48: 4.79 — 52.3 against 59.7 ms at 1024 utterances)
 #endif
 #ifndef WH_HV_ITEM_CAP
-#define WH_HV_ITEM_CAP 1680  // work-list slots in LDS; a block whose frames hold more takes them in several rounds of whole frames
+#define WH_HV_ITEM_CAP 1344  // work-list slots in LDS; a block whose frames hold more takes them in several rounds of whole frames
 #endif
 // lanes per candidate and frames per workgroup of the two refinement variants
 constexpr int refine_lanes(bool wtab) { return wtab ? WH_HV_ROW_LANES : 16; }
@@ -893,7 +942,8 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
   double* cl_val = yl + ((seglen + 1) & ~1);                 // kItems
   int* cl_meta = reinterpret_cast<int*>(cl_val + kItems);    // kItems
   int* order = cl_meta + kItems;                             // kItems
-  int* bucket = order + kItems;                              // kBuckets
+  int* key_s = order + kItems;                               // kItems: packed geometry of an item (refine_pack)
+  int* bucket = key_s + kItems;                              // kBuckets
   int& cl_n = bucket[kBuckets];
   uint32_t* nzmask = reinterpret_cast<uint32_t*>(bucket + kBuckets + 1);  // [kFramesPerBlock][4]: rows of a frame that hold a candidate
   int* foff = reinterpret_cast<int*>(nzmask + kFramesPerBlock * 4);       // [kFramesPerBlock + 1]: first list slot of a frame
@@ -999,6 +1049,10 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
     cl_val[slot] = cv[it];
     cl_meta[slot] = fl;
   }
+#if defined(WH_HV_REFINE_ABLATE) && WH_HV_REFINE_ABLATE == 1  // timing experiments: staging, gather and placement alone
+  if (threadIdx.x == 0 && fb == 123456) rf0[0] = 0;
+  return;
+#endif
   while (true) {
     const int s0 = foff[fa];
     const int n_items = foff[fb] - s0;
@@ -1008,36 +1062,19 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
     // work items per 10 s, 121 k distinct keys; the reference's own test recording: 83 k / 66 k).  One item of a class does the
     // sums; every member gets its own score from them (it is the score that looks at the candidate's value,
     // harvest.py:205-206) — same arithmetic, same results, a third less work.
-    // cl_meta fields: [0,5) frame; [5,11) iteration count (the counting sort's key); phase 1: [17,31) the bins' offsets from
-    // multiples of the first; phase 2: [17,28) successor in the class + 1, bit 28: not the class's first item.
-    int* key_a = order;  // (the schedule is built after the classes are known)
+    // cl_meta fields: [0,5) frame; [5,11) iteration count (the counting sort's key); [17,28) successor in the class + 1,
+    // bit 28: not the class's first item.  key_s: the packed geometry, which IS the class key.
     __syncthreads();
     // the keys, one thread per PLACED item (every lane busy; inside the gather loop above the same arithmetic ran seven
     // times per wave with a tenth of the lanes)
     for (int i = threadIdx.x; i < n_items; i += 256) {
-      const double v = cl_val[i];
-      const int hwl = (int)ceil(3 * fs / v / 2);
-      const int L = 2 * hwl + 1;
-      int nfft;
-      {
-        int ex = 0;
-        while ((1 << ex) < L) ++ex;
-        nfft = 1 << (ex + 1);
-      }
-      const int nh = (int)fmin(floor(fs / 2 / v), 6.0);
-      int bins[6];
-  #pragma unroll
-      for (int h = 0; h < 6; ++h) bins[h] = (int)(v * nfft / fs * (double)(h + 1) + 0.5);  // as hv_refine_row computes them
-      // bins[h] - (h+1)*bins[0] is within +-(h+2)/2: 2 + 3 + 3 + 3 + 3 bits; a value outside (not expected) makes the item
-      // a class of its own
-      const int d1 = bins[1] - 2 * bins[0] + 1, d2 = bins[2] - 3 * bins[0] + 3, d3 = bins[3] - 4 * bins[0] + 3;
-      const int d4 = bins[4] - 5 * bins[0] + 3, d5 = bins[5] - 6 * bins[0] + 3;
-      const bool fits = (unsigned)d1 < 4u && (unsigned)d2 < 8u && (unsigned)d3 < 8u && (unsigned)d4 < 8u && (unsigned)d5 < 8u &&
-                        hwl < 512 && bins[0] < 1024;
-      int skey = (L + RL - 1) / RL;  // iteration count of the sample loop: the counting sort's key
+      const RefineGeom g = refine_geom(cl_val[i], fs);
+      const int key = refine_pack(g);
+      // iteration count of the sample loop: the counting sort's key
+      int skey = (WTAB && WH_HV_SYMMETRIC && !WH_HV_SKEY_L) ? (g.hwl + RL - 1) / RL : (2 * g.hwl + 1 + RL - 1) / RL;
       skey = skey > kBuckets - 1 ? kBuckets - 1 : skey;
-      key_a[i] = fits ? (hwl | (bins[0] << 9) | (nh << 19)) : (int)(0x80000000u | (unsigned)i);
-      cl_meta[i] = cl_meta[i] | (skey << 5) | ((d1 | (d2 << 2) | (d3 << 5) | (d4 << 8) | (d5 << 11)) << 17);
+      key_s[i] = key >= 0 ? key : (int)(0x80000000u | (unsigned)i);  // (unpackable: a class of its own)
+      cl_meta[i] = cl_meta[i] | (skey << 5);
     }
     __syncthreads();
     if (threadIdx.x < kBuckets) bucket[threadIdx.x] = 0;  // (for the counting sort below: one barrier less)
@@ -1048,14 +1085,12 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
       const int i = threadIdx.x + r * 256;
       link[r] = 0;
       if (i < n_items) {
-        const int mi = cl_meta[i];
-        const int ka = key_a[i], kb = mi >> 17, fl = mi & 31;
+        const int ka = key_s[i], fl = cl_meta[i] & 31;
         const int lo = foff[fl] - s0, hi = foff[fl + 1] - s0;  // the frame's items
         bool has_pred = false;
         int succ = 0;
-        for (int j = lo; j < i; ++j) has_pred = has_pred || (key_a[j] == ka && (cl_meta[j] >> 17) == kb);
-        for (int j = hi - 1; j > i; --j)
-          if (key_a[j] == ka && (cl_meta[j] >> 17) == kb) succ = j + 1;
+        for (int j = lo; j < i; ++j) has_pred = has_pred || key_s[j] == ka;
+        for (int j = hi - 1; j > i; --j) succ = key_s[j] == ka ? j + 1 : succ;
   #if !WH_HV_CLASSES
         has_pred = false;  // (ablation: every item its own class)
         succ = 0;
@@ -1069,6 +1104,10 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
       const int i = threadIdx.x + r * 256;
       if (i < n_items) cl_meta[i] = (cl_meta[i] & 0x7ff) | (link[r] << 17);
     }
+#if defined(WH_HV_REFINE_ABLATE) && WH_HV_REFINE_ABLATE == 2  // ... + keys and class scan
+    if (threadIdx.x == 0 && fb == 123456) rf0[0] = 0;
+    return;
+#endif
     // A wave refines 64 / RL classes at once, one per group of RL lanes, and runs as long as its longest one: the
     // window length goes with 1/f0 (31 ... 340 samples at 8 kHz), and a frame's candidates are typically an f0 with its
     // octave neighbours.  Counting sort of the classes' first items by iteration count, so that the groups of a wave
@@ -1096,7 +1135,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
       for (int i = threadIdx.x; i < n_items; i += 256)
         if (!(cl_meta[i] >> 28 & 1)) order[atomicAdd(&bucket[(cl_meta[i] >> 5) & 63], 1)] = i;
       __syncthreads();
-  #ifdef WH_HV_REFINE_ABLATE  // timing experiments: the list building alone
+  #if defined(WH_HV_REFINE_ABLATE) && WH_HV_REFINE_ABLATE == 3  // timing experiments: the list building alone
       if (threadIdx.x == 0 && n_lead == 123456) rf0[0] = 0;
       return;
   #endif
@@ -1104,7 +1143,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
         const int src = order[it];
         const int64_t f = f_first + (cl_meta[src] & 31);
         hv_refine_row<TWL, WTAB, RL>(
-            yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], f0_floor, f0_ceil, tw_base, smem, tw_n, rot_tab, win_tab,
+            yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], key_s[src], f0_floor, f0_ceil, tw_base, smem, tw_n, rot_tab, win_tab,
             [&](auto eval) {
               int p = src;
               while (true) {
@@ -1511,7 +1550,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     const int fpb = refine_frames(use_wtab);
     const int seglen = 2 * hmax + 8 + (fpb - 1) * ((int)ceil(fs_d / 1000.0) + 1);
     const size_t lds = sizeof(double2) * (size_t)tw_n + sizeof(double) * (size_t)((seglen + 1) & ~1) +
-                       (sizeof(double) + 2 * sizeof(int)) * (size_t)refine_item_cap(use_wtab) + sizeof(int) * (72 + 5 * fpb + 1);
+                       (sizeof(double) + 3 * sizeof(int)) * (size_t)refine_item_cap(use_wtab) + sizeof(int) * (72 + 5 * fpb + 1);
     // 16-sample rotation (sin, cos)(16*pi*dx) of the window phase for every half length (hv_refine_row)
     double2* d_rot = nullptr;
     {

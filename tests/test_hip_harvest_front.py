@@ -67,7 +67,7 @@ def test_fused_front_end_equals_the_chain_and_the_oracle(tmp_path):
 
 def test_refinement_in_several_rounds_equals_one_round(tmp_path):
     """hv_refine_kernel takes the candidates of a block's 24 frames in rounds of whole frames that fit its LDS work list
-    (1680 slots: one round on real input).  With the list capped at 120 slots (WH_HV_ITEM_CAP_RT) every block needs
+    (1344 slots: one round on real input).  With the list capped at 120 slots (WH_HV_ITEM_CAP_RT) every block needs
     several rounds, the later ones fetching their rows again: the contour must not change by a bit."""
     base = _run(tmp_path, "default")
     capped = _run(tmp_path, "capped", WH_HV_ITEM_CAP_RT="120")

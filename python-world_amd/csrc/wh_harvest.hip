@@ -483,7 +483,7 @@ __device__ __forceinline__ double row_sum(double v) {
 // tables through tw_base.
 // WTAB: the Blackman window and its derivative twin depend on the window length alone (the frame time cancels out of the
 // reference's window argument, see the tabulated loop) — (w(j), dw(j)) come from a per-call table (win_tab, row hwl at
-// offset hwl^2) instead of being re-derived per sample by rotation + DPP neighbour exchange.
+// offset hwl*(hwl+2), a zero pair at either end) instead of being re-derived per sample by rotation + DPP neighbour exchange.
 // Window half length, transform length, harmonic count and the six rounded harmonic bins of a candidate
 // (harvest.py:171-174,203), and their packed form: two candidates with the same key have the same two spectra at the
 // same bins (hv_refine_kernel's classes), and the key is all the sample loop needs to know about the candidate.
@@ -533,15 +533,6 @@ __device__ __forceinline__ RefineGeom refine_unpack(int key) {
   g.bins[5] = 6 * b0 + ((key >> 25) & 7) - 3;
   return g;
 }
-#ifndef WH_HV_SYMMETRIC
-#define WH_HV_SYMMETRIC 1  // 0: one twiddle per sample instead of one per sample pair (timing experiments)
-#endif
-#ifndef WH_HV_SKEY_L
-#define WH_HV_SKEY_L 0
-#endif
-#ifndef WH_HV_SYM_PREFETCH
-#define WH_HV_SYM_PREFETCH 0  // window pairs fetched an iteration ahead: 12 more spilled registers, 2.63 against 2.57 ms at config 3
-#endif
 __device__ __forceinline__ bool rotation_path_ok(bool wtab, double a0, double a0_frac) {
   return !wtab && a0 > 1.0 && a0_frac > 1e-6 && a0_frac < 1.0 - 1e-6;
 }
@@ -639,15 +630,17 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
     // samples, and the window pair of row hwl applies as tabulated (only the sample PICK floor(index_raw) depends on
     // the frame, through i_first below).  The loop is the 24 FMAs, the six twiddle gathers and one table read
     // (fetched an iteration ahead).
-    const double2* wt = win_tab + hwl * hwl;
-#if WH_HV_SYMMETRIC
     // The sums run over the sample PAIRS (hwl + m, hwl - m), m = 1..hwl, around the window's centre: the twiddle of
     // bin b at -m is the conjugate of the one at +m, so with a = x*w and d = x*dw
     //   sum_j a_j e^{-i th (j - hwl)} = a_0 + sum_m (a_m + a_-m) cos(th m) - i (a_m - a_-m) sin(th m)
     // — one twiddle gather and four FMAs per harmonic and PAIR instead of per sample (half the gathers, half the FMAs of
-    // the loop).  Referring the phase to the centre multiplies both spectra by the same unit factor e^{i th hwl}: the
-    // power |X|^2 and the cross term Im(conj(X) D) that the instantaneous frequency is made of do not see it.
-    // (The window is NOT symmetric — its argument is (j - hwl - 0.499)/fs — so both window pairs are read.)
+    // the loop: 3.19 -> 2.57 ms at config 3).  Referring the phase to the centre multiplies both spectra by the same unit
+    // factor e^{i th hwl}: the power |X|^2 and the cross term Im(conj(X) D) that the instantaneous frequency is made of do
+    // not see it.  (The window is NOT symmetric — its argument is (j - hwl - 0.499)/fs — so both window pairs are read.)
+    // Row hwl of the table has a zero entry in front of and behind its 2*hwl + 1 pairs, and a lane past the window's end
+    // (m > hwl in the last iteration) reads those: no predicate and no select inside the loop; the staged signal
+    // replicates the utterance's edge samples, so the sample index needs no clamp either.
+    const double2* wt = win_tab + hwl * (hwl + 2) + (hwl + 1);  // the centre pair
     int tix[6], tstep[6];  // byte offsets into the twiddle table (see the rotation path below)
     const int tmask = ((nfft - 1) << tw_sh);
 #pragma unroll
@@ -656,34 +649,31 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       tstep[h] = ((bins[h] * RL) & (nfft - 1)) << tw_sh;
     }
     const int n_it = (hwl + RL - 1) / RL;
-    const int64_t i_first = (int64_t)a0;
-    const int i_lo = (int)(0 - ybase), i_hi = (int)(ylen - 1 - ybase);
-    const int sc0 = (int)(i_first - 1 - ybase) + hwl;  // staged-signal index of the centre sample
-    auto pick = [&](int si) -> double { return yl[si < i_lo ? i_lo : (si > i_hi ? i_hi : si)]; };
+    const double* yc = yl + ((int)((int64_t)a0 - 1 - ybase) + hwl);  // the centre sample in the staged signal
     if (l16 == 0) {  // the centre sample: cos = 1 for every bin
-      const double2 wc = wt[hwl];
-      const double smp = pick(sc0);
+      const double2 wc = wt[0];
+      const double smp = yc[0];
 #pragma unroll
       for (int h = 0; h < 6; ++h) {
         xr[h] = smp * wc.x;
         dr[h] = smp * wc.y;
       }
     }
-    int m = 1 + l16;
-    double2 cur_p = m <= hwl ? wt[hwl + m] : make_double2(0.0, 0.0);
-    double2 cur_m = m <= hwl ? wt[hwl - m] : make_double2(0.0, 0.0);
+    const int m_end = hwl + 1;  // the zero pair
+    int m = 1 + l16;            // (<= hwl + 1: RL <= 4 ... hwl >= RL is not required, the clamp covers it)
+    m = m < m_end ? m : m_end;
+    double2 cur_p = wt[m], cur_m = wt[-m];
     for (int it = 0; it < n_it; ++it) {
-      const int mn = m + RL;
-#if WH_HV_SYM_PREFETCH
-      const double2 nxt_p = mn <= hwl ? wt[hwl + mn] : make_double2(0.0, 0.0);
-      const double2 nxt_m = mn <= hwl ? wt[hwl - mn] : make_double2(0.0, 0.0);
-#endif
-      const double sp = pick(sc0 + m), sm = pick(sc0 - m);  // (past the window's end the window pair is zero)
+      int mn = m + RL;
+      mn = mn < m_end ? mn : m_end;
+      const double sp = yc[m], sm = yc[-m];
       const double ap = sp * cur_p.x, am = sm * cur_m.x, dp = sp * cur_p.y, dm = sm * cur_m.y;
       const double ea = ap + am, oa = ap - am, ed = dp + dm, od = dp - dm;
       double2 wv[6];  // all six gathers in flight before the first FMA needs one
 #pragma unroll
       for (int h = 0; h < 6; ++h) wv[h] = twiddle(tix[h]);
+      cur_p = wt[mn];  // the next iteration's window pairs
+      cur_m = wt[-mn];
 #pragma unroll
       for (int h = 0; h < 6; ++h) {
         const double2 w = wv[h];
@@ -693,53 +683,8 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
         di[h] = fma(od, w.y, di[h]);
         tix[h] = (tix[h] + tstep[h]) & tmask;
       }
-#if WH_HV_SYM_PREFETCH
-      cur_p = nxt_p;
-      cur_m = nxt_m;
-#else
-      cur_p = mn <= hwl ? wt[hwl + mn] : make_double2(0.0, 0.0);
-      cur_m = mn <= hwl ? wt[hwl - mn] : make_double2(0.0, 0.0);
-#endif
       m = mn;
     }
-#else
-    int tix[6], tstep[6];  // byte offsets into the twiddle table (see the rotation path below)
-    const int tmask = ((nfft - 1) << tw_sh);
-#pragma unroll
-    for (int h = 0; h < 6; ++h) {
-      tix[h] = ((bins[h] * l16) & (nfft - 1)) << tw_sh;
-      tstep[h] = ((bins[h] * RL) & (nfft - 1)) << tw_sh;
-    }
-    const int n_it = (L + RL - 1) / RL;
-    const int64_t i_first = (int64_t)a0;
-    const int i_lo = (int)(0 - ybase), i_hi = (int)(ylen - 1 - ybase);
-    int si = (int)(i_first - 1 - ybase) + l16;
-    int j = l16;
-    double2 cur = j < L ? wt[j] : make_double2(0.0, 0.0);
-    for (int it = 0; it < n_it; ++it) {
-      const int jn = j + RL;
-      const double2 nxt = jn < L ? wt[jn] : make_double2(0.0, 0.0);
-      const int sc = si < i_lo ? i_lo : (si > i_hi ? i_hi : si);
-      const double smp = j < L ? yl[sc] : 0.0;
-      si += RL;
-      const double a = smp * cur.x, d = smp * cur.y;
-      double2 wv[6];  // all six gathers in flight before the first FMA needs one (left to the compiler, every gather's
-                      // LDS latency sat in front of its own four FMAs)
-#pragma unroll
-      for (int h = 0; h < 6; ++h) wv[h] = twiddle(tix[h]);
-#pragma unroll
-      for (int h = 0; h < 6; ++h) {
-        const double2 w = wv[h];
-        xr[h] = fma(a, w.x, xr[h]);
-        xi[h] = fma(a, w.y, xi[h]);
-        dr[h] = fma(d, w.x, dr[h]);
-        di[h] = fma(d, w.y, di[h]);
-        tix[h] = (tix[h] + tstep[h]) & tmask;
-      }
-      cur = nxt;
-      j = jn;
-    }
-#endif
   } else if (rotation_path_ok(WTAB, a0, a0_frac)) {
     if constexpr (!WTAB) {
     // Every index of the frame is positive (all frames but the first few of an utterance): idx_raw, and with it the
@@ -951,12 +896,13 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
   if (TWL)
     for (int i = threadIdx.x; i < tw_n; i += 256) twl[i] = tw_base[tw_n + i];
   const int64_t centre0 = (int64_t)floor(((double)f_first * 1 / 1000) * fs + 0.5);
-  int64_t ybase = centre0 - hmax - 3;
-  if (ybase < 0) ybase = 0;
+  // (may be negative: the staged signal replicates the utterance's first and last sample beyond its ends, which is what
+  // the reference's index clamp reads there, harvest.py:179)
+  const int64_t ybase = centre0 - hmax - 3;
   const double* yu = y + m.y_off;
   for (int i = threadIdx.x; i < seglen; i += 256) {
     const int64_t g = ybase + i;
-    yl[i] = g < m.ylen ? yu[g] : 0.0;
+    yl[i] = yu[g < 0 ? 0 : (g > m.ylen - 1 ? m.ylen - 1 : g)];
   }
   if (threadIdx.x == 0) cl_n = 0;
   __syncthreads();
@@ -1071,7 +1017,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
       const RefineGeom g = refine_geom(cl_val[i], fs);
       const int key = refine_pack(g);
       // iteration count of the sample loop: the counting sort's key
-      int skey = (WTAB && WH_HV_SYMMETRIC && !WH_HV_SKEY_L) ? (g.hwl + RL - 1) / RL : (2 * g.hwl + 1 + RL - 1) / RL;
+      int skey = WTAB ? (g.hwl + RL - 1) / RL : (2 * g.hwl + 1 + RL - 1) / RL;
       skey = skey > kBuckets - 1 ? kBuckets - 1 : skey;
       key_s[i] = key >= 0 ? key : (int)(0x80000000u | (unsigned)i);  // (unpackable: a class of its own)
       cl_meta[i] = cl_meta[i] | (skey << 5);
@@ -1562,15 +1508,16 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
       }
       if (int rc = wh::persistent_upload(ctx, st, "hv.rot", rot, &d_rot)) return rc;
     }
-    // (w(j), dw(j)) of every window length, row hwl at offset hwl^2 (hv_refine_row, WTAB).  Built once per (rate,
+    // (w(j), dw(j)) of every window length, row hwl at offset hwl*(hwl+2) between two zero pairs (hv_refine_row, WTAB).  Built once per (rate,
     // longest window) and kept on the device.
     const double2* d_wtab = nullptr;
     if (use_wtab) {
       char key[96];
-      snprintf(key, sizeof key, "hv.wtab:%.17g:%d", fs_d, hmax);
+      snprintf(key, sizeof key, "hv.wtab2:%.17g:%d", fs_d, hmax);
       auto it = ctx->tables.find(key);
       if (it == ctx->tables.end()) {
-        std::vector<double> tab((size_t)2 * (hmax + 2) * (hmax + 2), 0.0);
+        // row h at offset h*(h+2): a zero pair, the 2h+1 window pairs, a zero pair
+        std::vector<double> tab((size_t)2 * (hmax + 2) * (hmax + 4), 0.0);
         std::vector<double> mw;
         for (int h = 0; h <= hmax + 1; ++h) {
           const int Lh = 2 * h + 1;
@@ -1582,7 +1529,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
             const double c = cos(M_PI * (2 * (((double)(j - h) + (0.001 + 0.5) - 1.0) / fs_d) / wlit));
             mw[j] = 0.42 + 0.5 * c + 0.08 * (2 * c * c - 1);
           }
-          double* row = tab.data() + 2 * (size_t)h * h;
+          double* row = tab.data() + 2 * ((size_t)h * (h + 2) + 1);
           for (int j = 0; j < Lh; ++j) {
             double dw;
             if (j == 0) dw = Lh > 1 ? -mw[1] / 2 : 0.0;

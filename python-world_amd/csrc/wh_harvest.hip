@@ -533,6 +533,9 @@ __device__ __forceinline__ RefineGeom refine_unpack(int key) {
   g.bins[5] = 6 * b0 + ((key >> 25) & 7) - 3;
   return g;
 }
+#ifndef WH_HV_WIN_FENCE
+#define WH_HV_WIN_FENCE 1
+#endif
 __device__ __forceinline__ bool rotation_path_ok(bool wtab, double a0, double a0_frac) {
   return !wtab && a0 > 1.0 && a0_frac > 1e-6 && a0_frac < 1.0 - 1e-6;
 }
@@ -630,6 +633,8 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
     // samples, and the window pair of row hwl applies as tabulated (only the sample PICK floor(index_raw) depends on
     // the frame, through i_first below).  The loop is the 24 FMAs, the six twiddle gathers and one table read
     // (fetched an iteration ahead).
+    // (Advancing some of the six twiddles by a rotation instead of gathering them — 4 more FP64 operations per harmonic and
+    // iteration, one LDS gather less — is slower: 2.32 ... 2.48 against 2.28 ms; the loop is bound by VALU issue, not LDS.)
     // The sums run over the sample PAIRS (hwl + m, hwl - m), m = 1..hwl, around the window's centre: the twiddle of
     // bin b at -m is the conjugate of the one at +m, so with a = x*w and d = x*dw
     //   sum_j a_j e^{-i th (j - hwl)} = a_0 + sum_m (a_m + a_-m) cos(th m) - i (a_m - a_-m) sin(th m)
@@ -672,8 +677,13 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       double2 wv[6];  // all six gathers in flight before the first FMA needs one
 #pragma unroll
       for (int h = 0; h < 6; ++h) wv[h] = twiddle(tix[h]);
-      cur_p = wt[mn];  // the next iteration's window pairs
+      cur_p = wt[mn];  // the next iteration's window pairs, in flight under this one's FMAs
       cur_m = wt[-mn];
+#if WH_HV_WIN_FENCE
+      // (without the fence the compiler folds the loop-carried pair into "load the current pair at the top of the
+      // iteration", and every iteration waits for a global round trip)
+      asm volatile("" ::: "memory");
+#endif
 #pragma unroll
       for (int h = 0; h < 6; ++h) {
         const double2 w = wv[h];

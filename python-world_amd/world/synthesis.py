@@ -121,8 +121,10 @@ def synthesis(source_object, filter_object):
     ny, t0, dt = time_axis_params(tp, fs)
     batch = rt.make_batch([0, 0], [0, nf])
     tp_d, f0_d, vuv_d = rt.to_device(tp), rt.to_device(f0), rt.to_device(vuv)
-    spec_d = rt.to_device(np.ascontiguousarray(spectrogram.T))
-    ap_d = rt.to_device(np.ascontiguousarray(aperiodicity.T))
+    # (bins, frames) as the reference holds them -> frame-major on the device: uploaded as they lie, transposed there (a
+    # strided host copy of the two 3.8 MB arrays was ~2 ms of this call's 3.4)
+    spec_d = rt.to_device(spectrogram).transpose(0, 1).contiguous()
+    ap_d = rt.to_device(aperiodicity).transpose(0, 1).contiguous()
     cap = safe_pulse_cap([ny])
     counts, draws = synthesis_plan(rt, batch, tp_d, f0_d, vuv_d, fs, [ny], [t0], [dt], cap)
     assert counts[0] > 0  # world/synthesis.py:131

@@ -125,8 +125,8 @@ def synthesisRequiem(source_object, filter_object, seeds_signals):
     geo = [time_axis_params(tp, fs)]
     batch = rt.make_batch([0, 0], [0, len(tp)])
     y, _ = synthesis_requiem_core(rt, batch, rt.to_device(tp), rt.to_device(f0), rt.to_device(vuv),
-                                  rt.to_device(np.ascontiguousarray(spectrogram.T)),
-                                  rt.to_device(np.ascontiguousarray(band.T)), fs, fft_size, geo,
+                                  rt.to_device(spectrogram).transpose(0, 1).contiguous(),
+                                  rt.to_device(band).transpose(0, 1).contiguous(), fs, fft_size, geo,
                                   [int((tp[1] - tp[0]) * fs)], seeds_signals,
                                   np.array([generate_noise.current_index]), pulse_cap=safe_pulse_cap([geo[0][0]]))
     rt.check_flags("synthesisRequiem")

@@ -1399,81 +1399,139 @@ __device__ __forceinline__ void bracket(const double* __restrict__ tp, int64_t n
   *il = *ih - 1;
 }
 
-__global__ __launch_bounds__(256) void req_noise_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
-                                                        const double* __restrict__ tp, const double* __restrict__ lin,
-                                                        int nb, const double* __restrict__ noise_seed, int64_t nlen,
-                                                        double* __restrict__ exc) {
+// Per pulse: the gain sqrt(max(1, next index - this one)) — 0 for a pulse the reference skips (unvoiced at its sample, or
+// lowest-band aperiodicity above 0.999, synthesisRequiem.py:55) — and the band weights 1 - ap_b at the pulse's sample
+// (synthesisRequiem.py:57-60,66-71).  One thread per pulse: the chain of dependent look-ups (pulse index, voicing,
+// bracketing frames, band rows) is paid once per pulse here, with no atomics behind it.
+__global__ __launch_bounds__(256) void req_pulse_weights_kernel(const SynUtt* __restrict__ meta, const double* __restrict__ tp,
+                                                                const double* __restrict__ lin, int nb,
+                                                                const int64_t* __restrict__ p_idx,
+                                                                const int32_t* __restrict__ p_count,
+                                                                const uint8_t* __restrict__ vuv_s,
+                                                                double* __restrict__ p_gain, double* __restrict__ p_w) {
   const SynUtt m = meta[blockIdx.y];
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= m.ny) return;
-  const double t = m.t0 + (double)i * m.dt;
-  const double* tpu = tp + m.f_off;
-  int64_t il, ih;
-  bracket(tpu, m.nf, t, &il, &ih);
-  const double dx = tpu[ih] - tpu[il];
-  double acc = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    const double y_lo = lin[(m.f_off + il) * nb + b], y_hi = lin[(m.f_off + ih) * nb + b];
-    const double ap = (y_hi - y_lo) / dx * (t - tpu[il]) + y_lo;
-    const int64_t pos = (rq[blockIdx.y].cursor[b] + i) % nlen;
-    acc += noise_seed[pos * nb + b] * ap;
-  }
-  exc[m.y_off + i] = acc;
-}
-
-__global__ __launch_bounds__(256) void req_pulse_kernel(const SynUtt* __restrict__ meta, const double* __restrict__ tp,
-                                                        const double* __restrict__ lin, int nb,
-                                                        const double* __restrict__ pulse_seed, int pfft,
-                                                        const int64_t* __restrict__ p_idx, const int32_t* __restrict__ p_count,
-                                                        const int64_t* __restrict__ p_base, int n_utt,
-                                                        const uint8_t* __restrict__ vuv_s, double* __restrict__ exc) {
-  // One WAVE per pulse: a pulse starts with a chain of a dozen dependent look-ups (utterance, pulse index, voicing,
-  // bracketing frames, band weights) before its 512 adds; four independent chains per workgroup hide each other
-  // better than one (0.37 -> 0.34 ms at config 4; what remains is the rate of the 37 M global atomic adds).
-  const int64_t total = p_base[n_utt];
-  const int lane = threadIdx.x & 63;
-  for (int64_t gp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); gp < total; gp += (int64_t)gridDim.x * 4) {
-    int u;
-    {
-      int lo = 0, hi = n_utt;
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (p_base[mid] <= gp) lo = mid; else hi = mid;
-      }
-      u = lo;
-    }
-    const SynUtt m = meta[u];
-    const int i = (int)(gp - p_base[u]);
-    const int count = p_count[u];
-    const int64_t pidx = p_idx[m.p_off + i];
-    int64_t p = pidx - 1;
-    p = p < 0 ? 0 : (p > m.ny - 1 ? m.ny - 1 : p);
-    if (vuv_s[m.y_off + p] == 0) continue;
+  const int count = p_count[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const int64_t pidx = p_idx[m.p_off + i];
+  int64_t p = pidx - 1;
+  p = p < 0 ? 0 : (p > m.ny - 1 ? m.ny - 1 : p);
+  double gain = 0.0;
+  if (vuv_s[m.y_off + p] != 0) {
     const double t = m.t0 + (double)p * m.dt;
     const double* tpu = tp + m.f_off;
     int64_t il, ih;
     bracket(tpu, m.nf, t, &il, &ih);
     const double dx = tpu[ih] - tpu[il];
-    double w[8];
+    double w0 = 0.0;
     for (int b = 0; b < nb; ++b) {
       const double y_lo = lin[(m.f_off + il) * nb + b], y_hi = lin[(m.f_off + ih) * nb + b];
-      w[b] = (y_hi - y_lo) / dx * (t - tpu[il]) + y_lo;
+      const double w = (y_hi - y_lo) / dx * (t - tpu[il]) + y_lo;
+      if (b == 0) w0 = w;
+      p_w[(m.p_off + i) * nb + b] = 1 - w;
     }
-    if (w[0] > 0.999) continue;  // synthesisRequiem.py:55
-    const int64_t nxt = p_idx[m.p_off + (i + 1 < count ? i + 1 : count - 1)];
-    const int64_t ns = nxt - pidx;
-    const double gain = sqrt((double)(ns > 1 ? ns : 1));
-    double* eu = exc + m.y_off;
-    for (int mm = lane; mm < pfft; mm += 64) {
-      double r = 0.0;
-      for (int b = 0; b < nb; ++b) r += pulse_seed[(int64_t)mm * nb + b] * (1 - w[b]);
-      r *= gain;
-      const int64_t tgt = pidx - pfft / 2 + 1 + mm;  // 1-based
-      if (tgt < 1) continue;
-      if (tgt < m.ny) atomicAdd(&eu[tgt - 1], r);
-      else if (mm == pfft - 1) atomicAdd(&eu[m.ny - 1], r);
+    if (!(w0 > 0.999)) {
+      const int64_t nxt = p_idx[m.p_off + (i + 1 < count ? i + 1 : count - 1)];
+      const int64_t ns = nxt - pidx;
+      gain = sqrt((double)(ns > 1 ? ns : 1));
     }
   }
+  p_gain[m.p_off + i] = gain;
+}
+
+// First pulse of an utterance at or behind 1-based index `lo` (its pulse indices are ascending): a 64-ary search by the
+// whole wave — probes at 64 evenly spaced pulses, a ballot, the same again inside the bracket — two rounds of loads for
+// the few thousand pulses of an utterance where a bisection takes twelve dependent ones.  Wave-uniform.
+__device__ __forceinline__ int first_pulse_at(const int64_t* __restrict__ pi, int count, int64_t lo) {
+  const int lane = threadIdx.x & 63;
+  int base = 0, n = count;  // the answer is in [base, base + n]
+  while (n > 0) {
+    const int stride = (n + 63) / 64;
+    const int idx = base + lane * stride;
+    const bool below = idx < base + n && pi[idx] < lo;
+    const int c = __popcll(__ballot(below));  // the probes are ascending: the first c of them are below
+    if (stride == 1) {
+      base += c;
+      break;
+    }
+    if (c == 0) break;  // pi[base] >= lo
+    const int nb_ = base + (c - 1) * stride + 1;
+    const int left = base + n - nb_;
+    n = stride - 1 < left ? stride - 1 : left;
+    base = nb_;
+  }
+  return base;
+}
+
+// The excitation signal (synthesisRequiem.py:27-63), one thread per output sample: the aperiodic component (band noises
+// weighted by the interpolated aperiodicities) plus the periodic one GATHERED from the pulses whose 512-tap band-mixed
+// seed covers the sample, in pulse order — the order in which the reference accumulates them, so the sum is the
+// reference's, bit for bit, and the same from run to run.  (The scatter form, one wave per pulse adding its taps with
+// atomics on top of the noise, was bound by the rate of those atomics: 5.4 + 1.2 ms for the two kernels at 1024
+// utterances.)  The reference's clipped fancy-index assignment (Q8) keeps, of the taps that fall before the first or
+// behind the last sample, only the LAST one written: taps before sample 1 are dropped (the in-range tap of index 1 is
+// written after them), and the last sample receives the last tap of every pulse that reaches it or beyond.
+__global__ __launch_bounds__(256) void req_excite_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
+                                                         const double* __restrict__ tp, const double* __restrict__ lin,
+                                                         int nb, const double* __restrict__ noise_seed, int64_t nlen,
+                                                         const double* __restrict__ pulse_seed, int pfft,
+                                                         const int64_t* __restrict__ p_idx, const int32_t* __restrict__ p_count,
+                                                         const double* __restrict__ p_gain, const double* __restrict__ p_w,
+                                                         double* __restrict__ exc) {
+  const SynUtt m = meta[blockIdx.y];
+  const int64_t n0 = (int64_t)blockIdx.x * 256;
+  if (n0 >= m.ny) return;
+  const int count = p_count[blockIdx.y];
+  const int64_t* pi = p_idx + m.p_off;
+  const double* pg = p_gain + m.p_off;
+  const double* pw = p_w + m.p_off * nb;
+  // pulses whose taps reach this tile: index in [first sample - pfft/2, last sample + pfft/2 - 1] (1-based)
+  const int64_t lo = n0 + 1 - pfft / 2, hi = n0 + 256 + pfft / 2 - 1;
+  const int k0 = first_pulse_at(pi, count, lo);
+  const int k_end = first_pulse_at(pi, count, m.ny - pfft / 2);  // first pulse whose last tap reaches the last sample
+  const int64_t i = n0 + threadIdx.x;
+  if (i >= m.ny) return;
+  const int64_t tgt = i + 1;
+  double periodic = 0.0;
+  // (the pulse records are read with scalar loads, the same for every thread of the tile; staging the tile's pulses in
+  // LDS first — one round of coalesced loads, two barriers — is slower: 3.77 against 3.45 ms at 1024 utterances)
+  if (tgt < m.ny) {
+    for (int k = k0; k < count; ++k) {
+      const int64_t pidx = pi[k];
+      if (pidx > hi) break;
+      const double gain = pg[k];
+      if (gain == 0.0) continue;
+      const int64_t mm = tgt - pidx + pfft / 2 - 1;
+      if (mm >= 0 && mm < pfft) {
+        double r = 0.0;
+        for (int b = 0; b < nb; ++b) r += pulse_seed[mm * nb + b] * pw[(int64_t)k * nb + b];
+        periodic += r * gain;
+      }
+    }
+  } else {
+    for (int k = k_end; k < count; ++k) {
+      const double gain = pg[k];
+      if (gain == 0.0) continue;
+      double r = 0.0;
+      for (int b = 0; b < nb; ++b) r += pulse_seed[(int64_t)(pfft - 1) * nb + b] * pw[(int64_t)k * nb + b];
+      periodic += r * gain;
+    }
+  }
+  const double t = m.t0 + (double)i * m.dt;
+  const double* tpu = tp + m.f_off;
+  int64_t il, ih;
+  bracket(tpu, m.nf, t, &il, &ih);
+  const double dx = tpu[ih] - tpu[il];
+  double aperiodic = 0.0;
+  const bool nlen_pow2 = (nlen & (nlen - 1)) == 0;
+  for (int b = 0; b < nb; ++b) {
+    const double y_lo = lin[(m.f_off + il) * nb + b], y_hi = lin[(m.f_off + ih) * nb + b];
+    const double ap = (y_hi - y_lo) / dx * (t - tpu[il]) + y_lo;
+    const int64_t at = rq[blockIdx.y].cursor[b] + i;  // circular read of the band's noise seed (synthesisRequiem.py:131-141)
+    const int64_t pos = nlen_pow2 ? (at & (nlen - 1)) : at % nlen;  // (the default table lengths are powers of two)
+    aperiodic += noise_seed[pos * nb + b] * ap;
+  }
+  exc[m.y_off + i] = periodic + aperiodic;  // synthesisRequiem.py:62
 }
 
 template <int N>
@@ -1898,9 +1956,9 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   const size_t o_pn = off; off += al(sizeof(int64_t) * B * pulse_cap);
   const size_t o_pc = off; off += al(sizeof(int32_t) * B);
   const size_t o_px = off; off += pulse_scratch_bytes(B, max_ny);
-  const size_t o_pb = off; off += al(sizeof(int64_t) * (B + 1));
   const size_t o_lin = off; off += al(sizeof(double) * F * n_bands);
   const size_t o_exc = off; off += al(sizeof(double) * ny_tot);
+  const size_t o_pw = off; off += al(sizeof(double) * B * pulse_cap * n_bands);  // band weights per pulse (the gains reuse o_pt)
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
   SynUtt* d_meta = nullptr;
@@ -1912,9 +1970,9 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   double* d_ps = reinterpret_cast<double*>(ws + o_ps);
   int64_t* d_pn = reinterpret_cast<int64_t*>(ws + o_pn);
   int32_t* d_pc = reinterpret_cast<int32_t*>(ws + o_pc);
-  int64_t* d_pb = reinterpret_cast<int64_t*>(ws + o_pb);
   double* d_lin = reinterpret_cast<double*>(ws + o_lin);
   double* d_exc = reinterpret_cast<double*>(ws + o_exc);
+  double* d_pw = reinterpret_cast<double*>(ws + o_pw);
   if (int rc = wh::persistent_upload(ctx, st, "syn.meta", meta, &d_meta)) return rc;
   if (int rc = wh::persistent_upload(ctx, st, "syn.req", rq, &d_rq)) return rc;
   WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
@@ -1922,18 +1980,12 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   WH_LAUNCH_CHECK("prep_kernel");
   if (int rc = exact_cumsum_segments(ctx, st, d_phase, h_y_off, B)) return rc;
   if (int rc = launch_pulses(ctx, st, B, max_ny, d_meta, d_phase, fs, d_pt, d_pi, d_ps, d_pn, d_pc, ws + o_px)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "pulse_base_kernel"); hipLaunchKernelGGL(pulse_base_kernel, dim3(1), dim3(64), 0, st, d_pc, B, d_pb); }
-  WH_LAUNCH_CHECK("pulse_base_kernel");
   { wh::KernelTimer _kt(ctx, st, "req_linap_kernel"); hipLaunchKernelGGL(req_linap_kernel, dim3((unsigned)((F * n_bands + 255) / 256)), dim3(256), 0, st, band_aperiodicity, F * n_bands, d_lin); }
   WH_LAUNCH_CHECK("req_linap_kernel");
-  { wh::KernelTimer _kt(ctx, st, "req_noise_kernel"); hipLaunchKernelGGL(req_noise_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, d_rq, tp, d_lin, n_bands, noise_seed, noise_len, d_exc); }
-  WH_LAUNCH_CHECK("req_noise_kernel");
-  {
-    int64_t grid = pulse_cap * B;
-    if (grid > 256 * 16) grid = 256 * 16;
-    { wh::KernelTimer _kt(ctx, st, "req_pulse_kernel"); hipLaunchKernelGGL(req_pulse_kernel, dim3((unsigned)grid), dim3(256), 0, st, d_meta, tp, d_lin, n_bands, pulse_seed, pulse_fft, d_pi, d_pc, d_pb, B, d_vuv, d_exc); }
-    WH_LAUNCH_CHECK("req_pulse_kernel");
-  }
+  { wh::KernelTimer _kt(ctx, st, "req_pulse_weights_kernel"); hipLaunchKernelGGL(req_pulse_weights_kernel, dim3((unsigned)((pulse_cap + 255) / 256), B), dim3(256), 0, st, d_meta, tp, d_lin, n_bands, d_pi, d_pc, d_vuv, d_pt, d_pw); }
+  WH_LAUNCH_CHECK("req_pulse_weights_kernel");
+  { wh::KernelTimer _kt(ctx, st, "req_excite_kernel"); hipLaunchKernelGGL(req_excite_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, d_rq, tp, d_lin, n_bands, noise_seed, noise_len, pulse_seed, pulse_fft, d_pi, d_pc, d_pt, d_pw, d_exc); }
+  WH_LAUNCH_CHECK("req_excite_kernel");
   switch (fft_size) {
     case 512: return launch_req_filter<512>(ctx, st, B, max_nf, d_meta, d_rq, spectrogram, d_exc, y);
     case 1024: return launch_req_filter<1024>(ctx, st, B, max_nf, d_meta, d_rq, spectrogram, d_exc, y);

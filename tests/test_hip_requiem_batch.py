@@ -54,6 +54,32 @@ def test_batched_requiem_decode_matches_chained_oracle(method):
     assert wb.rt.take_flags() == [0] * 16
 
 
+def test_requiem_decode_with_a_noise_table_that_is_not_a_power_of_two():
+    """The circular read of the band noises (synthesisRequiem.py:131-141) takes the index modulo the table length; the
+    default lengths are powers of two (a mask on the device), any other length takes the general path.  Short
+    utterances with a low pitch also put pulses within half a seed length of both ends, where the reference's clipped
+    fancy-index assignment keeps only the last tap written (the gathered excitation reproduces that per sample)."""
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+    from world.get_seeds_signals import get_seeds_signals
+
+    fs = 16000
+    xs = [synth_utterance(70 + i, fs, s) for i, s in enumerate((0.31, 0.52, 0.2))]
+    random.seed(11)
+    np.random.seed(11)
+    seeds = get_seeds_signals(fs, noise_length=6000)
+    assert seeds['noise'].shape[0] == 6000
+    wb = WorldBatch()
+    enc = wb.encode(xs, fs, f0_method="dio", is_requiem=True)
+    start = np.tile(np.array([5990.0, 17.0, 3000.0]), (len(xs), 1))[:, :seeds['noise'].shape[1]]
+    y, y_off = wb.decode_device(enc, seeds=seeds, cursor=start[0])
+    y = y.cpu().numpy()
+    ref, _ = _oracle_chain(enc.to_dicts(), fs, seeds, cursor=start[0].copy())
+    for u in range(len(xs)):
+        assert rel_rms(y[y_off[u]:y_off[u + 1]], ref[u]) < 1e-8, u
+    assert wb.rt.take_flags() == [0] * 16
+
+
 def test_batched_requiem_decode_after_modifiers_and_vs_single():
     """scale_pitch / scale_duration on the resident encoding, then the batched decode: per-utterance hops and
     output lengths follow the host formulas (Q9, Q11) and each utterance equals the single-utterance drop-in."""

@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
 
 // RemoveUnreliableCandidates (harvest.py:215-234): a candidate survives if some candidate of frame j-1
 // or j+1 lies within 5 %.  A workgroup takes kPruneFrames consecutive frames: the candidate lists of those frames and
-// their two outer neighbours are fetched once (one wave per frame), their non-zero entries compacted into LDS (ballot
+// their two outer neighbours are fetched once (half a wave per frame), their non-zero entries compacted into LDS (ballot
 // ranks), then every list entry is tested against the non-zero entries of its two neighbours.  (One 128-thread workgroup
 // per frame — 640 k of them for 64 x 10 s — was bound by the rate at which workgroups can be launched, and read every
 // frame three times.)
@@ -1146,21 +1146,27 @@ constexpr int kPruneFrames = 16;
 // score array and pruned copies.
 __global__ __launch_bounds__(256) void hv_prune_kernel(const HvUtt* __restrict__ meta, const double* __restrict__ rf0,
                                                        const int64_t* __restrict__ lst, uint32_t* __restrict__ keep) {
-  __shared__ double nzl[kPruneFrames + 2][kRows];  // non-zero candidates of frames f_first-1 .. f_first+16
+  constexpr int kRowPad = 128;                              // a row of nzl: the non-zero entries, then +inf
+  __shared__ double nzl[kPruneFrames + 2][kRowPad];         // non-zero candidates of frames f_first-1 .. f_first+16
   __shared__ int ln[kPruneFrames + 2];
+  static_assert(kRows <= kRowPad, "row padding");
   const HvUtt m = meta[blockIdx.y];
   const int64_t f_first = (int64_t)blockIdx.x * kPruneFrames;
   if (f_first >= m.nf1) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // a wave's frames (4-5 of the 18) are fetched together: the list heads first, then every list — independent loads in
-  // flight before the first ballot needs one.  Entry k of a list sits on lane k & 63 (pass k >> 6) and stays there: the
-  // wave that fetched a frame also tests it.
-  constexpr int kPer = (kPruneFrames + 2 + 3) / 4;
-  constexpr int kPass = (kRows + 63) / 64;
+  // HALF a wave per frame: a list holds ~17 entries on speech-like input (105 at most), so with a whole wave per frame
+  // three lanes in four idled through the neighbour loops; a half-wave takes entries l32 + 32 * pass, and a pass that
+  // neither of the wave's two frames reaches is skipped.  The eight half-waves take rows hw, hw + 8, hw + 16 of the 18.
+  const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+  const int hw = (threadIdx.x >> 6) * 2 + half;
+  constexpr int kPer = (kPruneFrames + 2 + 7) / 8;
+  constexpr int kPass = (kRows + 31) / 32;
+  for (int i = threadIdx.x; i < (kPruneFrames + 2) * kRowPad; i += 256) (&nzl[0][0])[i] = INFINITY;
+  // the list heads first, then every list — independent loads in flight before the first ballot needs one.  Entry k of
+  // a list sits on lane k & 31 of its half (pass k >> 5) and stays there: the half-wave that fetched a frame also tests it.
   int64_t ent[kPer];
 #pragma unroll
   for (int i = 0; i < kPer; ++i) {
-    const int fr = w + 4 * i;
+    const int fr = hw + 8 * i;
     const int64_t f = f_first - 1 + fr;
     const bool ok = fr < kPruneFrames + 2 && f >= 0 && f < m.nf1;
     ent[i] = ok ? lst[m.f1_off + f] : 0;
@@ -1172,54 +1178,60 @@ __global__ __launch_bounds__(256) void hv_prune_kernel(const HvUtt* __restrict__
     const int n = (int)(ent[i] & 255);
 #pragma unroll
     for (int pass = 0; pass < kPass; ++pass) {
-      const int e = lane + 64 * pass;
+      const int e = l32 + 32 * pass;
       val[i][pass] = e < n ? src[e] : 0.0;
     }
   }
+  __syncthreads();  // (the +inf fill is complete)
 #pragma unroll
   for (int i = 0; i < kPer; ++i) {
-    const int fr = w + 4 * i;
-    if (fr < kPruneFrames + 2) {
-      int n = 0;
+    const int fr = hw + 8 * i;
+    const bool row = fr < kPruneFrames + 2;
+    int n = 0;
 #pragma unroll
-      for (int pass = 0; pass < kPass; ++pass) {
-        const double a = val[i][pass];
-        const unsigned long long nz = __ballot(a != 0.0);  // zeros can never be the nearest candidate
-        if (a != 0.0) nzl[fr][n + __popcll(nz & ((1ull << lane) - 1))] = a;
-        n += __popcll(nz);
-      }
-      if (lane == 0) ln[fr] = n;
+    for (int pass = 0; pass < kPass; ++pass) {
+      const double a = val[i][pass];
+      const unsigned long long nz64 = __ballot(a != 0.0);  // zeros can never be the nearest candidate
+      const uint32_t nz = (uint32_t)(nz64 >> (32 * half));
+      if (row && a != 0.0) nzl[fr][n + __popc(nz & ((1u << l32) - 1u))] = a;
+      n += __popc(nz);
     }
+    if (row && l32 == 0) ln[fr] = n;
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < kPer; ++i) {
-    const int fr = w + 4 * i;
+    const int fr = hw + 8 * i;
     const int64_t f = f_first - 1 + fr;
-    if (fr < 1 || fr > kPruneFrames || f >= m.nf1) continue;  // (wave-uniform) rows 0 and 17 are neighbours only
-    const bool inner = f >= 1 && f <= m.nf1 - 2;
-    const int n_prev = ln[fr - 1], n_next = ln[fr + 1];
-    const double* nb_prev = nzl[fr - 1];
-    const double* nb_next = nzl[fr + 1];
+    const bool valid = fr >= 1 && fr <= kPruneFrames && f < m.nf1;  // rows 0 and 17 are neighbours only
+    const bool inner = valid && f >= 1 && f <= m.nf1 - 2;
+    const int n_prev = valid ? ln[fr - 1] : 0, n_next = valid ? ln[fr + 1] : 0;
+    const double* nb_prev = nzl[valid ? fr - 1 : 0];
+    const double* nb_next = nzl[valid ? fr + 1 : 0];
+    // loop bounds and the pass count of the wave: the larger of its two halves' (a half that reads past its own row's
+    // entries reads +inf, which no minimum takes)
+    const int cnt = valid ? (int)(ent[i] & 255) : 0;
+    const int t_next = max(__builtin_amdgcn_readlane(n_next, 0), __builtin_amdgcn_readlane(n_next, 32));
+    const int t_prev = max(__builtin_amdgcn_readlane(n_prev, 0), __builtin_amdgcn_readlane(n_prev, 32));
+    const int t_cnt = max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 32));
 #pragma unroll
     for (int pass = 0; pass < kPass; ++pass) {
       double v = val[i][pass];
-      if (inner && v != 0.0) {
-        double e1 = 1.0, e2 = 1.0;  // SelectBestF0 with allowed_range = 1 (a zero candidate gives exactly 1)
-        // min_k |v - nb_k| / v == (min_k |v - nb_k|) / v bit for bit (division by v > 0 is monotone): one divide per
-        // neighbour frame instead of one per neighbour candidate
-        double d1 = INFINITY, d2 = INFINITY;
-        for (int k = 0; k < n_next; ++k) d1 = fmin(d1, fabs(v - nb_next[k]));
-        for (int k = 0; k < n_prev; ++k) d2 = fmin(d2, fabs(v - nb_prev[k]));
-        if (n_next > 0) e1 = fmin(e1, d1 / v);
-        if (n_prev > 0) e2 = fmin(e2, d2 / v);
-        if (fmin(e1, e2) > 0.05) v = 0.0;
+      if (32 * pass < t_cnt) {
+        if (inner && v != 0.0) {
+          double e1 = 1.0, e2 = 1.0;  // SelectBestF0 with allowed_range = 1 (a zero candidate gives exactly 1)
+          // min_k |v - nb_k| / v == (min_k |v - nb_k|) / v bit for bit (division by v > 0 is monotone): one divide per
+          // neighbour frame instead of one per neighbour candidate
+          double d1 = INFINITY, d2 = INFINITY;
+          for (int k = 0; k < t_next; ++k) d1 = fmin(d1, fabs(v - nb_next[k]));
+          for (int k = 0; k < t_prev; ++k) d2 = fmin(d2, fabs(v - nb_prev[k]));
+          if (n_next > 0) e1 = fmin(e1, d1 / v);
+          if (n_prev > 0) e2 = fmin(e2, d2 / v);
+          if (fmin(e1, e2) > 0.05) v = 0.0;
+        }
       }
       const unsigned long long kept = __ballot(v != 0.0);
-      if (lane == 0) {
-        keep[(m.f1_off + f) * 4 + 2 * pass] = (uint32_t)kept;
-        keep[(m.f1_off + f) * 4 + 2 * pass + 1] = (uint32_t)(kept >> 32);
-      }
+      if (valid && l32 == 0) keep[(m.f1_off + f) * 4 + pass] = (uint32_t)(kept >> (32 * half));
     }
   }
 }

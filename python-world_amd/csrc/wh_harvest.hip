@@ -401,6 +401,9 @@ __device__ __forceinline__ double np_sum_strided(const double* __restrict__ a, i
   return res;
 }
 
+#ifndef WH_HV_DETECT_STAGE
+#define WH_HV_DETECT_STAGE 1
+#endif
 // The channel walk reads hv_raw's byte map (1 = a candidate survived the band's range test) instead of the candidates
 // themselves — an eighth of the bytes of a pass that runs at HBM speed — and fetches the values only for the runs that
 // count.
@@ -409,8 +412,9 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
                                                         const uint8_t* __restrict__ live_map, double* __restrict__ dc,
                                                         int32_t* __restrict__ dcount) {
   const HvUtt m = meta[blockIdx.y];
-  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (f >= m.nf1) return;
+  const int64_t f_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live_f = f_raw < m.nf1;  // (every thread stays for the block's output pass)
+  const int64_t f = live_f ? f_raw : m.nf1 - 1;
   const double* col = raw + m.f1_off * nb + f;  // element b at col[b * nf1]
   const uint8_t* lcol = live_map + m.f1_off * nb + f;
   double* out = dc + (m.f1_off + f) * kMaxC;
@@ -441,6 +445,28 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
       prev = live;
     }
   }
+#if WH_HV_DETECT_STAGE
+  // The kMaxC slots of a frame are 120 bytes apart: written from the walk's lanes, every store instruction touched 64
+  // cache lines.  They are collected in LDS (dense rows: an odd stride in doubles, conflict-free both ways) and leave as one
+  // contiguous block per workgroup.
+  __shared__ double s_out[256 * kMaxC];
+  for (int c = 0; c < kMaxC; ++c) {
+    double val = 0.0;
+    if (live_f && c < count) {
+      const int rr = runs[c][threadIdx.x];
+      const int n = rr & 0xff;
+      val = np_sum_strided(col + (int64_t)(rr >> 8) * m.nf1, m.nf1, n) / (double)n;
+    }
+    s_out[threadIdx.x * kMaxC + c] = val;
+  }
+  if (live_f) dcount[m.f1_off + f] = count;
+  __syncthreads();
+  const int64_t f_blk = (int64_t)blockIdx.x * 256;
+  const int n_blk = (int)(m.nf1 - f_blk < 256 ? m.nf1 - f_blk : 256);
+  double* ob = dc + (m.f1_off + f_blk) * kMaxC;
+  for (int q = threadIdx.x; q < n_blk * kMaxC; q += 256) ob[q] = s_out[q];
+#else
+  if (!live_f) return;
   for (int c = 0; c < kMaxC; ++c) {
     double val = 0.0;
     if (c < count) {
@@ -451,6 +477,7 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
     out[c] = val;
   }
   dcount[m.f1_off + f] = count;
+#endif
 }
 
 // ---- candidate refinement ------------------------------------------------------------------------

@@ -249,12 +249,18 @@ constexpr int kOlsPer = kOlsValid / 256;
 // channel of a one-channel workgroup fetches its own copy of each tile spectrum (54.5 against 52.4 ms).
 constexpr int kOlsBands = 4;  // band_events_ols2_kernel (the pair variant); band_events_ols_kernel is templated on it
 
-// T_b = rfft(taps_b zero-padded to kOlsN): [nb][kOlsN/2+1] complex
+// T_b = rfft(taps_b zero-padded to kOlsN): [nb][kOlsN/2+1] complex (the fused front end's product), and
+// R_b = the same transform of the taps rotated so that their centre tap sits at index 0: [nb][kOlsN/2+1] REAL.  A band
+// filter is symmetric about its centre tap (a Nuttall window times a cosine, harvest.py:253-256), so the rotated
+// sequence is even and its spectrum real — the imaginary parts are the taps' rounding asymmetry, ~1e-17 of the
+// passband, and are dropped.  The channel walker multiplies the tile spectrum by R_b: a real factor per bin instead of a
+// complex one (half the operands to fetch and keep in registers, a third of the product's arithmetic), and reads its
+// outputs half a filter length earlier (the rotation advances the output by `half` samples).
 static __global__ __launch_bounds__(256) void band_taps_fft_kernel(const double* __restrict__ taps_all,
                                                                    const int32_t* __restrict__ tap_off,
                                                                    const int32_t* __restrict__ tap_len,
                                                                    const double2* __restrict__ tw_base,
-                                                                   double2* __restrict__ tspec) {
+                                                                   double2* __restrict__ tspec, double* __restrict__ tre) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* buf = reinterpret_cast<double*>(smem);
   const int b = blockIdx.x;
@@ -264,6 +270,16 @@ static __global__ __launch_bounds__(256) void band_taps_fft_kernel(const double*
   rfft_lds<kOlsN, 256>(reinterpret_cast<double2*>(buf), tw_base);
   const double2* z = reinterpret_cast<const double2*>(buf);
   for (int k = threadIdx.x; k <= kOlsN / 2; k += 256) tspec[(int64_t)b * (kOlsN / 2 + 1) + k] = z[k];
+  if (!tre) return;
+  __syncthreads();
+  const int hb = (lb - 1) / 2;  // the centre tap
+  for (int i = threadIdx.x; i < kOlsN; i += 256) {
+    const int j = (i + hb) & (kOlsN - 1);  // rotated[i] = taps[i + hb] for i <= hb, taps[i + hb - N] for i >= N - hb
+    buf[i] = j < lb && (i <= hb || i >= kOlsN - hb) ? taps_all[tap_off[b] + j] : 0.0;
+  }
+  __syncthreads();
+  rfft_lds<kOlsN, 256>(reinterpret_cast<double2*>(buf), tw_base);
+  for (int k = threadIdx.x; k <= kOlsN / 2; k += 256) tre[(int64_t)b * (kOlsN / 2 + 1) + k] = z[k].x;
 }
 
 // Z_{u,tile} = rfft(z_u[t0 - H .. t0 - H + kOlsN)), t0 = tile * kOlsValid (samples outside the padded signal are 0)
@@ -294,14 +310,14 @@ static __global__ __launch_bounds__(256) void band_tile_fft_kernel(const BandJob
 template <int kOlsBands>
 static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kernel(const BandJob* __restrict__ jobs, int nb, int H,
                                                                      const int32_t* __restrict__ half,
-                                                                     const double2* __restrict__ tspec,
+                                                                     const double* __restrict__ tspec,
                                                                      const double2* __restrict__ zspec,
                                                                      const int64_t* __restrict__ tile_off,
                                                                      const double2* __restrict__ tw_base,
                                                                      int32_t* __restrict__ flags,
                                                                      const int32_t* __restrict__ gate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KS = kOlsN / 2 + 1;           // 2049 spectrum bins
+  constexpr int KS = kOlsN / 2 + 1;           // 2049 spectrum bins (tspec: the REAL tap spectra, band_taps_fft_kernel)
   double2* ybuf = reinterpret_cast<double2*>(smem);
   double* sig_all = reinterpret_cast<double*>(smem);
   unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(ybuf + KS + 1);  // 8
@@ -338,7 +354,18 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
   constexpr int NH = kOlsN / 2;
   constexpr int PQ = NH / 2 / 256;  // 4 bin pairs per thread
   constexpr int SLOTS = 2 * PQ + 1;
-  double2 zr[SLOTS], tr[SLOTS];
+  double2 zr[SLOTS];
+  double tr[SLOTS];
+  auto load_taps = [&](double (&dst)[SLOTS], const double* src) {
+    const int tid = WH_TID;
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+      const int k = tid + q * 256;
+      dst[2 * q] = src[k];
+      dst[2 * q + 1] = src[NH - k];
+    }
+    dst[2 * PQ] = src[NH / 2];
+  };
   auto load_spec = [&](double2 (&dst)[SLOTS], const double2* src) {
     // (the thread index read opaquely: as loop invariants the eight per-thread offsets were kept in registers across
     // the whole walk, spilled, and every prefetch load then waited for the scratch load of its own address)
@@ -353,7 +380,15 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
   };
 #else
   constexpr int PER = (KS + 255) / 256;  // 9 per thread
-  double2 zr[PER], tr[PER];
+  double2 zr[PER];
+  double tr[PER];
+  auto load_taps = [&](double (&dst)[PER], const double* src) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int k = threadIdx.x + q * 256;
+      dst[q] = k < KS ? src[k] : 0.0;
+    }
+  };
   auto load_spec = [&](double2 (&dst)[PER], const double2* src) {
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
@@ -362,9 +397,10 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
     }
   };
 #endif
+  auto scale = [](double2 z, double t) { return make_double2(z.x * t, z.y * t); };
   const int n_ch = nb - b0 < kOlsBands ? nb - b0 : kOlsBands;
   load_spec(zr, zspec + tile_off[u] * KS);
-  load_spec(tr, tspec + (int64_t)b0 * KS);
+  load_taps(tr, tspec + (int64_t)b0 * KS);
 #pragma unroll 1
   for (int64_t tile = 0; tile < tiles; ++tile) {
     const int64_t t0 = tile * kOlsValid;
@@ -390,7 +426,7 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
           const int k = threadIdx.x + q * 256;
-          double2 a = cmul(zr[2 * q], tr[2 * q]), bb = cmul(zr[2 * q + 1], tr[2 * q + 1]);
+          double2 a = scale(zr[2 * q], tr[2 * q]), bb = scale(zr[2 * q + 1], tr[2 * q + 1]);
           if (k == 0) {  // DC and Nyquist bins: only their real parts reach a real output
             a.y = 0.0;
             bb.y = 0.0;
@@ -401,7 +437,7 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
           if (k != 0) ybuf[NH - k] = hi;
         }
         if (threadIdx.x == 0) {  // k = N/4 pairs with itself; irfft_lds leaves the second of its two stores there
-          const double2 a = cmul(zr[2 * PQ], tr[2 * PQ]);
+          const double2 a = scale(zr[2 * PQ], tr[2 * PQ]);
           double2 lo, hi;
           fold(a, a, ldg2(w + NH / 2), &lo, &hi);
           ybuf[NH / 2] = hi;
@@ -413,19 +449,20 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int k = threadIdx.x + q * 256;
-        if (k < KS) ybuf[k] = cmul(zr[q], tr[q]);
+        if (k < KS) ybuf[k] = scale(zr[q], tr[q]);
       }
       sync_lds<256>();
       irfft_lds<kOlsN, 256>(ybuf, tw_base);
 #endif
       if (g + 1 < n_ch) {
-        load_spec(tr, tspec + (int64_t)(b + 1) * KS);
+        load_taps(tr, tspec + (int64_t)(b + 1) * KS);
       } else {
-        if (kOlsBands > 1) load_spec(tr, tspec + (int64_t)b0 * KS);  // (a single channel's tap spectrum never leaves the registers)
+        if (kOlsBands > 1) load_taps(tr, tspec + (int64_t)b0 * KS);  // (a single channel's tap spectrum never leaves the registers)
         if (tile + 1 < tiles) load_spec(zr, zspec + (tile_off[u] + tile + 1) * KS);
       }
-      // output i of the block is s[t0 + i - (H + h + 1)]: the tile's outputs start at index H + h + 1
-      const double* sig = sig_all + (H + half[b] + 1);
+      // output i of the block is s[t0 + i - (H + 1)]: the tile's outputs start at index H + 1 (H + h + 1 with the taps as
+      // they lie; the zero-phase rotation of band_taps_fft_kernel advances the output by the half length h)
+      const double* sig = sig_all + (H + 1);
       emit_crossings_block<1, kOlsPer>(sig, t0, M, job.edges, job.cap, base_cnt, scan_scratch, flags);
       __syncthreads();
       if (threadIdx.x < 4) s_cnt[g][threadIdx.x] = base_cnt[threadIdx.x];
@@ -521,10 +558,10 @@ static __global__ __launch_bounds__(256, 2) void band_events_ols2_kernel(const B
 inline int launch_band_events_ols(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs, int nb, int n_utt, int pad, int H,
                                   const double* d_taps, const int32_t* d_tap_off, const int32_t* d_tap_len,
                                   const int32_t* d_half, const int64_t* d_tile_off, int64_t max_tiles, double2* d_tspec,
-                                  double2* d_zspec, int32_t* d_flag, const int32_t* d_gate = nullptr,
+                                  double* d_tre, double2* d_zspec, int32_t* d_flag, const int32_t* d_gate = nullptr,
                                   const int32_t* d_gate_ch = nullptr, bool taps_done = false) {
   const size_t lds_fft = sizeof(double) * (kOlsN + 2);
-  if (!taps_done) { KernelTimer _kt(ctx, st, "band_taps_fft_kernel"); hipLaunchKernelGGL(band_taps_fft_kernel, dim3(nb), dim3(256), lds_fft, st, d_taps, d_tap_off, d_tap_len, ctx->d_twiddle, d_tspec); }
+  if (!taps_done) { KernelTimer _kt(ctx, st, "band_taps_fft_kernel"); hipLaunchKernelGGL(band_taps_fft_kernel, dim3(nb), dim3(256), lds_fft, st, d_taps, d_tap_off, d_tap_len, ctx->d_twiddle, d_tspec, d_tre); }
   { KernelTimer _kt(ctx, st, "band_tile_fft_kernel"); hipLaunchKernelGGL(band_tile_fft_kernel, dim3((unsigned)max_tiles, n_utt), dim3(256), lds_fft, st, d_jobs, nb, pad, H, d_tile_off, ctx->d_twiddle, d_zspec, d_gate); }
 #ifndef WH_OLS_PAIR
 #define WH_OLS_PAIR 0  // measured: 7.2 ms against 6.7 ms for the one-channel-per-transform walker at config 3
@@ -539,8 +576,8 @@ inline int launch_band_events_ols(wh_ctx* ctx, hipStream_t st, const BandJob* d_
   const bool single = d_gate_ch || WH_OLS_BANDS == 1 || (WH_OLS_BANDS == 0 && (int64_t)n_utt * ((nb + 3) / 4) < 16 * 3 * 256);
   {
     KernelTimer _kt(ctx, st, "band_events_kernel");
-    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(n_utt, nb), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag, d_gate_ch);
-    else hipLaunchKernelGGL(band_events_ols_kernel<4>, dim3(n_utt, (nb + 3) / 4), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tspec, d_zspec, d_tile_off, ctx->d_twiddle, d_flag, d_gate_ch);
+    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(n_utt, nb), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag, d_gate_ch);
+    else hipLaunchKernelGGL(band_events_ols_kernel<4>, dim3(n_utt, (nb + 3) / 4), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag, d_gate_ch);
   }
 #endif
   hipError_t e = hipGetLastError();

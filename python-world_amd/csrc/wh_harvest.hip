@@ -1400,6 +1400,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t spec_bins = wh::kOlsN / 2 + 1;
   const size_t o_tspec = off; off += use_ols ? al(sizeof(double2) * spec_bins * n_bands) : 0;
   const size_t o_zspec = off; off += use_ols ? al(sizeof(double2) * spec_bins * (size_t)tile_off[B]) : 0;
+  const size_t o_tre = off; off += use_ols ? al(sizeof(double) * spec_bins * n_bands) : 0;  // the real (zero-phase) tap spectra
   // fused front end (wh_harvest_front.h): tiles of frames, each with the block of kOlsN samples centred on it; the
   // lowest channel's valid outputs (kOlsN - 2 h_max - 2 samples) must cover the tile's frames and a margin either side
   // OPT-IN (WH_HV_FRONT=1): exact and five times lighter on HBM, but slower than the chain it replaces — these kernels are
@@ -1503,7 +1504,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     if (int rc = wh::persistent_upload(ctx, st, "hv.tile_geo", tile_geo, &d_geo)) return rc;
     WH_CHECK(hipMemsetAsync(d_gate, 0, sizeof(int32_t) * ((size_t)B + (size_t)B * n_bands), st));
     double2* d_tspec = reinterpret_cast<double2*>(ws + o_tspec);
-    { wh::KernelTimer _kt(ctx, st, "band_taps_fft_kernel"); hipLaunchKernelGGL(wh::band_taps_fft_kernel, dim3(n_bands), dim3(256), sizeof(double) * (wh::kOlsN + 2), st, d_taps, d_ti, d_ti + n_bands, ctx->d_twiddle, d_tspec); }
+    { wh::KernelTimer _kt(ctx, st, "band_taps_fft_kernel"); hipLaunchKernelGGL(wh::band_taps_fft_kernel, dim3(n_bands), dim3(256), sizeof(double) * (wh::kOlsN + 2), st, d_taps, d_ti, d_ti + n_bands, ctx->d_twiddle, d_tspec, reinterpret_cast<double*>(ws + o_tre)); }
     WH_LAUNCH_CHECK("band_taps_fft_kernel");
     const dim3 fgrid((unsigned)front_tiles, B);
     {
@@ -1520,7 +1521,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     if (int rc = wh::persistent_upload(ctx, st, "hv.tile_off", tile_off, &d_tile_off)) return rc;
     if (int rc = wh::launch_band_events_ols(ctx, st, d_jobs, n_bands, B, pad, h_max, d_taps, d_ti, d_ti + n_bands,
                                             d_ti + 2 * n_bands, d_tile_off, max_tiles,
-                                            reinterpret_cast<double2*>(ws + o_tspec), reinterpret_cast<double2*>(ws + o_zspec),
+                                            reinterpret_cast<double2*>(ws + o_tspec), reinterpret_cast<double*>(ws + o_tre), reinterpret_cast<double2*>(ws + o_zspec),
                                             ctx->d_flags + WH_FLAG_EVENT_OVERFLOW, d_gate, d_gate_ch, use_front))
       return rc;
   } else if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands,

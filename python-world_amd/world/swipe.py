@@ -13,7 +13,7 @@ from decimal import ROUND_HALF_UP, Decimal
 
 import numpy as np
 
-from . import _hip, _tables
+from . import _hip
 
 _FINE = 20  # refinement grid slots per candidate (the 1/768-octave grid over two candidate steps has 17-18 points)
 

@@ -286,12 +286,10 @@ static __global__ __launch_bounds__(256) void band_taps_fft_kernel(const double*
 static __global__ __launch_bounds__(256) void band_tile_fft_kernel(const BandJob* __restrict__ jobs, int nb, int pad, int H,
                                                                    const int64_t* __restrict__ tile_off,
                                                                    const double2* __restrict__ tw_base,
-                                                                   double2* __restrict__ zspec,
-                                                                   const int32_t* __restrict__ gate) {
+                                                                   double2* __restrict__ zspec) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* buf = reinterpret_cast<double*>(smem);
   const int u = blockIdx.y;
-  if (gate && !gate[u]) return;  // (gate: only the utterances of which the fused front end handed a channel back)
   const BandJob job = jobs[(int64_t)u * nb];  // z and M are the same for every band of the utterance
   const int64_t tiles = (job.M + kOlsValid - 1) / kOlsValid;
   if ((int64_t)blockIdx.x >= tiles) return;
@@ -314,19 +312,12 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
                                                                      const double2* __restrict__ zspec,
                                                                      const int64_t* __restrict__ tile_off,
                                                                      const double2* __restrict__ tw_base,
-                                                                     int32_t* __restrict__ flags,
-                                                                     const int32_t* __restrict__ gate) {
+                                                                     int32_t* __restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = kOlsN / 2 + 1;           // 2049 spectrum bins (tspec: the REAL tap spectra, band_taps_fft_kernel)
   double2* ybuf = reinterpret_cast<double2*>(smem);
   double* sig_all = reinterpret_cast<double*>(smem);
   unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(ybuf + KS + 1);  // 8
-  if (gate) {  // only the (utterance, channel) pairs the fused front end handed back (wh_harvest_front.h)
-    bool any = false;
-    for (int g = 0; g < kOlsBands; ++g)
-      any = any || (blockIdx.y * kOlsBands + g < nb && gate[(int64_t)blockIdx.x * nb + blockIdx.y * kOlsBands + g] != 0);
-    if (!any) return;
-  }
   // utterance-fastest workgroup order: the workgroups in flight at any time share a few channel groups, so the
   // 33 KB tap spectra they stream stay in every XCD's L2 (channel-fastest, each XCD cycled through all 5 MB of them
   // and half of the 8.6 GB requested per launch came from HBM)
@@ -558,11 +549,10 @@ static __global__ __launch_bounds__(256, 2) void band_events_ols2_kernel(const B
 inline int launch_band_events_ols(wh_ctx* ctx, hipStream_t st, const BandJob* d_jobs, int nb, int n_utt, int pad, int H,
                                   const double* d_taps, const int32_t* d_tap_off, const int32_t* d_tap_len,
                                   const int32_t* d_half, const int64_t* d_tile_off, int64_t max_tiles, double2* d_tspec,
-                                  double* d_tre, double2* d_zspec, int32_t* d_flag, const int32_t* d_gate = nullptr,
-                                  const int32_t* d_gate_ch = nullptr, bool taps_done = false) {
+                                  double* d_tre, double2* d_zspec, int32_t* d_flag) {
   const size_t lds_fft = sizeof(double) * (kOlsN + 2);
-  if (!taps_done) { KernelTimer _kt(ctx, st, "band_taps_fft_kernel"); hipLaunchKernelGGL(band_taps_fft_kernel, dim3(nb), dim3(256), lds_fft, st, d_taps, d_tap_off, d_tap_len, ctx->d_twiddle, d_tspec, d_tre); }
-  { KernelTimer _kt(ctx, st, "band_tile_fft_kernel"); hipLaunchKernelGGL(band_tile_fft_kernel, dim3((unsigned)max_tiles, n_utt), dim3(256), lds_fft, st, d_jobs, nb, pad, H, d_tile_off, ctx->d_twiddle, d_zspec, d_gate); }
+  { KernelTimer _kt(ctx, st, "band_taps_fft_kernel"); hipLaunchKernelGGL(band_taps_fft_kernel, dim3(nb), dim3(256), lds_fft, st, d_taps, d_tap_off, d_tap_len, ctx->d_twiddle, d_tspec, d_tre); }
+  { KernelTimer _kt(ctx, st, "band_tile_fft_kernel"); hipLaunchKernelGGL(band_tile_fft_kernel, dim3((unsigned)max_tiles, n_utt), dim3(256), lds_fft, st, d_jobs, nb, pad, H, d_tile_off, ctx->d_twiddle, d_zspec); }
 #ifndef WH_OLS_PAIR
 #define WH_OLS_PAIR 0  // measured: 7.2 ms against 6.7 ms for the one-channel-per-transform walker at config 3
 #endif
@@ -573,11 +563,11 @@ inline int launch_band_events_ols(wh_ctx* ctx, hipStream_t st, const BandJob* d_
 #else
   const size_t lds = sizeof(double2) * (kOlsN / 2 + 2) + 64;
   // one channel per workgroup while four-channel workgroups would be fewer than ~16 rounds of the chip (3 per CU): measured better at 64 and 256 utterances, worse at 1024
-  const bool single = d_gate_ch || WH_OLS_BANDS == 1 || (WH_OLS_BANDS == 0 && (int64_t)n_utt * ((nb + 3) / 4) < 16 * 3 * 256);
+  const bool single = WH_OLS_BANDS == 1 || (WH_OLS_BANDS == 0 && (int64_t)n_utt * ((nb + 3) / 4) < 16 * 3 * 256);
   {
     KernelTimer _kt(ctx, st, "band_events_kernel");
-    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(n_utt, nb), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag, d_gate_ch);
-    else hipLaunchKernelGGL(band_events_ols_kernel<4>, dim3(n_utt, (nb + 3) / 4), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag, d_gate_ch);
+    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(n_utt, nb), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+    else hipLaunchKernelGGL(band_events_ols_kernel<4>, dim3(n_utt, (nb + 3) / 4), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
   }
 #endif
   hipError_t e = hipGetLastError();

@@ -199,46 +199,6 @@ __device__ __forceinline__ void emit_crossings_block(const double* sig, int64_t 
   for (int t = 0; t < 4; ++t) base_cnt[t] += (int)((total >> (16 * t)) & 0xFFFF);
 }
 
-// emit_crossings_block for a tile whose edge lists live in LDS (the fused Harvest front end, wh_harvest_front.h):
-// positions p in [0, n_pos) of sig (p = 0 is sample g0 of the signal; sig[p], sig[p+1], sig[p+2] readable for every
-// p < PER * 256, flagged or not), lists start empty, cnt[4] = the four counts afterwards (block-uniform).  An entry
-// beyond `cap` is dropped and counted: the caller compares cnt with cap.  Same tests and the same edge arithmetic as
-// emit_crossings_block, value for value.  Contains barriers.
-template <int PER>
-__device__ __forceinline__ void emit_crossings_lds(const double* sig, int64_t g0, int n_pos, int64_t M, double* edges,
-                                                   int cap, int* cnt, unsigned long long* scratch) {
-  static_assert(PER <= 16, "masks are 16 bits, counts 16 bits per train");
-  const int tid = threadIdx.x;
-  const int i0 = tid * PER;
-  unsigned m01, m23;
-  int np = n_pos - i0;
-  np = np < 0 ? 0 : (np > PER ? PER : np);
-  crossing_flags<1, PER>(sig + i0, M - (g0 + i0), np, &m01, &m23);
-  const unsigned long long packed = (unsigned long long)__popc(m01 & 0xFFFFu) | ((unsigned long long)__popc(m01 >> 16) << 16) |
-                                    ((unsigned long long)__popc(m23 & 0xFFFFu) << 32) |
-                                    ((unsigned long long)__popc(m23 >> 16) << 48);
-  const unsigned long long incl = wave_scan_incl_u64(packed);
-  const int w = tid >> 6;
-  sync_lds<WH_BLOCK>();  // (LDS-only fences: the caller's spectrum prefetch and candidate stores stay in flight)
-  if ((tid & 63) == 63) scratch[w] = incl;
-  sync_lds<WH_BLOCK>();
-  unsigned long long excl = incl - packed;
-  unsigned long long total = 0;
-#pragma unroll
-  for (int i = 0; i < WH_BLOCK / 64; ++i) {
-    if (i < w) excl += scratch[i];
-    total += scratch[i];
-  }
-  int pos[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) pos[t] = (int)((excl >> (16 * t)) & 0xFFFF);
-  crossing_edges<1>(sig + i0, g0 + i0, m01, m23, pos, [&](int t, int at, double fe) {
-    if (at < cap) edges[t * cap + at] = fe;
-  });
-#pragma unroll
-  for (int t = 0; t < 4; ++t) cnt[t] = (int)((total >> (16 * t)) & 0xFFFF);
-}
-
 // Interpolate the four interval-F0 trains at time t (linear, end-segment extrapolation — SciPy's
 // interp1d(..., fill_value='extrapolate') arithmetic) and reduce: mean and, optionally, ddof=1 std.
 // Fewer than 3 intervals in any train → (0, 1000) (dio.py:159-162,182-184).

@@ -19,8 +19,6 @@
 //                      overlapped copies of one pitch track — share ONE pass over the samples (equal-key classes), every
 //                      member taking its own score from the class's spectra; 24 frames per workgroup
 //   hv_prune_kernel  : neighbour-frame consistency test (harvest.py:215-248), 16 frames per workgroup
-//   hv_front_kernel  : (wh_harvest_front.h, opt-in WH_HV_FRONT=1) band filter + crossings + raw candidates fused per
-//                      (utterance, tile of frames): exact, 3.4 x less HBM traffic, slower — see DESIGN.md section 4
 // Back end (wh_harvest_contour.h): contour tracking, smoothing, 5 ms pick.
 #include <math.h>
 #include <hip/hip_runtime.h>
@@ -226,10 +224,9 @@ constexpr int kRawChunk = 2 * kRawTile;    // intervals staged per train and til
 __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restrict__ meta, const wh::BandJob* __restrict__ jobs,
                                                      const double* __restrict__ band_f0, int nb, double fs_d,
                                                      double f0_floor, double f0_ceil, double* __restrict__ raw,
-                                                     uint8_t* __restrict__ live, const int32_t* __restrict__ gate) {
+                                                     uint8_t* __restrict__ live) {
   __shared__ double2 iv[4][kRawChunk];  // (location, frequency) of interval start + i
   __shared__ int s_next[4];
-  if (gate && !gate[(int64_t)blockIdx.y * nb + blockIdx.x]) return;  // (only the channels the fused front end handed back)
   const HvUtt m = meta[blockIdx.y];
   const int b = blockIdx.x;
   const wh::BandJob job = jobs[(int64_t)blockIdx.y * nb + b];
@@ -380,10 +377,6 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
   }
 }
 
-}  // namespace
-#include "wh_harvest_front.h"
-namespace {
-
 // NumPy's pairwise summation for n <= 128 (what np.mean does on the run of channel values)
 __device__ __forceinline__ double np_sum_strided(const double* __restrict__ a, int64_t stride, int n) {
   if (n < 8) {
@@ -412,12 +405,17 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
                                                         const uint8_t* __restrict__ live_map, double* __restrict__ dc,
                                                         int32_t* __restrict__ dcount) {
   const HvUtt m = meta[blockIdx.y];
+  // the grid is sized by the longest utterance of the batch: blocks wholly behind this utterance's end leave at once
+  // (also the nf1 == 0 case, where the clamp below would point in front of the column)
+  if ((int64_t)blockIdx.x * 256 >= m.nf1) return;
   const int64_t f_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live_f = f_raw < m.nf1;  // (every thread stays for the block's output pass)
+  const bool live_f = f_raw < m.nf1;  // (the tail threads of the last block stay for its output pass)
   const int64_t f = live_f ? f_raw : m.nf1 - 1;
   const double* col = raw + m.f1_off * nb + f;  // element b at col[b * nf1]
   const uint8_t* lcol = live_map + m.f1_off * nb + f;
+#if !WH_HV_DETECT_STAGE
   double* out = dc + (m.f1_off + f) * kMaxC;
+#endif
   // Phase 1: the runs.  Phase 2 sums them run by run: every lane of the wave is then inside the same summation loop at
   // the same time (its loads in flight together), where summing a run the moment the walk finds its end made the wave
   // go through one summation — two or three dependent rounds of global loads — per distinct end position among its
@@ -427,7 +425,7 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
   int run_start = -1;  // 'st': index of the last dead channel before a live run
   bool prev = false;   // channel 0 is forced dead
   // the channel walk is a chain of dependent branches; its loads are not: eight channels are fetched together
-  for (int b0 = 0; b0 < nb; b0 += 8) {
+  for (int b0 = 0; live_f && b0 < nb; b0 += 8) {
     uint8_t v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = lcol[(int64_t)(b0 + q < nb ? b0 + q : nb - 1) * m.nf1];  // clamped, not skipped: a
@@ -986,6 +984,8 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
   __syncthreads();
   const int64_t pool_base = (m.f1_off + f_first) * kRows;
   static_assert(kFramesPerBlock <= 64, "one lane per frame below");
+  // the work-list encoding: a 5-bit frame index and an 11-bit successor link in cl_meta, a 6-bit sort key
+  static_assert(kFramesPerBlock <= 32 && kItems < 2048 && kBuckets <= 64, "field widths of the hv_refine work list");
   if (threadIdx.x < 64) {  // per-frame counts -> list offsets: one lane per frame, a wave scan (one lane walking the frames
                            // was a chain of dependent LDS round trips with the other 255 threads at the barrier)
     const int fl = threadIdx.x;
@@ -1401,29 +1401,6 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t o_tspec = off; off += use_ols ? al(sizeof(double2) * spec_bins * n_bands) : 0;
   const size_t o_zspec = off; off += use_ols ? al(sizeof(double2) * spec_bins * (size_t)tile_off[B]) : 0;
   const size_t o_tre = off; off += use_ols ? al(sizeof(double) * spec_bins * n_bands) : 0;  // the real (zero-phase) tap spectra
-  // fused front end (wh_harvest_front.h): tiles of frames, each with the block of kOlsN samples centred on it; the
-  // lowest channel's valid outputs (kOlsN - 2 h_max - 2 samples) must cover the tile's frames and a margin either side
-  // OPT-IN (WH_HV_FRONT=1): exact and five times lighter on HBM, but slower than the chain it replaces — these kernels are
-  // bound by the instructions they issue, not by memory ("Harvest front end, fused": 95 against
-  // 70 ms at 1024 utterances; the crossing pass alone costs more than the transforms).
-  static const bool front_enabled = getenv("WH_HV_FRONT") && getenv("WH_HV_FRONT")[0] == '1';
-  std::vector<HvTile> tile_geo(B);
-  int64_t front_tiles = 0;
-  bool use_front = use_ols && front_enabled;
-  if (use_front) {
-    const int margin = hv_front_margin(fs_d, h_band_f0[0]);
-    const int64_t span = (int64_t)wh::kOlsN - 2 * h_max - 2 - 2 * margin;  // samples a tile's frames may span
-    int64_t tf_max = (int64_t)floor((double)span * 1000.0 / fs_d);
-    if (tf_max > kFrTFMax) tf_max = kFrTFMax;
-    if (tf_max < 64) use_front = false;  // (a floor so low that the margins eat the block: the unfused chain)
-    for (int u = 0; use_front && u < B; ++u) {
-      const int64_t nt = (meta[u].nf1 + tf_max - 1) / tf_max;
-      tile_geo[u].ntiles = (int32_t)nt;
-      tile_geo[u].tf = (int32_t)((meta[u].nf1 + nt - 1) / nt);
-      front_tiles = std::max(front_tiles, nt);
-    }
-  }
-  const size_t o_fb = off; off += al(sizeof(int32_t) * ((size_t)B + (size_t)B * n_bands));  // per utterance, then per channel
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
   HvUtt* d_meta = nullptr;
@@ -1495,34 +1472,13 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   if (dbg_y) WH_CHECK(hipMemcpyAsync(dbg_y, d_y, sizeof(double) * y_tot, hipMemcpyDeviceToDevice, st));
 
   // ---- 152 channels: FIR + crossings, then per-frame raw candidates ------------------------------------
-  int32_t* d_gate = nullptr;     // != nullptr: the unfused chain runs only for the (utterance, channel) pairs marked
-  int32_t* d_gate_ch = nullptr;  // in d_gate_ch[u * n_bands + b]; d_gate[u] = any channel of u
-  if (use_front) {
-    d_gate = reinterpret_cast<int32_t*>(ws + o_fb);
-    d_gate_ch = d_gate + B;
-    HvTile* d_geo = nullptr;
-    if (int rc = wh::persistent_upload(ctx, st, "hv.tile_geo", tile_geo, &d_geo)) return rc;
-    WH_CHECK(hipMemsetAsync(d_gate, 0, sizeof(int32_t) * ((size_t)B + (size_t)B * n_bands), st));
-    double2* d_tspec = reinterpret_cast<double2*>(ws + o_tspec);
-    { wh::KernelTimer _kt(ctx, st, "band_taps_fft_kernel"); hipLaunchKernelGGL(wh::band_taps_fft_kernel, dim3(n_bands), dim3(256), sizeof(double) * (wh::kOlsN + 2), st, d_taps, d_ti, d_ti + n_bands, ctx->d_twiddle, d_tspec, reinterpret_cast<double*>(ws + o_tre)); }
-    WH_LAUNCH_CHECK("band_taps_fft_kernel");
-    const dim3 fgrid((unsigned)front_tiles, B);
-    {
-      wh::KernelTimer _kt(ctx, st, "hv_front_kernel");
-      if (dbg_raw)  // (the debug copy of the whole candidate map needs its zeros too)
-        hipLaunchKernelGGL(hv_front_kernel<true>, fgrid, dim3(256), kFrLds, st, d_meta, d_geo, d_z, pad, n_bands, d_ti + 2 * n_bands, d_bf, d_tspec, ctx->d_twiddle, fs_d, f0_floor, f0_ceil, d_raw, d_live, d_gate, d_gate_ch);
-      else
-        hipLaunchKernelGGL(hv_front_kernel<false>, fgrid, dim3(256), kFrLds, st, d_meta, d_geo, d_z, pad, n_bands, d_ti + 2 * n_bands, d_bf, d_tspec, ctx->d_twiddle, fs_d, f0_floor, f0_ceil, d_raw, d_live, d_gate, d_gate_ch);
-    }
-    WH_LAUNCH_CHECK("hv_front_kernel");
-  }
   if (use_ols) {
     int64_t* d_tile_off = nullptr;
     if (int rc = wh::persistent_upload(ctx, st, "hv.tile_off", tile_off, &d_tile_off)) return rc;
     if (int rc = wh::launch_band_events_ols(ctx, st, d_jobs, n_bands, B, pad, h_max, d_taps, d_ti, d_ti + n_bands,
                                             d_ti + 2 * n_bands, d_tile_off, max_tiles,
                                             reinterpret_cast<double2*>(ws + o_tspec), reinterpret_cast<double*>(ws + o_tre), reinterpret_cast<double2*>(ws + o_zspec),
-                                            ctx->d_flags + WH_FLAG_EVENT_OVERFLOW, d_gate, d_gate_ch, use_front))
+                                            ctx->d_flags + WH_FLAG_EVENT_OVERFLOW))
       return rc;
   } else if (int rc = wh::launch_band_events(ctx, st, d_jobs, n_bands, B, pad, d_taps, d_ti, d_ti + n_bands,
                                              d_ti + 2 * n_bands, max_lb, true, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW)) {
@@ -1531,7 +1487,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   // frames of an (utterance, channel) cut into segments with a workgroup each while the grid is a few rounds of the chip
   // (2560 workgroups at ten per CU): 1.80 -> 1.70 ms at 64 utterances; large batches keep one (no second cursor search)
   const int raw_segs = WH_HV_RAW_SEGS > 1 ? WH_HV_RAW_SEGS : ((int64_t)n_bands * B < 16 * 2560 ? 4 : 1);
-  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B, raw_segs), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw, d_live, d_gate_ch); }
+  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B, raw_segs), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw, d_live); }
   WH_LAUNCH_CHECK("hv_raw_kernel");
   if (dbg_raw) WH_CHECK(hipMemcpyAsync(dbg_raw, d_raw, sizeof(double) * f1_tot * n_bands, hipMemcpyDeviceToDevice, st));
   { wh::KernelTimer _kt(ctx, st, "hv_detect_kernel"); hipLaunchKernelGGL(hv_detect_kernel, dim3((unsigned)((max_nf1 + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw, d_live, d_dc, d_dn); }

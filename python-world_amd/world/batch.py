@@ -250,11 +250,15 @@ class WorldBatch:
         ready.record(main)
         with torch.cuda.stream(tb.own_stream):
             tb.own_stream.wait_event(ready)
-            # a condition still pending in this context belongs to an earlier prefetch whose time base this one
-            # supersedes (its encoding can only be decoded in line from now on, which raises the condition again where
-            # it belongs): drop it instead of leaving it to be blamed on this batch
-            tb.post_flags(discard=True)
-            tb.poll_flags()
+            # Conditions still pending in this context (d_flags; everything raised since the last post, in stream order)
+            # belong to the previous prefetch.  If a decode rendered from that time base its caller is still owed
+            # them (check=False: until WorldBatch.check(); check='deferred': until the next poll): publish them,
+            # unread, so that the memset of the coming take/poll cycle cannot lose them — the next
+            # _deferred_begin / check() reports them.  If nobody used it (an encoding that was never decoded, or only
+            # in line), its conditions are moot and would be blamed on this batch: cleared unpublished.  Never polled
+            # here: a poll would drain what an earlier decode_device(check='deferred') has published for its caller.
+            tb.post_flags(discard=not getattr(tb, "timebase_consumed", False))
+            tb.timebase_consumed = False
             synthesis_timebase_device(tb, batch, tp_d, f0_copy, vuv_d, fs, ny, [g[1] for g in geo], [g[2] for g in geo],
                                       cap, f0_low_limit=fs * 3.0 / (ct_fft - 3.0))
             done = torch.cuda.Event()
@@ -489,6 +493,7 @@ class WorldBatch:
                 use_tb = tb is not None and (cap is None or cap == tb["pulse_cap"])
                 if use_tb:  # join: the render goes behind the prefetched time base
                     rt.torch.cuda.current_stream(rt.device).wait_event(tb["done"])
+                    tb["rt"].timebase_consumed = True  # its conditions are now owed to this caller (_prefetch_timebase)
                 y, y_off = synthesis_device(rt, enc.batch, enc.temporal_positions, enc.f0, enc.vuv, enc.spectrogram,
                                             enc.aperiodicity, enc.fs, enc.fft_size, ny, [g[1] for g in geo],
                                             [g[2] for g in geo], noise_d=noise_d, noise_off=noise_off, seed=seed,

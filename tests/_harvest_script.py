@@ -1,5 +1,5 @@
-"""Helper of tests/test_hip_harvest_front.py: Harvest of a small ragged batch in THIS process's library configuration
-(WH_HV_FRONT / WH_HV_FRONT_MARGIN are read once per process); results to an .npz."""
+"""Helper of tests/test_hip_harvest_rounds.py: Harvest of a small ragged batch in THIS process's library configuration
+(environment switches such as WH_HV_ITEM_CAP_RT are read once per process); results to an .npz."""
 import os
 import sys
 

@@ -245,6 +245,47 @@ def test_deferred_flag_check_reports_late_but_not_never():
     assert wb.rt.take_flags() == [0] * 16
 
 
+@pytest.mark.parametrize("mode", ["deferred", False])
+def test_prefetched_timebase_conditions_survive_the_next_prefetch(mode, monkeypatch):
+    """encode A (time base prefetched), decode A (asynchronous check), encode B.  B's prefetch used to clear
+    the shared time-base context's flags on the assumption that they belonged to a superseded prefetch — but A's time
+    base had been rendered, so its PULSE_OVERFLOW was still owed to the caller: truncated audio, no error.  The
+    default capacity is forced down to 8 pulses so that the prefetched time base itself overflows."""
+    from world import _hip, batch as wbatch
+    from world._synthetic import synth_utterance
+
+    fs = 16000
+    xs = [synth_utterance(66, fs, 0.5), synth_utterance(67, fs, 0.4)]
+    wb = wbatch.WorldBatch(prefetch_timebase=True)
+    wb.check()  # (the time-base context is shared per device and lane: start clean)
+    monkeypatch.setattr(wbatch, "default_pulse_cap", lambda ny: 8)
+    enc_a = wb.encode(xs, fs, f0_method='dio', check=mode)
+    assert enc_a._timebase is not None and enc_a._timebase["pulse_cap"] == 8
+    wb.decode_device(enc_a, check=mode)           # renders from the overflowing time base; returns without raising
+    monkeypatch.undo()
+    if mode == 'deferred':
+        with pytest.raises(_hip.WorldHipError, match="pulse_cap"):
+            for _ in range(3):                    # late (the post may not have executed at the first poll), never lost
+                wb.encode(xs, fs, f0_method='dio', check=mode)
+                wb.rt.torch.cuda.synchronize()
+    else:
+        wb.encode(xs, fs, f0_method='dio', check=mode)   # the next prefetch must not clear A's condition
+        with pytest.raises(_hip.WorldHipError, match="pulse_cap"):
+            wb.check()
+    wb.rt.torch.cuda.synchronize()
+    try:
+        wb.check()
+    except _hip.WorldHipError:
+        pass
+    # a time base that nobody rendered from takes its conditions with it: nothing is blamed on the next batch
+    monkeypatch.setattr(wbatch, "default_pulse_cap", lambda ny: 8)
+    wb.encode(xs, fs, f0_method='dio', check=False)
+    monkeypatch.undo()
+    enc_c = wb.encode(xs, fs, f0_method='dio', check=False)
+    wb.decode_device(enc_c, check=False)
+    wb.check()
+
+
 def test_encode_device_under_inference_mode():
     """Tensors made under torch.inference_mode() have no version counter: the time-base prefetch is skipped, the encode
     and decode work as without it."""

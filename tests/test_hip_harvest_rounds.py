@@ -1,0 +1,47 @@
+"""GPU: Harvest in library configurations that are read once per process (environment switches), each in its own
+subprocess (tests/_harvest_script.py), compared with the default configuration and the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(tmp_path, tag, **env):
+    out = str(tmp_path / ("harvest_%s.npz" % tag))
+    e = dict(os.environ)
+    for k in ("WH_HV_ITEM_CAP_RT",):
+        e.pop(k, None)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_harvest_script.py"), out], capture_output=True, text=True,
+                       timeout=600, env=e)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = dict(np.load(out))
+    d["prof"] = dict(zip([str(k) for k in d["kernels"]], d["ms"]))
+    return d
+
+
+def test_refinement_in_several_rounds_equals_one_round(tmp_path):
+    """hv_refine_kernel takes the candidates of a block's 24 frames in rounds of whole frames that fit its LDS work list
+    (1344 slots: one round on real input).  With the list capped at 120 slots (WH_HV_ITEM_CAP_RT) every block needs
+    several rounds, the later ones fetching their rows again: the contour must not change by a bit."""
+    from oracle import pitch_harvest
+    from _harvest_script import inputs, inputs_22k
+
+    base = _run(tmp_path, "default")
+    capped = _run(tmp_path, "capped", WH_HV_ITEM_CAP_RT="120")
+    assert np.array_equal(capped["vuv"], base["vuv"]) and np.array_equal(capped["f0"], base["f0"])
+    assert np.array_equal(capped["vuv_22k"], base["vuv_22k"]) and np.array_equal(capped["f0_22k"], base["f0_22k"])
+    # and both equal the oracle's harvest (world/harvest.py:17-54): 16 kHz batch with a 60 dB quiet stretch; 22.05 kHz
+    # (7350 Hz decimated rate, f0 floor 60 Hz)
+    for (fs, xs), fo, kf, kv, args in ((inputs(), base["frame_off"], "f0", "vuv", ()),
+                                       (inputs_22k(), base["frame_off_22k"], "f0_22k", "vuv_22k", (60, 700))):
+        for u, x in enumerate(xs):
+            ref = pitch_harvest.harvest_np(x, fs, *args)
+            a, b = int(fo[u]), int(fo[u + 1])
+            assert np.array_equal(base[kv][a:b], ref["vuv"])
+            assert np.max(np.abs(base[kf][a:b] - ref["f0"])) < 1e-6

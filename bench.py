@@ -17,6 +17,10 @@ The timed region replays the step from a captured hipGraph when capture succeeds
 same launches, no per-launch host work); the per-kernel HIP-event durations that feed `roofline` come from an
 un-captured pass of the same K steps right after it (events cannot be read back from inside a graph).
 
+`WH_BENCH_SHARE_GPU=1` (rehearsal only): every rank drives device 0 and the process group is gloo — the N > 1 code path
+(per-rank input generation, sharding, barrier, max / sum reductions, `per_rank_ms`) runs end to end on a one-GPU lease;
+the line says `"shared_gpu": true` and is NOT a scaling measurement.
+
 Rank 0 prints ONE JSON line.  On a single GPU it also carries (each timed by this process):
   cpu_baseline   : the NumPy oracle on the host cores (1 core and all cores, median of 3), bounded sample;
   with_transfers : config 2 once more with the H2D of x and the D2H of f0/vuv/spectrogram/aperiodicity/out through
@@ -239,7 +243,7 @@ def pmc_traffic(kernel, lanes, config):
     return None, None
 
 
-def measure_pmc_traffic(args, timeout_s=240):
+def measure_pmc_traffic(args, timeout_s=240, config=None, utts=None, seconds=None, steps=2):
     """HBM bytes per launch of every kernel of THIS workload, measured now: two child runs of this script under
     `rocprofv3 --pmc <counter> --kernel-trace` (FETCH_SIZE and WRITE_SIZE cannot share a pass; nothing but the kernel
     trace beside the counters), corrected as MI355X_MICROARCH.md prescribes for gfx950: (2*FETCH_SIZE + WRITE_SIZE) KiB.
@@ -255,9 +259,9 @@ def measure_pmc_traffic(args, timeout_s=240):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="wh_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
-    child = [sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--utts", str(args.utts),
-             "--seconds", str(args.seconds), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
-             "--no-graph", "--no-pmc"]
+    child = [sys.executable, os.path.abspath(__file__), "--config", str(config or args.config),
+             "--utts", str(utts or args.utts), "--seconds", str(seconds or args.seconds), "--steps", str(steps),
+             "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-graph", "--no-pmc"]
     per = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -342,10 +346,19 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # WH_BENCH_SHARE_GPU=1: rehearsal of the N > 1 path on ONE GPU — every rank on device 0, gloo for the barrier and the
+    # reductions (two RCCL ranks cannot share a device); never a scaling number
+    share_gpu = os.environ.get("WH_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or "RANK" in os.environ:  # under torch.distributed.run the RCCL path is exercised even for 1 rank
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if share_gpu else "cuda"  # where the timing / count reductions live (gloo reduces host tensors)
 
     from world.batch import WorldBatchLanes
 
@@ -400,11 +413,16 @@ def main():
         rt.profile(False)
         flags = [a | b for a, b in zip(flags, rt.take_flags())]
 
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)  # every rank's own clock: a straggler shows in the line, not only in the max
+        per_rank_ms = [float(e.item()) / args.steps * 1e3 for e in every]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([frames_per_step, count], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([frames_per_step, count], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         frames_all, utts_all = float(tot[0].item()), float(tot[1].item())
     else:
@@ -481,6 +499,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "per_rank_ms": [round(v, 4) for v in per_rank_ms],
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -498,6 +517,10 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kernel_ms.items(), key=lambda kv: -kv[1])},
             "device_flags": flags,
         }
+        if share_gpu:
+            out["shared_gpu"] = True
+            out["config"]["parallelism"] = "%d ranks time-sharing ONE GPU over gloo (WH_BENCH_SHARE_GPU=1): a rehearsal " \
+                                           "of the multi-rank path, not a scaling measurement" % world
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if world == 1 and not args.no_extras and args.config == 2 and args.scaling == "weak":
@@ -524,6 +547,8 @@ def main():
             if "value" in piped:  # SURVEY §8(d) states the metric with the API's H2D / D2H inside
                 out["value_with_transfers"] = piped["value"]
                 out["ms_per_step_with_transfers"] = piped["ms_per_step"]
+                # the figure SURVEY §8(d) words the metric on (wall time incl. H2D of x and D2H of every API output)
+                out["value_survey_8d"] = piped["value"]
             if "value" in out.get("roundtrip_out_only", {}):
                 out["value_roundtrip_out_only"] = out["roundtrip_out_only"]["value"]
             # `value` is the HBM-resident rate (the bench contract: inputs resident when the timed region starts); SURVEY
@@ -733,32 +758,67 @@ def decode_alone_block(torch, wl, fs, reps=10):
 
 
 def facade_batch_block(torch, xs, fs, reps=3):
-    """The public batched API with HOST arrays on both sides: `World().encode_batch(fs, xs, f0_method='dio')`
-    -> list of reference-layout dicts ((bins, frames) NumPy arrays: every dense tensor downloaded and transposed),
-    `World().decode_batch(dats)` -> dats with 'out' (every dense tensor uploaded again).  What a script that swaps the
-    reference's per-utterance loop for the batch calls sees, nothing resident, nothing pipelined."""
+    """The public batched API with HOST arrays on both sides, two callers:
+    (a) `resynthesis`: World().encode_batch -> scale_pitch -> scale_duration -> decode_batch, the reference's prosody
+        flow (example/prosody.py:38-57).  encode_batch returns lazy dicts (world.batch.EncodingDict): the dense tensors
+        that the caller never reads stay in HBM, so the waveforms, the per-frame scalars and the audio cross PCIe and
+        nothing else;
+    (b) `materialised`: the same two calls by a caller that reads every dense value (dict(d) per utterance: every
+        tensor downloaded and transposed to the reference's (bins, frames) layout, and uploaded again by decode_batch)
+        — what the eager dicts of the earlier rounds cost every caller."""
     from world import main
 
     W = main.World()
-    dats = W.encode_batch(fs, xs, f0_method="dio")
-    W.decode_batch(dats)
-    torch.cuda.synchronize()
-    enc_s, dec_s = [], []
-    for _ in range(reps):
-        t0 = time.perf_counter()
+
+    def resynthesis():
         dats = W.encode_batch(fs, xs, f0_method="dio")
+        for d in dats:
+            W.scale_pitch(d, 1.5)
+            W.scale_duration(d, 2.0)
+        return W.decode_batch(dats)
+
+    def materialised():
+        t0 = time.perf_counter()
+        dats = [dict(d) for d in W.encode_batch(fs, xs, f0_method="dio")]
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         W.decode_batch(dats)
         torch.cuda.synchronize()
-        enc_s.append(t1 - t0)
-        dec_s.append(time.perf_counter() - t1)
+        return dats, t1 - t0, time.perf_counter() - t1
+
+    def roundtrip():  # no modification: directly comparable with the resident step and with round 4's 46 + 40 ms
+        return W.decode_batch(W.encode_batch(fs, xs, f0_method="dio"))
+
+    resynthesis()
+    materialised()
+    roundtrip()
+    torch.cuda.synchronize()
+    flow_s, enc_s, dec_s, rt_s = [], [], [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        roundtrip()
+        torch.cuda.synchronize()
+        rt_s.append(time.perf_counter() - t0)
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dats = resynthesis()
+        torch.cuda.synchronize()
+        flow_s.append(time.perf_counter() - t0)
     frames = sum(len(d["f0"]) for d in dats)
-    e, d = float(np.median(enc_s)), float(np.median(dec_s))
-    return {"encode_batch_ms": e * 1e3, "decode_batch_ms": d * 1e3, "value": frames / (e + d), "unit": "frames/s",
-            "x_realtime": len(xs) * len(xs[0]) / fs / (e + d),
-            "note": "World.encode_batch + World.decode_batch on 64 x 10 s, NumPy in / NumPy dicts out / NumPy audio out; median "
-                    "of %d" % reps}
+    for _ in range(reps):
+        _, e, d = materialised()
+        enc_s.append(e)
+        dec_s.append(d)
+    f, e, d = float(np.median(flow_s)), float(np.median(enc_s)), float(np.median(dec_s))
+    return {"resynthesis_flow_ms": f * 1e3, "roundtrip_unmodified_ms": float(np.median(rt_s)) * 1e3,
+            "value": frames / f, "unit": "frames/s",
+            "x_realtime": len(xs) * len(xs[0]) / fs / f,
+            "resynthesis_flow": "World.encode_batch -> scale_pitch(1.5) -> scale_duration(2.0) -> decode_batch on 64 x 10 s, "
+                                "NumPy waveforms in, NumPy audio out (2 x 10 s per utterance); dense tensors never read, "
+                                "never moved; median of %d" % reps,
+            "materialised": {"encode_batch_ms": e * 1e3, "decode_batch_ms": d * 1e3, "value": frames / (e + d),
+                             "note": "encode_batch with every dense value read (reference-layout NumPy dicts) + "
+                                     "decode_batch of those dicts (everything uploaded again), no modification"}}
 
 
 def with_transfers_lanes_block(torch, device_index, xs, fs, lanes=4, steps=5):
@@ -970,7 +1030,8 @@ def swipe_block(torch, wl, fs, reps=3):
 def other_configs_block(torch, device_index, xs16, xs48):
     """BASELINE configs 3, 4 and 5 at their single-GPU sizes, timed by this process like the headline (the step replayed
     from a hipGraph; the eager figure, the host's enqueue time per step and the sum of the kernels' HIP-event durations
-    beside it, so that a gap between the step and its kernels is visible in the line): 3 = Harvest only on 64 x 10 s;
+    beside it, so that a gap between the step and its kernels is visible in the line): 3 = Harvest only on 256 x 10 s
+    (the size BASELINE.json states it on);
     4 = Harvest + CheapTrick + D4C-Requiem encode + Requiem decode on 64 x 10 s; 5 = 16 x 60 s at 48 kHz, Harvest
     encode, scale_pitch(1.5), scale_duration(2.0), decode."""
     import types
@@ -978,7 +1039,9 @@ def other_configs_block(torch, device_index, xs16, xs48):
     from world.batch import WorldBatchLanes
 
     out = {}
-    for cfg, xs, fs, steps in ((3, xs16, 16000, 5), (4, xs16, 16000, 5), (5, xs48, 48000, 2)):
+    # config 3 is stated on 256 x 10 s (BASELINE.json configs[2]): the 64 distinct utterances four times over
+    xs16_256 = None if xs16 is None else [xs16[i % len(xs16)] for i in range(256)]
+    for cfg, xs, fs, steps in ((3, xs16_256, 16000, 5), (4, xs16, 16000, 5), (5, xs48, 48000, 2)):
         if xs is None:
             out["config%d" % cfg] = {"error": "inputs unavailable"}
             continue
@@ -1014,7 +1077,8 @@ def other_configs_block(torch, device_index, xs16, xs48):
         rt.profile(False)
         wl.lanes[0].check("other_configs %d" % cfg)
         frames = wl.total_frames
-        out["config%d" % cfg] = {"utterances": len(xs), "seconds": len(xs[0]) / fs, "fs": fs, "steps": steps,
+        out["config%d" % cfg] = {"utterances": len(xs), "distinct_utterances": min(len(xs), 64 if fs == 16000 else 16),
+                                 "seconds": len(xs[0]) / fs, "fs": fs, "steps": steps,
                                  "ms_per_step": dt * 1e3, "value": frames / dt, "unit": "frames/s",
                                  "x_realtime": len(xs) * len(xs[0]) / fs / dt,
                                  "graph": dt is not eager, "eager_ms_per_step": eager * 1e3,
@@ -1025,26 +1089,41 @@ def other_configs_block(torch, device_index, xs16, xs48):
     return out
 
 
-def north_star_block(torch, device_index, xs_distinct, fs, args, steps=3):
-    """BASELINE.json north_star on ONE GPU: 1024 x 10 s at 16 kHz, encode(harvest, is_requiem=True) + Requiem decode."""
+def north_star_block(torch, device_index, xs_distinct, fs, args, steps=5):
+    """BASELINE.json north_star on ONE GPU: 1024 x 10 s at 16 kHz, encode(harvest, is_requiem=True) + Requiem decode.
+    Timed like the headline: `steps` (>= 5) replays of a hipGraph of one step between synchronisations (the eager figure
+    beside it), per-kernel HIP-event durations from one un-captured step, and a `roofline` block of its own for the
+    dominant kernel with the HBM traffic MEASURED in this run (two rocprofv3 --pmc child runs of config 4 at this size)."""
     from world.batch import WorldBatch
 
     n = args.north_star_utts
     xs = [xs_distinct[i % len(xs_distinct)] for i in range(n)]
     wb = WorldBatch(device_index)
     batch, x_d, tp_d = wb.upload(xs, fs)
+
     def one():
-        enc = wb.encode_device(batch, x_d, tp_d, fs, f0_method="harvest", is_requiem=True, check='deferred')
-        return wb.decode_device(enc, check='deferred')  # device-generated seed tables
+        enc = wb.encode_device(batch, x_d, tp_d, fs, f0_method="harvest", is_requiem=True, check=False)
+        return wb.decode_device(enc, check=False)  # device-generated seed tables
 
     one()
     torch.cuda.synchronize()
+    wb.check("north_star warm-up")
     t0 = time.perf_counter()
     for k in range(steps):
         one()
     enq = (time.perf_counter() - t0) / steps
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    eager = (time.perf_counter() - t0) / steps
+    graph = try_capture(torch, one)
+    dt = eager
+    if graph is not None:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    del graph
     wb.rt.profile(True)  # per-kernel durations from one more step (the event pairs stay out of the timed steps)
     one()
     agg = {}
@@ -1056,19 +1135,36 @@ def north_star_block(torch, device_index, xs_distinct, fs, args, steps=3):
     wb.check("north_star")
     frames = batch.total_frames
     dom = max(agg.items(), key=lambda kv: kv[1][0])[0]
-    per_k, path_b = algo_bytes_per_frame(fs, 1024)
+    per_k, path_b = algo_bytes_per_frame(fs, 1024, requiem=True)
     dom_ms = agg[dom][0] / agg[dom][1]
     # Requiem path: 9584 B/frame encode+decode; Harvest kernels are priced on the F0-only 664 B/frame
-    achieved = per_k.get(dom, 664) * frames / (dom_ms / 1e3) / 1e9
+    per_frame = per_k.get(dom, 664)
+    frames_per_launch = frames / agg[dom][1]
+    achieved = per_frame * frames_per_launch / (dom_ms / 1e3) / 1e9
+    traffic, traffic_all, traffic_src = None, None, {"source": "not measured (--no-pmc)"}
+    if not args.no_pmc:
+        del x_d, tp_d, batch  # the child runs need the HBM this block holds no longer
+        torch.cuda.empty_cache()
+        measured, how = measure_pmc_traffic(args, timeout_s=420, config=4, utts=n, seconds=len(xs[0]) / fs, steps=1)
+        if measured and dom in measured:
+            traffic, traffic_all, traffic_src = measured[dom], measured, {"source": how}
+        else:
+            traffic_src = {"source": "measurement unavailable", "reason": how if not measured else "kernel not in the trace"}
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_over_algorithmic": None if traffic is None else traffic / (per_frame * frames_per_launch),
+                "traffic_per_kernel_MB": None if traffic_all is None else
+                {k: round(v / 1e6, 1) for k, v in sorted(traffic_all.items(), key=lambda kv: -kv[1])[:8]},
+                "algorithmic_bytes_per_launch": per_frame * frames_per_launch, "frames_per_launch": frames_per_launch,
+                "avg_launch_ms": dom_ms, "timing": "HIP events around every launch, one un-captured step",
+                "path_algorithmic_GBps": path_b * frames / dt / 1e9}
     return {"workload": "%d x %.0f s synthetic 16 kHz utterances (%d distinct) on 1 GPU: Harvest+CheapTrick+"
                         "D4C-Requiem encode + Requiem decode, HBM-resident" % (n, len(xs[0]) / fs, min(n, len(xs_distinct))),
             "distinct_utterances": min(n, len(xs_distinct)), "host_enqueue_ms_per_step": enq * 1e3,
-            "flag_check": "deferred (no host wait per call)",
+            "graph": dt is not eager, "eager_ms_per_step": eager * 1e3,
             "ms_per_step": dt * 1e3, "value": frames / dt, "unit": "frames/s", "x_realtime": n * len(xs[0]) / fs / dt,
             "target_x_realtime": 500, "steps": steps, "frames_per_step": frames,
-            "dominant_kernel": dom, "dominant_kernel_ms": dom_ms,
-            "dominant_kernel_hbm_frac": achieved / HBM_PEAK_GBS,
-            "path_algorithmic_GBps": 9584 * frames / dt / 1e9,
+            "roofline": roofline,
             "kernel_ms": {k: round(v[0] / v[1], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]}}
 
 

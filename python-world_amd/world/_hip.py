@@ -194,6 +194,22 @@ class Runtime:
         a = np.ascontiguousarray(a, dtype=dtype)
         return self.torch.from_numpy(a).to(self.device)
 
+    def to_device_concat(self, arrays, pinned_limit=1 << 29):
+        """The concatenation of 1-D float64 host arrays as one device tensor.  Up to ``pinned_limit`` bytes the pieces
+        are copied straight into a pinned staging block (torch's caching host allocator: reused from call to call) and
+        leave with one asynchronous DMA — one pass over the host data instead of np.concatenate's pass plus the
+        runtime's chunked staging of a pageable source (64 x 10 s: ~10 ms instead of ~25)."""
+        total = int(sum(len(a) for a in arrays))
+        if total == 0 or total * 8 > pinned_limit:
+            return self.to_device(np.concatenate(arrays) if len(arrays) else np.zeros(0))
+        host = self.torch.empty((total,), dtype=self.torch.float64, pin_memory=True)
+        view = host.numpy()
+        at = 0
+        for a in arrays:
+            view[at:at + len(a)] = a
+            at += len(a)
+        return host.to(self.device, non_blocking=True)
+
     def to_host(self, t, transpose=False):
         """Device tensor -> NumPy array.  Large results go through pinned host memory from torch's caching host
         allocator (a pageable destination makes the runtime stage the copy in small chunks: the 22 MB that one

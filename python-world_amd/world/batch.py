@@ -19,6 +19,116 @@ from .synthesis import (default_pulse_cap, safe_pulse_cap, synthesis_device, syn
                         time_axis_params)
 
 
+class _Pending:
+    """Placeholder stored under a dense key of an EncodingDict whose value still lives in HBM only."""
+    __slots__ = ()
+
+    def __repr__(self):
+        return "<resident in HBM: materialised on first access>"
+
+
+_PENDING = _Pending()
+
+
+class EncodingDict(dict):
+    """One utterance's encode() dict out of a batch (World.encode_batch / BatchEncoding.to_dicts(lazy=True)) — a real
+    ``dict`` with the reference's keys and (bins, frames) layouts (world/main.py:144-152) whose DENSE values
+    ('spectrogram', 'aperiodicity', 'ps spectrogram') stay on the GPU until somebody reads them: the first
+    ``d['spectrogram']`` (or ``get`` / ``items`` / ``values`` / ``dict(d)`` / ``copy`` / pickling) downloads and
+    transposes that utterance's slice and stores the NumPy array in the dict, from then on it is an ordinary entry.
+    The per-frame scalars (temporal_positions, f0, vuv) are host arrays from the start — they are what scale_pitch /
+    scale_duration / modify_duration edit in place.
+
+    World.decode_batch looks at each dict: a dense value that was never handed out cannot have been edited, so its rows
+    are taken from the resident encoding (a device slice, no PCIe); one that was read (``np.asarray``, an in-place
+    ``dat['spectrogram'][...] = v``, ``warp_spectrum``) or replaced is uploaded from the host like any caller-built
+    array.  An ``encode_batch -> scale_pitch -> scale_duration -> decode_batch`` caller therefore moves the waveforms,
+    the per-frame scalars and the audio, and nothing else (SURVEY §7.2 "materialise NumPy lazily").
+
+    The dicts of one batch share the resident encoding and keep it alive (8 KB of HBM per frame) until the last of
+    them is dropped."""
+
+    DENSE = {'spectrogram': 'spectrogram', 'aperiodicity': 'aperiodicity', 'ps spectrogram': 'ps_spectrogram'}
+
+    def __init__(self, small, enc, utt, dense_keys, order):
+        dict.__init__(self)
+        self._enc, self._utt = enc, utt
+        for k in order:
+            dict.__setitem__(self, k, _PENDING if k in dense_keys else small[k])
+
+    # ---- what decode_batch asks --------------------------------------------------------------------------------
+    def resident_rows(self, key, rt):
+        """Frame-major device rows of a dense value that has not left the GPU (None once it has been read or replaced,
+        or when ``rt`` is another device's runtime)."""
+        if dict.get(self, key) is not _PENDING or self._enc.rt.index != rt.index:
+            return None
+        fo = self._enc.batch.frame_off
+        return getattr(self._enc, self.DENSE[key])[int(fo[self._utt]):int(fo[self._utt + 1])]
+
+    def _materialise(self, key):
+        rows = self.resident_rows(key, self._enc.rt)
+        with self._enc.rt.on_stream():
+            val = self._enc.rt.to_host(rows, transpose=True)
+        dict.__setitem__(self, key, val)
+        return val
+
+    # ---- dict protocol: every way of reading a value goes through __getitem__ ---------------------------------------
+    def __getitem__(self, key):
+        val = dict.__getitem__(self, key)
+        return self._materialise(key) if val is _PENDING else val
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __iter__(self):  # (overridden on purpose: dict(d) / {**d} then copy through keys() + __getitem__)
+        return dict.__iter__(self)
+
+    def items(self):
+        return [(k, self[k]) for k in dict.keys(self)]
+
+    def values(self):
+        return [self[k] for k in dict.keys(self)]
+
+    def copy(self):
+        return dict(self.items())
+
+    def pop(self, key, *default):
+        if key in self:
+            val = self[key]
+            dict.__delitem__(self, key)
+            return val
+        if default:
+            return default[0]
+        raise KeyError(key)
+
+    def popitem(self):
+        key = next(reversed(self))
+        return key, self.pop(key)
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            dict.__setitem__(self, key, default)
+        return self[key]
+
+    def update(self, *args, **kw):
+        for k, v in dict(*args, **kw).items():
+            self[k] = v
+
+    def __eq__(self, other):
+        return dict(self.items()) == other
+
+    __hash__ = None
+
+    def __ne__(self, other):
+        return not self == other
+
+    def __repr__(self):
+        return "EncodingDict(%s)" % dict.__repr__(self)
+
+    def __reduce__(self):
+        return (dict, (self.items(),))
+
+
 class BatchEncoding:
     """Result of WorldBatch.encode_device: the reference's encode() dict (world/main.py:144-152) for a whole batch,
     resident in HBM.  ``temporal_positions`` / ``f0`` / ``vuv`` are flat per-frame tensors (batch frame layout),
@@ -46,20 +156,41 @@ class BatchEncoding:
     @classmethod
     def from_dicts(cls, rt, dats):
         """Upload a list of encode() dicts (reference layout: (bins, frames) arrays) that share fs / is_requiem / FFT
-        size as one resident batch."""
+        size as one resident batch.  Dense values of ``EncodingDict``s (World.encode_batch) that never left the GPU
+        are taken from their resident encoding instead (device slices; the whole tensor as it is when the list is
+        that encoding's utterances in order)."""
+        torch = rt.torch
         nfs = [len(d['f0']) for d in dats]
         frame_off = np.concatenate([[0], np.cumsum(nfs)])
         batch = rt.make_batch(np.zeros(len(dats) + 1, dtype=np.int64), frame_off)
         flat = lambda key: rt.to_device(np.concatenate([np.asarray(d[key], dtype=np.float64) for d in dats]))  # noqa: E731
+
+        def resident(d, key):
+            return d.resident_rows(key, rt) if isinstance(d, EncodingDict) else None
+
         def rows(key):
             # (bins, frames) per utterance on the host -> one frame-major tensor: uploaded as they lie, transposed on the
             # device (strided host copies of the 64 x 10 s batch took as long as its whole decode)
-            parts = [rt.to_device(np.asarray(d[key], dtype=np.float64)).transpose(0, 1) for d in dats]
-            return rt.torch.cat(parts, dim=0).contiguous()
+            parts = [resident(d, key) for d in dats]
+            first = dats[0] if isinstance(dats[0], EncodingDict) else None
+            if first is not None and all(p is not None for p in parts):
+                src = getattr(first._enc, EncodingDict.DENSE[key])
+                if (all(isinstance(d, EncodingDict) and d._enc is first._enc and d._utt == u for u, d in enumerate(dats))
+                        and src.shape[0] == int(frame_off[-1])):
+                    return src  # the encoding's own tensor: nothing is copied
+            parts = [p if p is not None else rt.to_device(np.asarray(d[key], dtype=np.float64)).transpose(0, 1)
+                     for p, d in zip(parts, dats)]
+            return torch.cat(parts, dim=0).contiguous()
+
         tp_h = np.concatenate([np.asarray(d['temporal_positions'], dtype=np.float64) for d in dats])
-        fft_size = (dats[0]['spectrogram'].shape[0] - 1) * 2
-        return cls(rt, batch, dats[0]['fs'], rt.to_device(tp_h), flat('f0'), flat('vuv'), rows('spectrogram'),
-                   rows('aperiodicity'), fft_size, bool(dats[0]['is_requiem']), None, tp_host=tp_h)
+        d0 = dats[0]
+        if isinstance(d0, EncodingDict) and resident(d0, 'spectrogram') is not None:
+            fft_size = d0._enc.fft_size  # (asking the dict for its spectrogram's shape would download it)
+        else:
+            fft_size = (d0['spectrogram'].shape[0] - 1) * 2
+        with rt.on_stream():
+            return cls(rt, batch, d0['fs'], rt.to_device(tp_h), flat('f0'), flat('vuv'), rows('spectrogram'),
+                       rows('aperiodicity'), fft_size, bool(d0['is_requiem']), None, tp_host=tp_h)
 
     @property
     def temporal_positions(self):
@@ -172,10 +303,12 @@ class BatchEncoding:
         from .features import mcep_device
         return mcep_device(self.rt, self.spectrogram, n0, self.fs, lowhz, highhz)
 
-    def to_dicts(self, want_ps=False):
+    def to_dicts(self, want_ps=False, lazy=False):
         """List of per-utterance dicts with the reference's keys and (bins, frames) layouts.  ``want_ps``: include
         encode()'s 'ps spectrogram' (fft_size, frames) complex128 (world/main.py:149) — the encoding must have been made
-        with ``want_ps=True`` (16 B x fft_size per frame: 2 GB for the 64 x 10 s batch, which is why it is opt-in)."""
+        with ``want_ps=True`` (16 B x fft_size per frame: 2 GB for the 64 x 10 s batch, which is why it is opt-in).
+        ``lazy``: ``EncodingDict``s — the dense values are downloaded when first read, and World.decode_batch takes the
+        ones nobody read straight from this encoding (which the dicts keep alive)."""
         fo = self.batch.frame_off
         tp, f0, vuv = (t.cpu().numpy() for t in (self.temporal_positions, self.f0, self.vuv))
         if want_ps and self.ps_spectrogram is None:
@@ -184,13 +317,23 @@ class BatchEncoding:
         # is transposed ON THE DEVICE and lands in pinned host memory (Runtime.to_host) — a pageable download of the whole
         # batch followed by strided host copies took 0.43 s for the 64 x 10 s batch (1.05 GB), this 0.03 - 0.16 s
         to_rows = lambda t, s: self.rt.to_host(t[s], transpose=True)  # noqa: E731
+        order = ['temporal_positions', 'vuv', 'fs', 'f0', 'aperiodicity', 'spectrogram', 'is_requiem']
+        dense = {'aperiodicity', 'spectrogram'}
+        if want_ps:
+            order.append('ps spectrogram')
+            dense.add('ps spectrogram')
         out = []
         with self.rt.on_stream():
             for u in range(self.n_utt):
                 s = slice(int(fo[u]), int(fo[u + 1]))
-                out.append({'temporal_positions': tp[s].copy(), 'vuv': vuv[s].copy(), 'fs': self.fs, 'f0': f0[s].copy(),
-                            'aperiodicity': to_rows(self.aperiodicity, s), 'spectrogram': to_rows(self.spectrogram, s),
-                            'is_requiem': self.is_requiem})
+                small = {'temporal_positions': tp[s].copy(), 'vuv': vuv[s].copy(), 'fs': self.fs, 'f0': f0[s].copy(),
+                         'is_requiem': self.is_requiem}
+                if lazy:
+                    out.append(EncodingDict(small, self, u, dense, order))
+                    continue
+                out.append({'temporal_positions': small['temporal_positions'], 'vuv': small['vuv'], 'fs': self.fs,
+                            'f0': small['f0'], 'aperiodicity': to_rows(self.aperiodicity, s),
+                            'spectrogram': to_rows(self.spectrogram, s), 'is_requiem': self.is_requiem})
                 if want_ps:
                     out[-1]['ps spectrogram'] = to_rows(self.ps_spectrogram, s)
         return out
@@ -277,7 +420,7 @@ class WorldBatch:
         lens = [len(x) for x in xs]
         nfs = [_tables.frame_count(n, fs, frame_period) for n in lens]
         batch = rt.make_batch(np.concatenate([[0], np.cumsum(lens)]), np.concatenate([[0], np.cumsum(nfs)]))
-        x_d = rt.to_device(np.concatenate(xs))
+        x_d = rt.to_device_concat(xs)
         if swipe_grid:
             _require_swipe_period(frame_period)
             tp_h = np.concatenate([np.arange(0, n) * SWIPE_DT for n in nfs])

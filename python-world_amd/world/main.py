@@ -104,14 +104,18 @@ class World(object):
         fft_size x frames x 16 B per utterance) only with ``want_ps=True``.  Under an initialised
         torch.distributed process group (one process per GPU) the batch is sharded by utterance over the ranks and the
         list holds only this rank's utterances; use ``world.distributed.ShardedWorldBatch`` directly to keep results
-        on the device."""
+        on the device.
+
+        The dicts are ``world.batch.EncodingDict``s: real dicts whose dense values ('spectrogram', 'aperiodicity',
+        'ps spectrogram') are downloaded when first read; ``decode_batch`` takes whatever was never read straight from
+        HBM.  ``encode_batch -> scale_pitch -> scale_duration -> decode_batch`` moves no dense tensor over PCIe."""
         from .distributed import ShardedWorldBatch
 
         sb = ShardedWorldBatch()
         enc = sb.encode(xs, fs, f0_method=f0_method, f0_floor=f0_floor, f0_ceil=f0_ceil,
                         channels_in_octave=channels_in_octave, target_fs=target_fs, frame_period=frame_period,
                         allowed_range=allowed_range, fft_size=fft_size, is_requiem=is_requiem, want_ps=want_ps)
-        dats = enc.to_dicts(want_ps=want_ps) if enc is not None else []
+        dats = enc.to_dicts(want_ps=want_ps, lazy=True) if enc is not None else []
         for d in dats:
             d['_batch_range'] = sb.range
         return dats
@@ -132,9 +136,10 @@ class World(object):
         wb = WorldBatch()
         enc = BatchEncoding.from_dicts(wb.rt, dats)
         y, y_off = wb.decode_device(enc, **kw)
-        y = y.cpu().numpy()
+        with wb.rt.on_stream():
+            y = wb.rt.to_host(y)  # one pinned block; every utterance's 'out' is its own, disjoint, writeable slice of it
         for u, d in enumerate(dats):
-            d['out'] = y[int(y_off[u]):int(y_off[u + 1])].copy()
+            d['out'] = y[int(y_off[u]):int(y_off[u + 1])]
         return dats
 
     # ---- modification (all in place on the dict, like the reference) ------------------------------------------

@@ -84,6 +84,66 @@ def test_world_encode_batch_decode_batch():
         assert rel_rms(d['out'], y) < 1e-10
 
 
+def test_encode_batch_dicts_are_lazy_and_aliasing_holds():
+    """World.encode_batch returns world.batch.EncodingDict's (VERDICT r4 item 6): dense values stay in HBM until read;
+    decode_batch takes unread ones from the resident encoding and uploads what the caller read, edited or replaced.
+    The resynthesis flow encode_batch -> scale_pitch -> scale_duration -> decode_batch must give the audio of the same
+    flow on fully materialised plain dicts, and every reference-style way of editing a dict must take effect
+    (world/main.py:154-196: in-place `*=`, `dat['spectrogram'][...] = v`, warp_spectrum's `spec[:] = warped`)."""
+    from world import main
+    from world._synthetic import synth_utterance
+    from world.batch import EncodingDict
+
+    fs = 16000
+    xs = [synth_utterance(57 + i, fs, 0.5 + 0.2 * i) for i in range(3)]
+    W = main.World()
+
+    def flow(dats):
+        for d in dats:
+            W.scale_pitch(d, 1.5)
+            W.scale_duration(d, 2.0)
+        return W.decode_batch(dats, seed=4)
+
+    lazy = W.encode_batch(fs, xs, f0_method='dio')
+    assert all(type(d) is EncodingDict for d in lazy)
+    eager = [dict(d) for d in W.encode_batch(fs, xs, f0_method='dio')]   # dict(): everything downloaded, plain dicts
+    assert all(type(d) is dict and isinstance(d['spectrogram'], np.ndarray) for d in eager)
+    flow(lazy)
+    flow(eager)
+    for a, b in zip(lazy, eager):
+        assert a.resident_rows('spectrogram', W_rt()) is not None         # never read: never crossed PCIe
+        assert a.resident_rows('aperiodicity', W_rt()) is not None
+        assert len(a['out']) == len(b['out']) == len(np.arange(0, b['temporal_positions'][-1] + 1 / fs, 1 / fs))
+        assert np.allclose(a['out'], b['out'], atol=1e-12)
+        assert np.array_equal(a['f0'], b['f0']) and np.array_equal(a['temporal_positions'], b['temporal_positions'])
+        a['out'][:10] = 0.0                                                # 'out' is the caller's own writeable array
+    assert np.all(lazy[0]['out'][:10] == 0.0) and np.any(lazy[1]['out'][10:2000] != 0.0)
+    # edits of dense values reach the decode: in place after a read, through warp_spectrum, and by replacement
+    base = W.decode_batch(W.encode_batch(fs, xs, f0_method='dio'), seed=4)
+    edited = W.encode_batch(fs, xs, f0_method='dio')
+    plain = [dict(d) for d in W.encode_batch(fs, xs, f0_method='dio')]
+    edited[0]['spectrogram'][...] = edited[0]['spectrogram'] * 4.0        # read, then edited in place
+    plain[0]['spectrogram'][...] = plain[0]['spectrogram'] * 4.0
+    W.warp_spectrum(edited[1], 1.1)
+    W.warp_spectrum(plain[1], 1.1)
+    edited[2]['aperiodicity'] = np.full_like(plain[2]['aperiodicity'], 0.5)  # replaced without ever being read
+    plain[2]['aperiodicity'] = np.full_like(plain[2]['aperiodicity'], 0.5)
+    W.decode_batch(edited, seed=4)
+    W.decode_batch(plain, seed=4)
+    for u in range(3):
+        assert np.allclose(edited[u]['out'], plain[u]['out'], atol=1e-12), u
+        assert not np.allclose(edited[u]['out'], base[u]['out'], atol=1e-6), u  # the edit was heard
+    # utterances 0 and 1 kept their untouched aperiodicity on the device, utterance 2 its spectrogram
+    assert edited[0].resident_rows('aperiodicity', W_rt()) is not None
+    assert edited[2].resident_rows('spectrogram', W_rt()) is not None
+    assert edited[0].resident_rows('spectrogram', W_rt()) is None
+
+
+def W_rt():
+    from world import _hip
+    return _hip.Runtime.get()
+
+
 def test_encode_batch_defaults_are_encodes():
     """encode_batch(fs, xs) without keywords = encode(fs, x) without keywords: Harvest (world/main.py:106)."""
     from world import main
@@ -283,6 +343,39 @@ def test_prefetched_timebase_conditions_survive_the_next_prefetch(mode, monkeypa
     monkeypatch.undo()
     enc_c = wb.encode(xs, fs, f0_method='dio', check=False)
     wb.decode_device(enc_c, check=False)
+    wb.check()
+
+
+def test_timebase_lasts_until_the_next_workspace_call_of_its_context():
+    """C-ABI contract (include/world_hip.h, INTEGRATION.md "One context, one time base"): the time base of
+    wh_synthesis_timebase lives in its context's workspace and ANY later workspace-using call on that context drops it —
+    wh_synthesis_render then fails loudly instead of rendering from a workspace that has been laid out again."""
+    from world import _hip
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+    from world.synthesis import default_pulse_cap, synthesis_device, synthesis_timebase_device, time_axis_params
+
+    fs = 16000
+    xs = [synth_utterance(68, fs, 0.4)]
+    wb = WorldBatch(prefetch_timebase=False)
+    enc = wb.encode(xs, fs, f0_method='dio')
+    rt = wb.rt
+    geo = [time_axis_params(enc.host_times(), fs)]
+    ny, t0, dt = [geo[0][0]], [geo[0][1]], [geo[0][2]]
+    cap = default_pulse_cap(ny)
+    args = (enc.batch, enc.temporal_positions, enc.f0, enc.vuv, enc.spectrogram, enc.aperiodicity, fs, enc.fft_size, ny, t0, dt)
+    with rt.on_stream():
+        synthesis_timebase_device(rt, enc.batch, enc.temporal_positions, enc.f0, enc.vuv, fs, ny, t0, dt, cap)
+        y1, _ = synthesis_device(rt, *args, seed=5, pulse_cap=cap, timebase_rt=rt)   # right behind it: fine
+        y1b, _ = synthesis_device(rt, *args, seed=5, pulse_cap=cap, timebase_rt=rt)  # (a render reserves nothing: again)
+        with pytest.raises(_hip.WorldHipError, match="no matching time base"):       # another pulse capacity: not this one
+            synthesis_device(rt, *args, seed=5, pulse_cap=cap + 1, timebase_rt=rt)
+        wb._peak_normalise(y1.clone(), np.array([0, ny[0]], dtype=np.int64))                 # any workspace-using stage call
+        with pytest.raises(_hip.WorldHipError, match="no matching time base"):
+            synthesis_device(rt, *args, seed=5, pulse_cap=cap, timebase_rt=rt)
+        y2, _ = synthesis_device(rt, *args, seed=5, pulse_cap=cap)                   # the whole synthesis: as before
+    assert np.allclose(y1.cpu().numpy(), y2.cpu().numpy(), atol=1e-12)
+    assert np.allclose(y1b.cpu().numpy(), y2.cpu().numpy(), atol=1e-12)
     wb.check()
 
 

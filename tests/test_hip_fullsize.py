@@ -4,6 +4,8 @@ utterance-permutation equivariance, input-gain scaling laws, and waveform-level 
 import numpy as np
 import pytest
 
+from conftest import synth_cached
+
 pytestmark = pytest.mark.gpu
 
 FS = 16000
@@ -14,7 +16,7 @@ def full_batch():
     from world._synthetic import synth_utterance
     from world.batch import WorldBatch
 
-    xs = [synth_utterance(u, FS, 10.0) for u in range(64)]
+    xs = [synth_cached(u, FS, 10.0) for u in range(64)]
     wb = WorldBatch()
     enc = wb.encode(xs, FS, f0_method="dio")
     return xs, wb, enc

@@ -23,7 +23,8 @@ def longform():
     from world._synthetic import synth_utterance
     from world.batch import WorldBatch
 
-    x = synth_utterance(75, FS, SECONDS)
+    from conftest import synth_cached
+    x = synth_cached(75, FS, SECONDS)
     short = synth_utterance(76, FS, 0.7)
     wb = WorldBatch()
     enc = wb.encode([x], FS, f0_method="harvest")

@@ -263,3 +263,95 @@ def test_table_tag_is_content_identity():
     b[1, 2] += 1e-9
     assert table_tag(a) != table_tag(b)
     assert table_tag(a, b) != table_tag(b, a) and table_tag(a) < 2 ** 63
+
+
+def test_encoding_dict_materialises_on_read_and_remembers_it():
+    """world.batch.EncodingDict (the dicts World.encode_batch returns) on a stub encoding, no GPU: a real dict with
+    encode()'s keys; a dense value is downloaded by the first read — whatever the way of reading — and only a value
+    that was never handed out is still 'resident' for decode_batch (resident_rows)."""
+    import contextlib
+    import copy
+    import pickle
+    import types
+
+    import torch
+
+    from world.batch import EncodingDict, BatchEncoding
+
+    downloads = []
+
+    class StubRt:
+        index = 0
+
+        def on_stream(self):
+            return contextlib.nullcontext()
+
+        def to_host(self, t, transpose=False):
+            downloads.append(tuple(t.shape))
+            return (t.transpose(0, 1) if transpose else t).contiguous().numpy().copy()
+
+    nf, k = [4, 3], 5
+    fo = np.array([0, 4, 7])
+    spec = torch.arange(7 * k, dtype=torch.float64).reshape(7, k)
+    ap = spec + 0.5
+    rt = StubRt()
+    enc = BatchEncoding(rt, types.SimpleNamespace(frame_off=fo, n_utt=2), 16000, torch.arange(7, dtype=torch.float64) * 0.005,
+                        torch.full((7,), 100.0, dtype=torch.float64), torch.ones(7, dtype=torch.float64), spec, ap, 8, False, 5)
+    dats = enc.to_dicts(lazy=True)
+    assert all(type(d) is EncodingDict and isinstance(d, dict) for d in dats)
+    d = dats[1]
+    assert list(d.keys()) == ['temporal_positions', 'vuv', 'fs', 'f0', 'aperiodicity', 'spectrogram', 'is_requiem']
+    assert 'spectrogram' in d and len(d) == 7 and downloads == []  # membership, length, keys: nothing moves
+    assert "resident in HBM" in repr(d) and downloads == []
+    assert d['f0'].shape == (3,) and d['fs'] == 16000 and d['is_requiem'] is False and downloads == []
+    d['f0'] *= 1.5                                                      # scale_pitch: in place on the host scalars
+    assert np.all(d['f0'] == 150.0) and downloads == []
+    assert torch.equal(d.resident_rows('spectrogram', rt), spec[4:7])   # decode_batch would take the device rows
+    assert d.resident_rows('spectrogram', types.SimpleNamespace(index=1)) is None  # ... not on another device
+    s = d['spectrogram']                                                # first read: this utterance's slice, transposed
+    assert downloads == [(3, k)] and s.shape == (k, 3) and np.array_equal(s, spec[4:7].numpy().T)
+    assert d['spectrogram'] is s and downloads == [(3, k)]              # an ordinary entry from now on
+    assert d.resident_rows('spectrogram', rt) is None                   # handed out: may have been edited
+    assert d.resident_rows('aperiodicity', rt) is not None              # the other dense value is untouched
+    s[...] = 7.0                                                        # in-place edit of the array the caller holds
+    assert np.all(d['spectrogram'] == 7.0)
+    d['aperiodicity'] = np.zeros((k, 3))                                # replaced without ever being read
+    assert d.resident_rows('aperiodicity', rt) is None and downloads == [(3, k)]
+    # the other ways of reading: get / items / values / dict() / ** / copy / pop / pickle — each materialises
+    for read in (lambda e: e.get('spectrogram'), lambda e: dict(e.items())['spectrogram'], lambda e: e.values()[5],
+                 lambda e: dict(e)['spectrogram'], lambda e: {**e}['spectrogram'], lambda e: e.copy()['spectrogram'],
+                 lambda e: copy.copy(e)['spectrogram'], lambda e: np.asarray(e['spectrogram']),
+                 lambda e: pickle.loads(pickle.dumps(e))['spectrogram'], lambda e: e.pop('spectrogram'),
+                 lambda e: e.setdefault('spectrogram', None)):
+        e = enc.to_dicts(lazy=True)[0]
+        v = read(e)
+        assert isinstance(v, np.ndarray) and np.array_equal(v, spec[0:4].numpy().T)
+        assert e.resident_rows('spectrogram', rt) is None
+    e = enc.to_dicts(lazy=True)[0]
+    assert e.get('nothing', 3) == 3 and e.pop('nothing', 4) == 4
+    e.update(spectrogram=np.ones((k, 4)))
+    assert e.resident_rows('spectrogram', rt) is None and type(pickle.loads(pickle.dumps(e))) is dict
+    # the eager form is unchanged: plain dicts, everything downloaded
+    plain = enc.to_dicts()
+    assert type(plain[0]) is dict and np.array_equal(plain[1]['aperiodicity'], ap[4:7].numpy().T)
+    # from_dicts: all-resident in order -> the encoding's own tensors; a read / permuted list -> copies of the rows
+    class UpRt(StubRt):
+        torch = __import__("torch")
+
+        def make_batch(self, x_off, frame_off):
+            return types.SimpleNamespace(frame_off=np.asarray(frame_off), n_utt=len(frame_off) - 1)
+
+        def to_device(self, a, dtype=np.float64):
+            return self.torch.from_numpy(np.ascontiguousarray(a, dtype=dtype))
+
+    up = UpRt()
+    enc.rt = up
+    fresh = enc.to_dicts(lazy=True)
+    again = BatchEncoding.from_dicts(up, fresh)
+    assert again.spectrogram is spec and again.aperiodicity is ap and again.fft_size == 8
+    swapped = BatchEncoding.from_dicts(up, fresh[::-1])
+    assert torch.equal(swapped.spectrogram, torch.cat([spec[4:7], spec[0:4]]))
+    fresh[0]['spectrogram'][...] = -1.0                                  # read + edited: uploaded from the host
+    mixed = BatchEncoding.from_dicts(up, fresh)
+    assert torch.equal(mixed.spectrogram[:4], torch.full((4, k), -1.0, dtype=torch.float64))
+    assert torch.equal(mixed.spectrogram[4:], spec[4:7]) and mixed.aperiodicity is ap

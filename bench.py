@@ -104,6 +104,11 @@ def parse():
                     help="independent sub-batches in flight per GPU, each on its own HIP stream (world.batch."
                          "WorldBatchLanes).  The default keeps one lane and clean per-kernel attribution")
     ap.add_argument("--no-stagger", action="store_true", help="start all lanes together (ablation)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="whole steps in flight per GPU: step k runs on pipeline k %% D (its own context, workspace, HIP "
+                         "stream and hipGraph over its own resident copy of the batch), so that the latency-bound head of one "
+                         "step (the DIO / Harvest serial kernels) runs under the chip-filling kernels of the step before.  "
+                         "1 = one step at a time (`ms_per_step_one_in_flight` in the line either way)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config: 2 = DIO path encode+decode (the metric's config, default); "
                          "3 = Harvest F0 only; 4 = Harvest + CheapTrick + D4C-Requiem encode + Requiem decode; "
@@ -364,12 +369,22 @@ def main():
 
     # args.lanes independent sub-batches per GPU, each on its own HIP stream and library context; one "step" is
     # still one pass of the hot path over the whole per-GPU batch
-    wl = WorldBatchLanes(local_rank, lanes=max(1, min(args.lanes, max(count, 1))))
+    n_lanes = max(1, min(args.lanes, max(count, 1)))
+    depth = max(1, args.in_flight) if n_lanes == 1 else 1
+    # `depth` independent pipelines over the SAME batch (each with its own resident copy of the inputs, context,
+    # workspace arena and stream): step k of the timed region runs on pipeline k % depth.  Nothing is shared and
+    # nothing is skipped — every step is a full pass over the whole per-GPU batch; what two steps in flight buy is that
+    # the serial, latency-bound kernels at the head of a step (decimation IIRs, contour tracking: a few dozen
+    # workgroups) run under the chip-filling kernels at the tail of the step before instead of on an idle chip.
+    wls = [WorldBatchLanes(local_rank, lanes=n_lanes, first_lane=(d + 1) if depth > 1 else None) for d in range(depth)]
+    wl = wls[0]
     rts = [wb.rt for wb in wl.lanes]
-    wl.upload(xs, FS)  # inputs resident in HBM before the timed region
+    for w_ in wls:
+        w_.upload(xs, FS)  # inputs resident in HBM before the timed region
     frames_per_step = wl.total_frames
 
-    step = make_step(args, wl, FS)
+    steps_fn = [make_step(args, w_, FS) for w_ in wls]
+    step = steps_fn[0]
 
     def fence():
         if dist.is_initialized():
@@ -377,27 +392,45 @@ def main():
         torch.cuda.synchronize()
 
     for w in range(args.warmup):
-        step(w)
+        for fn in steps_fn:
+            fn(w)
     fence()
-    for wb in wl.lanes:
-        wb.check("bench warm-up")
+    for w_ in wls:
+        for wb in w_.lanes:
+            wb.check("bench warm-up")
 
-    # ---- hipGraph capture of one step (single lane; falls back to eager launches if anything refuses) --------------
-    graph = None
-    if not args.no_graph and len(rts) == 1:
-        graph = try_capture(torch, lambda: step(1000))
+    # ---- hipGraph capture of one step per pipeline (single lane each; falls back to eager launches if anything refuses) --
+    graphs = None
+    if not args.no_graph and n_lanes == 1:
+        graphs = [try_capture(torch, (lambda fn=fn: fn(1000)), stream=w_.lanes[0].rt.own_stream) for fn, w_ in zip(steps_fn, wls)]
+        if any(g is None for g in graphs):
+            graphs = None
+    graph = graphs[0] if graphs else None
+    pipe_streams = [w_.lanes[0].rt.own_stream for w_ in wls]
     fence()
 
-    t0 = time.perf_counter()
-    if graph is not None:
+    def run_steps(active):
+        """K steps dealt round-robin to the first `active` pipelines; returns (host enqueue time, wall time)."""
+        t0 = time.perf_counter()
         for k in range(args.steps):
-            graph.replay()
-    else:
-        for k in range(args.steps):
-            step(1000 + k)
-    host_enqueue = time.perf_counter() - t0  # the launches are asynchronous: host time to enqueue all K steps
-    fence()
-    elapsed = time.perf_counter() - t0
+            d = k % active
+            if graphs is not None:
+                if pipe_streams[d] is not None:
+                    with torch.cuda.stream(pipe_streams[d]):
+                        graphs[d].replay()
+                else:
+                    graphs[d].replay()
+            else:
+                steps_fn[d](1000 + k)
+        enq = time.perf_counter() - t0  # the launches are asynchronous: host time to enqueue all K steps
+        fence()
+        return enq, time.perf_counter() - t0
+
+    host_enqueue, elapsed = run_steps(depth)
+    one_in_flight = None
+    if depth > 1:  # the same K steps with one step in flight at a time (pipeline 0 alone), for the record
+        fence()
+        _, one_in_flight = run_steps(1)
 
     # ---- un-captured pass of the same K steps with a HIP-event pair around every kernel launch ------------------
     for rt in rts:
@@ -499,6 +532,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "steps_in_flight": depth,
+            "ms_per_step_one_in_flight": None if one_in_flight is None else one_in_flight / args.steps * 1e3,
             "per_rank_ms": [round(v, 4) for v in per_rank_ms],
             "higher_is_better": True,
             "scaling": args.scaling,
@@ -524,7 +559,15 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if world == 1 and not args.no_extras and args.config == 2 and args.scaling == "weak":
-            del graph
+            graph = graphs = None  # (the graphs' private pools go back to the allocator)
+            if depth > 1:
+                # the blocks below drive ONE pipeline from torch's current stream (copies and kernels in one order): lane 0
+                del steps_fn, step
+                for w_ in wls:
+                    w_.resident = None
+                wl = WorldBatchLanes(local_rank, lanes=1)
+                wl.upload(xs, FS)
+                torch.cuda.empty_cache()
             blocks = [("with_transfers", lambda: with_transfers_block(torch, wl, xs, FS)),
                       ("with_transfers_pipelined", lambda: with_transfers_pipelined_block(torch, wl, xs, FS)),
                       ("roundtrip_out_only", lambda: roundtrip_out_only_block(torch, wl, xs, FS))]
@@ -589,19 +632,21 @@ def make_step(args, wl, fs):
     return step
 
 
-def try_capture(torch, fn):
+def try_capture(torch, fn, stream=None):
     """Capture one call of `fn` (kernel launches on torch's current stream, allocations from torch's graph pool) into
-    a hipGraph.  None if capture is refused (a synchronous call inside the step, an unsupported node...)."""
+    a hipGraph.  None if capture is refused (a synchronous call inside the step, an unsupported node...).
+    ``stream``: capture on this stream (a pipeline whose calls launch on a private stream of its own)."""
     try:
         g = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream()
+        s = stream if stream is not None else torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             with torch.cuda.graph(g, stream=s):
                 keep = fn()
         g._keep = keep  # outputs live in the graph's private pool
         torch.cuda.current_stream().wait_stream(s)
-        g.replay()
+        with torch.cuda.stream(s):
+            g.replay()
         torch.cuda.synchronize()
         return g
     except Exception as e:

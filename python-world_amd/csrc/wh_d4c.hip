@@ -56,6 +56,9 @@ constexpr int d4c_rmaxr(int n) { return WH_D4C_RMAXR ? WH_D4C_RMAXR : ((n <= 102
 #ifndef WH_D4C_WIN_UNROLL
 #define WH_D4C_WIN_UNROLL 4
 #endif
+#ifndef WH_D4C_CENT_LOOP
+#define WH_D4C_CENT_LOOP 0
+#endif
 // -DWH_D4C_STAGE_TIMER: thread 0 of every workgroup adds the shader-clock cycles between stage boundaries to
 // g_d4c_stage[] (read with wh_debug_d4c_stages, tools/d4c_stage_timer.py) — the per-stage latencies quoted in DESIGN.md.
 #ifdef WH_D4C_STAGE_TIMER
@@ -966,10 +969,20 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
 #endif
   STAGE_MARK(0)
   // ---- static centroid from two frames at +-T0/4 (d4c.py:132-142) ---------------------------------------
+#if WH_D4C_CENT_LOOP
+  // ONE copy of the centroid frame's code, run twice (cent starts at 0: 0 + c == c): the kernel's instruction stream
+  // shrinks by a fifth (66 KB -> 52 KB), below the 64 KB instruction cache that two CUs share
+#pragma unroll 1
+  for (int c = 0; c < 2; ++c) {
+    add_centroid<N>(xu, wtab + (2 + c) * kWinTab, e_frame, buf, cent, false, tw_base, scratch);
+    STAGE_MARK(1 + c)
+  }
+#else
   add_centroid<N>(xu, wtab + 2 * kWinTab, e_frame, buf, cent, true, tw_base, scratch);
   STAGE_MARK(1)
   add_centroid<N>(xu, wtab + 3 * kWinTab, e_frame, buf, cent, false, tw_base, scratch);
   STAGE_MARK(2)
+#endif
   low_band_replica_runs<N>(cent, zr, fs, cf, 1.2 * cf);
   STAGE_MARK(3)
 

@@ -962,6 +962,30 @@ __device__ __forceinline__ void min_phase_response(double2* zb, const double2* t
 // keep the 16-byte pair reads of lanes that are 4..8 samples apart on different LDS banks
 __device__ __forceinline__ int rap_index(int i) { return i + 2 * (i >> 5); }
 
+// First pulse of an utterance at or behind 1-based index `lo` (its pulse indices are ascending): a 64-ary search by the
+// whole wave — probes at 64 evenly spaced pulses, a ballot, the same again inside the bracket — two rounds of loads for
+// the few thousand pulses of an utterance where a bisection takes twelve dependent ones.  Wave-uniform.
+__device__ __forceinline__ int first_pulse_at(const int64_t* __restrict__ pi, int count, int64_t lo) {
+  const int lane = threadIdx.x & 63;
+  int base = 0, n = count;  // the answer is in [base, base + n]
+  while (n > 0) {
+    const int stride = (n + 63) / 64;
+    const int idx = base + lane * stride;
+    const bool below = idx < base + n && pi[idx] < lo;
+    const int c = __popcll(__ballot(below));  // the probes are ascending: the first c of them are below
+    if (stride == 1) {
+      base += c;
+      break;
+    }
+    if (c == 0) break;  // pi[base] >= lo
+    const int nb_ = base + (c - 1) * stride + 1;
+    const int left = base + n - nb_;
+    n = stride - 1 < left ? stride - 1 : left;
+    base = nb_;
+  }
+  return base;
+}
+
 // Everything one pulse needs (kernel arguments bundled so that the per-pulse body can be a real function).
 struct RespArgs {
   const SynUtt* meta;
@@ -976,36 +1000,51 @@ struct RespArgs {
   uint64_t seed;
   const double* dc_base;
   const double2* tw_base;
-  double* y;
+  double* rows;             // overlap-add rows of the runs (response_gather_kernel sums them into y)
+  int64_t row_stride;       // doubles per utterance in `rows`
+  const int64_t* run_base;  // [n_utt + 1] first run of every utterance (pulse_run_base_kernel)
 };
 
-// Overlap-add state of a workgroup's run of consecutive pulses: the run's contributions are accumulated in an
-// N-sample LDS ring that covers the window of the current pulse; when the window moves on, the samples that leave it
-// are final for this run and go to y with ONE atomic each (instead of one per pulse that touches them: a sample is
-// covered by N / pulse-spacing ~ 6-30 pulses).
+// Overlap-add of a workgroup's run of consecutive pulses OF ONE UTTERANCE: the run's contributions are accumulated, in
+// pulse order, in an N-sample LDS ring that covers the window of the current pulse; when the window moves on, the
+// samples that leave it are final for this run and go to the run's ROW (plain stores, zeros included) — row r of an
+// utterance holds the sum of run r over the samples its pulses cover, and response_gather_kernel adds the rows that
+// cover an output sample in run order.  No atomics anywhere: the decode is the same from run to run, and the same
+// whether an utterance is decoded alone, in a batch or on another rank (runs are numbered per utterance).  The
+// reference adds pulse after pulse into y (synthesis.py:67-81); summing runs of pulses first is another association
+// of the same sum (1e-17 relative).
+// Row layout (per utterance a region of row_stride doubles): row r starts at r * (N + 1) + start_r - 1, start_r =
+// max(1, first tap of the run's first pulse) — rows cannot overlap because the first tap of run r + 1 lies behind the
+// first tap of run r's last pulse; slot 0 = what the run adds to the LAST sample (Q8, below), slot 1 + (t - start_r) =
+// its sum at the 1-based sample t < ny.
 struct RunState {
-  int u;              // utterance of the pulses accumulated so far (-1: ring empty)
+  bool any;           // a pulse has been accumulated (the ring holds something)
   int64_t win_start;  // 1-based output index of the first sample of the ring's window
+  int64_t row_start;  // start_r
+  double last;        // thread FT-1: the run's contribution to the utterance's last sample
 };
 #ifndef WH_RESP_RUN
 #define WH_RESP_RUN 0  // pulses per workgroup; 0: by transform length (resp_run below)
 #endif
 
-// Samples [a, b) (1-based, within the ring's current window) are final for this run: add them to y, clear the ring.
+// Samples [a, b) (1-based, within the ring's current window) are final for this run: to the row, clear the ring.
 template <int N>
-__device__ __forceinline__ void ring_flush(double* ring, int64_t a, int64_t b, double* __restrict__ yu, int64_t ny) {
+__device__ __forceinline__ void ring_flush(double* ring, int64_t a, int64_t b, double* __restrict__ row, int64_t row_start,
+                                           int64_t ny) {
   constexpr int FT = ft_syn(N);
+  a = a < 1 ? 1 : a;
+  b = b > ny ? ny : b;
   for (int64_t tgt = a + WH_TID; tgt < b; tgt += FT) {
     const int slot = (int)(tgt & (N - 1));
-    const double v = ring[slot];
+    row[1 + (tgt - row_start)] = ring[slot];
     ring[slot] = 0.0;
-    if (v != 0.0 && tgt >= 1 && tgt < ny) atomicAdd(&yu[tgt - 1], v);
   }
 }
 
 // One pulse of a run.
 template <int N>
 __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec& rec, char* smem, double* ring, RunState& rs,
+                                               double* __restrict__ row,
                                                const double (&dcw)[N / ft_syn(N) <= 4 ? N / ft_syn(N) : 1]) {
   const SynUtt* __restrict__ meta = A.meta;
   const double* __restrict__ spectrogram = A.spectrogram;
@@ -1016,7 +1055,6 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   const double* __restrict__ dc_base = A.dc_base;
   const double2* __restrict__ tw_base = A.tw_base;
   asm volatile("" : "+s"(tw_base));  // per pulse: no twiddle address / value of one pulse survives into the next
-  double* __restrict__ y = A.y;
   constexpr int FT = ft_syn(N);
   constexpr int K = N / 2 + 1;
   constexpr int NZ = 256;
@@ -1142,7 +1180,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   // ---- minimum-phase responses (synthesis.py:86-116): aperiodic chain on thread group 0, periodic chain on
   //      group 1, advancing through the same barrier phases (with a single group: one after the other) --------
 #if WH_RESP_ABLATE == 2
-  if (WH_TID == 0) A.y[m.y_off] = zrA[3] + zrP[5] + mean;
+  if (WH_TID == 0) row[0] = zrA[3] + zrP[5] + mean;
   return;
 #endif
   const double coef_pi = 2.0 * fs / N;  // coefficient = 2*pi*fs/N (synthesis.py:59), kept in units of pi
@@ -1256,19 +1294,17 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   }
 
   // ---- overlap-add with the reference's clipped fancy-index semantics (Q8), through the run's ring ----------
-  double* yu = y + m.y_off;
   const int64_t s1 = pidx - N / 2 + 1;  // 1-based index of this pulse's first tap
-  if (rs.u >= 0) {
-    if (rs.u != u || s1 < rs.win_start) {  // the run moved on to the next utterance: everything pending is final
-      const SynUtt mp = meta[rs.u];
-      ring_flush<N>(ring, rs.win_start, rs.win_start + N, y + mp.y_off, mp.ny);
-    } else {
-      const int64_t e = s1 < rs.win_start + N ? s1 : rs.win_start + N;
-      ring_flush<N>(ring, rs.win_start, e, yu, m.ny);
-    }
+  if (rs.any) {
+    const int64_t e = s1 < rs.win_start + N ? s1 : rs.win_start + N;  // the samples the window leaves behind
+    ring_flush<N>(ring, rs.win_start, e, row, rs.row_start, m.ny);
+    // (pulses more than N samples apart — f0 below fs / N: the samples between the two windows belong to the row too)
+    for (int64_t tgt = rs.win_start + N + WH_TID; tgt < (s1 < m.ny ? s1 : m.ny); tgt += FT) row[1 + (tgt - rs.row_start)] = 0.0;
     wh::sync<FT>();
+  } else {
+    rs.row_start = s1 < 1 ? 1 : s1;
   }
-  rs.u = u;
+  rs.any = true;
   rs.win_start = s1;
 #pragma unroll
   for (int q = 0; q < R; ++q) {
@@ -1278,7 +1314,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
     if (voiced) v += (zrP[(mm + N / 2) & (N - 1)] / N + (R <= 4 ? dcw[R <= 4 ? q : 0] : dc_base[mm]) * -dc_total) * gain;
     if (tgt < 1) continue;                    // clipped to 1 and overwritten by the in-range tap
     if (tgt < m.ny) ring[(int)(tgt & (N - 1))] += v;    // this thread is the only writer of its R slots
-    else if (mm == N - 1) atomicAdd(&yu[m.ny - 1], v);  // last duplicate wins on the high side
+    else if (mm == N - 1) rs.last += v;                 // last duplicate wins on the high side: the last sample's share
   }
   RSTAGE_MARK(4)
 }
@@ -1288,24 +1324,47 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
 // against 41.6 ms for 8: the flush of the longer ring is what a short run does not amortise).
 constexpr int resp_run(int n) { return WH_RESP_RUN > 0 ? WH_RESP_RUN : (n <= 1024 ? 6 : 8); }
 
-// One workgroup per RUN of resp_run(N) consecutive pulses (flat pulse numbering: utterance by utterance, in time
-// order).  The grid is sized from the host's pulse capacity; the runs that exist (device-side pulse count) are dealt
-// to the XCDs in contiguous ranges, so that the spectrogram / aperiodicity rows neighbouring pulses share are fetched
-// into one L2 — the surplus workgroups exit at once.
+// First run of every utterance: runs never straddle utterances, so that what a run sums does not depend on the
+// utterance's position in the batch.
+__global__ void pulse_run_base_kernel(const int32_t* __restrict__ p_count, int n_utt, int run, int64_t* __restrict__ base) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int64_t at = 0;
+    for (int u = 0; u < n_utt; ++u) {
+      base[u] = at;
+      at += (p_count[u] + run - 1) / run;
+    }
+    base[n_utt] = at;
+  }
+}
+
+// One workgroup per RUN of resp_run(N) consecutive pulses of one utterance (runs numbered utterance by utterance, in
+// time order).  The grid is sized from the host's pulse capacity; the runs that exist (device-side pulse counts) are
+// dealt to the XCDs in contiguous ranges, so that the spectrogram / aperiodicity rows neighbouring pulses share are
+// fetched into one L2 — the surplus workgroups exit at once.
 template <int N>
 __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int FT = ft_syn(N);
-  const int64_t total = A.p_base[A.n_utt];
   constexpr int RUN = resp_run(N);
-  const int64_t n_runs = (total + RUN - 1) / RUN;
+  const int64_t n_runs = A.run_base[A.n_utt];
   const int64_t run = wh::xcd_unit(blockIdx.x, n_runs);
   if (run >= n_runs) return;
+  int u = 0;
+  {  // the utterance of this run: last u with run_base[u] <= run (scalar loads, block-uniform)
+    int lo = 0, hi = A.n_utt;  // run_base[lo] <= run < run_base[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (A.run_base[mid] <= run) lo = mid; else hi = mid;
+    }
+    u = lo;
+  }
+  const int64_t r_in_utt = run - A.run_base[u];
   double* ring = reinterpret_cast<double*>(smem) + (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32);
   for (int i = threadIdx.x; i < N; i += FT) ring[i] = 0.0;
-  RunState rs{-1, 0};
-  const int64_t gp0 = run * RUN;
-  const int64_t gp1 = gp0 + RUN < total ? gp0 + RUN : total;
+  RunState rs{false, 0, 1, 0.0};
+  const int64_t gp0 = A.p_base[u] + r_in_utt * RUN;
+  const int64_t gp1 = gp0 + RUN < A.p_base[u + 1] ? gp0 + RUN : A.p_base[u + 1];
+  double* row = A.rows + (int64_t)u * A.row_stride + r_in_utt * (N + 1) - 1;  // + start_r: slot i of the row at row[start_r + i]
   // A pulse's record travels as ONE dword per lane (lane i & 15 holds dword i) and is turned into scalars by
   // v_readlane at the top of the pulse that uses it — a pulse after its load was issued.  Fetched as a struct the
   // compiler made scalars of it (readfirstlane) right behind the load: the "prefetch" was waited for at once.
@@ -1339,25 +1398,76 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
   } else {
     dcw[0] = 0.0;
   }
+  // the row's first sample is known from the run's first pulse: max(1, its first tap)
+  int64_t row_start;
+  {
+    const int64_t pidx0 = reinterpret_cast<const int64_t*>(A.p_rec + gp0)[0];
+    row_start = pidx0 - N / 2 + 1;
+    row_start = row_start < 1 ? 1 : row_start;
+  }
+  row += row_start;
 #pragma unroll 1
   for (int64_t gp = gp0; gp < gp1; ++gp) {
     const PulseRec cur = unpack_rec(cur_w);
     const uint32_t nxt_w = fetch_rec(gp + 1 < gp1 ? gp + 1 : gp);  // in flight under this whole pulse
-    response_pulse<N>(A, cur, smem, ring, rs, dcw);
+    response_pulse<N>(A, cur, smem, ring, rs, row, dcw);
     cur_w = nxt_w;
   }
   wh::sync<FT>();
-  if (rs.u >= 0) {
-    const SynUtt mp = A.meta[rs.u];
-    ring_flush<N>(ring, rs.win_start, rs.win_start + N, A.y + mp.y_off, mp.ny);
+  if (rs.any) ring_flush<N>(ring, rs.win_start, rs.win_start + N, row, rs.row_start, A.meta[u].ny);
+  if (threadIdx.x == FT - 1) row[0] = rs.last;
+}
+
+// y[t] = sum of the rows that cover t, in run order (see RunState): one thread per output sample.  The runs whose
+// pulses reach a tile of 256 samples follow from the utterance's ascending pulse indices (the wave search of the
+// Requiem excitation); a run's extent from its first and last pulse.  The utterance's LAST sample receives, of every
+// pulse whose window reaches it or beyond, the last tap only (the reference's clipped fancy-index assignment keeps the
+// last of the duplicates, Q8): the rows' slot 0.
+template <int N>
+__global__ __launch_bounds__(256) void response_gather_kernel(const SynUtt* __restrict__ meta,
+                                                              const int64_t* __restrict__ p_idx,
+                                                              const int32_t* __restrict__ p_count,
+                                                              const double* __restrict__ rows, int64_t row_stride,
+                                                              double* __restrict__ y) {
+  constexpr int RUN = resp_run(N);
+  const SynUtt m = meta[blockIdx.y];
+  const int64_t n0 = (int64_t)blockIdx.x * 256;
+  if (n0 >= m.ny) return;
+  const int count = p_count[blockIdx.y];
+  const int64_t* pi = p_idx + m.p_off;
+  const double* ru = rows + (int64_t)blockIdx.y * row_stride - 1;
+  // pulses whose window [pidx - N/2 + 1, pidx + N/2] reaches the tile's samples n0 + 1 .. n0 + 256
+  const int k0 = first_pulse_at(pi, count, n0 + 1 - N / 2);
+  const int k_end = first_pulse_at(pi, count, m.ny - N / 2);  // first pulse whose last tap reaches the last sample
+  const int n_runs = (count + RUN - 1) / RUN;
+  const int64_t i = n0 + threadIdx.x;
+  if (i >= m.ny) return;
+  const int64_t tgt = i + 1;
+  double sum = 0.0;
+  if (tgt < m.ny) {
+    for (int r = k0 / RUN; r < n_runs; ++r) {
+      const int kf = r * RUN;
+      const int kl = (kf + RUN < count ? kf + RUN : count) - 1;
+      const int64_t s1f = pi[kf] - N / 2 + 1;
+      if (s1f > n0 + 256) break;
+      const int64_t start = s1f < 1 ? 1 : s1f;
+      const int64_t end = pi[kl] + N / 2 + 1;  // one behind the last tap of the run's last pulse
+      if (tgt >= start && tgt < end) sum += ru[(int64_t)r * (N + 1) + start + 1 + (tgt - start)];
+    }
+  } else {
+    for (int r = k_end / RUN; r < n_runs; ++r) {
+      const int64_t s1f = pi[r * RUN] - N / 2 + 1;
+      sum += ru[(int64_t)r * (N + 1) + (s1f < 1 ? 1 : s1f)];
+    }
   }
+  y[m.y_off + i] = sum;
 }
 
 
 template <int N>
-int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynUtt* d_meta, const double* tp,
+int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, int64_t max_ny, const SynUtt* d_meta, const double* tp,
                 const double* spec, const double* ap, double fs, const PulseRec* p_rec, const int64_t* p_base,
-                const double* noise, uint64_t seed, double* y) {
+                const int64_t* p_idx, const int32_t* p_count, const double* noise, uint64_t seed, double* y) {
   std::vector<double> dc(N);
   double sum = 0.0;
   for (int n = 0; n < N; ++n) {  // hanning(N+2)[1:-1] normalised (synthesis.py:57-58)
@@ -1369,11 +1479,23 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
   if (int rc = wh::const_table(ctx, "dc_base:" + std::to_string(N), dc, &d_dc)) return rc;
   const size_t lds = sizeof(double) * (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32 + N);  // ... + the overlap-add ring
   if (int rc = wh::allow_lds(&response_kernel<N>, lds)) return rc;
+  // overlap-add rows (RunState): per utterance ceil(pcap / RUN) rows of N + 1 slots laid along the time axis.  Held in a
+  // buffer of its own, not in the arena: the render reserves no workspace (the time base may live in this context's)
+  const int64_t runs_cap = (pcap_max + resp_run(N) - 1) / resp_run(N);
+  const int64_t row_stride = max_ny + runs_cap * (N + 1) + N + 8;
+  void* d_rows = nullptr;
+  void* d_rb = nullptr;
+  if (int rc = wh::persistent_scratch(ctx, "syn.ola_rows", sizeof(double) * (size_t)row_stride * B, &d_rows)) return rc;
+  if (int rc = wh::persistent_scratch(ctx, "syn.run_base", sizeof(int64_t) * ((size_t)B + 1), &d_rb)) return rc;
+  { wh::KernelTimer _kt(ctx, st, "pulse_run_base_kernel"); hipLaunchKernelGGL(pulse_run_base_kernel, dim3(1), dim3(64), 0, st, p_count, B, resp_run(N), reinterpret_cast<int64_t*>(d_rb)); }
+  WH_LAUNCH_CHECK("pulse_run_base_kernel");
   // one workgroup per run of resp_run(N) pulse slots; runs past the real pulse count exit at once
-  const int64_t grid = wh::xcd_grid((pcap_max * B + resp_run(N) - 1) / resp_run(N));
-  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_rec, p_base, B, noise, seed, d_dc, ctx->d_twiddle, y};
+  const int64_t grid = wh::xcd_grid(runs_cap * B);
+  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_rec, p_base, B, noise, seed, d_dc, ctx->d_twiddle, reinterpret_cast<double*>(d_rows), row_stride, reinterpret_cast<const int64_t*>(d_rb)};
   hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(ft_syn(N)), lds, st, ra); }
   WH_LAUNCH_CHECK("response_kernel");
+  { wh::KernelTimer _kt(ctx, st, "response_gather_kernel"); hipLaunchKernelGGL(response_gather_kernel<N>, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, p_idx, p_count, reinterpret_cast<const double*>(d_rows), row_stride, y); }
+  WH_LAUNCH_CHECK("response_gather_kernel");
   return 0;
 }
 
@@ -1385,6 +1507,8 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, const SynU
 struct ReqUtt {
   int64_t hop;        // int((tp[1]-tp[0])*fs), host-evaluated
   int64_t cursor[8];  // per-band start position in the circular noise seed
+  int64_t row_off;    // first overlap-add row of the utterance (req_filter_kernel), in doubles
+  int64_t n_runs;     // its runs of frames
 };
 
 __global__ __launch_bounds__(256) void req_linap_kernel(const double* __restrict__ band_db, int64_t count,
@@ -1437,30 +1561,6 @@ __global__ __launch_bounds__(256) void req_pulse_weights_kernel(const SynUtt* __
     }
   }
   p_gain[m.p_off + i] = gain;
-}
-
-// First pulse of an utterance at or behind 1-based index `lo` (its pulse indices are ascending): a 64-ary search by the
-// whole wave — probes at 64 evenly spaced pulses, a ballot, the same again inside the bracket — two rounds of loads for
-// the few thousand pulses of an utterance where a bisection takes twelve dependent ones.  Wave-uniform.
-__device__ __forceinline__ int first_pulse_at(const int64_t* __restrict__ pi, int count, int64_t lo) {
-  const int lane = threadIdx.x & 63;
-  int base = 0, n = count;  // the answer is in [base, base + n]
-  while (n > 0) {
-    const int stride = (n + 63) / 64;
-    const int idx = base + lane * stride;
-    const bool below = idx < base + n && pi[idx] < lo;
-    const int c = __popcll(__ballot(below));  // the probes are ascending: the first c of them are below
-    if (stride == 1) {
-      base += c;
-      break;
-    }
-    if (c == 0) break;  // pi[base] >= lo
-    const int nb_ = base + (c - 1) * stride + 1;
-    const int left = base + n - nb_;
-    n = stride - 1 < left ? stride - 1 : left;
-    base = nb_;
-  }
-  return base;
 }
 
 // The excitation signal (synthesisRequiem.py:27-63), one thread per output sample: the aperiodic component (band noises
@@ -1534,65 +1634,154 @@ __global__ __launch_bounds__(256) void req_excite_kernel(const SynUtt* __restric
   exc[m.y_off + i] = periodic + aperiodic;  // synthesisRequiem.py:62
 }
 
-template <int N>
+// Frame-wise minimum-phase filtering of the excitation with overlap-add (synthesisRequiem.py:74-101), WITHOUT atomics:
+// a workgroup takes a run of RUNF consecutive frames of one utterance, adds their responses — in frame order — into an
+// LDS accumulator that spans the run ((RUNF - 1) hop + N samples), and writes the sum as the run's ROW; req_gather_kernel
+// then adds, per output sample, the two or three rows that cover it, in run order.  The same sum from launch to launch
+// and wherever the utterance sits in a batch (runs are numbered per utterance); the reference adds frame after frame
+// into y — runs of frames first is another association of that sum.  Row r of an utterance: W = (RUNF - 1) hop + N + 1
+// doubles at row_off + r W; slot 0 = the run's share of the utterance's LAST sample (Q8: of the taps clipped onto it
+// only the last one written survives — the last tap of every frame whose response reaches it or beyond), slot 1 + j =
+// the sum at the 1-based sample a_r + j, a_r = r RUNF hop + 1.  RUNF = 1 (long transforms, whose LDS has no room for
+// the accumulator): the row is the frame's own response, written straight from the transform buffer.
+// (Round 4 measured runs of 1 / 4 / 8 / 16 / 32 frames with one atomic per run and sample: 1.65 / 1.63 / 1.65 / 1.69 / 1.78
+// ms at config 4 — the kernel is issue-bound, the run length is free; rows instead of atomics take 1.07 GB of
+// read-modify-write traffic per 64 utterances down to a 0.2 GB row write + read.)
+template <int N, int RUNF>
 __global__ __launch_bounds__(ft_syn(N)) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
                                                         const double* __restrict__ spectrogram,
                                                         const double* __restrict__ exc,
-                                                        const double2* __restrict__ tw_base, double* __restrict__ y) {
+                                                        const double2* __restrict__ tw_base, double* __restrict__ rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int FT = ft_syn(N);
   constexpr int K = N / 2 + 1;
   double2* zb = reinterpret_cast<double2*>(smem);        // minimum-phase half spectrum (N/2+1 complex)
   double2* sb = zb + (N / 2 + 1);                         // windowed excitation frame / its half spectrum
   double* sr = reinterpret_cast<double*>(sb);
+  double* acc = reinterpret_cast<double*>(sb + (N / 2 + 1));  // RUNF > 1: (RUNF - 1) hop + N sums of the run
   const SynUtt m = meta[blockIdx.y];
-  const int64_t i = (int64_t)blockIdx.x + 2;  // frames 2 .. F-2  (synthesisRequiem.py:83)
-  if (i > m.nf - 2) return;
-  const int64_t hop = rq[blockIdx.y].hop;
+  const ReqUtt q = rq[blockIdx.y];
+  if ((int64_t)blockIdx.x >= q.n_runs) return;
+  const int64_t hop = q.hop;
   const int64_t wlen = 2 * hop - 1;
-  const int64_t origin = (i - 1) * hop - (hop - 1);  // 1-based
+  const int64_t i0 = (int64_t)blockIdx.x * RUNF + 2;  // frames 2 .. F-2  (synthesisRequiem.py:83)
+  const int64_t i1 = i0 + RUNF - 1 < m.nf - 2 ? i0 + RUNF - 1 : m.nf - 2;
+  const int64_t a_r = (i0 - 2) * hop + 1;  // 1-based sample of the run's first tap (= the first frame's origin)
+  const int64_t W = (RUNF - 1) * hop + N + 1;
+  double* row = rows + q.row_off + (int64_t)blockIdx.x * W;
+  const int span = (int)(W - 1);
+  double last = 0.0;  // (thread FT-1 holds tap N-1 of every frame)
+  if (RUNF > 1) {
+    for (int j = threadIdx.x; j < span; j += FT) acc[j] = 0.0;
+  }
   const double* eu = exc + m.y_off;
-  for (int j = threadIdx.x; j < N; j += FT) {
-    double v = 0.0;
-    if (j < wlen) {
-      int64_t g = origin + j;
-      g = g > m.ny ? m.ny : g;
-      g = g < 1 ? 1 : g;
-      const double wv = 0.5 - 0.5 * cospi(2.0 * (double)(j + 1) / (double)(wlen + 1));  // hanning(wlen+2)[1:-1]
-      v = eu[g - 1] * wv;
-    }
-    sr[j] = v;
-  }
-  const double* sp = spectrogram + (m.f_off + (i - 1)) * K;
   double* zr = reinterpret_cast<double*>(zb);
-  for (int k = threadIdx.x; k < K; k += FT) {  // log|S| / 2, Hermitian-mirrored: the input of the chain's first transform
-    const double lw = log_call(fabs(sp[k])) / 2;
-    zr[k] = lw;
-    if (k > 0 && k < N / 2) zr[N - k] = lw;
+#pragma unroll 1
+  for (int64_t i = i0; i <= i1; ++i) {
+    const int64_t origin = (i - 1) * hop - (hop - 1);  // 1-based
+    if (RUNF > 1) wh::sync<FT>();  // the previous frame's response has been added (zr is about to be overwritten)
+    for (int j = threadIdx.x; j < N; j += FT) {
+      double v = 0.0;
+      if (j < wlen) {
+        int64_t g = origin + j;
+        g = g > m.ny ? m.ny : g;
+        g = g < 1 ? 1 : g;
+        const double wv = 0.5 - 0.5 * cospi(2.0 * (double)(j + 1) / (double)(wlen + 1));  // hanning(wlen+2)[1:-1]
+        v = eu[g - 1] * wv;
+      }
+      sr[j] = v;
+    }
+    const double* sp = spectrogram + (m.f_off + (i - 1)) * K;
+    for (int k = threadIdx.x; k < K; k += FT) {  // log|S| / 2, Hermitian-mirrored: the input of the chain's first transform
+      const double lw = log_call(fabs(sp[k])) / 2;
+      zr[k] = lw;
+      if (k > 0 && k < N / 2) zr[N - k] = lw;
+    }
+    wh::sync<FT>();
+    wh::rfft_lds<N, FT>(sb, tw_base);
+    // minimum-phase spectrum x excitation spectrum (both Hermitian, so is the product), straight into the inverse
+    // transform: the fused chain of the pulse responses with the product applied to the register-held bin pairs
+    min_phase_response<N, FT>(zb, tw_base, 0.0, [&](int k, double2 e) { return wh::cmul(e, sb[k]); });
+    const int shift = (int)(origin - a_r);  // (i - i0) * hop
+    for (int mm = threadIdx.x; mm < N; mm += FT) {
+      const int64_t tgt = origin + mm;
+      const double v = zr[mm] / N;
+      if (tgt < m.ny) {  // (tgt >= 1 always: origin >= 1)
+        if (RUNF > 1) acc[shift + mm] += v;  // one writer per slot and frame; frames are separated by barriers
+        else row[1 + mm] = v;
+      } else {
+        if (RUNF == 1) row[1 + mm] = 0.0;
+        if (mm == N - 1) last += v;
+      }
+    }
   }
-  wh::sync<FT>();
-  wh::rfft_lds<N, FT>(sb, tw_base);
-  // minimum-phase spectrum x excitation spectrum (both Hermitian, so is the product), straight into the inverse
-  // transform: the fused chain of the pulse responses with the product applied to the register-held bin pairs
-  min_phase_response<N, FT>(zb, tw_base, 0.0, [&](int k, double2 e) { return wh::cmul(e, sb[k]); });
-  double* yu = y + m.y_off;
-  for (int mm = threadIdx.x; mm < N; mm += FT) {
-    const int64_t tgt = origin + mm;
-    const double v = zr[mm] / N;
-    if (tgt < 1) continue;
-    if (tgt < m.ny) atomicAdd(&yu[tgt - 1], v);
-    else if (mm == N - 1) atomicAdd(&yu[m.ny - 1], v);
+  if (RUNF > 1) {
+    wh::sync<FT>();
+    for (int j = threadIdx.x; j < span; j += FT) row[1 + j] = acc[j];
   }
+  if (threadIdx.x == FT - 1) row[0] = last;
 }
 
+// y[t] = sum of the rows of req_filter_kernel that cover t, in run order; the last sample: the rows' slot 0.
+template <int N, int RUNF>
+__global__ __launch_bounds__(256) void req_gather_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
+                                                         const double* __restrict__ rows, double* __restrict__ y) {
+  const SynUtt m = meta[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m.ny) return;
+  const ReqUtt q = rq[blockIdx.y];
+  const int64_t adv = RUNF * q.hop;               // samples from one run's first tap to the next run's
+  const int64_t W = (RUNF - 1) * q.hop + N + 1;
+  const double* ru = rows + q.row_off;
+  const int64_t tgt = i + 1;
+  double sum = 0.0;
+  if (tgt < m.ny) {
+    // run r covers the samples a_r .. a_r + W - 2, a_r = r adv + 1
+    int64_t r_hi = (tgt - 1) / adv;
+    r_hi = r_hi > q.n_runs - 1 ? q.n_runs - 1 : r_hi;
+    int64_t r_lo = tgt - (W - 1) <= 0 ? 0 : (tgt - (W - 1) - 1) / adv + 1;  // first r with a_r + W - 2 >= tgt
+    for (int64_t r = r_lo; r <= r_hi; ++r) sum += ru[r * W + 1 + (tgt - (r * adv + 1))];
+  } else {
+    // frames whose last tap reaches the last sample live in the runs from (ny - N) / adv - 1 on; the others hold 0 there
+    int64_t r_lo = (m.ny - N) / adv - 1;
+    r_lo = r_lo < 0 ? 0 : r_lo;
+    for (int64_t r = r_lo; r < q.n_runs; ++r) sum += ru[r * W];
+  }
+  y[m.y_off + i] = sum;
+}
+
+// frames per run of req_filter_kernel: 8 while the accumulator fits beside the transform buffers at full occupancy
+// (N <= 1024: 16 KB + 12.4 KB at a hop of 80), else the frame's own row
+#ifndef WH_REQ_RUNF
+#define WH_REQ_RUNF 8
+#endif
+constexpr int req_runf(int n) { return n <= 1024 ? WH_REQ_RUNF : 1; }
+
 template <int N>
-int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, const SynUtt* d_meta, const ReqUtt* d_rq,
-                      const double* spec, const double* exc, double* y) {
-  const size_t lds = sizeof(double2) * 2 * (N / 2 + 1) + 64;  // the chain's buffer and the excitation frame's
-  if (int rc = wh::allow_lds(&req_filter_kernel<N>, lds)) return rc;
-  if (max_nf < 4) return 0;
-  { wh::KernelTimer _kt(ctx, st, "req_filter_kernel"); hipLaunchKernelGGL(req_filter_kernel<N>, dim3((unsigned)(max_nf - 3), B), dim3(ft_syn(N)), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, y); }
-  WH_LAUNCH_CHECK("req_filter_kernel");
+int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, int64_t max_ny, int64_t max_hop, bool runs,
+                      const SynUtt* d_meta, const ReqUtt* d_rq, const double* spec, const double* exc, double* rows,
+                      double* y) {
+  constexpr int RUNF = req_runf(N);
+  if (max_nf >= 4) {
+    if (runs && RUNF > 1) {
+      const size_t lds = sizeof(double2) * 2 * (N / 2 + 1) + sizeof(double) * (size_t)((RUNF - 1) * max_hop + N) + 64;
+      if (int rc = wh::allow_lds(&req_filter_kernel<N, RUNF>, lds)) return rc;
+      wh::KernelTimer _kt(ctx, st, "req_filter_kernel");
+      hipLaunchKernelGGL((req_filter_kernel<N, RUNF>), dim3((unsigned)((max_nf - 3 + RUNF - 1) / RUNF), B), dim3(ft_syn(N)), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, rows);
+    } else {
+      const size_t lds = sizeof(double2) * 2 * (N / 2 + 1) + 64;  // the chain's buffer and the excitation frame's
+      if (int rc = wh::allow_lds(&req_filter_kernel<N, 1>, lds)) return rc;
+      wh::KernelTimer _kt(ctx, st, "req_filter_kernel");
+      hipLaunchKernelGGL((req_filter_kernel<N, 1>), dim3((unsigned)(max_nf - 3), B), dim3(ft_syn(N)), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, rows);
+    }
+    WH_LAUNCH_CHECK("req_filter_kernel");
+  }
+  {
+    wh::KernelTimer _kt(ctx, st, "req_gather_kernel");
+    if (runs && RUNF > 1) hipLaunchKernelGGL((req_gather_kernel<N, RUNF>), dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, d_rq, rows, y);
+    else hipLaunchKernelGGL((req_gather_kernel<N, 1>), dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, d_rq, rows, y);
+  }
+  WH_LAUNCH_CHECK("req_gather_kernel");
   return 0;
 }
 
@@ -1710,8 +1899,8 @@ extern "C" int wh_synthesis_render(wh_ctx* ctx, void* stream, const wh_batch* b,
   const char* ws = reinterpret_cast<const char*>(timebase_ctx->ws);
   SynUtt* d_meta = nullptr;
   if (int rc = wh::persistent_upload(ctx, st, "syn.meta", meta, &d_meta)) return rc;
-  WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * t.ny_tot, st));
   const int64_t* d_pb = reinterpret_cast<const int64_t*>(ws + t.o_pb);
+  const int64_t* d_pi = reinterpret_cast<const int64_t*>(ws + t.o_pi);
   const PulseRec* d_rec = reinterpret_cast<const PulseRec*>(ws + t.o_rec);
   const int32_t* d_pc = reinterpret_cast<const int32_t*>(ws + t.o_pc);
   if (noise) {  // (the time base knows nothing about the noise stream: the cover test belongs to the call that is given one)
@@ -1721,10 +1910,10 @@ extern "C" int wh_synthesis_render(wh_ctx* ctx, void* stream, const wh_batch* b,
   WH_LAUNCH_CHECK("noise_cover_kernel");
   int rc;
   switch (fft_size) {
-    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, noise, seed, y); break;
-    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, noise, seed, y); break;
-    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, noise, seed, y); break;
-    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, noise, seed, y); break;
+    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, max_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
+    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, max_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
+    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, max_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
+    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, max_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
     default: return wh::fail_msg("wh_synthesis_render", "fft_size must be a power of two in [512, 4096]");
   }
   if (rc) return rc;
@@ -1924,7 +2113,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   const int B = b->n_utt;
   std::vector<SynUtt> meta(B);
   std::vector<ReqUtt> rq(B);
-  int64_t max_ny = 0, max_nf = 0;
+  int64_t max_ny = 0, max_nf = 0, max_hop = 0;
   for (int u = 0; u < B; ++u) {
     SynUtt& m = meta[u];
     m.f_off = b->h_frame_off[u];
@@ -1940,12 +2129,32 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
     m.dt = h_dt[u];
     rq[u].hop = h_hop[u];
     if (rq[u].hop < 1) return wh::fail_msg("wh_synthesis_requiem", "frame hop below one sample");
+    max_hop = std::max(max_hop, rq[u].hop);
     for (int k = 0; k < 8; ++k) rq[u].cursor[k] = k < n_bands ? ((h_cursor[(int64_t)u * n_bands + k] % noise_len) + noise_len) % noise_len : 0;
     max_ny = std::max(max_ny, m.ny);
     max_nf = std::max(max_nf, m.nf);
   }
   const int64_t ny_tot = h_y_off[B];
   const int64_t F = b->total_frames;
+  // overlap-add rows of req_filter_kernel: runs of frames while the run's accumulator fits the LDS beside the transform
+  // buffers (a hop beyond ~4 N / 7 samples — frame periods of tens of milliseconds — falls back to one row per frame)
+  int runf = 1;
+  switch (fft_size) {
+    case 512: runf = req_runf(512); break;
+    case 1024: runf = req_runf(1024); break;
+    case 2048: runf = req_runf(2048); break;
+    case 4096: runf = req_runf(4096); break;
+    default: return wh::fail_msg("wh_synthesis_requiem", "fft_size must be a power of two in [512, 4096]");
+  }
+  const bool runs = runf > 1 && (runf - 1) * max_hop <= 4 * (int64_t)fft_size;
+  if (!runs) runf = 1;
+  int64_t rows_tot = 0;
+  for (int u = 0; u < B; ++u) {
+    const int64_t frames = meta[u].nf >= 4 ? meta[u].nf - 3 : 0;  // frames 2 .. F-2
+    rq[u].n_runs = (frames + runf - 1) / runf;
+    rq[u].row_off = rows_tot;
+    rows_tot += rq[u].n_runs * ((runf - 1) * rq[u].hop + fft_size + 1);
+  }
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
   const size_t o_phase = off; off += al(sizeof(double) * ny_tot);
@@ -1959,6 +2168,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   const size_t o_lin = off; off += al(sizeof(double) * F * n_bands);
   const size_t o_exc = off; off += al(sizeof(double) * ny_tot);
   const size_t o_pw = off; off += al(sizeof(double) * B * pulse_cap * n_bands);  // band weights per pulse (the gains reuse o_pt)
+  const size_t o_rows = off; off += al(sizeof(double) * (size_t)(rows_tot + 8));
   if (int rc = wh::ws_reserve(ctx, off)) return rc;
   char* ws = reinterpret_cast<char*>(ctx->ws);
   SynUtt* d_meta = nullptr;
@@ -1975,7 +2185,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   double* d_pw = reinterpret_cast<double*>(ws + o_pw);
   if (int rc = wh::persistent_upload(ctx, st, "syn.meta", meta, &d_meta)) return rc;
   if (int rc = wh::persistent_upload(ctx, st, "syn.req", rq, &d_rq)) return rc;
-  WH_CHECK(hipMemsetAsync(y, 0, sizeof(double) * ny_tot, st));
+  double* d_rows = reinterpret_cast<double*>(ws + o_rows);
   { wh::KernelTimer _kt(ctx, st, "prep_kernel"); hipLaunchKernelGGL(prep_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, tp, f0, vuv, fs, 0.0, d_phase, d_vuv); }
   WH_LAUNCH_CHECK("prep_kernel");
   if (int rc = exact_cumsum_segments(ctx, st, d_phase, h_y_off, B)) return rc;
@@ -1987,10 +2197,10 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   { wh::KernelTimer _kt(ctx, st, "req_excite_kernel"); hipLaunchKernelGGL(req_excite_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, d_rq, tp, d_lin, n_bands, noise_seed, noise_len, pulse_seed, pulse_fft, d_pi, d_pc, d_pt, d_pw, d_exc); }
   WH_LAUNCH_CHECK("req_excite_kernel");
   switch (fft_size) {
-    case 512: return launch_req_filter<512>(ctx, st, B, max_nf, d_meta, d_rq, spectrogram, d_exc, y);
-    case 1024: return launch_req_filter<1024>(ctx, st, B, max_nf, d_meta, d_rq, spectrogram, d_exc, y);
-    case 2048: return launch_req_filter<2048>(ctx, st, B, max_nf, d_meta, d_rq, spectrogram, d_exc, y);
-    case 4096: return launch_req_filter<4096>(ctx, st, B, max_nf, d_meta, d_rq, spectrogram, d_exc, y);
+    case 512: return launch_req_filter<512>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 1024: return launch_req_filter<1024>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 2048: return launch_req_filter<2048>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 4096: return launch_req_filter<4096>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
     default: return wh::fail_msg("wh_synthesis_requiem", "fft_size must be a power of two in [512, 4096]");
   }
 }

@@ -681,8 +681,13 @@ class WorldBatchLanes:
     the exact phase scan, pulse compaction), which occupy a handful of CUs.  ``lanes=1`` is plain WorldBatch.
     """
 
-    def __init__(self, device_index=None, lanes=2):
-        self.lanes = [WorldBatch(device_index, lane=(i + 1 if lanes > 1 else 0)) for i in range(lanes)]
+    def __init__(self, device_index=None, lanes=2, first_lane=None):
+        """``first_lane``: lane id of the first sub-batch (default: 0 for a single lane = torch's current stream, 1.. for
+        several).  Two single-lane objects with different ids are two independent pipelines on one GPU — contexts,
+        workspaces and streams of their own — e.g. for two whole batches in flight (bench.py --in-flight)."""
+        if first_lane is None:
+            first_lane = 1 if lanes > 1 else 0
+        self.lanes = [WorldBatch(device_index, lane=first_lane + i) for i in range(lanes)]
         self.resident = None
 
     @staticmethod

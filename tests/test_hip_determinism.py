@@ -41,7 +41,10 @@ def test_encode_is_bitwise_deterministic(method, requiem):
 
 
 @pytest.mark.parametrize("requiem", [False, True])
-def test_decode_is_deterministic_up_to_atomic_order(requiem):
+def test_decode_is_bitwise_deterministic(requiem):
+    """The overlap-add of the pulse responses / Requiem frames is summed in a fixed order (rows of runs of pulses /
+    frames, then a gather in run order: wh_synthesis.hip RunState, req_filter_kernel) — no atomics since round 5, so the
+    decode repeats bit for bit (rounds 1-4: equal up to the order of the FP64 atomics, 1e-17)."""
     from world.batch import WorldBatch
 
     xs = _batch(4)
@@ -51,20 +54,57 @@ def test_decode_is_deterministic_up_to_atomic_order(requiem):
     for r in range(4):
         y, y_off = wb.decode_device(enc, seed=7)
         outs.append(y.cpu().numpy().copy())
-    scale = np.max(np.abs(outs[0]))
     for o in outs[1:]:
-        assert o.shape == outs[0].shape
-        assert np.max(np.abs(o - outs[0])) <= 1e-15 * max(scale, 1.0)
+        assert np.array_equal(o, outs[0])
     # host-noise path (reference-parity mode): the same property with caller-supplied noise
     if not requiem:
         rng = np.random.RandomState(3)
         noise = [rng.randn(2 * len(x)) for x in xs]
         a = wb.decode_device(enc, noise=noise)[0].cpu().numpy()
         b = wb.decode_device(enc, noise=noise)[0].cpu().numpy()
-        assert np.max(np.abs(a - b)) <= 1e-15 * max(scale, 1.0)
+        assert np.array_equal(a, b)
         # a different Philox seed really changes the audio (the determinism above is not a constant output)
         c = wb.decode_device(enc, seed=8)[0].cpu().numpy()
         assert np.max(np.abs(c - outs[0])) > 1e-6
+
+
+@pytest.mark.parametrize("requiem", [False, True])
+def test_decode_of_an_utterance_does_not_depend_on_its_batch(requiem):
+    """SURVEY §7.1c "sharded == unsharded bitwise", now for the decode too: the overlap-add runs are numbered per
+    utterance, so an utterance decoded alone, in the middle of a batch or on another rank's shard gives the same samples
+    bit for bit (host-supplied noise / explicit Requiem cursors, so that the random streams are the same)."""
+    from world.batch import WorldBatch
+    from world.synthesisRequiem import _advance, _default_seeds
+
+    xs = _batch(5)
+    wb = WorldBatch()
+    enc = wb.encode(xs, FS, f0_method="dio", is_requiem=requiem)
+    rng = np.random.RandomState(11)
+    noise = [rng.randn(2 * len(x)) for x in xs]
+    kw = {} if requiem else {"noise": noise}
+    y, y_off = wb.decode_device(enc, **kw)
+    y = y.cpu().numpy()
+    cur = np.zeros(3)
+    for u, x in enumerate(xs):
+        alone = WorldBatch()
+        e1 = alone.encode([x], FS, f0_method="dio", is_requiem=requiem)
+        k1 = {"cursor": cur} if requiem else {"noise": [noise[u]]}
+        y1 = alone.decode_device(e1, **k1)[0].cpu().numpy()
+        assert np.array_equal(y1, y[int(y_off[u]):int(y_off[u + 1])]), u
+        if requiem:
+            nlen = int(_default_seeds[(FS, wb.rt.index)]["noise_d"].shape[0])
+            cur = _advance(cur, int(y_off[u + 1] - y_off[u]), nlen)
+    # two "ranks": the batch split into shards decodes to the same samples as the whole
+    for lo, hi in ((0, 2), (2, 5)):
+        es = WorldBatch().encode(xs[lo:hi], FS, f0_method="dio", is_requiem=requiem)
+        if requiem:
+            c0 = np.zeros(3)
+            for u in range(lo):
+                c0 = _advance(c0, int(y_off[u + 1] - y_off[u]), nlen)
+            ys = wb.decode_device(es, cursor=c0)[0].cpu().numpy()
+        else:
+            ys = wb.decode_device(es, noise=noise[lo:hi])[0].cpu().numpy()
+        assert np.array_equal(ys, y[int(y_off[lo]):int(y_off[hi])]), (lo, hi)
 
 
 def test_guard_bands_around_outputs_stay_intact():

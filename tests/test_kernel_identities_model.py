@@ -205,3 +205,160 @@ def test_gathered_periodic_excitation_equals_the_references_scatter(case):
         R._ola(ref, int(pidx[k]), base_index, R._seed_mix(seed, ap[k]) * np.sqrt(max(1, int(nxt[k] - pidx[k]))))
     got = _gathered_periodic(ny, pidx, gain, wm, seed)
     assert np.array_equal(got, ref)
+
+
+# ---- round 5: overlap-add without atomics (response_kernel rows + response_gather_kernel; wh_synthesis.hip RunState) --------
+def _rows_of_runs(ny, pidx, resp, n, run):
+    """response_kernel's overlap-add, thread loops flattened: runs of `run` consecutive pulses accumulate in an n-sample
+    ring; what leaves the ring's window goes to the run's row at r*(n+1) + start_r - 1 (slot 0: the last sample's
+    share).  Unwritten slots stay NaN so that a gather that reads one is caught."""
+    count = len(pidx)
+    runs_cap = (count + run - 1) // run
+    rows = np.full(ny + runs_cap * (n + 1) + n + 8, np.nan)
+    for r in range(runs_cap):
+        ring = np.zeros(n)
+        any_, win_start, row_start, last = False, 0, 1, 0.0
+        base = r * (n + 1) - 1
+        for k in range(r * run, min((r + 1) * run, count)):
+            s1 = int(pidx[k]) - n // 2 + 1
+            if any_:
+                e = min(s1, win_start + n)
+                for tgt in range(max(win_start, 1), min(e, ny)):          # ring_flush
+                    rows[base + row_start + 1 + (tgt - row_start)] = ring[tgt & (n - 1)]
+                    ring[tgt & (n - 1)] = 0.0
+                for tgt in range(win_start + n, min(s1, ny)):              # pulses more than n apart
+                    rows[base + row_start + 1 + (tgt - row_start)] = 0.0
+            else:
+                row_start = max(s1, 1)
+            any_, win_start = True, s1
+            for mm in range(n):
+                tgt = s1 + mm
+                if tgt < 1:
+                    continue
+                if tgt < ny:
+                    ring[tgt & (n - 1)] += resp[k][mm]
+                elif mm == n - 1:
+                    last += resp[k][mm]
+        if any_:
+            for tgt in range(max(win_start, 1), min(win_start + n, ny)):
+                rows[base + row_start + 1 + (tgt - row_start)] = ring[tgt & (n - 1)]
+            rows[base + row_start] = last
+    return rows
+
+
+def _gather_rows(ny, pidx, rows, n, run):
+    """response_gather_kernel, one tile of 256 samples at a time."""
+    count = len(pidx)
+    n_runs = (count + run - 1) // run
+    y = np.zeros(ny)
+    for n0 in range(0, ny, 256):
+        k0 = _first_pulse_at(pidx, n0 + 1 - n // 2)
+        k_end = _first_pulse_at(pidx, ny - n // 2)
+        for i in range(n0, min(n0 + 256, ny)):
+            tgt, acc = i + 1, 0.0
+            if tgt < ny:
+                for r in range(k0 // run, n_runs):
+                    kf = r * run
+                    kl = min(kf + run, count) - 1
+                    s1f = int(pidx[kf]) - n // 2 + 1
+                    if s1f > n0 + 256:
+                        break
+                    start, end = max(s1f, 1), int(pidx[kl]) + n // 2 + 1
+                    if start <= tgt < end:
+                        acc += rows[r * (n + 1) - 1 + start + 1 + (tgt - start)]
+            else:
+                for r in range(k_end // run, n_runs):
+                    acc += rows[r * (n + 1) - 1 + max(int(pidx[r * run]) - n // 2 + 1, 1)]
+            y[i] = acc
+    return y
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_response_rows_and_gather_equal_the_references_scatter(case):
+    """Integer-valued responses: every association of the sum is exact, so the gathered rows must EQUAL the reference's
+    pulse-by-pulse clipped fancy-index += (world/synthesis.py:67-81), including both clipped ends, pulses closer than,
+    as far as and farther apart than the transform length, and a pulse count that is no multiple of the run."""
+    rng = np.random.default_rng(300 + case)
+    n, run = 64, (3 if case % 2 else 6)
+    ny = int(rng.integers(300, 900))
+    count = int(rng.integers(1, 40))
+    if case == 5:  # sparse: gaps longer than n between pulses
+        pidx = np.sort(rng.choice(np.arange(1, ny + 1, 90), size=min(count, len(np.arange(1, ny + 1, 90))), replace=False))
+    else:
+        pidx = np.sort(rng.choice(np.arange(1, ny + 1), size=min(count, ny), replace=False))
+    if case % 3 == 0:
+        pidx[0], pidx[-1] = 1, ny
+    resp = rng.integers(-9, 10, size=(len(pidx), n)).astype(np.float64)
+    base_index = np.arange(-n // 2 + 1, n // 2 + 1)
+    ref = np.zeros(ny)
+    for k in range(len(pidx)):
+        R._ola(ref, int(pidx[k]), base_index, resp[k])
+    rows = _rows_of_runs(ny, pidx, resp, n, run)
+    got = _gather_rows(ny, pidx, rows, n, run)
+    assert not np.any(np.isnan(got))
+    assert np.array_equal(got, ref)
+
+
+def _req_rows(ny, nf, hop, n, runf, resp):
+    """req_filter_kernel<N, RUNF>'s rows: frames 2 .. nf-2 in runs of runf, each run's responses summed in frame order
+    over (runf - 1) hop + n samples; slot 0 = the run's share of the last sample."""
+    frames = max(nf - 3, 0)
+    n_runs = (frames + runf - 1) // runf
+    w = (runf - 1) * hop + n + 1
+    rows = np.full(n_runs * w, np.nan)
+    for r in range(n_runs):
+        i0 = r * runf + 2
+        i1 = min(i0 + runf - 1, nf - 2)
+        a_r = (i0 - 2) * hop + 1
+        acc, last = np.zeros(w - 1), 0.0
+        for i in range(i0, i1 + 1):
+            origin = (i - 1) * hop - (hop - 1)
+            for mm in range(n):
+                tgt = origin + mm
+                if tgt < ny:
+                    acc[origin - a_r + mm] += resp[i][mm]
+                elif mm == n - 1:
+                    last += resp[i][mm]
+        rows[r * w + 1:(r + 1) * w] = acc
+        rows[r * w] = last
+    return rows, n_runs, w
+
+
+def _req_gather(ny, hop, n, runf, rows, n_runs, w):
+    adv = runf * hop
+    y = np.zeros(ny)
+    for i in range(ny):
+        tgt, acc = i + 1, 0.0
+        if tgt < ny:
+            r_hi = min((tgt - 1) // adv, n_runs - 1)
+            x = tgt - (w - 1)
+            r_lo = 0 if x <= 0 else (x - 1) // adv + 1
+            for r in range(r_lo, r_hi + 1):
+                acc += rows[r * w + 1 + (tgt - (r * adv + 1))]
+        else:
+            r_lo = max(int((ny - n) / adv) - 1, 0)  # (C++ division truncates towards zero)
+            for r in range(r_lo, n_runs):
+                acc += rows[r * w]
+        y[i] = acc
+    return y
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_requiem_frame_rows_and_gather_equal_the_references_overlap_add(case):
+    """req_filter_kernel / req_gather_kernel against the reference's frame loop (world/synthesisRequiem.py:83-100:
+    y[clip(origin + arange(fft))] += response, frames 2 .. F-2), integer-valued responses so that every association of
+    the sum is exact: runs of 8, 3 and 1 frames, output lengths that cut the last responses short, fewer than 4 frames."""
+    rng = np.random.default_rng(400 + case)
+    n = 64
+    hop = int(rng.integers(3, 12))
+    runf = (8, 3, 1, 8)[case % 4]
+    nf = int(rng.integers(2, 40)) if case != 6 else 3
+    ny = max(2, (nf - 1) * hop + int(rng.integers(-hop, hop + 1)) + 1)  # about one hop around the last frame time
+    resp = rng.integers(-9, 10, size=(nf + 1, n)).astype(np.float64)
+    ref = np.zeros(ny)
+    for i in range(2, nf - 1):  # i = 2 .. nf-2
+        origin = (i - 1) * hop - (hop - 1)
+        R._ola(ref, origin, np.arange(n), resp[i])
+    rows, n_runs, w = _req_rows(ny, nf, hop, n, runf, resp)
+    got = _req_gather(ny, hop, n, runf, rows, n_runs, w)
+    assert not np.any(np.isnan(got)) and np.array_equal(got, ref)

@@ -1423,6 +1423,10 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
 // Requiem excitation); a run's extent from its first and last pulse.  The utterance's LAST sample receives, of every
 // pulse whose window reaches it or beyond, the last tap only (the reference's clipped fancy-index assignment keeps the
 // last of the duplicates, Q8): the rows' slot 0.
+#ifndef WH_GATHER_PER
+#define WH_GATHER_PER 4
+#endif
+constexpr int kGatherTile = 256 * WH_GATHER_PER;  // output samples per workgroup: one pulse search for all of them
 template <int N>
 __global__ __launch_bounds__(256) void response_gather_kernel(const SynUtt* __restrict__ meta,
                                                               const int64_t* __restrict__ p_idx,
@@ -1430,37 +1434,51 @@ __global__ __launch_bounds__(256) void response_gather_kernel(const SynUtt* __re
                                                               const double* __restrict__ rows, int64_t row_stride,
                                                               double* __restrict__ y) {
   constexpr int RUN = resp_run(N);
+  constexpr int PER = WH_GATHER_PER;
   const SynUtt m = meta[blockIdx.y];
-  const int64_t n0 = (int64_t)blockIdx.x * 256;
+  const int64_t n0 = (int64_t)blockIdx.x * kGatherTile;
   if (n0 >= m.ny) return;
   const int count = p_count[blockIdx.y];
   const int64_t* pi = p_idx + m.p_off;
   const double* ru = rows + (int64_t)blockIdx.y * row_stride - 1;
-  // pulses whose window [pidx - N/2 + 1, pidx + N/2] reaches the tile's samples n0 + 1 .. n0 + 256
+  // pulses whose window [pidx - N/2 + 1, pidx + N/2] reaches the tile's samples n0 + 1 .. n0 + kGatherTile
   const int k0 = first_pulse_at(pi, count, n0 + 1 - N / 2);
-  const int k_end = first_pulse_at(pi, count, m.ny - N / 2);  // first pulse whose last tap reaches the last sample
   const int n_runs = (count + RUN - 1) / RUN;
-  const int64_t i = n0 + threadIdx.x;
-  if (i >= m.ny) return;
-  const int64_t tgt = i + 1;
-  double sum = 0.0;
-  if (tgt < m.ny) {
-    for (int r = k0 / RUN; r < n_runs; ++r) {
-      const int kf = r * RUN;
-      const int kl = (kf + RUN < count ? kf + RUN : count) - 1;
-      const int64_t s1f = pi[kf] - N / 2 + 1;
-      if (s1f > n0 + 256) break;
-      const int64_t start = s1f < 1 ? 1 : s1f;
-      const int64_t end = pi[kl] + N / 2 + 1;  // one behind the last tap of the run's last pulse
-      if (tgt >= start && tgt < end) sum += ru[(int64_t)r * (N + 1) + start + 1 + (tgt - start)];
-    }
-  } else {
-    for (int r = k_end / RUN; r < n_runs; ++r) {
-      const int64_t s1f = pi[r * RUN] - N / 2 + 1;
-      sum += ru[(int64_t)r * (N + 1) + (s1f < 1 ? 1 : s1f)];
+  double sum[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) sum[q] = 0.0;
+  const int64_t t0 = n0 + 1 + threadIdx.x;  // this thread's samples: t0 + 256 q (1-based)
+  for (int r = k0 / RUN; r < n_runs; ++r) {
+    const int kf = r * RUN;
+    const int kl = (kf + RUN < count ? kf + RUN : count) - 1;
+    const int64_t s1f = pi[kf] - N / 2 + 1;
+    if (s1f > n0 + kGatherTile) break;
+    const int64_t start = s1f < 1 ? 1 : s1f;
+    int64_t end = pi[kl] + N / 2 + 1;  // one behind the last tap of the run's last pulse ...
+    end = end < m.ny ? end : m.ny;     // ... and the last sample takes the rows' slot 0 only (below)
+    const double* rr = ru + (int64_t)r * (N + 1) + 1;  // sample t of the run at rr[t] (slot 1 + (t - start) of a row that begins at start - 1)
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int64_t tgt = t0 + 256 * q;
+      if (tgt >= start && tgt < end) sum[q] += rr[tgt];
     }
   }
-  y[m.y_off + i] = sum;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int64_t tgt = t0 + 256 * q;
+    if (tgt < m.ny) y[m.y_off + tgt - 1] = sum[q];
+  }
+  if (n0 + kGatherTile >= m.ny) {  // the tile that holds the utterance's last sample: block-uniform
+    const int k_end = first_pulse_at(pi, count, m.ny - N / 2);  // first pulse whose last tap reaches the last sample
+    if (threadIdx.x == 0) {
+      double last = 0.0;
+      for (int r = k_end / RUN; r < n_runs; ++r) {
+        const int64_t s1f = pi[r * RUN] - N / 2 + 1;
+        last += ru[(int64_t)r * (N + 1) + (s1f < 1 ? 1 : s1f)];
+      }
+      y[m.y_off + m.ny - 1] = last;
+    }
+  }
 }
 
 
@@ -1494,7 +1512,7 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, int64_t ma
   { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_rec, p_base, B, noise, seed, d_dc, ctx->d_twiddle, reinterpret_cast<double*>(d_rows), row_stride, reinterpret_cast<const int64_t*>(d_rb)};
   hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(ft_syn(N)), lds, st, ra); }
   WH_LAUNCH_CHECK("response_kernel");
-  { wh::KernelTimer _kt(ctx, st, "response_gather_kernel"); hipLaunchKernelGGL(response_gather_kernel<N>, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, p_idx, p_count, reinterpret_cast<const double*>(d_rows), row_stride, y); }
+  { wh::KernelTimer _kt(ctx, st, "response_gather_kernel"); hipLaunchKernelGGL(response_gather_kernel<N>, dim3((unsigned)((max_ny + kGatherTile - 1) / kGatherTile), B), dim3(256), 0, st, d_meta, p_idx, p_count, reinterpret_cast<const double*>(d_rows), row_stride, y); }
   WH_LAUNCH_CHECK("response_gather_kernel");
   return 0;
 }
@@ -1634,53 +1652,60 @@ __global__ __launch_bounds__(256) void req_excite_kernel(const SynUtt* __restric
   exc[m.y_off + i] = periodic + aperiodic;  // synthesisRequiem.py:62
 }
 
+// frames per run of req_filter_kernel: 4 up to N = 1024 — measured at config 4 (filter + gather) with the run's sums in
+// LDS: 1 frame 1.40 + 0.22 ms, 4 frames 1.57 + 0.08, 8 frames 1.70 + 0.06, 16 frames 1.96 + 0.05; one frame per row
+// beyond (no benchmark config decodes Requiem there)
+#ifndef WH_REQ_RUNF
+#define WH_REQ_RUNF 4
+#endif
+constexpr int req_runf(int n) { return n <= 1024 ? WH_REQ_RUNF : 1; }
+
 // Frame-wise minimum-phase filtering of the excitation with overlap-add (synthesisRequiem.py:74-101), WITHOUT atomics:
-// a workgroup takes a run of RUNF consecutive frames of one utterance, adds their responses — in frame order — into an
-// LDS accumulator that spans the run ((RUNF - 1) hop + N samples), and writes the sum as the run's ROW; req_gather_kernel
+// a workgroup takes a run of RUNF consecutive frames of one utterance and adds their responses — in frame order —
+// into the run's ROW, which spans the run ((RUNF - 1) hop + N samples); req_gather_kernel
 // then adds, per output sample, the two or three rows that cover it, in run order.  The same sum from launch to launch
 // and wherever the utterance sits in a batch (runs are numbered per utterance); the reference adds frame after frame
 // into y — runs of frames first is another association of that sum.  Row r of an utterance: W = (RUNF - 1) hop + N + 1
 // doubles at row_off + r W; slot 0 = the run's share of the utterance's LAST sample (Q8: of the taps clipped onto it
 // only the last one written survives — the last tap of every frame whose response reaches it or beyond), slot 1 + j =
-// the sum at the 1-based sample a_r + j, a_r = r RUNF hop + 1.  RUNF = 1 (long transforms, whose LDS has no room for
-// the accumulator): the row is the frame's own response, written straight from the transform buffer.
-// (Round 4 measured runs of 1 / 4 / 8 / 16 / 32 frames with one atomic per run and sample: 1.65 / 1.63 / 1.65 / 1.69 / 1.78
-// ms at config 4 — the kernel is issue-bound, the run length is free; rows instead of atomics take 1.07 GB of
-// read-modify-write traffic per 64 utterances down to a 0.2 GB row write + read.)
+// the sum at the 1-based sample a_r + j, a_r = r RUNF hop + 1.  RUNF = 1 (long transforms, long hops): the row is the
+// frame's own response, written straight from the transform buffer.  Rows instead of atomics take the 1.07 GB of
+// read-modify-write traffic per 64 utterances down to a 0.3 GB row write + read.
+#ifndef WH_REQ_MINW
+#define WH_REQ_MINW 1
+#endif
 template <int N, int RUNF>
-__global__ __launch_bounds__(ft_syn(N)) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
+__global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1)) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
                                                         const double* __restrict__ spectrogram,
                                                         const double* __restrict__ exc,
-                                                        const double2* __restrict__ tw_base, double* __restrict__ rows) {
+                                                        const double2* __restrict__ tw_base_arg, double* rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int FT = ft_syn(N);
   constexpr int K = N / 2 + 1;
+  const double2* tw_base = tw_base_arg;
   double2* zb = reinterpret_cast<double2*>(smem);        // minimum-phase half spectrum (N/2+1 complex)
   double2* sb = zb + (N / 2 + 1);                         // windowed excitation frame / its half spectrum
   double* sr = reinterpret_cast<double*>(sb);
-  double* acc = reinterpret_cast<double*>(sb + (N / 2 + 1));  // RUNF > 1: (RUNF - 1) hop + N sums of the run
   const SynUtt m = meta[blockIdx.y];
   const ReqUtt q = rq[blockIdx.y];
   if ((int64_t)blockIdx.x >= q.n_runs) return;
   const int64_t hop = q.hop;
-  const int64_t wlen = 2 * hop - 1;
+  int64_t wlen = 2 * hop - 1;
   const int64_t i0 = (int64_t)blockIdx.x * RUNF + 2;  // frames 2 .. F-2  (synthesisRequiem.py:83)
   const int64_t i1 = i0 + RUNF - 1 < m.nf - 2 ? i0 + RUNF - 1 : m.nf - 2;
   const int64_t a_r = (i0 - 2) * hop + 1;  // 1-based sample of the run's first tap (= the first frame's origin)
   const int64_t W = (RUNF - 1) * hop + N + 1;
   double* row = rows + q.row_off + (int64_t)blockIdx.x * W;
-  const int span = (int)(W - 1);
-  double last = 0.0;  // (thread FT-1 holds tap N-1 of every frame)
-  if (RUNF > 1) {
-    for (int j = threadIdx.x; j < span; j += FT) acc[j] = 0.0;
-  }
+  double last = 0.0;  // (thread FT-1: tap N-1 of every frame whose response reaches the utterance's last sample)
   const double* eu = exc + m.y_off;
   double* zr = reinterpret_cast<double*>(zb);
 #pragma unroll 1
   for (int64_t i = i0; i <= i1; ++i) {
     const int64_t origin = (i - 1) * hop - (hop - 1);  // 1-based
-    if (RUNF > 1) wh::sync<FT>();  // the previous frame's response has been added (zr is about to be overwritten)
-    for (int j = threadIdx.x; j < N; j += FT) {
+    // per frame: neither the twiddles nor the window values of one frame are parked in registers for the next (both are
+    // the same for every frame, and hoisted out of this loop they cost a wave per SIMD)
+    asm volatile("" : "+s"(tw_base), "+s"(wlen));
+    for (int j = WH_TID; j < N; j += FT) {
       double v = 0.0;
       if (j < wlen) {
         int64_t g = origin + j;
@@ -1692,7 +1717,7 @@ __global__ __launch_bounds__(ft_syn(N)) void req_filter_kernel(const SynUtt* __r
       sr[j] = v;
     }
     const double* sp = spectrogram + (m.f_off + (i - 1)) * K;
-    for (int k = threadIdx.x; k < K; k += FT) {  // log|S| / 2, Hermitian-mirrored: the input of the chain's first transform
+    for (int k = WH_TID; k < K; k += FT) {  // log|S| / 2, Hermitian-mirrored: the input of the chain's first transform
       const double lw = log_call(fabs(sp[k])) / 2;
       zr[k] = lw;
       if (k > 0 && k < N / 2) zr[N - k] = lw;
@@ -1702,22 +1727,21 @@ __global__ __launch_bounds__(ft_syn(N)) void req_filter_kernel(const SynUtt* __r
     // minimum-phase spectrum x excitation spectrum (both Hermitian, so is the product), straight into the inverse
     // transform: the fused chain of the pulse responses with the product applied to the register-held bin pairs
     min_phase_response<N, FT>(zb, tw_base, 0.0, [&](int k, double2 e) { return wh::cmul(e, sb[k]); });
-    const int shift = (int)(origin - a_r);  // (i - i0) * hop
-    for (int mm = threadIdx.x; mm < N; mm += FT) {
-      const int64_t tgt = origin + mm;
-      const double v = zr[mm] / N;
-      if (tgt < m.ny) {  // (tgt >= 1 always: origin >= 1)
-        if (RUNF > 1) acc[shift + mm] += v;  // one writer per slot and frame; frames are separated by barriers
-        else row[1 + mm] = v;
-      } else {
-        if (RUNF == 1) row[1 + mm] = 0.0;
-        if (mm == N - 1) last += v;
-      }
+    // The run's sums are kept in the row itself (global memory, L2-resident): this frame's taps in front of N - hop fall
+    // on samples earlier frames of the run have written — read, add, write back, each sample by one thread —, the last
+    // hop taps on fresh ones.  The barriers of the chain order one frame's stores before the next frame's loads (a
+    // workgroup's waves share the CU's vector cache).  Neither registers nor LDS are held across the frames: an LDS
+    // accumulator costs the kernel three of its eight waves per SIMD (1.70 against 1.40 ms at config 4).
+    const int shift = (int)(origin - a_r);  // (i - i0) * hop: where this frame's tap 0 falls in the run
+    const int fresh = (i == i0) ? 0 : N - (int)hop;  // first tap that no earlier frame of the run reached
+    double* rw = row + 1 + shift;
+    for (int mm = WH_TID; mm < N; mm += FT) {
+      double v = origin + mm < m.ny ? zr[mm] / N : 0.0;  // (origin + mm >= 1 always)
+      if (RUNF > 1 && mm < fresh) v = rw[mm] + v;
+      rw[mm] = v;
     }
-  }
-  if (RUNF > 1) {
-    wh::sync<FT>();
-    for (int j = threadIdx.x; j < span; j += FT) row[1 + j] = acc[j];
+    if (WH_TID == FT - 1 && origin + (N - 1) >= m.ny) last += zr[N - 1] / N;
+    if (RUNF > 1) wh::sync<FT>();  // zr is free for the next frame, and this frame's row stores are visible to it
   }
   if (threadIdx.x == FT - 1) row[0] = last;
 }
@@ -1740,7 +1764,12 @@ __global__ __launch_bounds__(256) void req_gather_kernel(const SynUtt* __restric
     int64_t r_hi = (tgt - 1) / adv;
     r_hi = r_hi > q.n_runs - 1 ? q.n_runs - 1 : r_hi;
     int64_t r_lo = tgt - (W - 1) <= 0 ? 0 : (tgt - (W - 1) - 1) / adv + 1;  // first r with a_r + W - 2 >= tgt
-    for (int64_t r = r_lo; r <= r_hi; ++r) sum += ru[r * W + 1 + (tgt - (r * adv + 1))];
+    for (int64_t r = r_lo; r <= r_hi; ++r) {
+      // (the last run of an utterance may hold fewer frames: its row is written as far as they reach)
+      const int64_t nfr = r == q.n_runs - 1 ? (m.nf - 3) - r * RUNF : RUNF;
+      const int64_t j = tgt - (r * adv + 1);
+      if (j < (nfr - 1) * q.hop + N) sum += ru[r * W + 1 + j];
+    }
   } else {
     // frames whose last tap reaches the last sample live in the runs from (ny - N) / adv - 1 on; the others hold 0 there
     int64_t r_lo = (m.ny - N) / adv - 1;
@@ -1752,30 +1781,24 @@ __global__ __launch_bounds__(256) void req_gather_kernel(const SynUtt* __restric
 
 // frames per run of req_filter_kernel: 8 while the accumulator fits beside the transform buffers at full occupancy
 // (N <= 1024: 16 KB + 12.4 KB at a hop of 80), else the frame's own row
-#ifndef WH_REQ_RUNF
-#define WH_REQ_RUNF 8
-#endif
-constexpr int req_runf(int n) { return n <= 1024 ? WH_REQ_RUNF : 1; }
 
 template <int N>
-int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, int64_t max_ny, int64_t max_hop, bool runs,
+int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, int64_t max_ny, bool runs,
                       const SynUtt* d_meta, const ReqUtt* d_rq, const double* spec, const double* exc, double* rows,
                       double* y) {
   constexpr int RUNF = req_runf(N);
+  const size_t lds = sizeof(double2) * 2 * (N / 2 + 1) + 64;  // the chain's buffer and the excitation frame's
   if (max_nf >= 4) {
+    wh::KernelTimer _kt(ctx, st, "req_filter_kernel");
     if (runs && RUNF > 1) {
-      const size_t lds = sizeof(double2) * 2 * (N / 2 + 1) + sizeof(double) * (size_t)((RUNF - 1) * max_hop + N) + 64;
       if (int rc = wh::allow_lds(&req_filter_kernel<N, RUNF>, lds)) return rc;
-      wh::KernelTimer _kt(ctx, st, "req_filter_kernel");
       hipLaunchKernelGGL((req_filter_kernel<N, RUNF>), dim3((unsigned)((max_nf - 3 + RUNF - 1) / RUNF), B), dim3(ft_syn(N)), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, rows);
     } else {
-      const size_t lds = sizeof(double2) * 2 * (N / 2 + 1) + 64;  // the chain's buffer and the excitation frame's
       if (int rc = wh::allow_lds(&req_filter_kernel<N, 1>, lds)) return rc;
-      wh::KernelTimer _kt(ctx, st, "req_filter_kernel");
       hipLaunchKernelGGL((req_filter_kernel<N, 1>), dim3((unsigned)(max_nf - 3), B), dim3(ft_syn(N)), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, rows);
     }
-    WH_LAUNCH_CHECK("req_filter_kernel");
   }
+  WH_LAUNCH_CHECK("req_filter_kernel");
   {
     wh::KernelTimer _kt(ctx, st, "req_gather_kernel");
     if (runs && RUNF > 1) hipLaunchKernelGGL((req_gather_kernel<N, RUNF>), dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, d_rq, rows, y);
@@ -2136,8 +2159,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   }
   const int64_t ny_tot = h_y_off[B];
   const int64_t F = b->total_frames;
-  // overlap-add rows of req_filter_kernel: runs of frames while the run's accumulator fits the LDS beside the transform
-  // buffers (a hop beyond ~4 N / 7 samples — frame periods of tens of milliseconds — falls back to one row per frame)
+  // overlap-add rows of req_filter_kernel: runs of frames (one row per frame beyond N = 1024 and for hops >= N)
   int runf = 1;
   switch (fft_size) {
     case 512: runf = req_runf(512); break;
@@ -2146,7 +2168,8 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
     case 4096: runf = req_runf(4096); break;
     default: return wh::fail_msg("wh_synthesis_requiem", "fft_size must be a power of two in [512, 4096]");
   }
-  const bool runs = runf > 1 && (runf - 1) * max_hop <= 4 * (int64_t)fft_size;
+  // (a frame adds onto the N - hop samples its predecessors wrote: the hop must be shorter than the transform)
+  const bool runs = runf > 1 && max_hop < fft_size;
   if (!runs) runf = 1;
   int64_t rows_tot = 0;
   for (int u = 0; u < B; ++u) {
@@ -2197,10 +2220,10 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   { wh::KernelTimer _kt(ctx, st, "req_excite_kernel"); hipLaunchKernelGGL(req_excite_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, d_rq, tp, d_lin, n_bands, noise_seed, noise_len, pulse_seed, pulse_fft, d_pi, d_pc, d_pt, d_pw, d_exc); }
   WH_LAUNCH_CHECK("req_excite_kernel");
   switch (fft_size) {
-    case 512: return launch_req_filter<512>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
-    case 1024: return launch_req_filter<1024>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
-    case 2048: return launch_req_filter<2048>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
-    case 4096: return launch_req_filter<4096>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 512: return launch_req_filter<512>(ctx, st, B, max_nf, max_ny, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 1024: return launch_req_filter<1024>(ctx, st, B, max_nf, max_ny, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 2048: return launch_req_filter<2048>(ctx, st, B, max_nf, max_ny, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 4096: return launch_req_filter<4096>(ctx, st, B, max_nf, max_ny, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
     default: return wh::fail_msg("wh_synthesis_requiem", "fft_size must be a power of two in [512, 4096]");
   }
 }

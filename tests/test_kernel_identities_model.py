@@ -246,26 +246,26 @@ def _rows_of_runs(ny, pidx, resp, n, run):
     return rows
 
 
-def _gather_rows(ny, pidx, rows, n, run):
-    """response_gather_kernel, one tile of 256 samples at a time."""
+def _gather_rows(ny, pidx, rows, n, run, tile=256):
+    """response_gather_kernel, one tile of samples at a time."""
     count = len(pidx)
     n_runs = (count + run - 1) // run
     y = np.zeros(ny)
-    for n0 in range(0, ny, 256):
+    for n0 in range(0, ny, tile):
         k0 = _first_pulse_at(pidx, n0 + 1 - n // 2)
         k_end = _first_pulse_at(pidx, ny - n // 2)
-        for i in range(n0, min(n0 + 256, ny)):
+        for i in range(n0, min(n0 + tile, ny)):
             tgt, acc = i + 1, 0.0
             if tgt < ny:
                 for r in range(k0 // run, n_runs):
                     kf = r * run
                     kl = min(kf + run, count) - 1
                     s1f = int(pidx[kf]) - n // 2 + 1
-                    if s1f > n0 + 256:
+                    if s1f > n0 + tile:
                         break
                     start, end = max(s1f, 1), int(pidx[kl]) + n // 2 + 1
                     if start <= tgt < end:
-                        acc += rows[r * (n + 1) - 1 + start + 1 + (tgt - start)]
+                        acc += rows[r * (n + 1) + tgt]  # (= slot 1 + (tgt - start) of the row that begins at start - 1)
             else:
                 for r in range(k_end // run, n_runs):
                     acc += rows[r * (n + 1) - 1 + max(int(pidx[r * run]) - n // 2 + 1, 1)]
@@ -294,14 +294,15 @@ def test_response_rows_and_gather_equal_the_references_scatter(case):
     for k in range(len(pidx)):
         R._ola(ref, int(pidx[k]), base_index, resp[k])
     rows = _rows_of_runs(ny, pidx, resp, n, run)
-    got = _gather_rows(ny, pidx, rows, n, run)
-    assert not np.any(np.isnan(got))
-    assert np.array_equal(got, ref)
+    for tile in (256, 1024, 96):
+        got = _gather_rows(ny, pidx, rows, n, run, tile)
+        assert not np.any(np.isnan(got))
+        assert np.array_equal(got, ref)
 
 
 def _req_rows(ny, nf, hop, n, runf, resp):
     """req_filter_kernel<N, RUNF>'s rows: frames 2 .. nf-2 in runs of runf, each run's responses summed in frame order
-    over (runf - 1) hop + n samples; slot 0 = the run's share of the last sample."""
+    over (runf - 1) hop + n samples; slot 0 = the run's share of the last sample.  Unwritten slots stay NaN."""
     frames = max(nf - 3, 0)
     n_runs = (frames + runf - 1) // runf
     w = (runf - 1) * hop + n + 1
@@ -310,21 +311,21 @@ def _req_rows(ny, nf, hop, n, runf, resp):
         i0 = r * runf + 2
         i1 = min(i0 + runf - 1, nf - 2)
         a_r = (i0 - 2) * hop + 1
-        acc, last = np.zeros(w - 1), 0.0
-        for i in range(i0, i1 + 1):
+        last = 0.0
+        for i in range(i0, i1 + 1):  # the sums live in the row itself: read-add-write over what earlier frames wrote
             origin = (i - 1) * hop - (hop - 1)
+            fresh = 0 if i == i0 else n - hop
             for mm in range(n):
-                tgt = origin + mm
-                if tgt < ny:
-                    acc[origin - a_r + mm] += resp[i][mm]
-                elif mm == n - 1:
-                    last += resp[i][mm]
-        rows[r * w + 1:(r + 1) * w] = acc
+                v = resp[i][mm] if origin + mm < ny else 0.0
+                at = r * w + 1 + (origin - a_r) + mm
+                rows[at] = rows[at] + v if (runf > 1 and mm < fresh) else v
+            if origin + n - 1 >= ny:
+                last += resp[i][n - 1]
         rows[r * w] = last
     return rows, n_runs, w
 
 
-def _req_gather(ny, hop, n, runf, rows, n_runs, w):
+def _req_gather(ny, nf, hop, n, runf, rows, n_runs, w):
     adv = runf * hop
     y = np.zeros(ny)
     for i in range(ny):
@@ -334,7 +335,10 @@ def _req_gather(ny, hop, n, runf, rows, n_runs, w):
             x = tgt - (w - 1)
             r_lo = 0 if x <= 0 else (x - 1) // adv + 1
             for r in range(r_lo, r_hi + 1):
-                acc += rows[r * w + 1 + (tgt - (r * adv + 1))]
+                nfr = (nf - 3) - r * runf if r == n_runs - 1 else runf  # the last run may hold fewer frames
+                j = tgt - (r * adv + 1)
+                if j < (nfr - 1) * hop + n:
+                    acc += rows[r * w + 1 + j]
         else:
             r_lo = max(int((ny - n) / adv) - 1, 0)  # (C++ division truncates towards zero)
             for r in range(r_lo, n_runs):
@@ -360,5 +364,5 @@ def test_requiem_frame_rows_and_gather_equal_the_references_overlap_add(case):
         origin = (i - 1) * hop - (hop - 1)
         R._ola(ref, origin, np.arange(n), resp[i])
     rows, n_runs, w = _req_rows(ny, nf, hop, n, runf, resp)
-    got = _req_gather(ny, hop, n, runf, rows, n_runs, w)
+    got = _req_gather(ny, nf, hop, n, runf, rows, n_runs, w)
     assert not np.any(np.isnan(got)) and np.array_equal(got, ref)

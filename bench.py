@@ -587,7 +587,7 @@ def main():
             blocks.append(("config1_latency", lambda: config1_latency_block(torch)))
             blocks.append(("feature_heads", lambda: feature_heads_block(torch, wl, FS)))
             blocks.append(("swipe", lambda: swipe_block(torch, wl, FS)))
-            blocks.append(("other_configs", lambda: other_configs_block(torch, local_rank, xs_distinct, xs_cfg5)))
+            blocks.append(("other_configs", lambda: other_configs_block(torch, local_rank, xs_distinct, xs_cfg5, max(1, args.in_flight))))
             for key, fn in blocks + [("north_star", lambda: north_star_block(torch, local_rank, xs_north or xs_distinct, FS, args))]:
                 try:
                     out[key] = fn()
@@ -1079,13 +1079,47 @@ def swipe_block(torch, wl, fs, reps=3):
             "kernel_ms": {k: round(v, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])}}
 
 
-def other_configs_block(torch, device_index, xs16, xs48):
-    """BASELINE configs 3, 4 and 5 at their single-GPU sizes, timed by this process like the headline (the step replayed
-    from a hipGraph; the eager figure, the host's enqueue time per step and the sum of the kernels' HIP-event durations
-    beside it, so that a gap between the step and its kernels is visible in the line): 3 = Harvest only on 256 x 10 s
-    (the size BASELINE.json states it on);
-    4 = Harvest + CheapTrick + D4C-Requiem encode + Requiem decode on 64 x 10 s; 5 = 16 x 60 s at 48 kHz, Harvest
-    encode, scale_pitch(1.5), scale_duration(2.0), decode."""
+def time_pipelines(torch, pipes, steps):
+    """`pipes`: [(step function, HIP stream or None)] — independent pipelines over copies of one batch.  Times `steps`
+    eager steps on pipeline 0 (host enqueue time and wall time per step), then, replayed from one hipGraph per pipeline,
+    `steps` steps dealt round-robin to all pipelines and `steps` steps on pipeline 0 alone.  Returns a dict of seconds per
+    step: enqueue, eager, pipelined (all in flight), one (one in flight), and graph (bool)."""
+    fn0 = pipes[0][0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        fn0(1 + k)
+    enq = (time.perf_counter() - t0) / steps
+    torch.cuda.synchronize()
+    eager = (time.perf_counter() - t0) / steps
+    graphs = [try_capture(torch, (lambda fn=fn: fn(1000)), stream=st) for fn, st in pipes]
+    out = {"enqueue": enq, "eager": eager, "pipelined": eager, "one": eager, "graph": False}
+    if all(g is not None for g in graphs):
+        def run(active):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(steps):
+                d = k % active
+                if pipes[d][1] is not None:
+                    with torch.cuda.stream(pipes[d][1]):
+                        graphs[d].replay()
+                else:
+                    graphs[d].replay()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / steps
+        out["pipelined"] = run(len(pipes))
+        out["one"] = run(1) if len(pipes) > 1 else out["pipelined"]
+        out["graph"] = True
+    del graphs
+    return out
+
+
+def other_configs_block(torch, device_index, xs16, xs48, depth=2):
+    """BASELINE configs 3, 4 and 5 at their single-GPU sizes, timed by this process like the headline (hipGraph replays,
+    `depth` whole steps in flight; the one-in-flight figure, the eager figure, the host's enqueue time per step and the sum
+    of the kernels' HIP-event durations beside it, so that a gap between the step and its kernels is visible in the line):
+    3 = Harvest only on 256 x 10 s (the size BASELINE.json states it on); 4 = Harvest + CheapTrick + D4C-Requiem encode +
+    Requiem decode on 64 x 10 s; 5 = 16 x 60 s at 48 kHz, Harvest encode, scale_pitch(1.5), scale_duration(2.0), decode."""
     import types
 
     from world.batch import WorldBatchLanes
@@ -1093,89 +1127,75 @@ def other_configs_block(torch, device_index, xs16, xs48):
     out = {}
     # config 3 is stated on 256 x 10 s (BASELINE.json configs[2]): the 64 distinct utterances four times over
     xs16_256 = None if xs16 is None else [xs16[i % len(xs16)] for i in range(256)]
-    for cfg, xs, fs, steps in ((3, xs16_256, 16000, 5), (4, xs16, 16000, 5), (5, xs48, 48000, 2)):
+    for cfg, xs, fs, steps in ((3, xs16_256, 16000, 6), (4, xs16, 16000, 6), (5, xs48, 48000, 4)):
         if xs is None:
             out["config%d" % cfg] = {"error": "inputs unavailable"}
             continue
-        wl = WorldBatchLanes(device_index, lanes=1)
-        wl.upload(xs, fs)
-        step = make_step(types.SimpleNamespace(config=cfg, no_stagger=True), wl, fs)
-        step(0)
+        wls = [WorldBatchLanes(device_index, lanes=1, first_lane=(d + 1) if depth > 1 else None) for d in range(depth)]
+        pipes = []
+        for w_ in wls:
+            w_.upload(xs, fs)
+            pipes.append((make_step(types.SimpleNamespace(config=cfg, no_stagger=True), w_, fs), w_.lanes[0].rt.own_stream))
+        for fn, _ in pipes:
+            fn(0)
         torch.cuda.synchronize()
-        # eager launches: the host enqueues every kernel of every step (flags unchecked until the end of the block)
-        t0 = time.perf_counter()
-        for k in range(steps):
-            step(1 + k)
-        enq = (time.perf_counter() - t0) / steps
-        torch.cuda.synchronize()
-        eager = (time.perf_counter() - t0) / steps
-        # the same step replayed from a hipGraph: no per-launch host work (what the headline does)
-        graph = try_capture(torch, lambda: step(1000))
-        dt = eager
-        if graph is not None:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(steps):
-                graph.replay()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
-        del graph
+        t = time_pipelines(torch, pipes, steps)
+        dt = t["pipelined"]
+        wl = wls[0]
         rt = wl.lanes[0].rt
         rt.profile(True)
-        step(99)
+        pipes[0][0](99)
         agg = {}
         for name, ms in rt.profile_collect():
             agg[name] = agg.get(name, 0.0) + ms
         rt.profile(False)
-        wl.lanes[0].check("other_configs %d" % cfg)
+        for w_ in wls:
+            w_.lanes[0].check("other_configs %d" % cfg)
         frames = wl.total_frames
         out["config%d" % cfg] = {"utterances": len(xs), "distinct_utterances": min(len(xs), 64 if fs == 16000 else 16),
                                  "seconds": len(xs[0]) / fs, "fs": fs, "steps": steps,
                                  "ms_per_step": dt * 1e3, "value": frames / dt, "unit": "frames/s",
-                                 "x_realtime": len(xs) * len(xs[0]) / fs / dt,
-                                 "graph": dt is not eager, "eager_ms_per_step": eager * 1e3,
-                                 "host_enqueue_ms_per_step": enq * 1e3, "kernel_ms_sum": sum(agg.values()),
+                                 "x_realtime": len(xs) * len(xs[0]) / fs / dt, "steps_in_flight": depth,
+                                 "ms_per_step_one_in_flight": t["one"] * 1e3,
+                                 "graph": t["graph"], "eager_ms_per_step": t["eager"] * 1e3,
+                                 "host_enqueue_ms_per_step": t["enqueue"] * 1e3, "kernel_ms_sum": sum(agg.values()),
                                  "kernel_ms": {k: round(v, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:6]}}
-        del wl, step
+        del wls, wl, pipes
         torch.cuda.empty_cache()
     return out
 
 
-def north_star_block(torch, device_index, xs_distinct, fs, args, steps=5):
+def north_star_block(torch, device_index, xs_distinct, fs, args, steps=6):
     """BASELINE.json north_star on ONE GPU: 1024 x 10 s at 16 kHz, encode(harvest, is_requiem=True) + Requiem decode.
-    Timed like the headline: `steps` (>= 5) replays of a hipGraph of one step between synchronisations (the eager figure
-    beside it), per-kernel HIP-event durations from one un-captured step, and a `roofline` block of its own for the
-    dominant kernel with the HBM traffic MEASURED in this run (two rocprofv3 --pmc child runs of config 4 at this size)."""
+    Timed like the headline: `steps` (>= 5) replays of hipGraphs of one step between synchronisations, dealt to
+    --in-flight pipelines (each with its own resident copy of the batch, context, arena and stream), the one-in-flight and
+    eager figures beside it; per-kernel HIP-event durations from one un-captured step, and a `roofline` block of its own
+    for the dominant kernel with the HBM traffic MEASURED in this run (two rocprofv3 --pmc child runs of config 4 at this
+    size)."""
     from world.batch import WorldBatch
 
     n = args.north_star_utts
     xs = [xs_distinct[i % len(xs_distinct)] for i in range(n)]
-    wb = WorldBatch(device_index)
-    batch, x_d, tp_d = wb.upload(xs, fs)
+    depth = max(1, getattr(args, "in_flight", 1))
+    wbs = [WorldBatch(device_index, lane=(d + 1) if depth > 1 else 0) for d in range(depth)]
+    res = [w.upload(xs, fs) for w in wbs]
+    wb, (batch, x_d, tp_d) = wbs[0], res[0]
 
-    def one():
-        enc = wb.encode_device(batch, x_d, tp_d, fs, f0_method="harvest", is_requiem=True, check=False)
-        return wb.decode_device(enc, check=False)  # device-generated seed tables
+    def make_one(w, r):
+        def one():
+            enc = w.encode_device(r[0], r[1], r[2], fs, f0_method="harvest", is_requiem=True, check=False)
+            return w.decode_device(enc, check=False)  # device-generated seed tables
+        return one
 
-    one()
+    ones = [make_one(w, r) for w, r in zip(wbs, res)]
+    one = ones[0]
+    for fn in ones:
+        fn()
     torch.cuda.synchronize()
-    wb.check("north_star warm-up")
-    t0 = time.perf_counter()
-    for k in range(steps):
-        one()
-    enq = (time.perf_counter() - t0) / steps
-    torch.cuda.synchronize()
-    eager = (time.perf_counter() - t0) / steps
-    graph = try_capture(torch, one)
-    dt = eager
-    if graph is not None:
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            graph.replay()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-    del graph
+    for w in wbs:
+        w.check("north_star warm-up")
+    t = time_pipelines(torch, [((lambda k, fn=fn: fn()), w.rt.own_stream) for fn, w in zip(ones, wbs)], steps)
+    enq, eager, dt, dt_one = t["enqueue"], t["eager"], t["pipelined"], t["one"]
     wb.rt.profile(True)  # per-kernel durations from one more step (the event pairs stay out of the timed steps)
     one()
     agg = {}
@@ -1184,7 +1204,8 @@ def north_star_block(torch, device_index, xs_distinct, fs, args, steps=5):
         a[0] += ms
         a[1] += 1
     wb.rt.profile(False)
-    wb.check("north_star")
+    for w in wbs:
+        w.check("north_star")
     frames = batch.total_frames
     dom = max(agg.items(), key=lambda kv: kv[1][0])[0]
     per_k, path_b = algo_bytes_per_frame(fs, 1024, requiem=True)
@@ -1195,7 +1216,7 @@ def north_star_block(torch, device_index, xs_distinct, fs, args, steps=5):
     achieved = per_frame * frames_per_launch / (dom_ms / 1e3) / 1e9
     traffic, traffic_all, traffic_src = None, None, {"source": "not measured (--no-pmc)"}
     if not args.no_pmc:
-        del x_d, tp_d, batch  # the child runs need the HBM this block holds no longer
+        del x_d, tp_d, batch, res, ones, one  # the child runs need the HBM this block holds no longer
         torch.cuda.empty_cache()
         measured, how = measure_pmc_traffic(args, timeout_s=420, config=4, utts=n, seconds=len(xs[0]) / fs, steps=1)
         if measured and dom in measured:
@@ -1213,7 +1234,8 @@ def north_star_block(torch, device_index, xs_distinct, fs, args, steps=5):
     return {"workload": "%d x %.0f s synthetic 16 kHz utterances (%d distinct) on 1 GPU: Harvest+CheapTrick+"
                         "D4C-Requiem encode + Requiem decode, HBM-resident" % (n, len(xs[0]) / fs, min(n, len(xs_distinct))),
             "distinct_utterances": min(n, len(xs_distinct)), "host_enqueue_ms_per_step": enq * 1e3,
-            "graph": dt is not eager, "eager_ms_per_step": eager * 1e3,
+            "graph": t["graph"], "eager_ms_per_step": eager * 1e3, "steps_in_flight": depth,
+            "ms_per_step_one_in_flight": dt_one * 1e3,
             "ms_per_step": dt * 1e3, "value": frames / dt, "unit": "frames/s", "x_realtime": n * len(xs[0]) / fs / dt,
             "target_x_realtime": 500, "steps": steps, "frames_per_step": frames,
             "roofline": roofline,

@@ -38,6 +38,12 @@ __device__ unsigned long long g_resp_stage[8];
 #endif
 namespace {
 
+// The spectral half (pulse responses, Requiem frames) may fuse a*b+c into one FP64 instruction; the TIME BASE may not:
+// pulse positions are read off its arithmetic, which must round like the reference's (the library is built with
+// -ffp-contract=off for that reason).  1: `#pragma clang fp contract(fast)` inside response_pulse / min_phase_response.
+#ifndef WH_SYN_CONTRACT
+#define WH_SYN_CONTRACT 0
+#endif
 #ifndef WH_RESP_TRANS_UNROLL
 #define WH_RESP_TRANS_UNROLL 1
 #endif
@@ -876,6 +882,9 @@ struct SpectrumIdentity {
 };
 template <int N, int GT, class Mul = SpectrumIdentity>
 __device__ __forceinline__ void min_phase_response(double2* zb, const double2* tw_base, double delay_pi, Mul mul = Mul()) {
+#if WH_SYN_CONTRACT
+#pragma clang fp contract(fast)
+#endif
   constexpr int FT = ft_syn(N);
   constexpr int M = N / 2;
   constexpr int PP = (M / 2 + 1 + GT - 1) / GT;  // bin pairs (k, M-k), k <= M/2, per thread
@@ -1046,6 +1055,9 @@ template <int N>
 __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec& rec, char* smem, double* ring, RunState& rs,
                                                double* __restrict__ row,
                                                const double (&dcw)[N / ft_syn(N) <= 4 ? N / ft_syn(N) : 1]) {
+#if WH_SYN_CONTRACT
+#pragma clang fp contract(fast)
+#endif
   const SynUtt* __restrict__ meta = A.meta;
   const double* __restrict__ spectrogram = A.spectrogram;
   const double* __restrict__ aperiodicity = A.aperiodicity;
@@ -1672,7 +1684,7 @@ constexpr int req_runf(int n) { return n <= 1024 ? WH_REQ_RUNF : 1; }
 // frame's own response, written straight from the transform buffer.  Rows instead of atomics take the 1.07 GB of
 // read-modify-write traffic per 64 utterances down to a 0.3 GB row write + read.
 #ifndef WH_REQ_MINW
-#define WH_REQ_MINW 1
+#define WH_REQ_MINW 8
 #endif
 template <int N, int RUNF>
 __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1)) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
@@ -1704,7 +1716,12 @@ __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1
     const int64_t origin = (i - 1) * hop - (hop - 1);  // 1-based
     // per frame: neither the twiddles nor the window values of one frame are parked in registers for the next (both are
     // the same for every frame, and hoisted out of this loop they cost a wave per SIMD)
-    asm volatile("" : "+s"(tw_base), "+s"(wlen));
+    asm volatile("" : "+s"(tw_base));
+    {
+      int hop_s = __builtin_amdgcn_readfirstlane((int)hop);  // (uniform by construction; said so for the constraint)
+      asm volatile("" : "+s"(hop_s));
+      wlen = 2 * (int64_t)hop_s - 1;
+    }
     for (int j = WH_TID; j < N; j += FT) {
       double v = 0.0;
       if (j < wlen) {

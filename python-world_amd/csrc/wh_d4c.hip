@@ -1127,6 +1127,9 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     const bool qexact = (qden & (qden - 1)) == 0;
     const double qstep = fs / (double)qden;
     for (int k = threadIdx.x; k < k_spec; k += FT) {
+      // unfused like the reference's interpolation (d4c.py:60-62) whatever the translation unit's setting: with a 0 dB
+      // band a fused slope * dx + y_lo can land an ulp ABOVE 0 dB, i.e. an aperiodicity above 1
+#pragma clang fp contract(off)
       const double q = qexact ? (double)k * qstep : (double)k * fs / (double)qden;
       int cnt = 0;  // searchsorted-left over the coarse axis
       for (int m = 0; m < nn; ++m) {

@@ -42,7 +42,7 @@ namespace {
 // pulse positions are read off its arithmetic, which must round like the reference's (the library is built with
 // -ffp-contract=off for that reason).  1: `#pragma clang fp contract(fast)` inside response_pulse / min_phase_response.
 #ifndef WH_SYN_CONTRACT
-#define WH_SYN_CONTRACT 0
+#define WH_SYN_CONTRACT 0  // (python-world_amd/build.py builds with 1)
 #endif
 #ifndef WH_RESP_TRANS_UNROLL
 #define WH_RESP_TRANS_UNROLL 1

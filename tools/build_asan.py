@@ -23,7 +23,7 @@ def main():
 
     def one(u):
         obj = os.path.join(odir, u[:-4] + ".o")
-        r = subprocess.run([B._hipcc()] + FLAGS + ["-c", os.path.join(B.CSRC, u), "-o", obj], capture_output=True, text=True)
+        r = subprocess.run([B._hipcc()] + FLAGS + B.TU_FLAGS.get(u, []) + ["-c", os.path.join(B.CSRC, u), "-o", obj], capture_output=True, text=True)
         return u, obj, r.returncode, (r.stdout + r.stderr)[-2000:]
 
     objs = []

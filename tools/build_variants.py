@@ -29,7 +29,7 @@ def one(spec):
         base = u[:-4]
         if base in per_tu:
             obj = os.path.join(odir, base + ".o")
-            cmd = [B._hipcc()] + B.FLAGS + per_tu[base] + ["-c", os.path.join(B.CSRC, u), "-o", obj]
+            cmd = [B._hipcc()] + B.FLAGS + B.TU_FLAGS.get(u, []) + per_tu[base] + ["-c", os.path.join(B.CSRC, u), "-o", obj]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 return name, False, r.stdout + r.stderr

@@ -19,7 +19,7 @@ ARCH = "gfx950"
 # -ffp-contract=off: the reference is NumPy float64 without FMA contraction; keeping mul/add
 # separate keeps the discrete F0 decisions on the same side of their thresholds.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
-# Per translation unit, appended after FLAGS (the last -ffp-contract wins).  The SPECTRAL kernels — CheapTrick, D4C, the
+# Per translation unit, appended after FLAGS (the last -ffp-contract wins; "fast-honor-pragmas", HIP's own default: plain "fast" lets the backend fuse across a `#pragma clang fp contract(off)`).  The SPECTRAL kernels — CheapTrick, D4C, the
 # pulse responses / Requiem frames — may fuse a*b+c into one FP64 instruction: their outputs are compared with the
 # reference at tolerances (1e-9 ... 1e-7), no discrete decision is read off the fused arithmetic (the D4C output
 # interpolation that must not exceed 0 dB keeps contract(off), wh_d4c.hip), and it is worth 1.1 % of the config-2 step
@@ -27,8 +27,8 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
 # Harvest, SWIPE') and the synthesis TIME BASE stay unfused: voicing decisions and pulse positions are bit-exact
 # against the reference (wh_synthesis.hip fuses inside response_pulse / min_phase_response only).
 TU_FLAGS = {
-    "wh_d4c.hip": ["-ffp-contract=fast"],
-    "wh_cheaptrick.hip": ["-ffp-contract=fast"],
+    "wh_d4c.hip": ["-ffp-contract=fast-honor-pragmas"],
+    "wh_cheaptrick.hip": ["-ffp-contract=fast-honor-pragmas"],
     "wh_synthesis.hip": ["-DWH_SYN_CONTRACT=1"],
 }
 

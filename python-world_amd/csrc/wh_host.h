@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <map>
 #include <string>
@@ -96,11 +98,21 @@ inline int allow_lds(K kernel, size_t bytes) {
 }
 // RAII bracket around one kernel launch: records a start/stop event pair on the launch stream when
 // profiling is enabled (zero cost otherwise).
+// WH_TRACE_LAUNCH=1 (environment, debugging): every launch is announced on stderr and waited for — the last name printed
+// before an abort (a device-side sanitizer finding, a memory fault) is the kernel that caused it.
+inline bool trace_launches() {
+  static const bool on = getenv("WH_TRACE_LAUNCH") && getenv("WH_TRACE_LAUNCH")[0] == '1';
+  return on;
+}
 struct KernelTimer {
   wh_ctx* c;
   hipStream_t st;
   int slot = -1;
   KernelTimer(wh_ctx* ctx, hipStream_t s, const char* name) : c(ctx), st(s) {
+    if (trace_launches()) {
+      fprintf(stderr, "[wh] launch %s\n", name);
+      fflush(stderr);
+    }
     if (!c->prof) return;
     const size_t rec = c->prof_names.size();
     while (c->prof_events.size() < 2 * (rec + 1)) {
@@ -114,6 +126,7 @@ struct KernelTimer {
   }
   ~KernelTimer() {
     if (slot >= 0) (void)hipEventRecord(c->prof_events[2 * slot + 1], st);
+    if (trace_launches()) (void)hipStreamSynchronize(st);
   }
 };
 }  // namespace wh

@@ -1498,6 +1498,10 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     while (tw_n < 2 * hmax + 1) tw_n <<= 1;
     tw_n <<= 1;
     if (tw_n > 2048) tw_n = 0;  // 32 KB of LDS at most for the table; beyond that gather from the global tables
+#ifndef WH_HV_LDS_TWIDDLES
+#define WH_HV_LDS_TWIDDLES 1  // 0 (the sanitizer build): always the global tables — the LDS form needs its block at LDS
+#endif                        // address 0 and traps otherwise, and the sanitizer puts bookkeeping of its own there
+    if (!WH_HV_LDS_TWIDDLES) tw_n = 0;
     const bool use_wtab = WH_HV_WIN_TABLE && tw_n != 0;
     const int fpb = refine_frames(use_wtab);
     const int seglen = 2 * hmax + 8 + (fpb - 1) * ((int)ceil(fs_d / 1000.0) + 1);

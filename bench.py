@@ -1122,6 +1122,7 @@ def other_configs_block(torch, device_index, xs16, xs48, depth=2):
     Requiem decode on 64 x 10 s; 5 = 16 x 60 s at 48 kHz, Harvest encode, scale_pitch(1.5), scale_duration(2.0), decode."""
     import types
 
+    from world import _hip
     from world.batch import WorldBatchLanes
 
     out = {}
@@ -1161,7 +1162,7 @@ def other_configs_block(torch, device_index, xs16, xs48, depth=2):
                                  "host_enqueue_ms_per_step": t["enqueue"] * 1e3, "kernel_ms_sum": sum(agg.values()),
                                  "kernel_ms": {k: round(v, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:6]}}
         del wls, wl, pipes
-        torch.cuda.empty_cache()
+        _hip.Runtime.trim_all()
     return out
 
 
@@ -1176,7 +1177,12 @@ def north_star_block(torch, device_index, xs_distinct, fs, args, steps=6):
 
     n = args.north_star_utts
     xs = [xs_distinct[i % len(xs_distinct)] for i in range(n)]
-    depth = max(1, getattr(args, "in_flight", 1))
+    from world import _hip
+    _hip.Runtime.trim_all()  # the arenas of the earlier blocks (they only grow) go back to the device first
+    # ONE step in flight here: the Harvest workspace of 1024 utterances is ~105 GB (52 GB of crossing lists, 12.5 GB of raw
+    # candidates, 17 GB of refined ones ...), two pipelines plus the profiler's child process do not fit 288 GB — and at
+    # this size the serial head of a step is 1-2 % of it
+    depth = 1 if n > 256 else max(1, getattr(args, "in_flight", 1))
     wbs = [WorldBatch(device_index, lane=(d + 1) if depth > 1 else 0) for d in range(depth)]
     res = [w.upload(xs, fs) for w in wbs]
     wb, (batch, x_d, tp_d) = wbs[0], res[0]
@@ -1217,7 +1223,7 @@ def north_star_block(torch, device_index, xs_distinct, fs, args, steps=6):
     traffic, traffic_all, traffic_src = None, None, {"source": "not measured (--no-pmc)"}
     if not args.no_pmc:
         del x_d, tp_d, batch, res, ones, one  # the child runs need the HBM this block holds no longer
-        torch.cuda.empty_cache()
+        _hip.Runtime.trim_all()
         measured, how = measure_pmc_traffic(args, timeout_s=420, config=4, utts=n, seconds=len(xs[0]) / fs, steps=1)
         if measured and dom in measured:
             traffic, traffic_all, traffic_src = measured[dom], measured, {"source": how}

@@ -39,6 +39,9 @@ const char* wh_last_error(void);
 int wh_device_count(int* count);
 int wh_ctx_create(int device, wh_ctx** out);
 int wh_ctx_destroy(wh_ctx* ctx);
+/* Free the context's scratch (workspace arena, per-call buffers: they only grow with the largest batch served); tables and
+ * flags stay, the next call allocates again.  Synchronises the device.  A time base held by the context is dropped. */
+int wh_ctx_trim(wh_ctx* ctx);
 int wh_malloc(void** dptr, size_t bytes);
 int wh_free(void* dptr);
 int wh_memcpy_h2d(void* dst, const void* h_src, size_t bytes, void* stream);

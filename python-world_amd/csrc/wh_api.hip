@@ -125,7 +125,7 @@ int persistent_scratch(wh_ctx* ctx, const std::string& slot, size_t bytes, void*
 
 extern "C" {
 
-int wh_version(void) { return 103; }
+int wh_version(void) { return 104; }
 const char* wh_last_error(void) { return g_last_error.c_str(); }
 
 int wh_device_count(int* count) {
@@ -188,6 +188,28 @@ int wh_ctx_destroy(wh_ctx* ctx) {
     }
   }
   delete ctx;
+  return 0;
+}
+
+// Give the context's scratch back to the device: the workspace arena and the per-call buffers (utterance tables, overlap-
+// add rows ...).  They only ever grow — a context that has served a 1024-utterance Harvest batch keeps ~100 GB — so a
+// process that moves on to other work calls this between phases.  Constant tables, twiddles and flags stay; the next
+// call allocates what it needs again.  Synchronises the device (kernels of earlier calls may still use the buffers).
+int wh_ctx_trim(wh_ctx* ctx) {
+  if (!ctx) return wh::fail_msg("wh_ctx_trim", "null ctx");
+  WH_ENTER(ctx);
+  WH_CHECK(hipDeviceSynchronize());
+  if (ctx->ws) WH_CHECK(hipFree(ctx->ws));
+  ctx->ws = nullptr;
+  ctx->ws_bytes = 0;
+  ctx->timebase.valid = false;
+  for (auto& kv : ctx->persist) {
+    wh_ctx::Persist& e = kv.second;
+    if (e.d) WH_CHECK(hipFree(e.d));
+    e.d = nullptr;
+    e.cap = 0;
+    e.host.clear();  // (nothing is resident any more: the next identical call uploads again)
+  }
   return 0;
 }
 

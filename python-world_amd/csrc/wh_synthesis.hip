@@ -1012,6 +1012,8 @@ struct RespArgs {
   double* rows;             // overlap-add rows of the runs (response_gather_kernel sums them into y)
   int64_t row_stride;       // doubles per utterance in `rows`
   const int64_t* run_base;  // [n_utt + 1] first run of every utterance (pulse_run_base_kernel)
+  const int64_t* row_off;   // [n_utt][runs_cap] where run r's row begins in the utterance's region (pulse_rows_kernel)
+  int64_t runs_cap;
 };
 
 // Overlap-add of a workgroup's run of consecutive pulses OF ONE UTTERANCE: the run's contributions are accumulated, in
@@ -1022,10 +1024,12 @@ struct RespArgs {
 // whether an utterance is decoded alone, in a batch or on another rank (runs are numbered per utterance).  The
 // reference adds pulse after pulse into y (synthesis.py:67-81); summing runs of pulses first is another association
 // of the same sum (1e-17 relative).
-// Row layout (per utterance a region of row_stride doubles): row r starts at r * (N + 1) + start_r - 1, start_r =
-// max(1, first tap of the run's first pulse) — rows cannot overlap because the first tap of run r + 1 lies behind the
-// first tap of run r's last pulse; slot 0 = what the run adds to the LAST sample (Q8, below), slot 1 + (t - start_r) =
-// its sum at the 1-based sample t < ny.
+// Row layout (per utterance a region of row_stride doubles): the rows lie one behind the other, row r at row_off[r]
+// (pulse_rows_kernel: an exclusive scan of the row lengths, which follow from the pulse positions); slot 0 = what the
+// run adds to the LAST sample (Q8, below), slot 1 + (t - start_r) = its sum at the 1-based sample t < ny, start_r =
+// max(1, first tap of the run's first pulse).  A region holds 8 doubles per output sample (mean f0 up to ~fs / 21 at
+// N = 1024); an utterance that needs more raises WH_FLAG_PULSE_OVERFLOW like one that runs out of pulse slots, and the
+// retry with the safe pulse capacity sizes the region for it.
 struct RunState {
   bool any;           // a pulse has been accumulated (the ring holds something)
   int64_t win_start;  // 1-based output index of the first sample of the ring's window
@@ -1349,6 +1353,48 @@ __global__ void pulse_run_base_kernel(const int32_t* __restrict__ p_count, int n
   }
 }
 
+// Where every run's row begins in its utterance's region: row r holds 1 + (end_r - start_r) doubles (RunState), the rows
+// lie one behind the other.  One workgroup per utterance scans its runs in chunks of 256.  A row that does not fit the
+// region gets offset -1 (its run is skipped, its samples are not gathered) and raises WH_FLAG_PULSE_OVERFLOW.
+template <int N>
+__global__ __launch_bounds__(256) void pulse_rows_kernel(const SynUtt* __restrict__ meta, const int64_t* __restrict__ p_idx,
+                                                         const int32_t* __restrict__ p_count, int64_t runs_cap,
+                                                         int64_t row_stride, int64_t* __restrict__ row_off,
+                                                         int32_t* __restrict__ flags) {
+  constexpr int RUN = resp_run(N);
+  __shared__ int wsum[4];
+  const SynUtt m = meta[blockIdx.x];
+  const int count = p_count[blockIdx.x];
+  const int64_t* pi = p_idx + m.p_off;
+  const int n_runs = (count + RUN - 1) / RUN;
+  int64_t* out = row_off + (int64_t)blockIdx.x * runs_cap;
+  int64_t carry = 0;
+  bool over = false;
+  for (int base = 0; base < n_runs; base += 256) {
+    const int r = base + threadIdx.x;
+    int len = 0;
+    if (r < n_runs) {
+      const int kf = r * RUN;
+      const int kl = (kf + RUN < count ? kf + RUN : count) - 1;
+      int64_t start = pi[kf] - N / 2 + 1, end = pi[kl] + N / 2 + 1;
+      start = start < 1 ? 1 : start;
+      end = end < m.ny ? end : m.ny;
+      len = 1 + (int)(end > start ? end - start : 0);
+    }
+    int total;
+    const int excl = block_excl_scan_256(len, wsum, &total);
+    if (r < n_runs) {
+      const int64_t at = carry + excl;
+      const bool fits = at + len <= row_stride;
+      out[r] = fits ? at : -1;
+      over = over || !fits;
+    }
+    carry += total;
+    __syncthreads();  // wsum is reused by the next chunk
+  }
+  if (over) atomicOr(flags + WH_FLAG_PULSE_OVERFLOW, 1);
+}
+
 // One workgroup per RUN of resp_run(N) consecutive pulses of one utterance (runs numbered utterance by utterance, in
 // time order).  The grid is sized from the host's pulse capacity; the runs that exist (device-side pulse counts) are
 // dealt to the XCDs in contiguous ranges, so that the spectrogram / aperiodicity rows neighbouring pulses share are
@@ -1376,7 +1422,9 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
   RunState rs{false, 0, 1, 0.0};
   const int64_t gp0 = A.p_base[u] + r_in_utt * RUN;
   const int64_t gp1 = gp0 + RUN < A.p_base[u + 1] ? gp0 + RUN : A.p_base[u + 1];
-  double* row = A.rows + (int64_t)u * A.row_stride + r_in_utt * (N + 1) - 1;  // + start_r: slot i of the row at row[start_r + i]
+  const int64_t my_off = A.row_off[(int64_t)u * A.runs_cap + r_in_utt];
+  if (my_off < 0) return;  // the utterance's row region is full (flagged by pulse_rows_kernel)
+  double* row = A.rows + (int64_t)u * A.row_stride + my_off;  // slot i of the row at row[i]
   // A pulse's record travels as ONE dword per lane (lane i & 15 holds dword i) and is turned into scalars by
   // v_readlane at the top of the pulse that uses it — a pulse after its load was issued.  Fetched as a struct the
   // compiler made scalars of it (readfirstlane) right behind the load: the "prefetch" was waited for at once.
@@ -1417,7 +1465,7 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
     row_start = pidx0 - N / 2 + 1;
     row_start = row_start < 1 ? 1 : row_start;
   }
-  row += row_start;
+  (void)row_start;
 #pragma unroll 1
   for (int64_t gp = gp0; gp < gp1; ++gp) {
     const PulseRec cur = unpack_rec(cur_w);
@@ -1444,6 +1492,7 @@ __global__ __launch_bounds__(256) void response_gather_kernel(const SynUtt* __re
                                                               const int64_t* __restrict__ p_idx,
                                                               const int32_t* __restrict__ p_count,
                                                               const double* __restrict__ rows, int64_t row_stride,
+                                                              const int64_t* __restrict__ row_off, int64_t runs_cap,
                                                               double* __restrict__ y) {
   constexpr int RUN = resp_run(N);
   constexpr int PER = WH_GATHER_PER;
@@ -1452,7 +1501,8 @@ __global__ __launch_bounds__(256) void response_gather_kernel(const SynUtt* __re
   if (n0 >= m.ny) return;
   const int count = p_count[blockIdx.y];
   const int64_t* pi = p_idx + m.p_off;
-  const double* ru = rows + (int64_t)blockIdx.y * row_stride - 1;
+  const double* ru = rows + (int64_t)blockIdx.y * row_stride;
+  const int64_t* ro = row_off + (int64_t)blockIdx.y * runs_cap;
   // pulses whose window [pidx - N/2 + 1, pidx + N/2] reaches the tile's samples n0 + 1 .. n0 + kGatherTile
   const int k0 = first_pulse_at(pi, count, n0 + 1 - N / 2);
   const int n_runs = (count + RUN - 1) / RUN;
@@ -1468,7 +1518,9 @@ __global__ __launch_bounds__(256) void response_gather_kernel(const SynUtt* __re
     const int64_t start = s1f < 1 ? 1 : s1f;
     int64_t end = pi[kl] + N / 2 + 1;  // one behind the last tap of the run's last pulse ...
     end = end < m.ny ? end : m.ny;     // ... and the last sample takes the rows' slot 0 only (below)
-    const double* rr = ru + (int64_t)r * (N + 1) + 1;  // sample t of the run at rr[t] (slot 1 + (t - start) of a row that begins at start - 1)
+    const int64_t off = ro[r];
+    if (off < 0) continue;  // (dropped: the region was full — flagged)
+    const double* rr = ru + off + 1 - start;  // sample t of the run at rr[t]: slot 1 + (t - start)
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int64_t tgt = t0 + 256 * q;
@@ -1485,8 +1537,8 @@ __global__ __launch_bounds__(256) void response_gather_kernel(const SynUtt* __re
     if (threadIdx.x == 0) {
       double last = 0.0;
       for (int r = k_end / RUN; r < n_runs; ++r) {
-        const int64_t s1f = pi[r * RUN] - N / 2 + 1;
-        last += ru[(int64_t)r * (N + 1) + (s1f < 1 ? 1 : s1f)];
+        const int64_t off = ro[r];
+        if (off >= 0) last += ru[off];
       }
       y[m.y_off + m.ny - 1] = last;
     }
@@ -1512,19 +1564,27 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, int64_t ma
   // overlap-add rows (RunState): per utterance ceil(pcap / RUN) rows of N + 1 slots laid along the time axis.  Held in a
   // buffer of its own, not in the arena: the render reserves no workspace (the time base may live in this context's)
   const int64_t runs_cap = (pcap_max + resp_run(N) - 1) / resp_run(N);
-  const int64_t row_stride = max_ny + runs_cap * (N + 1) + N + 8;
+  // doubles per output sample in an utterance's row region: 8 with the default pulse capacity (ny / 8: the rows of speech
+  // take ~5), up to 48 with the safe capacity of the retry (ny / 2)
+  int64_t per_sample = (64 * pcap_max + max_ny - 1) / (max_ny > 0 ? max_ny : 1);
+  per_sample = per_sample < 8 ? 8 : (per_sample > 48 ? 48 : per_sample);
+  const int64_t row_stride = per_sample * max_ny + 4 * (N + 1);
   void* d_rows = nullptr;
   void* d_rb = nullptr;
+  void* d_ro = nullptr;
   if (int rc = wh::persistent_scratch(ctx, "syn.ola_rows", sizeof(double) * (size_t)row_stride * B, &d_rows)) return rc;
   if (int rc = wh::persistent_scratch(ctx, "syn.run_base", sizeof(int64_t) * ((size_t)B + 1), &d_rb)) return rc;
+  if (int rc = wh::persistent_scratch(ctx, "syn.row_off", sizeof(int64_t) * (size_t)runs_cap * B, &d_ro)) return rc;
   { wh::KernelTimer _kt(ctx, st, "pulse_run_base_kernel"); hipLaunchKernelGGL(pulse_run_base_kernel, dim3(1), dim3(64), 0, st, p_count, B, resp_run(N), reinterpret_cast<int64_t*>(d_rb)); }
   WH_LAUNCH_CHECK("pulse_run_base_kernel");
+  { wh::KernelTimer _kt(ctx, st, "pulse_rows_kernel"); hipLaunchKernelGGL(pulse_rows_kernel<N>, dim3(B), dim3(256), 0, st, d_meta, p_idx, p_count, runs_cap, row_stride, reinterpret_cast<int64_t*>(d_ro), ctx->d_flags); }
+  WH_LAUNCH_CHECK("pulse_rows_kernel");
   // one workgroup per run of resp_run(N) pulse slots; runs past the real pulse count exit at once
   const int64_t grid = wh::xcd_grid(runs_cap * B);
-  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_rec, p_base, B, noise, seed, d_dc, ctx->d_twiddle, reinterpret_cast<double*>(d_rows), row_stride, reinterpret_cast<const int64_t*>(d_rb)};
+  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_rec, p_base, B, noise, seed, d_dc, ctx->d_twiddle, reinterpret_cast<double*>(d_rows), row_stride, reinterpret_cast<const int64_t*>(d_rb), reinterpret_cast<const int64_t*>(d_ro), runs_cap};
   hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(ft_syn(N)), lds, st, ra); }
   WH_LAUNCH_CHECK("response_kernel");
-  { wh::KernelTimer _kt(ctx, st, "response_gather_kernel"); hipLaunchKernelGGL(response_gather_kernel<N>, dim3((unsigned)((max_ny + kGatherTile - 1) / kGatherTile), B), dim3(256), 0, st, d_meta, p_idx, p_count, reinterpret_cast<const double*>(d_rows), row_stride, y); }
+  { wh::KernelTimer _kt(ctx, st, "response_gather_kernel"); hipLaunchKernelGGL(response_gather_kernel<N>, dim3((unsigned)((max_ny + kGatherTile - 1) / kGatherTile), B), dim3(256), 0, st, d_meta, p_idx, p_count, reinterpret_cast<const double*>(d_rows), row_stride, reinterpret_cast<const int64_t*>(d_ro), runs_cap, y); }
   WH_LAUNCH_CHECK("response_gather_kernel");
   return 0;
 }

@@ -27,6 +27,7 @@ SIGNATURES = {
     "wh_device_count": (_int, [ctypes.POINTER(_int)]),
     "wh_ctx_create": (_int, [_int, ctypes.POINTER(_vp)]),
     "wh_ctx_destroy": (_int, [_vp]),
+    "wh_ctx_trim": (_int, [_vp]),
     "wh_malloc": (_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
     "wh_free": (_int, [_vp]),
     "wh_memcpy_h2d": (_int, [_vp, _vp, ctypes.c_size_t, _vp]),
@@ -194,6 +195,23 @@ class Runtime:
             rt = cls(device_index, lane)
             cls._instances[(device_index, lane)] = rt
         return rt
+
+    def trim(self):
+        """Give this lane's scratch back to the device (wh_ctx_trim: the arena and per-call buffers only grow)."""
+        check(self.lib.wh_ctx_trim(self.ctx))
+        if hasattr(self, "timebase_generation"):  # a time-base context (world.batch): what it held is gone —
+            self.timebase_generation += 1         # encodings that point at it decode with an in-line time base
+
+    @classmethod
+    def trim_all(cls):
+        """trim() every runtime of the process and empty torch's cache: between phases of very different batch sizes."""
+        for rt in list(cls._instances.values()):
+            rt.trim()
+        try:
+            import torch
+            torch.cuda.empty_cache()
+        except Exception:
+            pass
 
     def on_stream(self):
         """Context manager: make this lane's stream torch's current stream (no-op for lane 0)."""

@@ -379,6 +379,38 @@ def test_timebase_lasts_until_the_next_workspace_call_of_its_context():
     wb.check()
 
 
+def test_ctx_trim_gives_scratch_back_and_the_next_call_allocates_again():
+    """wh_ctx_trim (ABI 104): the arena and the per-call buffers of a context only grow; trimming frees them (device memory
+    in use drops), drops a held time base, and the next calls — same batch, so the cached per-call tables would have been
+    taken as resident — allocate, upload and compute the same results again."""
+    import torch
+    from world import _hip
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+
+    fs = 16000
+    xs = [synth_utterance(70 + i, fs, 1.0 + 0.3 * i) for i in range(3)]
+    wb = WorldBatch()
+    enc = wb.encode(xs, fs, f0_method='harvest', is_requiem=True)
+    y, _ = wb.decode_device(enc, cursor=np.zeros(3))
+    enc2 = wb.encode(xs, fs, f0_method='dio')
+    y2, _ = wb.decode_device(enc2, seed=2)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    assert enc2._timebase is not None
+    _hip.Runtime.trim_all()
+    assert torch.cuda.mem_get_info()[0] > free_before  # (the Harvest arena alone is tens of MB at this size)
+    assert enc2.timebase_for(wb, None) is None          # the prefetched time base went with its context's arena:
+    y2b, _ = wb.decode_device(enc2, seed=2)             # the decode computes it in line
+    assert np.array_equal(y2b.cpu().numpy(), y2.cpu().numpy())
+    again = wb.encode(xs, fs, f0_method='harvest', is_requiem=True)
+    for name in ("f0", "vuv", "spectrogram", "aperiodicity"):
+        assert torch.equal(getattr(again, name), getattr(enc, name)), name
+    ya, _ = wb.decode_device(again, cursor=np.zeros(3))
+    assert torch.equal(ya, y)
+    wb.check()
+
+
 def test_encode_device_under_inference_mode():
     """Tensors made under torch.inference_mode() have no version counter: the time-base prefetch is skipped, the encode
     and decode work as without it."""

@@ -208,26 +208,41 @@ def test_gathered_periodic_excitation_equals_the_references_scatter(case):
 
 
 # ---- round 5: overlap-add without atomics (response_kernel rows + response_gather_kernel; wh_synthesis.hip RunState) --------
-def _rows_of_runs(ny, pidx, resp, n, run):
-    """response_kernel's overlap-add, thread loops flattened: runs of `run` consecutive pulses accumulate in an n-sample
-    ring; what leaves the ring's window goes to the run's row at r*(n+1) + start_r - 1 (slot 0: the last sample's
-    share).  Unwritten slots stay NaN so that a gather that reads one is caught."""
+def _row_offsets(ny, pidx, n, run, capacity):
+    """pulse_rows_kernel: rows one behind the other, row r of 1 + (end_r - start_r) doubles at the exclusive prefix of
+    the lengths; -1 (dropped) where the region is full."""
     count = len(pidx)
-    runs_cap = (count + run - 1) // run
-    rows = np.full(ny + runs_cap * (n + 1) + n + 8, np.nan)
-    for r in range(runs_cap):
+    offs, at = [], 0
+    for r in range((count + run - 1) // run):
+        kf, kl = r * run, min((r + 1) * run, count) - 1
+        start, end = max(int(pidx[kf]) - n // 2 + 1, 1), min(int(pidx[kl]) + n // 2 + 1, ny)
+        ln = 1 + max(end - start, 0)
+        offs.append(at if at + ln <= capacity else -1)
+        at += ln
+    return offs, at
+
+
+def _rows_of_runs(ny, pidx, resp, n, run, offs, capacity):
+    """response_kernel's overlap-add, thread loops flattened: runs of `run` consecutive pulses accumulate in an n-sample
+    ring; what leaves the ring's window goes to the run's row (slot 0: the last sample's share, slot 1 + (t - start_r):
+    sample t).  Unwritten slots stay NaN so that a gather that reads one is caught."""
+    count = len(pidx)
+    rows = np.full(capacity, np.nan)
+    for r in range((count + run - 1) // run):
+        if offs[r] < 0:
+            continue
         ring = np.zeros(n)
         any_, win_start, row_start, last = False, 0, 1, 0.0
-        base = r * (n + 1) - 1
+        base = offs[r]
         for k in range(r * run, min((r + 1) * run, count)):
             s1 = int(pidx[k]) - n // 2 + 1
             if any_:
                 e = min(s1, win_start + n)
                 for tgt in range(max(win_start, 1), min(e, ny)):          # ring_flush
-                    rows[base + row_start + 1 + (tgt - row_start)] = ring[tgt & (n - 1)]
+                    rows[base + 1 + (tgt - row_start)] = ring[tgt & (n - 1)]
                     ring[tgt & (n - 1)] = 0.0
                 for tgt in range(win_start + n, min(s1, ny)):              # pulses more than n apart
-                    rows[base + row_start + 1 + (tgt - row_start)] = 0.0
+                    rows[base + 1 + (tgt - row_start)] = 0.0
             else:
                 row_start = max(s1, 1)
             any_, win_start = True, s1
@@ -241,12 +256,12 @@ def _rows_of_runs(ny, pidx, resp, n, run):
                     last += resp[k][mm]
         if any_:
             for tgt in range(max(win_start, 1), min(win_start + n, ny)):
-                rows[base + row_start + 1 + (tgt - row_start)] = ring[tgt & (n - 1)]
-            rows[base + row_start] = last
+                rows[base + 1 + (tgt - row_start)] = ring[tgt & (n - 1)]
+            rows[base] = last
     return rows
 
 
-def _gather_rows(ny, pidx, rows, n, run, tile=256):
+def _gather_rows(ny, pidx, rows, n, run, offs, tile=256):
     """response_gather_kernel, one tile of samples at a time."""
     count = len(pidx)
     n_runs = (count + run - 1) // run
@@ -263,12 +278,13 @@ def _gather_rows(ny, pidx, rows, n, run, tile=256):
                     s1f = int(pidx[kf]) - n // 2 + 1
                     if s1f > n0 + tile:
                         break
-                    start, end = max(s1f, 1), int(pidx[kl]) + n // 2 + 1
-                    if start <= tgt < end:
-                        acc += rows[r * (n + 1) + tgt]  # (= slot 1 + (tgt - start) of the row that begins at start - 1)
+                    start, end = max(s1f, 1), min(int(pidx[kl]) + n // 2 + 1, ny)
+                    if offs[r] >= 0 and start <= tgt < end:
+                        acc += rows[offs[r] + 1 + (tgt - start)]
             else:
                 for r in range(k_end // run, n_runs):
-                    acc += rows[r * (n + 1) - 1 + max(int(pidx[r * run]) - n // 2 + 1, 1)]
+                    if offs[r] >= 0:
+                        acc += rows[offs[r]]
             y[i] = acc
     return y
 
@@ -293,11 +309,17 @@ def test_response_rows_and_gather_equal_the_references_scatter(case):
     ref = np.zeros(ny)
     for k in range(len(pidx)):
         R._ola(ref, int(pidx[k]), base_index, resp[k])
-    rows = _rows_of_runs(ny, pidx, resp, n, run)
+    offs, need = _row_offsets(ny, pidx, n, run, 10 ** 9)
+    assert min(offs) >= 0 and len(set(offs)) == len(offs)
+    rows = _rows_of_runs(ny, pidx, resp, n, run, offs, need)   # a region of exactly the size the rows take
+    assert not np.any(np.isnan(rows))                          # every slot of every row is written, once
     for tile in (256, 1024, 96):
-        got = _gather_rows(ny, pidx, rows, n, run, tile)
+        got = _gather_rows(ny, pidx, rows, n, run, offs, tile)
         assert not np.any(np.isnan(got))
         assert np.array_equal(got, ref)
+    if len(offs) > 2:  # a region that is too small: the rows that fit are intact, the others dropped (and flagged)
+        short, _ = _row_offsets(ny, pidx, n, run, need - 1)
+        assert short[:-1] == offs[:-1] and short[-1] == -1
 
 
 def _req_rows(ny, nf, hop, n, runf, resp):

@@ -123,22 +123,27 @@ class NoTorchRuntime:
 
 
 def main():
+    """usage: notorch_harness.py [fs method requiem]  (default: every combination in one process)"""
     rt = NoTorchRuntime()
     _hip.Runtime.get = classmethod(lambda cls, device_index=None, lane=0: rt)
     from world import main as wmain
     from world._synthetic import synth_utterance
 
     W = wmain.World()
+    if len(sys.argv) > 3:
+        combos = [(int(sys.argv[1]), sys.argv[2], sys.argv[3] == "1")]
+    else:
+        combos = [(fs, m, r) for fs in (16000, 22050, 48000) for m, r in (("dio", False), ("harvest", True), ("harvest", False))]
     done = []
-    for fs, seconds in ((16000, 1.2), (22050, 0.7), (48000, 0.6)):
-        x = synth_utterance(900 + fs // 1000, fs, seconds)
-        for method, requiem in (("dio", False), ("harvest", True), ("harvest", False)):
-            dat = W.encode(fs, x, f0_method=method, is_requiem=requiem)
-            np.random.seed(1)
-            out = W.decode(dict(dat))["out"]
-            assert np.all(np.isfinite(out)) and np.all(np.isfinite(dat["spectrogram"])) and len(out) > 0
-            done.append((fs, method, requiem, len(dat["f0"]), int(np.sum(dat["vuv"] > 0))))
-            print("ok", done[-1], flush=True)
+    for fs, method, requiem in combos:
+        x = synth_utterance(900 + fs // 1000, fs, {16000: 1.2, 22050: 0.7, 48000: 0.6}.get(fs, 0.8))
+        dat = W.encode(fs, x, f0_method=method, is_requiem=requiem)
+        print("encoded", (fs, method, requiem), flush=True)
+        np.random.seed(1)
+        out = W.decode(dict(dat))["out"]
+        assert np.all(np.isfinite(out)) and np.all(np.isfinite(dat["spectrogram"])) and len(out) > 0
+        done.append((fs, method, requiem, len(dat["f0"]), int(np.sum(dat["vuv"] > 0))))
+        print("ok", done[-1], flush=True)
     assert sys.modules.get("torch") is None
     print("HARNESS OK: %d encode+decode passes without torch" % len(done))
 

@@ -19,7 +19,11 @@ FLAGS = ["--offload-arch=gfx950:xnack+", "-fsanitize=address", "-shared-libsan",
 # Two kernels address a twiddle table by its LDS byte offset and trap unless their dynamic LDS block starts at LDS address 0
 # (stonemask_tab_kernel, hv_refine_kernel<TWL>); the sanitizer places LDS bookkeeping of its own in front, so this build
 # takes their general forms (the staged StoneMask kernel, refinement twiddles from the global tables).
-ASAN_TU_FLAGS = {"wh_stonemask.hip": ["-DWH_STONEMASK_TABLE=0"], "wh_harvest.hip": ["-DWH_HV_LDS_TWIDDLES=0"]}
+# The exact phase scan declares 74 KB of static LDS per workgroup (two padded 4096-sample tiles); with the sanitizer's
+# LDS redzones the kernel no longer loads ("HSA_STATUS_ERROR_INVALID_ISA" at dispatch): this build scans 1024-sample tiles
+# on 128 threads — the same arithmetic (the tile size does not enter the sums).
+ASAN_TU_FLAGS = {"wh_stonemask.hip": ["-DWH_STONEMASK_TABLE=0"], "wh_harvest.hip": ["-DWH_HV_LDS_TWIDDLES=0"],
+                 "wh_synthesis.hip": ["-DWH_XTILE=1024", "-DWH_XTHREADS=128"]}
 
 
 def main():

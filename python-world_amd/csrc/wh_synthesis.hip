@@ -530,7 +530,10 @@ int exact_cumsum_segments(wh_ctx* ctx, hipStream_t st, double* d_data, const int
 //   pulse_finish_kernel : one workgroup per utterance: fractional shifts and the noise-stream offsets
 //                         (exclusive prefix sum of max(3, noise_size), synthesis.py:65).
 constexpr int kPTile = 1024;
-constexpr int kPFinish = 1024;
+#ifndef WH_PFINISH
+#define WH_PFINISH 1024  // threads of pulse_finish_kernel (one workgroup per utterance); the sanitizer build takes 256
+#endif
+constexpr int kPFinish = WH_PFINISH;
 
 __device__ __forceinline__ int block_excl_scan_256(int c, int* wsum, int* total) {
   int incl = c;

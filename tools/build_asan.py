@@ -23,7 +23,8 @@ FLAGS = ["--offload-arch=gfx950:xnack+", "-fsanitize=address", "-shared-libsan",
 # LDS redzones the kernel no longer loads ("HSA_STATUS_ERROR_INVALID_ISA" at dispatch): this build scans 1024-sample tiles
 # on 128 threads — the same arithmetic (the tile size does not enter the sums).
 ASAN_TU_FLAGS = {"wh_stonemask.hip": ["-DWH_STONEMASK_TABLE=0"], "wh_harvest.hip": ["-DWH_HV_LDS_TWIDDLES=0"],
-                 "wh_synthesis.hip": ["-DWH_XTILE=1024", "-DWH_XTHREADS=128"]}
+                 "wh_synthesis.hip": ["-DWH_XTILE=1024", "-DWH_XTHREADS=128", "-DWH_PFINISH=256"]}  # (a 1024-thread
+# workgroup of the instrumented pulse_finish_kernel does not load either: fewer threads, the same per-pulse arithmetic)
 
 
 def main():

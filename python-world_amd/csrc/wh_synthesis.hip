@@ -1736,8 +1736,8 @@ __global__ __launch_bounds__(256) void req_excite_kernel(const SynUtt* __restric
 constexpr int req_runf(int n) { return n <= 1024 ? WH_REQ_RUNF : 1; }
 
 // Frame-wise minimum-phase filtering of the excitation with overlap-add (synthesisRequiem.py:74-101), WITHOUT atomics:
-// a workgroup takes a run of RUNF consecutive frames of one utterance and adds their responses — in frame order —
-// into the run's ROW, which spans the run ((RUNF - 1) hop + N samples); req_gather_kernel
+// a workgroup takes a run of RUNF consecutive frames of one utterance, adds their responses — in frame order — into an
+// LDS accumulator that spans the run ((RUNF - 1) hop + N samples), and writes it as the run's ROW; req_gather_kernel
 // then adds, per output sample, the two or three rows that cover it, in run order.  The same sum from launch to launch
 // and wherever the utterance sits in a batch (runs are numbered per utterance); the reference adds frame after frame
 // into y — runs of frames first is another association of that sum.  Row r of an utterance: W = (RUNF - 1) hop + N + 1
@@ -1745,9 +1745,9 @@ constexpr int req_runf(int n) { return n <= 1024 ? WH_REQ_RUNF : 1; }
 // only the last one written survives — the last tap of every frame whose response reaches it or beyond), slot 1 + j =
 // the sum at the 1-based sample a_r + j, a_r = r RUNF hop + 1.  RUNF = 1 (long transforms, long hops): the row is the
 // frame's own response, written straight from the transform buffer.  Rows instead of atomics take the 1.07 GB of
-// read-modify-write traffic per 64 utterances down to a 0.3 GB row write + read.
+// read-modify-write traffic per 64 utterances down to a 0.33 GB row write + as much read by the gather.
 #ifndef WH_REQ_MINW
-#define WH_REQ_MINW 8
+#define WH_REQ_MINW 1
 #endif
 template <int N, int RUNF>
 __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1)) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
@@ -1761,6 +1761,7 @@ __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1
   double2* zb = reinterpret_cast<double2*>(smem);        // minimum-phase half spectrum (N/2+1 complex)
   double2* sb = zb + (N / 2 + 1);                         // windowed excitation frame / its half spectrum
   double* sr = reinterpret_cast<double*>(sb);
+  double* acc = reinterpret_cast<double*>(sb + (N / 2 + 1));  // RUNF > 1: the run's sums, (RUNF - 1) hop + N doubles
   const SynUtt m = meta[blockIdx.y];
   const ReqUtt q = rq[blockIdx.y];
   if ((int64_t)blockIdx.x >= q.n_runs) return;
@@ -1771,6 +1772,10 @@ __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1
   const int64_t a_r = (i0 - 2) * hop + 1;  // 1-based sample of the run's first tap (= the first frame's origin)
   const int64_t W = (RUNF - 1) * hop + N + 1;
   double* row = rows + q.row_off + (int64_t)blockIdx.x * W;
+  const int span = (int)(W - 1);
+  if (RUNF > 1) {
+    for (int j = threadIdx.x; j < span; j += FT) acc[j] = 0.0;  // (ordered before the first add by the chain's barriers)
+  }
   double last = 0.0;  // (thread FT-1: tap N-1 of every frame whose response reaches the utterance's last sample)
   const double* eu = exc + m.y_off;
   double* zr = reinterpret_cast<double*>(zb);
@@ -1807,21 +1812,21 @@ __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1
     // minimum-phase spectrum x excitation spectrum (both Hermitian, so is the product), straight into the inverse
     // transform: the fused chain of the pulse responses with the product applied to the register-held bin pairs
     min_phase_response<N, FT>(zb, tw_base, 0.0, [&](int k, double2 e) { return wh::cmul(e, sb[k]); });
-    // The run's sums are kept in the row itself (global memory, L2-resident): this frame's taps in front of N - hop fall
-    // on samples earlier frames of the run have written — read, add, write back, each sample by one thread —, the last
-    // hop taps on fresh ones.  The barriers of the chain order one frame's stores before the next frame's loads (a
-    // workgroup's waves share the CU's vector cache).  Neither registers nor LDS are held across the frames: an LDS
-    // accumulator costs the kernel three of its eight waves per SIMD (1.70 against 1.40 ms at config 4).
+    // The run's sums live in LDS and go to the row ONCE, at the end of the run.  (Kept in the row itself — read, add,
+    // write back per frame — the kernel is 3 % faster, 1.52 against 1.57 ms at config 4: the accumulator's 10 KB cost two
+    // of its eight workgroups per CU; but every frame's 8 KB then travel to HBM and the kernel moves 2.2 GB per 64
+    // utterances where this form moves ~1 GB.  Register-held sums spill: 90 VGPRs.)
     const int shift = (int)(origin - a_r);  // (i - i0) * hop: where this frame's tap 0 falls in the run
-    const int fresh = (i == i0) ? 0 : N - (int)hop;  // first tap that no earlier frame of the run reached
-    double* rw = row + 1 + shift;
     for (int mm = WH_TID; mm < N; mm += FT) {
-      double v = origin + mm < m.ny ? zr[mm] / N : 0.0;  // (origin + mm >= 1 always)
-      if (RUNF > 1 && mm < fresh) v = rw[mm] + v;
-      rw[mm] = v;
+      const double v = origin + mm < m.ny ? zr[mm] / N : 0.0;  // (origin + mm >= 1 always)
+      if (RUNF > 1) acc[shift + mm] += v;  // one writer per slot and frame; frames are separated by barriers
+      else row[1 + mm] = v;
     }
     if (WH_TID == FT - 1 && origin + (N - 1) >= m.ny) last += zr[N - 1] / N;
-    if (RUNF > 1) wh::sync<FT>();  // zr is free for the next frame, and this frame's row stores are visible to it
+    if (RUNF > 1) wh::sync<FT>();  // zr is free for the next frame, this frame's adds are visible to its successor
+  }
+  if (RUNF > 1) {
+    for (int j = threadIdx.x; j < span; j += FT) row[1 + j] = acc[j];  // (zeros behind a short last run's frames)
   }
   if (threadIdx.x == FT - 1) row[0] = last;
 }
@@ -1844,12 +1849,7 @@ __global__ __launch_bounds__(256) void req_gather_kernel(const SynUtt* __restric
     int64_t r_hi = (tgt - 1) / adv;
     r_hi = r_hi > q.n_runs - 1 ? q.n_runs - 1 : r_hi;
     int64_t r_lo = tgt - (W - 1) <= 0 ? 0 : (tgt - (W - 1) - 1) / adv + 1;  // first r with a_r + W - 2 >= tgt
-    for (int64_t r = r_lo; r <= r_hi; ++r) {
-      // (the last run of an utterance may hold fewer frames: its row is written as far as they reach)
-      const int64_t nfr = r == q.n_runs - 1 ? (m.nf - 3) - r * RUNF : RUNF;
-      const int64_t j = tgt - (r * adv + 1);
-      if (j < (nfr - 1) * q.hop + N) sum += ru[r * W + 1 + j];
-    }
+    for (int64_t r = r_lo; r <= r_hi; ++r) sum += ru[r * W + 1 + (tgt - (r * adv + 1))];  // (rows are written in full)
   } else {
     // frames whose last tap reaches the last sample live in the runs from (ny - N) / adv - 1 on; the others hold 0 there
     int64_t r_lo = (m.ny - N) / adv - 1;
@@ -1863,7 +1863,7 @@ __global__ __launch_bounds__(256) void req_gather_kernel(const SynUtt* __restric
 // (N <= 1024: 16 KB + 12.4 KB at a hop of 80), else the frame's own row
 
 template <int N>
-int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, int64_t max_ny, bool runs,
+int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, int64_t max_ny, int64_t max_hop, bool runs,
                       const SynUtt* d_meta, const ReqUtt* d_rq, const double* spec, const double* exc, double* rows,
                       double* y) {
   constexpr int RUNF = req_runf(N);
@@ -1871,8 +1871,9 @@ int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, int64_
   if (max_nf >= 4) {
     wh::KernelTimer _kt(ctx, st, "req_filter_kernel");
     if (runs && RUNF > 1) {
-      if (int rc = wh::allow_lds(&req_filter_kernel<N, RUNF>, lds)) return rc;
-      hipLaunchKernelGGL((req_filter_kernel<N, RUNF>), dim3((unsigned)((max_nf - 3 + RUNF - 1) / RUNF), B), dim3(ft_syn(N)), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, rows);
+      const size_t lds_run = lds + sizeof(double) * (size_t)((RUNF - 1) * max_hop + N);  // + the run's sums
+      if (int rc = wh::allow_lds(&req_filter_kernel<N, RUNF>, lds_run)) return rc;
+      hipLaunchKernelGGL((req_filter_kernel<N, RUNF>), dim3((unsigned)((max_nf - 3 + RUNF - 1) / RUNF), B), dim3(ft_syn(N)), lds_run, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, rows);
     } else {
       if (int rc = wh::allow_lds(&req_filter_kernel<N, 1>, lds)) return rc;
       hipLaunchKernelGGL((req_filter_kernel<N, 1>), dim3((unsigned)(max_nf - 3), B), dim3(ft_syn(N)), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, rows);
@@ -2239,7 +2240,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   }
   const int64_t ny_tot = h_y_off[B];
   const int64_t F = b->total_frames;
-  // overlap-add rows of req_filter_kernel: runs of frames (one row per frame beyond N = 1024 and for hops >= N)
+  // overlap-add rows of req_filter_kernel: runs of frames (one row per frame beyond N = 1024 and for long hops)
   int runf = 1;
   switch (fft_size) {
     case 512: runf = req_runf(512); break;
@@ -2248,8 +2249,8 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
     case 4096: runf = req_runf(4096); break;
     default: return wh::fail_msg("wh_synthesis_requiem", "fft_size must be a power of two in [512, 4096]");
   }
-  // (a frame adds onto the N - hop samples its predecessors wrote: the hop must be shorter than the transform)
-  const bool runs = runf > 1 && max_hop < fft_size;
+  // (the run's sums are an LDS accumulator of (RUNF - 1) hop + N doubles: at most 2 N, i.e. 16 KB at N = 1024)
+  const bool runs = runf > 1 && (runf - 1) * max_hop <= (int64_t)fft_size;
   if (!runs) runf = 1;
   int64_t rows_tot = 0;
   for (int u = 0; u < B; ++u) {
@@ -2300,10 +2301,10 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   { wh::KernelTimer _kt(ctx, st, "req_excite_kernel"); hipLaunchKernelGGL(req_excite_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, d_rq, tp, d_lin, n_bands, noise_seed, noise_len, pulse_seed, pulse_fft, d_pi, d_pc, d_pt, d_pw, d_exc); }
   WH_LAUNCH_CHECK("req_excite_kernel");
   switch (fft_size) {
-    case 512: return launch_req_filter<512>(ctx, st, B, max_nf, max_ny, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
-    case 1024: return launch_req_filter<1024>(ctx, st, B, max_nf, max_ny, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
-    case 2048: return launch_req_filter<2048>(ctx, st, B, max_nf, max_ny, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
-    case 4096: return launch_req_filter<4096>(ctx, st, B, max_nf, max_ny, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 512: return launch_req_filter<512>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 1024: return launch_req_filter<1024>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 2048: return launch_req_filter<2048>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 4096: return launch_req_filter<4096>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
     default: return wh::fail_msg("wh_synthesis_requiem", "fft_size must be a power of two in [512, 4096]");
   }
 }

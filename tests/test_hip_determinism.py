@@ -1,10 +1,10 @@
-"""Race / memory-safety evidence that can be produced without a device sanitizer (this image ships the device-side
-asanrtl.bc but neither the host libclang_rt.asan nor the ASan-instrumented ROCm runtime under /opt/rocm/lib/asan, so an
--fsanitize=address build of the library cannot run).  Three checks over the whole pipeline:
+"""Race / memory-safety evidence from the product's own outputs (the sanitizer pass this image allows is
+tools/asan_probe.sh: profiles/r05_asan_*.log).  Checks over the whole pipeline:
 
-* determinism: every output that does not pass through an FP64 atomic is BITWISE identical from run to run (a data race
-  in an LDS exchange, a ballot compaction or an XCD-remapped grid shows up as run-to-run differences); the overlap-add
-  outputs (FP64 atomics, order-dependent rounding) agree to 1e-15 of the signal's scale;
+* determinism: every output is BITWISE identical from run to run (a data race in an LDS exchange, a ballot compaction or
+  an XCD-remapped grid shows up as run-to-run differences) — since round 5 including the decode, whose overlap-add is
+  summed in a fixed order (rows of runs + gather) instead of by FP64 atomics — and an utterance decodes to the same
+  samples alone, anywhere in a batch and on a shard of it;
 * guard bands: the caller-visible output buffers are allocated with NaN-patterned guard regions on both sides and
   the guards are intact after the kernels ran (out-of-bounds stores past either end of an output);
 * poisoned scratch: outputs do not depend on what the workspace arena and the outputs held before the call

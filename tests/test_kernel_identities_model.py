@@ -333,16 +333,14 @@ def _req_rows(ny, nf, hop, n, runf, resp):
         i0 = r * runf + 2
         i1 = min(i0 + runf - 1, nf - 2)
         a_r = (i0 - 2) * hop + 1
-        last = 0.0
-        for i in range(i0, i1 + 1):  # the sums live in the row itself: read-add-write over what earlier frames wrote
+        acc, last = np.zeros(w - 1), 0.0
+        for i in range(i0, i1 + 1):  # the run's sums: an accumulator over the run's span, written to the row once
             origin = (i - 1) * hop - (hop - 1)
-            fresh = 0 if i == i0 else n - hop
             for mm in range(n):
-                v = resp[i][mm] if origin + mm < ny else 0.0
-                at = r * w + 1 + (origin - a_r) + mm
-                rows[at] = rows[at] + v if (runf > 1 and mm < fresh) else v
+                acc[origin - a_r + mm] += resp[i][mm] if origin + mm < ny else 0.0
             if origin + n - 1 >= ny:
                 last += resp[i][n - 1]
+        rows[r * w + 1:(r + 1) * w] = acc
         rows[r * w] = last
     return rows, n_runs, w
 
@@ -357,10 +355,7 @@ def _req_gather(ny, nf, hop, n, runf, rows, n_runs, w):
             x = tgt - (w - 1)
             r_lo = 0 if x <= 0 else (x - 1) // adv + 1
             for r in range(r_lo, r_hi + 1):
-                nfr = (nf - 3) - r * runf if r == n_runs - 1 else runf  # the last run may hold fewer frames
-                j = tgt - (r * adv + 1)
-                if j < (nfr - 1) * hop + n:
-                    acc += rows[r * w + 1 + j]
+                acc += rows[r * w + 1 + (tgt - (r * adv + 1))]
         else:
             r_lo = max(int((ny - n) / adv) - 1, 0)  # (C++ division truncates towards zero)
             for r in range(r_lo, n_runs):

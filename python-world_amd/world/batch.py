@@ -742,3 +742,41 @@ class WorldBatchLanes:
         if check:
             for wb in self.lanes:
                 wb.check("WorldBatchLanes")
+
+
+class WorldBatchPipeline:
+    """``depth`` independent WorldBatch pipelines on one GPU — contexts, workspace arenas and HIP streams of their own —
+    handed out round-robin: a caller that processes a stream of batches runs batch k on ``pipeline.next()``.  Nothing is
+    shared between two batches in flight and nothing is skipped; what two in flight buy is that the serial,
+    latency-bound head of one batch's encode (decimation IIRs, contour tracking: a few dozen workgroups) runs under the
+    chip-filling kernels at the tail of the batch before instead of on an idle chip (bench.py --in-flight: config 2
+    10.13 -> 9.76 ms per 64 x 10 s step, config 4 13.5 -> 12.5).  Calls are asynchronous by default (``check=False``):
+    ``synchronize()`` waits for every pipeline and raises for the conditions their kernels reported.  Memory: every
+    pipeline keeps an arena sized for its largest batch (1024 x 10 s of Harvest: ~105 GB — one in flight at that size)."""
+
+    def __init__(self, device_index=None, depth=2):
+        self.pipes = [WorldBatch(device_index, lane=d + 1) for d in range(max(1, int(depth)))]
+        self._k = 0
+
+    def next(self):
+        wb = self.pipes[self._k % len(self.pipes)]
+        self._k += 1
+        return wb
+
+    def encode_decode(self, xs, fs, decode_kw=None, **encode_kw):
+        """One batch through the next pipeline: (encoding, y, y_off), enqueued on that pipeline's stream."""
+        wb = self.next()
+        encode_kw.setdefault("check", False)
+        enc = wb.encode(xs, fs, **encode_kw)
+        kw = dict(decode_kw or {})
+        kw.setdefault("check", False)
+        y, y_off = wb.decode_device(enc, **kw)
+        return enc, y, y_off
+
+    def synchronize(self, check=True):
+        for wb in self.pipes:
+            wb.rt.own_stream.synchronize()
+        if check:
+            for wb in self.pipes:
+                wb.check("WorldBatchPipeline")
+

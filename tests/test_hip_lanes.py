@@ -44,3 +44,30 @@ def test_lanes_equal_single_stream(lanes):
                 assert np.max(np.abs(seg - want)) <= 1e-13 * max(1.0, np.max(np.abs(want))), (u, rep)
     for wbl in wl.lanes:
         assert wbl.rt.take_flags() == [0] * 16
+
+
+def test_two_batches_in_flight_equal_one_at_a_time():
+    """WorldBatchPipeline: batches dealt to two independent pipelines (what bench.py --in-flight 2 times) give the
+    results of one WorldBatch processing them one after the other, bit for bit — encode and (atomics-free) decode."""
+    import torch
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch, WorldBatchPipeline
+
+    fs = 16000
+    batches = [[synth_utterance(400 + 10 * b + i, fs, 0.7 + 0.2 * i) for i in range(3)] for b in range(4)]
+    rng = np.random.RandomState(9)
+    noises = [[rng.randn(2 * len(x)) for x in xs] for xs in batches]
+    one = WorldBatch()
+    ref = []
+    for xs, nz in zip(batches, noises):
+        enc = one.encode(xs, fs, f0_method="dio")
+        y, _ = one.decode_device(enc, noise=nz)
+        ref.append((enc.f0.clone(), enc.spectrogram.clone(), enc.aperiodicity.clone(), y.clone()))
+    pipe = WorldBatchPipeline(depth=2)
+    got = [pipe.encode_decode(xs, fs, decode_kw={"noise": nz}, f0_method="dio") for xs, nz in zip(batches, noises)]
+    pipe.synchronize()
+    assert pipe.pipes[0].rt is not pipe.pipes[1].rt and pipe.pipes[0].rt.own_stream is not pipe.pipes[1].rt.own_stream
+    for (enc, y, _), (f0, sp, ap, yr) in zip(got, ref):
+        assert torch.equal(enc.f0, f0) and torch.equal(enc.spectrogram, sp) and torch.equal(enc.aperiodicity, ap)
+        assert torch.equal(y, yr)
+

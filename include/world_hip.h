@@ -40,7 +40,8 @@ int wh_device_count(int* count);
 int wh_ctx_create(int device, wh_ctx** out);
 int wh_ctx_destroy(wh_ctx* ctx);
 /* Free the context's scratch (workspace arena, per-call buffers: they only grow with the largest batch served); tables and
- * flags stay, the next call allocates again.  Synchronises the device.  A time base held by the context is dropped. */
+ * flags stay, the next call allocates again.  Synchronises the device.  A time base held by the context is dropped, and a
+ * hipGraph captured over calls of this context holds the freed addresses: capture again instead of replaying it. */
 int wh_ctx_trim(wh_ctx* ctx);
 int wh_malloc(void** dptr, size_t bytes);
 int wh_free(void* dptr);

@@ -65,7 +65,7 @@ int wh_copy_mapped(wh_ctx* ctx, void* stream, void* dst, const void* src, size_t
 #define WH_FLAG_EVENT_OVERFLOW 1   /* a zero-crossing list exceeded its capacity (cannot happen for cap = len/2+2) */
 #define WH_FLAG_NOISE_SHORT 2      /* synthesis ran out of host-supplied noise samples */
 #define WH_FLAG_NO_PULSE 3         /* an utterance produced no pulse (reference asserts, synthesis.py:131) */
-#define WH_FLAG_PULSE_OVERFLOW 4   /* more pulses than the pulse capacity */
+#define WH_FLAG_PULSE_OVERFLOW 4   /* more pulses than the pulse capacity, or more overlap-add rows than its row region holds */
 int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16);
 /* The same flags without a host wait, for callers that keep a pipeline of batches in flight:
  *   wh_flags_post — enqueue (one 16-lane kernel on `stream`) the publication of the flags raised by everything before

@@ -1030,7 +1030,7 @@ struct RespArgs {
 // Row layout (per utterance a region of row_stride doubles): the rows lie one behind the other, row r at row_off[r]
 // (pulse_rows_kernel: an exclusive scan of the row lengths, which follow from the pulse positions); slot 0 = what the
 // run adds to the LAST sample (Q8, below), slot 1 + (t - start_r) = its sum at the 1-based sample t < ny, start_r =
-// max(1, first tap of the run's first pulse).  A region holds 8 doubles per output sample (mean f0 up to ~fs / 21 at
+// max(1, first tap of the run's first pulse).  A region holds 12 doubles per output sample (a mean f0 up to ~fs / 16 at
 // N = 1024); an utterance that needs more raises WH_FLAG_PULSE_OVERFLOW like one that runs out of pulse slots, and the
 // retry with the safe pulse capacity sizes the region for it.
 struct RunState {
@@ -1567,10 +1567,11 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, int64_t ma
   // overlap-add rows (RunState): per utterance ceil(pcap / RUN) rows of N + 1 slots laid along the time axis.  Held in a
   // buffer of its own, not in the arena: the render reserves no workspace (the time base may live in this context's)
   const int64_t runs_cap = (pcap_max + resp_run(N) - 1) / resp_run(N);
-  // doubles per output sample in an utterance's row region: 8 with the default pulse capacity (ny / 8: the rows of speech
-  // take ~5), up to 48 with the safe capacity of the retry (ny / 2)
-  int64_t per_sample = (64 * pcap_max + max_ny - 1) / (max_ny > 0 ? max_ny : 1);
-  per_sample = per_sample < 8 ? 8 : (per_sample > 48 ? 48 : per_sample);
+  // doubles per output sample in an utterance's row region: 12 with the default pulse capacity (ny / 8) — the rows take
+  // 6.2 where the reference places its 500 Hz unvoiced pulses at 16 kHz, 5 at a voiced 400 Hz, 12 at ~1 kHz — up to 48 with
+  // the safe capacity of the retry (ny / 2: f0 up to fs / 4 at N = 1024)
+  int64_t per_sample = (96 * pcap_max + max_ny - 1) / (max_ny > 0 ? max_ny : 1);
+  per_sample = per_sample < 12 ? 12 : (per_sample > 48 ? 48 : per_sample);
   const int64_t row_stride = per_sample * max_ny + 4 * (N + 1);
   void* d_rows = nullptr;
   void* d_rb = nullptr;

@@ -95,7 +95,8 @@ FLAG_MESSAGES = {
     FLAG_EVENT_OVERFLOW: "a zero-crossing event list exceeded its capacity (pathological input)",
     FLAG_NOISE_SHORT: "synthesis ran out of host-supplied noise samples",
     FLAG_NO_PULSE: "an utterance produced no pulse (the reference asserts, world/synthesis.py:131)",
-    FLAG_PULSE_OVERFLOW: "more pulses than pulse_cap: trailing pulses were dropped",
+    FLAG_PULSE_OVERFLOW: "more pulses (or overlap-add rows) than pulse_cap provides for: trailing pulses / runs were dropped "
+                         "(pass pulse_cap=world.synthesis.safe_pulse_cap(ny))",
 }
 
 

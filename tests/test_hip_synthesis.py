@@ -208,3 +208,33 @@ def test_peak_normalisation_branches():
     off = np.array([0, 3, 3, 5], dtype=np.int64)
     _hip.check(rt.lib.wh_peak_normalise(rt.ctx, rt.stream(), rt.ptr(d), off.ctypes.data_as(ctypes.c_void_p), 3))
     assert np.array_equal(d.cpu().numpy(), np.array([0.5, -1.0, 0.25, 0.25, -0.5]))
+
+
+def test_row_region_overflow_takes_the_pulse_capacity_retry():
+    """The overlap-add rows of an utterance live in a region of 12 doubles per output sample (wh_synthesis.hip RunState);
+    a pitch so high that the runs' rows do not fit — here a contour scaled to ~1.2-1.6 kHz at 16 kHz — raises
+    WH_FLAG_PULSE_OVERFLOW from pulse_rows_kernel although the pulse slots themselves suffice, and decode_device's
+    retry with the safe capacity (which sizes the region too) gives exactly what an explicit safe capacity gives."""
+    from world import _hip
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+    from world.synthesis import safe_pulse_cap, time_axis_params
+
+    fs = 16000
+    xs = [synth_utterance(610, fs, 0.8), synth_utterance(611, fs, 0.6)]
+    wb = WorldBatch()
+    enc = wb.encode(xs, fs, f0_method="dio")
+    enc.scale_pitch(7.0)
+    rng = np.random.RandomState(4)
+    noise = [rng.randn(4 * len(x)) for x in xs]
+    y, y_off = wb.decode_device(enc, noise=noise)                      # default capacity -> overflow -> retried inside
+    fo = enc.batch.frame_off
+    tp = enc.host_times()
+    ny = [time_axis_params(tp[int(fo[u]):int(fo[u + 1])], fs)[0] for u in range(2)]
+    y_safe, _ = wb.decode_device(enc, noise=noise, pulse_cap=safe_pulse_cap(ny))
+    assert np.array_equal(y.cpu().numpy(), y_safe.cpu().numpy())
+    assert np.all(np.isfinite(y.cpu().numpy())) and float(y.abs().max()) > 1e-3
+    wb.decode_device(enc, noise=noise, check=False)                     # asynchronous: the condition is reported ...
+    with pytest.raises(_hip.WorldHipError, match="pulse_cap"):
+        wb.check()                                                      # ... by check()
+

@@ -144,13 +144,13 @@ _pool = None
 
 
 class _copy_pool:
-    """The process-wide 4-thread pool for host-side staging copies (created on first use, kept)."""
+    """The process-wide 8-thread pool for host-side staging copies (created on first use, kept)."""
 
     def __enter__(self):
         global _pool
         if _pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            _pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="wh-stage")
+            _pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="wh-stage")
         return _pool
 
     def __exit__(self, *exc):
@@ -246,8 +246,8 @@ class Runtime:
             for k in range(lo, hi):
                 view[offs[k]:offs[k + 1]] = arrays[k]  # (NumPy releases the GIL for the copy)
 
-        workers = min(4, len(arrays)) if total * 8 >= (1 << 24) else 1
-        if workers > 1:  # 82 MB of waveforms: ~9 ms on one host thread, ~3 on four
+        workers = min(8, len(arrays)) if total * 8 >= (1 << 24) else 1
+        if workers > 1:  # 82 MB of waveforms: ~9 ms on one host thread, ~3 on four, ~2 on eight
             cuts = [len(arrays) * w // workers for w in range(workers + 1)]
             with _copy_pool() as pool:
                 list(pool.map(lambda w: fill(cuts[w], cuts[w + 1]), range(workers)))

@@ -266,7 +266,7 @@ def measure_pmc_traffic(args, timeout_s=240, config=None, utts=None, seconds=Non
     tmp = tempfile.mkdtemp(prefix="wh_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     child = [sys.executable, os.path.abspath(__file__), "--config", str(config or args.config),
              "--utts", str(utts or args.utts), "--seconds", str(seconds or args.seconds), "--steps", str(steps),
-             "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-graph", "--no-pmc"]
+             "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-graph", "--no-pmc", "--in-flight", "1"]
     per = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -750,7 +750,7 @@ class WorldBatchPipeline:
     shared between two batches in flight and nothing is skipped; what two in flight buy is that the serial,
     latency-bound head of one batch's encode (decimation IIRs, contour tracking: a few dozen workgroups) runs under the
     chip-filling kernels at the tail of the batch before instead of on an idle chip (bench.py --in-flight: config 2
-    10.13 -> 9.76 ms per 64 x 10 s step, config 4 13.5 -> 12.5).  Calls are asynchronous by default (``check=False``):
+    10.09 -> 9.78 ms per 64 x 10 s step, config 4 13.5 -> 12.6).  Calls are asynchronous by default (``check=False``):
     ``synchronize()`` waits for every pipeline and raises for the conditions their kernels reported.  Memory: every
     pipeline keeps an arena sized for its largest batch (1024 x 10 s of Harvest: ~105 GB — one in flight at that size)."""
 

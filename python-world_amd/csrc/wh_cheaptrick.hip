@@ -198,7 +198,11 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
   // transform — one pass over the half spectrum instead of three (wh::rfft_lds / multiply / wh::irfft_lds).
   {
     constexpr int M = N / 2;
+#if defined(WH_CT_ABLATE_T) && WH_CT_ABLATE_T
+    wh::sync<FT>();  // TIMING EXPERIMENT ONLY (wrong results): one of the two lifter transforms costs nothing — the upper bound
+#else                // of halving both (real-even data: DCT-I through quarter-size transforms)
     wh::fft_lds<M, false, FT>(zb, tw_base + M);  // (its barriers also complete the lifter table for the loop below)
+#endif
     const double2* __restrict__ wtw = tw_base + N;
     for (int k = threadIdx.x; k <= M / 2; k += FT) {
       const double2 a = zb[k], b = zb[M - k];

@@ -383,6 +383,9 @@ __device__ __forceinline__ void fft_pass_finish(double2* __restrict__ s, double2
 #pragma unroll
         for (int r = 1; r < R; ++r) v[p][r] = INV ? cmul_conj(v[p][r], w[p][r]) : cmul(v[p][r], w[p][r]);
       }
+#if defined(WH_ABLATE_FIRSTPASS) && WH_ABLATE_FIRSTPASS
+      if (NS != 1)  // TIMING EXPERIMENT ONLY (wrong results): the first pass's butterflies cost nothing — an upper bound of
+#endif           // what pruning them for zero-padded inputs could buy
       dft_small<R, INV>(v[p]);
       const int base = (j - k) * R + k;
 #pragma unroll

@@ -894,7 +894,11 @@ __device__ __forceinline__ void min_phase_response(double2* zb, const double2* t
   double* zr = reinterpret_cast<double*>(zb);
   const int gt = WH_TID & (GT - 1);
   const double2* __restrict__ w = tw_base + N;
+#if defined(WH_RESP_ABLATE_T1) && WH_RESP_ABLATE_T1
+  wh::sync<FT>();  // TIMING EXPERIMENT ONLY (wrong results): the chain's first transform costs nothing — twice the upper
+#else              // bound of packing the two chains' real-even first transforms into one (DCT-I)
   wh::fft_lds<M, false, GT, FT>(zb, tw_base + M);
+#endif
   {
     double ck[PP], cm[PP];
 #pragma unroll

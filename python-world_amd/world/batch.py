@@ -163,7 +163,10 @@ class BatchEncoding:
         nfs = [len(d['f0']) for d in dats]
         frame_off = np.concatenate([[0], np.cumsum(nfs)])
         batch = rt.make_batch(np.zeros(len(dats) + 1, dtype=np.int64), frame_off)
-        flat = lambda key: rt.to_device(np.concatenate([np.asarray(d[key], dtype=np.float64) for d in dats]))  # noqa: E731
+        # the three per-frame scalar arrays travel as ONE upload (three pageable copies cost three round trips)
+        tp_h = np.concatenate([np.asarray(d['temporal_positions'], dtype=np.float64) for d in dats])
+        scal_h = np.stack([tp_h, np.concatenate([np.asarray(d['f0'], dtype=np.float64) for d in dats]),
+                           np.concatenate([np.asarray(d['vuv'], dtype=np.float64) for d in dats])])
 
         def resident(d, key):
             return d.resident_rows(key, rt) if isinstance(d, EncodingDict) else None
@@ -182,14 +185,14 @@ class BatchEncoding:
                      for p, d in zip(parts, dats)]
             return torch.cat(parts, dim=0).contiguous()
 
-        tp_h = np.concatenate([np.asarray(d['temporal_positions'], dtype=np.float64) for d in dats])
         d0 = dats[0]
         if isinstance(d0, EncodingDict) and resident(d0, 'spectrogram') is not None:
             fft_size = d0._enc.fft_size  # (asking the dict for its spectrogram's shape would download it)
         else:
             fft_size = (d0['spectrogram'].shape[0] - 1) * 2
         with rt.on_stream():
-            return cls(rt, batch, d0['fs'], rt.to_device(tp_h), flat('f0'), flat('vuv'), rows('spectrogram'),
+            scal = rt.to_device(scal_h)
+            return cls(rt, batch, d0['fs'], scal[0], scal[1], scal[2], rows('spectrogram'),
                        rows('aperiodicity'), fft_size, bool(d0['is_requiem']), None, tp_host=tp_h)
 
     @property
@@ -310,7 +313,8 @@ class BatchEncoding:
         ``lazy``: ``EncodingDict``s — the dense values are downloaded when first read, and World.decode_batch takes the
         ones nobody read straight from this encoding (which the dicts keep alive)."""
         fo = self.batch.frame_off
-        tp, f0, vuv = (t.cpu().numpy() for t in (self.temporal_positions, self.f0, self.vuv))
+        with self.rt.on_stream():  # (one download instead of three round trips)
+            tp, f0, vuv = self.rt.torch.stack([self.temporal_positions, self.f0, self.vuv]).cpu().numpy()
         if want_ps and self.ps_spectrogram is None:
             raise ValueError("this encoding holds no 'ps spectrogram': encode with want_ps=True")
         # the dense tensors are frame-major on the device; the reference's layout is (bins, frames): every utterance's slice

@@ -280,8 +280,11 @@ def test_encoding_dict_materialises_on_read_and_remembers_it():
 
     downloads = []
 
+    torch_mod = torch
+
     class StubRt:
         index = 0
+        torch = torch_mod
 
         def on_stream(self):
             return contextlib.nullcontext()
@@ -336,8 +339,6 @@ def test_encoding_dict_materialises_on_read_and_remembers_it():
     assert type(plain[0]) is dict and np.array_equal(plain[1]['aperiodicity'], ap[4:7].numpy().T)
     # from_dicts: all-resident in order -> the encoding's own tensors; a read / permuted list -> copies of the rows
     class UpRt(StubRt):
-        torch = __import__("torch")
-
         def make_batch(self, x_off, frame_off):
             return types.SimpleNamespace(frame_off=np.asarray(frame_off), n_utt=len(frame_off) - 1)
 

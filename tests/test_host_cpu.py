@@ -356,3 +356,20 @@ def test_encoding_dict_materialises_on_read_and_remembers_it():
     mixed = BatchEncoding.from_dicts(up, fresh)
     assert torch.equal(mixed.spectrogram[:4], torch.full((4, k), -1.0, dtype=torch.float64))
     assert torch.equal(mixed.spectrogram[4:], spec[4:7]) and mixed.aperiodicity is ap
+
+
+def test_bench_defaults_match_the_contract(monkeypatch):
+    """`python bench.py` with no flags: N = 1, config 2 at its BASELINE size, a K / W that finish within minutes, two
+    whole steps in flight (and `--in-flight 1` available); config 5 switches to its own size."""
+    import sys
+
+    import bench
+
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.config, a.utts, a.seconds, a.scaling, a.in_flight, a.lanes) == (1, 2, 64, 10.0, "weak", 2, 1)
+    assert 5 <= a.steps <= 50 and 1 <= a.warmup <= 10 and a.north_star_utts == 1024
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "5", "--in-flight", "1"])
+    b = bench.parse()
+    assert (b.utts, b.seconds, b.in_flight) == (16, 60.0, 1)
+

@@ -861,8 +861,23 @@ def facade_batch_block(torch, xs, fs, reps=3):
         _, e, d = materialised()
         enc_s.append(e)
         dec_s.append(d)
+    # the same flow as ONE batch (main.FACADE_SPLIT_BYTES: by default a batch of this size runs as two parts on two
+    # pipelines, one part's PCIe transfer under the other's kernels)
+    split_bytes, single_s = main.FACADE_SPLIT_BYTES, []
+    main.FACADE_SPLIT_BYTES = 1 << 62
+    try:
+        resynthesis()
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            resynthesis()
+            torch.cuda.synchronize()
+            single_s.append(time.perf_counter() - t0)
+    finally:
+        main.FACADE_SPLIT_BYTES = split_bytes
     f, e, d = float(np.median(flow_s)), float(np.median(enc_s)), float(np.median(dec_s))
     return {"resynthesis_flow_ms": f * 1e3, "roundtrip_unmodified_ms": float(np.median(rt_s)) * 1e3,
+            "resynthesis_flow_single_batch_ms": float(np.median(single_s)) * 1e3,
+            "parts": 2 if 8 * sum(len(x) for x in xs) >= split_bytes and len(xs) >= 2 else 1,
             "value": frames / f, "unit": "frames/s",
             "x_realtime": len(xs) * len(xs[0]) / fs / f,
             "resynthesis_flow": "World.encode_batch -> scale_pitch(1.5) -> scale_duration(2.0) -> decode_batch on 64 x 10 s, "

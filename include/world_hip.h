@@ -85,7 +85,8 @@ int wh_profile_collect(wh_ctx* ctx, char* names, size_t names_bytes, float* ms, 
 
 /* ---- batch descriptor --------------------------------------------------------------------- */
 /* h_x_off[n_utt+1]: sample offsets into the concatenated waveform; h_frame_off[n_utt+1]: frame
- * offsets into the concatenated per-frame arrays.  Synchronous (small H2D copies). */
+ * offsets into the concatenated per-frame arrays.  Synchronous: the descriptor is complete on return (small H2D
+ * copies and one kernel on the NULL stream, which is waited for — work in flight on non-blocking streams is not). */
 int wh_batch_create(wh_ctx* ctx, int n_utt, const int64_t* h_x_off, const int64_t* h_frame_off, wh_batch** out);
 int wh_batch_destroy(wh_batch* b);
 /* Frame count of one utterance: int(1000*n/fs/frame_period + 1) — world/dio.py:28, world/harvest.py:46. */

@@ -383,7 +383,10 @@ int wh_batch_create(wh_ctx* ctx, int n_utt, const int64_t* h_x_off, const int64_
     if (blocks > 4096) blocks = 4096;
     frame_utt_kernel<<<blocks, 256>>>(b->d_frame_off, n_utt, b->total_frames, b->d_frame_utt);
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipDeviceSynchronize();
+    // The descriptor is complete when this call returns (it has no stream argument: whichever stream uses the batch next
+    // finds the table written).  Only the null stream is waited for — a device-wide wait here made every batch created
+    // while another context's kernels were running (a second pipeline on its own non-blocking stream) wait for them.
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   }
   if (e != hipSuccess) {
     wh_batch_destroy(b);

@@ -163,10 +163,12 @@ class BatchEncoding:
         nfs = [len(d['f0']) for d in dats]
         frame_off = np.concatenate([[0], np.cumsum(nfs)])
         batch = rt.make_batch(np.zeros(len(dats) + 1, dtype=np.int64), frame_off)
-        # the three per-frame scalar arrays travel as ONE upload (three pageable copies cost three round trips)
-        tp_h = np.concatenate([np.asarray(d['temporal_positions'], dtype=np.float64) for d in dats])
-        scal_h = np.stack([tp_h, np.concatenate([np.asarray(d['f0'], dtype=np.float64) for d in dats]),
-                           np.concatenate([np.asarray(d['vuv'], dtype=np.float64) for d in dats])])
+        # the three per-frame scalar arrays travel as ONE upload through a pinned staging block (three pageable copies
+        # cost three round trips — and a pageable copy of this size waits for whatever another pipeline has in flight on
+        # the device: 6.5 ms behind the other half's decode, measured)
+        tp_parts = [np.asarray(d['temporal_positions'], dtype=np.float64) for d in dats]
+        tp_h = np.concatenate(tp_parts)
+        scal_parts = tp_parts + [np.asarray(d[k], dtype=np.float64) for k in ('f0', 'vuv') for d in dats]
 
         def resident(d, key):
             return d.resident_rows(key, rt) if isinstance(d, EncodingDict) else None
@@ -191,7 +193,7 @@ class BatchEncoding:
         else:
             fft_size = (d0['spectrogram'].shape[0] - 1) * 2
         with rt.on_stream():
-            scal = rt.to_device(scal_h)
+            scal = rt.to_device_concat(scal_parts).view(3, -1)
             return cls(rt, batch, d0['fs'], scal[0], scal[1], scal[2], rows('spectrogram'),
                        rows('aperiodicity'), fft_size, bool(d0['is_requiem']), None, tp_host=tp_h)
 
@@ -667,6 +669,23 @@ class WorldBatch:
                 rt.check_flags("decode_device")
         return y, y_off
 
+    @_on_lane_stream
+    def settle_decode(self, enc, result, noise=None, seed=0, pulse_cap=None, seeds=None, cursor=None, check=None):
+        """The ending of ``decode_device(check=True)`` for a decode that was enqueued with ``check=False`` (same keywords)
+        once its stream has been waited for: reads the condition flags; an overflow of the DEFAULT pulse capacity
+        renders again with the safe one, anything else raises.  Returns the (y, y_off) to use."""
+        rt = self.rt
+        flags = rt.take_flags()
+        if self._tb_rt is not None:
+            flags = [a | b for a, b in zip(flags, self._tb_rt.take_flags())]
+        rt.raise_for_flags(flags, "decode_device", allow=() if pulse_cap is not None else (_hip.FLAG_PULSE_OVERFLOW,))
+        if flags[_hip.FLAG_PULSE_OVERFLOW]:
+            y_off = result[1]
+            ny = [int(y_off[u + 1] - y_off[u]) for u in range(len(y_off) - 1)]
+            return self.decode_device(enc, noise=noise, seed=seed, pulse_cap=safe_pulse_cap(ny), seeds=seeds,
+                                      cursor=cursor, check=True)
+        return result
+
     def _peak_normalise(self, y, y_off):
         """y /= max|y| where it exceeds 1 (world/main.py:209-212), per utterance, on the device."""
         import ctypes
@@ -675,6 +694,19 @@ class WorldBatch:
         off = np.ascontiguousarray(y_off, dtype=np.int64)
         _hip.check(rt.lib.wh_peak_normalise(rt.ctx, rt.stream(), rt.ptr(y), off.ctypes.data_as(ctypes.c_void_p),
                                             len(off) - 1))
+
+
+def _check_all(batches, where):
+    """WorldBatch.check() of every one of ``batches`` — all of them are read (and cleared) even if one raises: a condition
+    left standing in a context would be blamed on the next batch that runs there — then the first error is raised."""
+    err = None
+    for wb in batches:
+        try:
+            wb.check(where)
+        except _hip.WorldHipError as e:
+            err = err or e
+    if err is not None:
+        raise err
 
 
 class WorldBatchLanes:
@@ -744,8 +776,7 @@ class WorldBatchLanes:
             else:
                 wb.rt.torch.cuda.current_stream(wb.rt.device).synchronize()
         if check:
-            for wb in self.lanes:
-                wb.check("WorldBatchLanes")
+            _check_all(self.lanes, "WorldBatchLanes")
 
 
 class WorldBatchPipeline:
@@ -758,8 +789,9 @@ class WorldBatchPipeline:
     ``synchronize()`` waits for every pipeline and raises for the conditions their kernels reported.  Memory: every
     pipeline keeps an arena sized for its largest batch (1024 x 10 s of Harvest: ~105 GB — one in flight at that size)."""
 
-    def __init__(self, device_index=None, depth=2):
-        self.pipes = [WorldBatch(device_index, lane=d + 1) for d in range(max(1, int(depth)))]
+    def __init__(self, device_index=None, depth=2, prefetch_timebase=True):
+        self.pipes = [WorldBatch(device_index, lane=d + 1, prefetch_timebase=prefetch_timebase)
+                      for d in range(max(1, int(depth)))]
         self._k = 0
 
     def next(self):
@@ -781,6 +813,5 @@ class WorldBatchPipeline:
         for wb in self.pipes:
             wb.rt.own_stream.synchronize()
         if check:
-            for wb in self.pipes:
-                wb.check("WorldBatchPipeline")
+            _check_all(self.pipes, "WorldBatchPipeline")
 

@@ -6,9 +6,11 @@ and its inverse, context stacking: world/features.py) are provided; the referenc
 (draw, encode_vae) are not part of this build.
 """
 import logging
+import os
 
 import numpy as np
 
+from . import _hip
 from . import cheaptrick as _ct
 from . import d4c as _d4c
 from . import d4cRequiem as _d4cr
@@ -47,6 +49,35 @@ def _aperiodicity(x, fs, source, fft_size, is_requiem):
     if is_requiem:
         return _d4cr.d4cRequiem(x, fs, source, fft_size=fft_size)
     return _d4c.d4c(x, fs, source, fft_size_for_spectrum=fft_size)
+
+
+# World.encode_batch / decode_batch cut a batch of at least this many bytes of waveform (audio to be rendered) into two
+# parts that run on two pipelines, so that one part's PCIe transfer lies under the other's kernels
+FACADE_SPLIT_BYTES = int(os.environ.get("WH_FACADE_SPLIT_BYTES", str(16 << 20)))
+FACADE_LANE = 1  # the pipelines the parts run on (world.batch.WorldBatchPipeline's lanes: contexts and arenas are shared)
+# (Measured and not kept: the later part's stream at high priority, and its decode time base computed ahead under the
+# earlier part's responses — 23.0 ... 24.6 ms against 23.4 for the resynthesis flow of 64 x 10 s, within the noise.)
+
+
+def _decode_groups(dats, kw):
+    """Consecutive [start, end) parts of a decode_batch list: one part for small batches, for Requiem (its noise cursor
+    runs through the utterances in order) and for a caller that steers the checks itself; otherwise two — cut where the
+    list passes from one resident encoding to the next if it does so exactly once (the two halves of encode_batch: each
+    keeps its tensors as they are), else balanced by frames."""
+    from .distributed import shard_ranges
+
+    n = len(dats)
+    if n < 2 or bool(dats[0]['is_requiem']) or any(k in kw for k in ('seeds', 'cursor', 'check')):
+        return [(0, n)]
+    frames = [len(d['f0']) for d in dats]
+    seconds = sum(float(d['temporal_positions'][-1]) for d in dats if len(d['temporal_positions']))
+    if 8 * seconds * dats[0]['fs'] < FACADE_SPLIT_BYTES:  # the audio to be rendered
+        return [(0, n)]
+    encs = [getattr(d, '_enc', None) for d in dats]
+    cuts = [i for i in range(1, n) if encs[i] is not encs[i - 1]]
+    if len(cuts) == 1:
+        return [(0, cuts[0]), (cuts[0], n)]
+    return [(a, b) for a, b in shard_ranges(frames, 2) if b > a]
 
 
 class World(object):
@@ -109,13 +140,27 @@ class World(object):
         The dicts are ``world.batch.EncodingDict``s: real dicts whose dense values ('spectrogram', 'aperiodicity',
         'ps spectrogram') are downloaded when first read; ``decode_batch`` takes whatever was never read straight from
         HBM.  ``encode_batch -> scale_pitch -> scale_duration -> decode_batch`` moves no dense tensor over PCIe."""
-        from .distributed import ShardedWorldBatch
+        from .batch import WorldBatchPipeline
+        from .distributed import ShardedWorldBatch, shard_ranges
 
         sb = ShardedWorldBatch()
-        enc = sb.encode(xs, fs, f0_method=f0_method, f0_floor=f0_floor, f0_ceil=f0_ceil,
-                        channels_in_octave=channels_in_octave, target_fs=target_fs, frame_period=frame_period,
-                        allowed_range=allowed_range, fft_size=fft_size, is_requiem=is_requiem, want_ps=want_ps)
-        dats = enc.to_dicts(want_ps=want_ps, lazy=True) if enc is not None else []
+        kw = dict(f0_method=f0_method, f0_floor=f0_floor, f0_ceil=f0_ceil, channels_in_octave=channels_in_octave,
+                  target_fs=target_fs, frame_period=frame_period, allowed_range=allowed_range, fft_size=fft_size,
+                  is_requiem=is_requiem, want_ps=want_ps)
+        lo, hi = sb.shard([len(x) for x in xs])
+        mine = list(xs[lo:hi])
+        if len(mine) >= 2 and 8 * sum(len(x) for x in mine) >= FACADE_SPLIT_BYTES:
+            # Two halves on two pipelines (contexts and streams of their own): the second half's waveforms cross PCIe
+            # under the first half's kernels.  Utterances are independent and every stage numbers its work per
+            # utterance, so the dicts are the ones the single batch gives, bit for bit.
+            pipe = WorldBatchPipeline(sb.backend.rt.index, depth=2, prefetch_timebase=False)
+            parts = [(a, b) for a, b in shard_ranges([len(x) for x in mine], 2) if b > a]
+            encs = [pipe.next().encode(mine[a:b], fs, check=False, **kw) for a, b in parts]
+            pipe.synchronize(check=True)
+            dats = [d for e in encs for d in e.to_dicts(want_ps=want_ps, lazy=True)]
+        else:
+            enc = sb.encode(xs, fs, **kw)
+            dats = enc.to_dicts(want_ps=want_ps, lazy=True) if enc is not None else []
         for d in dats:
             d['_batch_range'] = sb.range
         return dats
@@ -133,6 +178,9 @@ class World(object):
 
         if not dats:
             return dats
+        groups = _decode_groups(dats, kw)
+        if len(groups) > 1:
+            return self._decode_batch_parts(dats, groups, kw)
         wb = WorldBatch()
         enc = BatchEncoding.from_dicts(wb.rt, dats)
         y, y_off = wb.decode_device(enc, **kw)
@@ -140,6 +188,59 @@ class World(object):
             y = wb.rt.to_host(y)  # one pinned block; every utterance's 'out' is its own, disjoint, writeable slice of it
         for u, d in enumerate(dats):
             d['out'] = y[int(y_off[u]):int(y_off[u + 1])]
+        return dats
+
+    def _decode_batch_parts(self, dats, groups, kw):
+        """decode_batch with the batch cut into consecutive parts, each on a pipeline of its own (context, stream): part
+        g + 1 renders behind part g's kernels, so part g's audio crosses PCIe under them.  Same samples as the single
+        batch: the overlap-add runs are numbered per utterance and the Philox stream of utterance u is re-keyed to its
+        index in the whole list (synthesis.philox_seed_for_offset)."""
+        from .batch import BatchEncoding, WorldBatch
+
+        noise, seed = kw.get('noise'), kw.get('seed', 0)
+        index = WorldBatch().rt.index
+        pend, prev = [], None
+        for g, (a, b) in enumerate(groups):
+            wb = WorldBatch(index, lane=FACADE_LANE + g, prefetch_timebase=False)
+            rt, torch = wb.rt, wb.rt.torch
+            enc = BatchEncoding.from_dicts(rt, dats[a:b])
+            kw_g = dict(kw, seed=_syn.philox_seed_for_offset(seed, a), check=False)
+            if noise is not None:
+                kw_g['noise'] = noise[a:b]
+            if prev is not None:
+                rt.own_stream.wait_event(prev)
+            y, y_off = wb.decode_device(enc, **kw_g)
+            with rt.on_stream():
+                prev = torch.cuda.Event()
+                prev.record(torch.cuda.current_stream(rt.device))
+                host = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
+                nbytes = y.numel() * y.element_size()
+                if g + 1 < len(groups) and y.is_contiguous() and nbytes % 8 == 0:
+                    # a few workgroups write the pinned block through its device mapping.  (The runtime's own D2H copy is
+                    # a chip-wide kernel whose waves sit on PCIe: the next part's kernels made no progress under it —
+                    # rocprofv3 trace: its first 0.05 ms kernel ended when the 1.5 ms copy did.)
+                    _hip.check(rt.lib.wh_copy_mapped(rt.ctx, rt.stream(), _hip._vp(host.data_ptr()), rt.ptr(y), nbytes, 16))
+                else:
+                    host.copy_(y, non_blocking=True)
+            pend.append((wb, enc, kw_g, y, y_off, host))
+        for wb, *_ in pend:
+            wb.rt.own_stream.synchronize()
+        settled, err = [], None
+        for wb, enc, kw_g, y, y_off, host in pend:  # (every part's conditions are read, whichever raises)
+            try:
+                settled.append(wb.settle_decode(enc, (y, y_off), **kw_g))
+            except _hip.WorldHipError as e:
+                settled.append(None)
+                err = err or e
+        if err is not None:
+            raise err
+        for (a, b), (wb, enc, kw_g, y, y_off, host), (y2, y_off2) in zip(groups, pend, settled):
+            out = host.numpy()
+            if y2 is not y:  # rendered again with the safe pulse capacity
+                with wb.rt.on_stream():
+                    out = wb.rt.to_host(y2)
+            for u, d in enumerate(dats[a:b]):
+                d['out'] = out[int(y_off2[u]):int(y_off2[u + 1])]
         return dats
 
     # ---- modification (all in place on the dict, like the reference) ------------------------------------------

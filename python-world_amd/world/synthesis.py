@@ -77,6 +77,17 @@ def synthesis_device(rt, batch, tp_d, f0_d, vuv_d, spec_d, ap_d, fs, fft_size, n
     return y, y_off
 
 
+_PHILOX_SEED_MUL, _PHILOX_UTT_MUL = 0x9E3779B97F4A7C15, 0xD1B54A32D192ED03  # philox_key (csrc/wh_synthesis.hip)
+
+
+def philox_seed_for_offset(seed, first_utt):
+    """The seed under which utterance u of a batch draws the noise that utterance ``first_utt + u`` draws under ``seed``
+    (the stream key of an utterance is seed * A + u * B + 1 mod 2**64 with A odd, so seed' = seed + first_utt * B / A):
+    what lets a batch be decoded in consecutive parts with the noise of the whole."""
+    m = 1 << 64
+    return (int(seed) + int(first_utt) * _PHILOX_UTT_MUL * pow(_PHILOX_SEED_MUL, -1, m)) % m
+
+
 def philox_normals(rt, seed, utt, n, q0=0):
     """Samples [q0, q0 + n) of the standard-normal stream that the device-noise decode (``noise=None``) reads for
     utterance ``utt`` of a batch under ``seed`` (wh_philox_normals): a device tensor.  Feeding it back as that

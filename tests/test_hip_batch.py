@@ -139,6 +139,90 @@ def test_encode_batch_dicts_are_lazy_and_aliasing_holds():
     assert edited[0].resident_rows('spectrogram', W_rt()) is None
 
 
+def test_facade_batches_in_two_parts_equal_the_single_batch(monkeypatch):
+    """World.encode_batch / decode_batch cut a large batch into two parts on two pipelines (one part's PCIe transfer under
+    the other's kernels).  Forced here on a small batch: the dicts and the audio are those of the single batch bit for
+    bit — encode and the overlap-add number their work per utterance, and the Philox stream of an utterance is re-keyed
+    to its index in the whole list — whether the dicts stayed resident, were materialised, or came from one encoding."""
+    from world import main
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+
+    fs = 16000
+    xs = [synth_utterance(80 + i, fs, 0.4 + 0.15 * i) for i in range(5)]
+    W = main.World()
+
+    def flow(dats, **kw):
+        for d in dats:
+            W.scale_pitch(d, 1.25)
+            W.scale_duration(d, 1.5)
+        return W.decode_batch(dats, seed=9, **kw)
+
+    monkeypatch.setattr(main, "FACADE_SPLIT_BYTES", 1 << 60)
+    assert main._decode_groups(W.encode_batch(fs, xs, f0_method='dio'), {}) == [(0, 5)]
+    whole = flow(W.encode_batch(fs, xs, f0_method='dio'))
+    whole_plain = [dict(d) for d in W.encode_batch(fs, xs, f0_method='dio')]
+    monkeypatch.setattr(main, "FACADE_SPLIT_BYTES", 0)
+    parts = W.encode_batch(fs, xs, f0_method='dio')
+    assert len({id(d._enc) for d in parts}) == 2 and parts[0]['_batch_range'] == (0, 5)
+    groups = main._decode_groups(parts, {})
+    assert len(groups) == 2 and groups[0][0] == 0 and groups[0][1] == groups[1][0] and groups[1][1] == 5
+    for a, b in zip(parts, whole_plain):
+        for key in ('f0', 'vuv', 'temporal_positions'):
+            assert np.array_equal(a[key], b[key]), key
+    flow(parts)
+    for u, (a, b) in enumerate(zip(parts, whole)):
+        assert a.resident_rows('spectrogram', W_rt()) is not None      # still never read
+        assert np.array_equal(a['out'], b['out']), u
+        assert np.array_equal(a['spectrogram'], whole_plain[u]['spectrogram'])
+        assert np.array_equal(a['aperiodicity'], whole_plain[u]['aperiodicity'])
+    # plain dicts (everything uploaded again) and the lazy dicts of ONE encoding take the balanced split
+    plain = flow([dict(d) for d in whole_plain])
+    one = WorldBatch().encode(xs, fs, f0_method='dio').to_dicts(lazy=True)
+    assert len(main._decode_groups(one, {})) == 2
+    flow(one)
+    rng = np.random.RandomState(3)
+    noise = [rng.randn(4 * len(x)) for x in xs]
+    with_noise = flow(W.encode_batch(fs, xs, f0_method='dio'), noise=noise)
+    monkeypatch.setattr(main, "FACADE_SPLIT_BYTES", 1 << 60)
+    with_noise_whole = flow(W.encode_batch(fs, xs, f0_method='dio'), noise=noise)
+    for u in range(5):
+        assert np.array_equal(plain[u]['out'], whole[u]['out']), u
+        assert np.array_equal(one[u]['out'], whole[u]['out']), u
+        assert np.array_equal(with_noise[u]['out'], with_noise_whole[u]['out']), u
+        assert not np.array_equal(with_noise[u]['out'], whole[u]['out']), u
+
+
+def test_facade_parts_retry_an_overflow_of_the_default_pulse_capacity(monkeypatch):
+    """A part whose pulses overflow the default capacity (mean f0 above fs/8) is rendered again with the safe one, as
+    decode_device(check=True) does for a single batch; an explicit, too small ``pulse_cap`` raises."""
+    from world import _hip, main
+    from world._synthetic import synth_utterance
+
+    fs = 16000
+    xs = [synth_utterance(90 + i, fs, 0.5) for i in range(4)]
+    W = main.World()
+    monkeypatch.setattr(main, "FACADE_SPLIT_BYTES", 1 << 60)
+    ref = W.encode_batch(fs, xs, f0_method='dio')
+    for d in ref:
+        d['f0'][:] = 3000.0
+        d['vuv'][:] = 1.0
+    W.decode_batch(ref, seed=2)
+    monkeypatch.setattr(main, "FACADE_SPLIT_BYTES", 0)
+    hot = W.encode_batch(fs, xs, f0_method='dio')
+    for d in hot[2:]:                       # only the second part overflows
+        d['f0'][:] = 3000.0
+        d['vuv'][:] = 1.0
+    W.decode_batch(hot, seed=2)
+    for u in (2, 3):
+        assert np.array_equal(hot[u]['out'], ref[u]['out']), u
+    with pytest.raises(_hip.WorldHipError):
+        W.decode_batch(hot, seed=2, pulse_cap=64)
+    for lane in (0, main.FACADE_LANE, main.FACADE_LANE + 1):
+        assert _hip.Runtime.get(None, lane).take_flags() == [0] * 16   # nothing left standing for the next batch
+    W.decode_batch(W.encode_batch(fs, xs, f0_method='dio'), seed=2)
+
+
 def W_rt():
     from world import _hip
     return _hip.Runtime.get()

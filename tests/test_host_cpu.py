@@ -345,17 +345,65 @@ def test_encoding_dict_materialises_on_read_and_remembers_it():
         def to_device(self, a, dtype=np.float64):
             return self.torch.from_numpy(np.ascontiguousarray(a, dtype=dtype))
 
+        def to_device_concat(self, arrays):
+            return self.torch.from_numpy(np.concatenate([np.asarray(a, dtype=np.float64) for a in arrays]))
+
     up = UpRt()
     enc.rt = up
     fresh = enc.to_dicts(lazy=True)
     again = BatchEncoding.from_dicts(up, fresh)
     assert again.spectrogram is spec and again.aperiodicity is ap and again.fft_size == 8
+    # the per-frame scalars of every utterance, one staged upload: frame times, f0, vuv
+    assert torch.equal(again.temporal_positions, torch.arange(7, dtype=torch.float64) * 0.005)
+    assert torch.equal(again.f0, torch.full((7,), 100.0, dtype=torch.float64)) and torch.equal(again.vuv, torch.ones(7, dtype=torch.float64))
     swapped = BatchEncoding.from_dicts(up, fresh[::-1])
     assert torch.equal(swapped.spectrogram, torch.cat([spec[4:7], spec[0:4]]))
     fresh[0]['spectrogram'][...] = -1.0                                  # read + edited: uploaded from the host
     mixed = BatchEncoding.from_dicts(up, fresh)
     assert torch.equal(mixed.spectrogram[:4], torch.full((4, k), -1.0, dtype=torch.float64))
     assert torch.equal(mixed.spectrogram[4:], spec[4:7]) and mixed.aperiodicity is ap
+
+
+def test_philox_seed_for_offset_rekeys_the_utterance_streams():
+    """World.decode_batch renders a large batch in consecutive parts; utterance u of a part that starts at utterance
+    `base` must draw the noise of utterance base + u of the whole batch.  The device keys a stream with
+    seed * A + u * B + 1 mod 2**64 (philox_key, csrc/wh_synthesis.hip:837): the shifted seed solves that for every u."""
+    from world.synthesis import _PHILOX_SEED_MUL as A, _PHILOX_UTT_MUL as B, philox_seed_for_offset
+
+    src = open(os.path.join(os.path.dirname(__file__), "..", "python-world_amd", "csrc", "wh_synthesis.hip")).read()
+    assert "return seed * 0x%Xull + u * 0x%Xull + 1;" % (A, B) in src  # the constants are the kernel's
+    m = 1 << 64
+    key = lambda seed, u: (seed * A + u * B + 1) % m  # noqa: E731
+    for seed in (0, 1, 9, 2**63 + 12345, m - 1):
+        assert philox_seed_for_offset(seed, 0) == seed
+        for base in (1, 32, 511, 70000):
+            shifted = philox_seed_for_offset(seed, base)
+            assert 0 <= shifted < m
+            for u in (0, 1, 31, 1023):
+                assert key(shifted, u) == key(seed, base + u)
+
+
+def test_decode_batch_parts_of_plain_dicts():
+    """_decode_groups: one part for small batches, Requiem and callers that steer the checks; two consecutive,
+    non-empty parts balanced by frames otherwise."""
+    from world import main
+
+    def dat(frames, requiem=False):
+        tp = np.arange(frames) * 0.005
+        return {'f0': np.zeros(frames), 'temporal_positions': tp, 'fs': 16000, 'is_requiem': requiem}
+
+    big = [dat(2001) for _ in range(64)]               # 64 x 10 s @16 kHz: 82 MB of audio
+    assert main.FACADE_SPLIT_BYTES == 16 << 20
+    assert main._decode_groups(big, {}) == [(0, 32), (32, 64)]
+    assert main._decode_groups(big, {'seed': 3, 'noise': None}) == [(0, 32), (32, 64)]
+    assert main._decode_groups(big, {'check': False}) == [(0, 64)]
+    assert main._decode_groups(big, {'cursor': np.zeros(3)}) == [(0, 64)]
+    assert main._decode_groups([dat(2001, True) for _ in range(64)], {}) == [(0, 64)]
+    assert main._decode_groups(big[:1], {}) == [(0, 1)]
+    assert main._decode_groups([dat(201) for _ in range(8)], {}) == [(0, 8)]   # 8 s of audio: a single batch
+    ragged = [dat(12001)] + [dat(801) for _ in range(30)]
+    (a0, a1), (b0, b1) = main._decode_groups(ragged, {})
+    assert a0 == 0 and a1 == b0 and b1 == 31 and a1 >= 1
 
 
 def test_bench_defaults_match_the_contract(monkeypatch):

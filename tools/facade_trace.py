@@ -4,7 +4,7 @@ when each host call starts and returns (no synchronisation added), for the two-p
 python tools/facade_trace.py"""
 import sys, time, functools
 sys.path.insert(0, "."); sys.path.insert(0, "python-world_amd")
-import numpy as np, torch
+import torch
 import bench
 from world import main, batch, _hip
 

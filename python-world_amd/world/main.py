@@ -200,29 +200,36 @@ class World(object):
         noise, seed = kw.get('noise'), kw.get('seed', 0)
         index = WorldBatch().rt.index
         pend, prev = [], None
-        for g, (a, b) in enumerate(groups):
-            wb = WorldBatch(index, lane=FACADE_LANE + g, prefetch_timebase=False)
-            rt, torch = wb.rt, wb.rt.torch
-            enc = BatchEncoding.from_dicts(rt, dats[a:b])
-            kw_g = dict(kw, seed=_syn.philox_seed_for_offset(seed, a), check=False)
-            if noise is not None:
-                kw_g['noise'] = noise[a:b]
-            if prev is not None:
-                rt.own_stream.wait_event(prev)
-            y, y_off = wb.decode_device(enc, **kw_g)
-            with rt.on_stream():
-                prev = torch.cuda.Event()
-                prev.record(torch.cuda.current_stream(rt.device))
-                host = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
-                nbytes = y.numel() * y.element_size()
-                if g + 1 < len(groups) and y.is_contiguous() and nbytes % 8 == 0:
-                    # a few workgroups write the pinned block through its device mapping.  (The runtime's own D2H copy is
-                    # a chip-wide kernel whose waves sit on PCIe: the next part's kernels made no progress under it —
-                    # rocprofv3 trace: its first 0.05 ms kernel ended when the 1.5 ms copy did.)
-                    _hip.check(rt.lib.wh_copy_mapped(rt.ctx, rt.stream(), _hip._vp(host.data_ptr()), rt.ptr(y), nbytes, 16))
-                else:
-                    host.copy_(y, non_blocking=True)
-            pend.append((wb, enc, kw_g, y, y_off, host))
+        try:
+            for g, (a, b) in enumerate(groups):
+                wb = WorldBatch(index, lane=FACADE_LANE + g, prefetch_timebase=False)
+                rt, torch = wb.rt, wb.rt.torch
+                enc = BatchEncoding.from_dicts(rt, dats[a:b])
+                kw_g = dict(kw, seed=_syn.philox_seed_for_offset(seed, a), check=False)
+                if noise is not None:
+                    kw_g['noise'] = noise[a:b]
+                if prev is not None:
+                    rt.own_stream.wait_event(prev)
+                y, y_off = wb.decode_device(enc, **kw_g)
+                with rt.on_stream():
+                    prev = torch.cuda.Event()
+                    prev.record(torch.cuda.current_stream(rt.device))
+                    host = torch.empty(y.shape, dtype=y.dtype, pin_memory=True)
+                    nbytes = y.numel() * y.element_size()
+                    if g + 1 < len(groups) and y.is_contiguous() and nbytes % 8 == 0:
+                        # a few workgroups write the pinned block through its device mapping.  (The runtime's own
+                        # D2H copy is a chip-wide kernel whose waves sit on PCIe: the next part's kernels made no
+                        # progress under it — rocprofv3 trace: its first 0.05 ms kernel ended when the 1.5 ms copy did.)
+                        _hip.check(rt.lib.wh_copy_mapped(rt.ctx, rt.stream(), _hip._vp(host.data_ptr()), rt.ptr(y),
+                                                         nbytes, 16))
+                    else:
+                        host.copy_(y, non_blocking=True)
+                pend.append((wb, enc, kw_g, y, y_off, host))
+        except BaseException:
+            for wb, *_ in pend:  # nothing of an abandoned batch is left standing in the pipelines' contexts
+                wb.rt.own_stream.synchronize()
+                wb.rt.take_flags()
+            raise
         for wb, *_ in pend:
             wb.rt.own_stream.synchronize()
         settled, err = [], None

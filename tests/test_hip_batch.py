@@ -221,6 +221,16 @@ def test_facade_parts_retry_an_overflow_of_the_default_pulse_capacity(monkeypatc
     for lane in (0, main.FACADE_LANE, main.FACADE_LANE + 1):
         assert _hip.Runtime.get(None, lane).take_flags() == [0] * 16   # nothing left standing for the next batch
     W.decode_batch(W.encode_batch(fs, xs, f0_method='dio'), seed=2)
+    # a part that cannot even be enqueued (a spectrogram of another size in the second half): the first part's work is
+    # waited for and its conditions dropped before the error reaches the caller
+    bad = W.encode_batch(fs, xs, f0_method='dio')
+    bad[3]['spectrogram'] = np.zeros((17, len(bad[3]['f0'])))
+    with pytest.raises(Exception):
+        W.decode_batch(bad, seed=2)
+    for lane in (main.FACADE_LANE, main.FACADE_LANE + 1):
+        assert _hip.Runtime.get(None, lane).take_flags() == [0] * 16
+    good = W.decode_batch(W.encode_batch(fs, xs, f0_method='dio'), seed=2)
+    assert all(np.all(np.isfinite(d['out'])) for d in good)
 
 
 def W_rt():

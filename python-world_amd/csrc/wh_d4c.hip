@@ -99,7 +99,12 @@ __device__ __forceinline__ double stage_fence(double v) {
 #ifndef WH_FT_D4C_1024
 #define WH_FT_D4C_1024 (WH_D4C_REGFED ? WH_FT_D4C / 2 : WH_FT_D4C)
 #endif
-constexpr int ft_of(int n) { return n >= 4096 ? 2 * WH_FT_D4C : (n == 1024 ? WH_FT_D4C_1024 : WH_FT_D4C); }
+#ifndef WH_FT_D4C_4096
+#define WH_FT_D4C_4096 (2 * WH_FT_D4C)  // (1024 threads, staged windows: 62.9 ms at config 5 — 50.8 compiled for 8 waves
+                                        // per SIMD with 164 spilled registers — against 31.8: occupancy is what this
+                                        // instance lacks, but LDS (66 KB) and registers (111) both stop it at 4 waves)
+#endif
+constexpr int ft_of(int n) { return n >= 8192 ? 2 * WH_FT_D4C : n >= 4096 ? WH_FT_D4C_4096 : (n == 1024 ? WH_FT_D4C_1024 : WH_FT_D4C); }
 // Waves per SIMD the register allocation must leave room for (HIP's second __launch_bounds__ argument is
 // MIN_WAVES_PER_EU).  LDS per frame is the 2N-double transform buffer (33 KB at N = 2048: 4 workgroups of 4 waves
 // per CU, 66 KB at N = 4096: 2 workgroups of 8 waves), i.e. 4 waves per SIMD either way -> 128 VGPRs.

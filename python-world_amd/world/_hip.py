@@ -167,6 +167,7 @@ class Runtime:
     """
 
     _instances = {}
+    _instances_lock = threading.Lock()  # (world.pool creates runtimes from several host threads)
 
     def __init__(self, device_index, lane=0):
         import torch
@@ -193,10 +194,11 @@ class Runtime:
 
         if device_index is None:
             device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
-        rt = cls._instances.get((device_index, lane))
-        if rt is None:
-            rt = cls(device_index, lane)
-            cls._instances[(device_index, lane)] = rt
+        with cls._instances_lock:
+            rt = cls._instances.get((device_index, lane))
+            if rt is None:
+                rt = cls(device_index, lane)
+                cls._instances[(device_index, lane)] = rt
         return rt
 
     def trim(self):

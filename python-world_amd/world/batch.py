@@ -789,8 +789,11 @@ class WorldBatchPipeline:
     ``synchronize()`` waits for every pipeline and raises for the conditions their kernels reported.  Memory: every
     pipeline keeps an arena sized for its largest batch (1024 x 10 s of Harvest: ~105 GB — one in flight at that size)."""
 
-    def __init__(self, device_index=None, depth=2, prefetch_timebase=True):
-        self.pipes = [WorldBatch(device_index, lane=d + 1, prefetch_timebase=prefetch_timebase)
+    def __init__(self, device_index=None, depth=2, prefetch_timebase=True, first_lane=1):
+        """``first_lane``: lane id of the first pipeline (lanes are contexts + streams, `_hip.Runtime`): two pipeline
+        objects with the same lane ids SHARE contexts, flags and streams — the facade (world/main.py) keeps ids of its
+        own so that its flag reads never consume a condition of the caller's own pipelines in flight."""
+        self.pipes = [WorldBatch(device_index, lane=first_lane + d, prefetch_timebase=prefetch_timebase)
                       for d in range(max(1, int(depth)))]
         self._k = 0
 

@@ -73,7 +73,7 @@ def get_seeds_signals(fs: int, fft_size: int = None, noise_length: int = None):
     return {'pulse': pulse, 'noise': noise}
 
 
-def get_seeds_signals_device(fs, seed=0, fft_size=None, noise_length=None, device_index=None, want_velvet=False):
+def get_seeds_signals_device(fs, seed=0, fft_size=None, noise_length=None, device_index=None, want_velvet=False, rt=None):
     """The same tables generated ON the device (wh_requiem_seeds): {'pulse_d', 'noise_d'} torch tensors that
     WorldBatch.decode_device(..., seeds=...) uses in place — no host RNG, no upload.  The pulses are the exact
     deterministic ones; the velvet noise follows the reference's construction with a counter-based Philox stream
@@ -82,7 +82,8 @@ def get_seeds_signals_device(fs, seed=0, fft_size=None, noise_length=None, devic
 
     from . import _hip
 
-    rt = _hip.Runtime.get(device_index)
+    if rt is None:  # ``rt``: the runtime (context + stream) to generate on; default: lane 0 of ``device_index``
+        rt = _hip.Runtime.get(device_index)
     if fft_size is None:
         fft_size = int(1024 * (2 ** np.ceil(np.log2(fs / 48000))))
     if noise_length is None:

@@ -54,7 +54,9 @@ def _aperiodicity(x, fs, source, fft_size, is_requiem):
 # World.encode_batch / decode_batch cut a batch of at least this many bytes of waveform (audio to be rendered) into two
 # parts that run on two pipelines, so that one part's PCIe transfer lies under the other's kernels
 FACADE_SPLIT_BYTES = int(os.environ.get("WH_FACADE_SPLIT_BYTES", str(16 << 20)))
-FACADE_LANE = 1  # the pipelines the parts run on (world.batch.WorldBatchPipeline's lanes: contexts and arenas are shared)
+FACADE_LANE = 2001  # the pipelines the parts run on: lane ids (contexts, flags, streams) no public class hands out, so the
+# facade's flag reads never consume — or raise for — a condition of the caller's own WorldBatchPipeline / WorldBatchLanes
+# work in flight
 # (Measured and not kept: the later part's stream at high priority, and its decode time base computed ahead under the
 # earlier part's responses — 23.0 ... 24.6 ms against 23.4 for the resynthesis flow of 64 x 10 s, within the noise.)
 
@@ -78,6 +80,23 @@ def _decode_groups(dats, kw):
     if len(cuts) == 1:
         return [(0, cuts[0]), (cuts[0], n)]
     return [(a, b) for a, b in shard_ranges(frames, 2) if b > a]
+
+
+def _hand_out(dats, block, y_off, copy_out):
+    """d['out'] for every dict from the batch's host block (page-locked): arrays of their own in pageable memory — the
+    copies run on the staging pool's threads, NumPy releases the GIL for them — or, ``copy_out=False``, views."""
+    cuts = [(int(y_off[u]), int(y_off[u + 1])) for u in range(len(dats))]
+    if not copy_out:
+        for d, (a, b) in zip(dats, cuts):
+            d['out'] = block[a:b]
+        return
+    if block.nbytes < (1 << 22) or len(dats) < 4:
+        outs = [np.array(block[a:b]) for a, b in cuts]
+    else:
+        with _hip._copy_pool() as pool:
+            outs = list(pool.map(lambda ab: np.array(block[ab[0]:ab[1]]), cuts))
+    for d, y in zip(dats, outs):
+        d['out'] = y
 
 
 class World(object):
@@ -129,8 +148,11 @@ class World(object):
 
     # ---- batched convenience (not in the reference; SURVEY.md §8(b): "World.encode_batch/decode_batch") ----------
     def encode_batch(self, fs, xs, f0_method='harvest', f0_floor=71, f0_ceil=800, channels_in_octave=2, target_fs=4000,
-                     frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False, want_ps=False):
+                     frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False, want_ps=False, devices=None):
         """encode() — same arguments, same defaults (Harvest) — for a list of utterances in one pass per kernel.
+        ``devices``: a list of GPU indices — the batch is cut into contiguous ranges balanced by samples and every range
+        runs on its device from a host thread of its own (``world.pool.WorldBatchPool``: one process, no
+        torch.distributed); the dicts are the single-device ones, bit for bit.
         Each dict has encode()'s keys; 'ps spectrogram' (the complex pitch-synchronous spectra of world/main.py:149,
         fft_size x frames x 16 B per utterance) only with ``want_ps=True``.  Under an initialised
         torch.distributed process group (one process per GPU) the batch is sharded by utterance over the ranks and the
@@ -143,17 +165,23 @@ class World(object):
         from .batch import WorldBatchPipeline
         from .distributed import ShardedWorldBatch, shard_ranges
 
-        sb = ShardedWorldBatch()
         kw = dict(f0_method=f0_method, f0_floor=f0_floor, f0_ceil=f0_ceil, channels_in_octave=channels_in_octave,
                   target_fs=target_fs, frame_period=frame_period, allowed_range=allowed_range, fft_size=fft_size,
                   is_requiem=is_requiem, want_ps=want_ps)
+        if devices is not None:
+            from .pool import WorldBatchPool
+            dats = WorldBatchPool.shared(devices).encode(list(xs), fs, **kw).to_dicts(want_ps=want_ps, lazy=True)
+            for d in dats:
+                d['_batch_range'] = (0, len(dats))
+            return dats
+        sb = ShardedWorldBatch()
         lo, hi = sb.shard([len(x) for x in xs])
         mine = list(xs[lo:hi])
         if len(mine) >= 2 and 8 * sum(len(x) for x in mine) >= FACADE_SPLIT_BYTES:
             # Two halves on two pipelines (contexts and streams of their own): the second half's waveforms cross PCIe
             # under the first half's kernels.  Utterances are independent and every stage numbers its work per
             # utterance, so the dicts are the ones the single batch gives, bit for bit.
-            pipe = WorldBatchPipeline(sb.backend.rt.index, depth=2, prefetch_timebase=False)
+            pipe = WorldBatchPipeline(sb.backend.rt.index, depth=2, prefetch_timebase=False, first_lane=FACADE_LANE)
             parts = [(a, b) for a, b in shard_ranges([len(x) for x in mine], 2) if b > a]
             encs = [pipe.next().encode(mine[a:b], fs, check=False, **kw) for a, b in parts]
             pipe.synchronize(check=True)
@@ -165,9 +193,14 @@ class World(object):
             d['_batch_range'] = sb.range
         return dats
 
-    def decode_batch(self, dats, **kw):
+    def decode_batch(self, dats, devices=None, copy_out=True, **kw):
         """decode() for a list of encode()/encode_batch() dicts that share fs / is_requiem / fft size: one batched
         synthesis; adds 'out' to every dict (peak-normalised like decode()) and returns the list.
+        ``devices``: as in encode_batch — one host thread per listed GPU, each decoding a contiguous range (dicts that
+        encode_batch(devices=...) made go back to the device that holds them); same samples as the single batch.
+        ``copy_out`` (default): every 'out' is an array of its own in pageable memory, as decode() returns it;
+        False: views into ONE page-locked block per batch (part) — no host copy, but a caller that keeps a single
+        utterance keeps the whole batch's block locked.
         Randomness differs from decode() unless asked otherwise: the noise comes from the device Philox stream
         (``seed=``) and Requiem batches use device-built seed tables with the noise cursor restarted at 0 on every
         call, whereas decode() draws from NumPy's global stream / get_seeds_signals() and keeps
@@ -178,19 +211,23 @@ class World(object):
 
         if not dats:
             return dats
+        if devices is not None:
+            from .pool import WorldBatchPool
+            for d, y in zip(dats, WorldBatchPool.shared(devices).decode_dicts(dats, **kw)):
+                d['out'] = y
+            return dats
         groups = _decode_groups(dats, kw)
         if len(groups) > 1:
-            return self._decode_batch_parts(dats, groups, kw)
+            return self._decode_batch_parts(dats, groups, kw, copy_out)
         wb = WorldBatch()
         enc = BatchEncoding.from_dicts(wb.rt, dats)
         y, y_off = wb.decode_device(enc, **kw)
         with wb.rt.on_stream():
-            y = wb.rt.to_host(y)  # one pinned block; every utterance's 'out' is its own, disjoint, writeable slice of it
-        for u, d in enumerate(dats):
-            d['out'] = y[int(y_off[u]):int(y_off[u + 1])]
+            y = wb.rt.to_host(y)  # one pinned block
+        _hand_out(dats, y, y_off, copy_out)
         return dats
 
-    def _decode_batch_parts(self, dats, groups, kw):
+    def _decode_batch_parts(self, dats, groups, kw, copy_out=True):
         """decode_batch with the batch cut into consecutive parts, each on a pipeline of its own (context, stream): part
         g + 1 renders behind part g's kernels, so part g's audio crosses PCIe under them.  Same samples as the single
         batch: the overlap-add runs are numbered per utterance and the Philox stream of utterance u is re-keyed to its
@@ -199,7 +236,7 @@ class World(object):
 
         noise, seed = kw.get('noise'), kw.get('seed', 0)
         index = WorldBatch().rt.index
-        pend, prev = [], None
+        pend, prev, wb = [], None, None
         try:
             for g, (a, b) in enumerate(groups):
                 wb = WorldBatch(index, lane=FACADE_LANE + g, prefetch_timebase=False)
@@ -226,9 +263,14 @@ class World(object):
                         host.copy_(y, non_blocking=True)
                 pend.append((wb, enc, kw_g, y, y_off, host))
         except BaseException:
-            for wb, *_ in pend:  # nothing of an abandoned batch is left standing in the pipelines' contexts
-                wb.rt.own_stream.synchronize()
-                wb.rt.take_flags()
+            # nothing of an abandoned batch is left standing in the pipelines' contexts: the parts in flight AND the part
+            # whose enqueueing failed (its stream may hold half a decode, its flags a condition of it)
+            for w in {id(w): w for w in [p[0] for p in pend] + ([wb] if wb is not None else [])}.values():
+                try:
+                    w.rt.own_stream.synchronize()
+                    w.rt.take_flags()
+                except _hip.WorldHipError:
+                    pass
             raise
         for wb, *_ in pend:
             wb.rt.own_stream.synchronize()
@@ -246,8 +288,7 @@ class World(object):
             if y2 is not y:  # rendered again with the safe pulse capacity
                 with wb.rt.on_stream():
                     out = wb.rt.to_host(y2)
-            for u, d in enumerate(dats[a:b]):
-                d['out'] = out[int(y_off2[u]):int(y_off2[u + 1])]
+            _hand_out(dats[a:b], out, y_off2, copy_out)
         return dats
 
     # ---- modification (all in place on the dict, like the reference) ------------------------------------------

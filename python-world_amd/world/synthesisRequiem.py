@@ -51,6 +51,26 @@ def _advance(cursor, ny, noise_len):
     return np.remainder(cursor + ny - 1, noise_len)
 
 
+def seed_table_shape(fs, seeds=None):
+    """(noise_length, nb) of the seed tables a decode at ``fs`` reads: those of ``seeds`` or the default ones."""
+    if seeds is not None:
+        shape = seeds['noise_d'].shape if 'noise_d' in seeds else seeds['noise'].shape
+        return int(shape[0]), int(shape[1])
+    from .get_seeds_signals import _BAND_STEP, _UPPER
+    return int(2 ** np.ceil(np.log2(fs / 2))), int(2 + np.floor(min(_UPPER, fs / 2 - _BAND_STEP) / _BAND_STEP))
+
+
+def cursor_after(frame_times, fs, cursor, noise_len):
+    """The noise-seed read position (nb,) after utterances with the given per-utterance ``frame_times`` arrays have been
+    rendered from ``cursor`` one after the other — computed on the host from the output lengths alone: where a decode
+    that follows (the next range of a batch cut over several devices, world.pool) has to start to draw what the single
+    batch draws."""
+    cur = np.array(cursor, dtype=np.float64)
+    for tp in frame_times:
+        cur = _advance(cur, time_axis_params(tp, fs)[0], noise_len)
+    return cur
+
+
 def synthesis_requiem_core(rt, batch, tp_d, f0_d, vuv_d, spec_d, band_d, fs, fft_size, geo, hops, seeds, cursors,
                            pulse_cap=None):
     """Device-resident core.  geo: [(ny, t0, dt)] per utterance; cursors: (n_utt, nb) start positions."""
@@ -83,11 +103,13 @@ def synthesis_requiem_device(rt, enc, ny, geo, seeds=None, cursor=None, pulse_ca
     world/main.py:205-206); ``cursor`` (nb,) is the position the first utterance starts at (default zeros)."""
     from .get_seeds_signals import get_seeds_signals_device
 
-    if seeds is None:  # default of the batched path: tables generated on the device, once per (fs, device)
-        key = (enc.fs, rt.index)
+    if seeds is None:  # default of the batched path: tables generated on the device, once per (fs, device, lane) — a
+        # lane is a context and a stream of its own, possibly driven by a host thread of its own (world.pool): tables
+        # made on another lane's stream would be read here without any ordering
+        key = (enc.fs, rt.index, rt.lane)
         seeds = _default_seeds.get(key)
         if seeds is None:
-            seeds = _default_seeds[key] = get_seeds_signals_device(enc.fs, seed=0, device_index=rt.index)
+            seeds = _default_seeds[key] = get_seeds_signals_device(enc.fs, seed=0, rt=rt)
     _, _, pshape, nshape = seeds_on_device(rt, seeds)
     nb = int(pshape[1])
     nlen = int(nshape[0])

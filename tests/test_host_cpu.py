@@ -108,12 +108,13 @@ def test_encode_batch_mirrors_encode_signature():
 
     a = inspect.signature(main.World.encode).parameters
     b = inspect.signature(main.World.encode_batch).parameters
-    extra = ("want_ps",)  # batch-only: encode() always returns 'ps spectrogram', the batch keeps it on request
+    # batch-only: encode() always returns 'ps spectrogram', the batch keeps it on request; `devices`: one host thread per GPU
+    extra = ("want_ps", "devices")
     assert [k for k in a if k not in ("self", "fs", "x")] == [k for k in b if k not in ("self", "fs", "xs") + extra]
     for k in b:
         if k not in ("self", "fs", "xs") + extra:
             assert a[k].default == b[k].default, k
-    assert b["want_ps"].default is False
+    assert b["want_ps"].default is False and b["devices"].default is None
     assert b["f0_method"].default == "harvest"
 
 

@@ -21,8 +21,11 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # Per translation unit, appended after FLAGS (the last -ffp-contract wins; "fast-honor-pragmas", HIP's own default: plain "fast" lets the backend fuse across a `#pragma clang fp contract(off)`).  The SPECTRAL kernels — CheapTrick, D4C, the
 # pulse responses / Requiem frames — may fuse a*b+c into one FP64 instruction: their outputs are compared with the
-# reference at tolerances (1e-9 ... 1e-7), no discrete decision is read off the fused arithmetic (the D4C output
-# interpolation that must not exceed 0 dB keeps contract(off), wh_d4c.hip), and it is worth 1.1 % of the config-2 step
+# reference at tolerances (1e-9 ... 1e-7); the two places of wh_d4c.hip where a discrete outcome is read keep
+# `#pragma clang fp contract(off)`: the output interpolation that must not exceed 0 dB, and the love-train powers, sums
+# and ratio of the voicing gate s1/s2 > 0.85 (d4c.py:86; the transform in front of the gate is fused — its rounding
+# differs from NumPy's pocketfft at the 1e-16 level with or without contraction, so a frame whose ratio lies within
+# ~1e-15 of the threshold can fall on either side either way).  It is worth 1.1 % of the config-2 step
 # (round 5: d4c 4.64 -> 4.56 ms, cheaptrick 1.14 -> 1.11, responses 3.45 -> 3.43).  The F0 stages (DIO, StoneMask,
 # Harvest, SWIPE') and the synthesis TIME BASE stay unfused: voicing decisions and pulse positions are bit-exact
 # against the reference (wh_synthesis.hip fuses inside response_pulse / min_phase_response only).

@@ -481,11 +481,16 @@ __global__ __launch_bounds__(ft_love(NLT)) void love_train_kernel(
   const int b1 = (int)(ceil(4000.0 / (fs / NLT)) + 1);
   const int b2 = (int)(ceil(7900.0 / (fs / NLT)) + 1);
   double s1 = 0.0, s2 = 0.0;
-  for (int k = b0 + threadIdx.x; k < b2 && k < NLT; k += FT) {
-    const double2 z = zb[k <= NLT / 2 ? k : NLT - k];  // |X[k]|^2 is even about NLT/2
-    const double p = z.x * z.x + z.y * z.y;
-    s2 += p;
-    if (k < b1) s1 += p;
+  {
+    // the voicing decision s1 / s2 > 0.85 (d4c.py:86): powers, sums and ratio stay unfused, like NumPy's (ADVICE r5 — the
+    // translation unit is compiled with contraction for its transforms; what feeds a discrete decision is not)
+#pragma clang fp contract(off)
+    for (int k = b0 + threadIdx.x; k < b2 && k < NLT; k += FT) {
+      const double2 z = zb[k <= NLT / 2 ? k : NLT - k];  // |X[k]|^2 is even about NLT/2
+      const double p = z.x * z.x + z.y * z.y;
+      s2 += p;
+      if (k < b1) s1 += p;
+    }
   }
   wh::block_sum2<FT>(s1, s2, scratch);
   if (threadIdx.x == 0) gate[f] = (s1 / s2 > threshold) ? 1 : 0;
@@ -933,6 +938,9 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
     STAGE_MARK(8)
     const int b0 = lc.b0, b1 = lc.b1, b2 = lc.b2;
     double s1 = 0.0, s2 = 0.0;
+    {
+    // (the love-train powers feed the voicing decision below: unfused, see love_train_kernel)
+#pragma clang fp contract(off)
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
       const int k = k0 + r;
@@ -952,6 +960,7 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
           if (km < b1) s1 += pa;
         }
       }
+    }
     }
     wh::block_sum2<FT>(s1, s2, scratch);  // (its barriers also free buf for the next stage)
     voiced = s1 / s2 > threshold;  // d4c.py:86

@@ -94,7 +94,7 @@ def synthesis_requiem_core(rt, batch, tp_d, f0_d, vuv_d, spec_d, band_d, fs, fft
     return y, y_off
 
 
-_default_seeds = {}  # (fs, device) -> device-resident seed tables (the batched path's default when the caller passes none)
+_default_seeds = {}  # (fs, device, lane) -> device-resident seed tables (the batched path's default when the caller passes none)
 
 
 def synthesis_requiem_device(rt, enc, ny, geo, seeds=None, cursor=None, pulse_cap=None):

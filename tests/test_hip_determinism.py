@@ -92,7 +92,7 @@ def test_decode_of_an_utterance_does_not_depend_on_its_batch(requiem):
         y1 = alone.decode_device(e1, **k1)[0].cpu().numpy()
         assert np.array_equal(y1, y[int(y_off[u]):int(y_off[u + 1])]), u
         if requiem:
-            nlen = int(_default_seeds[(FS, wb.rt.index)]["noise_d"].shape[0])
+            nlen = int(_default_seeds[(FS, wb.rt.index, wb.rt.lane)]["noise_d"].shape[0])
             cur = _advance(cur, int(y_off[u + 1] - y_off[u]), nlen)
     # two "ranks": the batch split into shards decodes to the same samples as the whole
     for lo, hi in ((0, 2), (2, 5)):

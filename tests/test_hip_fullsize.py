@@ -98,6 +98,30 @@ def test_resynthesis_tracks_input(full_batch):
         assert np.corrcoef(ex, ey)[0, 1] > 0.9
 
 
+def test_decoded_rows_equal_the_single_utterance_decode_bitwise(full_batch):
+    """The pulse-wise decode of config 2 at its full size, sample by sample: row u of the 64 x 10 s batch == the same
+    utterance decoded alone under ``philox_seed_for_offset(seed, u)`` — the seed under which utterance 0 of a batch draws
+    the noise utterance u of the whole batch draws.  The overlap-add (response_kernel's runs of pulses +
+    response_gather_kernel) numbers its work per utterance and adds in a fixed order, so this is an equality of bits;
+    the reference adds pulse after pulse into one array (world/synthesis.py:61-81)."""
+    from world.batch import WorldBatch
+    from world.synthesis import philox_seed_for_offset
+
+    xs, wb, enc = full_batch
+    y, y_off = wb.decode_device(enc, seed=7)
+    fo = enc.batch.frame_off
+    for u in (0, 1, 37, 63):
+        single = WorldBatch().encode([xs[u]], FS, f0_method="dio")
+        ys, _ = WorldBatch().decode_device(single, seed=philox_seed_for_offset(7, u))
+        a = y[int(y_off[u]):int(y_off[u + 1])]
+        assert a.shape == ys.shape and bool((a == ys).all()), u
+        assert float(a.abs().max()) > 0.05
+    # (a row decoded alone under the batch's own seed is utterance 0's stream: another noise)
+    single = WorldBatch().encode([xs[37]], FS, f0_method="dio")
+    other, _ = WorldBatch().decode_device(single, seed=7)
+    assert not bool((other == y[int(y_off[37]):int(y_off[38])]).all())
+
+
 def test_harvest_batch_rows_equal_single_utterance():
     """Harvest on a ragged batch of 24 utterances of 9-10 s (config 3's shape at a size every stage's grid is busy:
     utterance-fastest band walkers, 16-frame refinement / pruning blocks that straddle utterance ends): every utterance

@@ -68,7 +68,8 @@ def test_three_slots_and_an_empty_range():
     pool = WorldBatchPool([0, 0, 0])
     try:
         penc = pool.encode(xs, fs, f0_method='dio')
-        assert [b - a for a, b in penc.ranges] == [1, 1, 0] and penc.encs[2] is None
+        sizes = [b - a for a, b in penc.ranges]
+        assert sorted(sizes) == [0, 1, 1] and penc.encs[sizes.index(0)] is None
         dicts, ref = penc.to_dicts(lazy=False), enc.to_dicts()
         for d, r in zip(dicts, ref):
             for k in DENSE:

@@ -305,8 +305,11 @@ static __global__ __launch_bounds__(256) void band_tile_fft_kernel(const BandJob
   for (int k = threadIdx.x; k <= kOlsN / 2; k += 256) out[k] = z[k];
 }
 
+#ifndef WH_OLS_XCD
+#define WH_OLS_XCD 1
+#endif
 template <int kOlsBands>
-static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kernel(const BandJob* __restrict__ jobs, int nb, int H,
+static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kernel(const BandJob* __restrict__ jobs, int nb, int n_utt, int H,
                                                                      const int32_t* __restrict__ half,
                                                                      const double* __restrict__ tspec,
                                                                      const double2* __restrict__ zspec,
@@ -318,11 +321,26 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
   double2* ybuf = reinterpret_cast<double2*>(smem);
   double* sig_all = reinterpret_cast<double*>(smem);
   unsigned long long* scan_scratch = reinterpret_cast<unsigned long long*>(ybuf + KS + 1);  // 8
+#if WH_OLS_XCD
+  // Workgroup -> (utterance, channel group), XCD-aware (round 6).  Every channel group of an utterance walks the SAME tile
+  // spectra (754 KB per 10 s utterance); with the groups of an utterance dealt over the whole launch (utterance-fastest
+  // order, rounds 2-5) each of them fetched its own copy from HBM: 38 x 0.77 GB = 29 GB of the 46.5 GB this kernel moved
+  // per 1024 utterances.  Workgroup ids go to the 8 XCDs round-robin (wh::xcd_unit), so id -> XCD id % 8, and XCD x takes
+  // the utterances u = x (mod 8), all groups of one utterance on consecutive local ids: they start together, walk the
+  // tiles in step, and a tile spectrum comes from HBM once and from that XCD's L2 for the other groups.  The real tap
+  // spectra (2.5 MB for 152 channels, re-read per tile) fit the 4 MB L2 next to them.
+  const int groups = (nb + kOlsBands - 1) / kOlsBands;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int u = (local / groups) * 8 + xcd;
+  if (u >= n_utt) return;
+  const int b0 = (local % groups) * kOlsBands;
+#else
   // utterance-fastest workgroup order: the workgroups in flight at any time share a few channel groups, so the
   // 33 KB tap spectra they stream stay in every XCD's L2 (channel-fastest, each XCD cycled through all 5 MB of them
   // and half of the 8.6 GB requested per launch came from HBM)
   const int u = blockIdx.x;
   const int b0 = blockIdx.y * kOlsBands;
+#endif
   const BandJob job0 = jobs[(int64_t)u * nb + b0];
   const int64_t M = job0.M;
   const int64_t tiles = (M + kOlsValid - 1) / kOlsValid;
@@ -566,8 +584,17 @@ inline int launch_band_events_ols(wh_ctx* ctx, hipStream_t st, const BandJob* d_
   const bool single = WH_OLS_BANDS == 1 || (WH_OLS_BANDS == 0 && (int64_t)n_utt * ((nb + 3) / 4) < 16 * 3 * 256);
   {
     KernelTimer _kt(ctx, st, "band_events_kernel");
-    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(n_utt, nb), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
-    else hipLaunchKernelGGL(band_events_ols_kernel<4>, dim3(n_utt, (nb + 3) / 4), dim3(256), lds, st, d_jobs, nb, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+#if WH_OLS_XCD
+#ifndef WH_OLS_GROUP
+#define WH_OLS_GROUP 4  // channels per workgroup of the large-batch form
+#endif
+    const unsigned u8 = (unsigned)xcd_grid(n_utt);
+    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(u8 * nb), dim3(256), lds, st, d_jobs, nb, n_utt, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+    else hipLaunchKernelGGL(band_events_ols_kernel<WH_OLS_GROUP>, dim3(u8 * ((nb + WH_OLS_GROUP - 1) / WH_OLS_GROUP)), dim3(256), lds, st, d_jobs, nb, n_utt, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+#else
+    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(n_utt, nb), dim3(256), lds, st, d_jobs, nb, n_utt, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+    else hipLaunchKernelGGL(band_events_ols_kernel<4>, dim3(n_utt, (nb + 3) / 4), dim3(256), lds, st, d_jobs, nb, n_utt, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+#endif
   }
 #endif
   hipError_t e = hipGetLastError();

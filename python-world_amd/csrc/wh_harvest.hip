@@ -58,6 +58,7 @@ struct HvUtt {
   int64_t z_off;          // zero-padded, mean-removed copy: ylen + 2*pad
   int64_t pick0;          // index into the filtfilt output of y[0]
   int64_t f1_off, nf1;    // 1 ms frames
+  int64_t l_off, ntile;   // live-candidate bit map: word l_off + channel * ntile + tile holds the tile's 64 frames
   int64_t f_off, nf;      // output frames
 };
 
@@ -224,14 +225,20 @@ constexpr int kRawChunk = 2 * kRawTile;    // intervals staged per train and til
 __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restrict__ meta, const wh::BandJob* __restrict__ jobs,
                                                      const double* __restrict__ band_f0, int nb, double fs_d,
                                                      double f0_floor, double f0_ceil, double* __restrict__ raw,
-                                                     uint8_t* __restrict__ live) {
+                                                     unsigned long long* __restrict__ live, int dense) {
+  static_assert(kRawTile == 64, "a tile's live bits are one wave ballot");
   __shared__ double2 iv[4][kRawChunk];  // (location, frequency) of interval start + i
   __shared__ int s_next[4];
   const HvUtt m = meta[blockIdx.y];
   const int b = blockIdx.x;
   const wh::BandJob job = jobs[(int64_t)blockIdx.y * nb + b];
   double* out = raw + m.f1_off * nb + (int64_t)b * m.nf1;
-  uint8_t* lv = live + m.f1_off * nb + (int64_t)b * m.nf1;  // 1 where a candidate survives: what hv_detect scans
+  // What hv_detect scans: ONE BIT per (channel, frame) — set where a candidate survived the range tests — as a 64-bit
+  // word per (channel, 64-frame tile), the wave's ballot.  The candidate VALUES are written only where that bit is set
+  // (round 6; `dense`: everywhere, for the debug read-out): hv_detect reads a value only inside a run of live channels,
+  // and most of the [channel][frame] map is dead — it used to leave as 12.2 MB of doubles + 1.5 MB of bytes per 10 s
+  // utterance, nearly all of it zeros nobody read.
+  unsigned long long* lv = live + m.l_off + (int64_t)b * m.ntile;
   int cnt[4];
   bool usable = true;
 #pragma unroll
@@ -240,10 +247,9 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
     usable = usable && (cnt[k] - 1 >= 3);
   }
   if (!usable) {  // fewer than 3 intervals in a train: no candidate anywhere (dio.py:159-162)
-    for (int64_t f = threadIdx.x; f < m.nf1; f += kRawTile) {
-      out[f] = 0.0;
-      lv[f] = 0;
-    }
+    for (int64_t t = threadIdx.x; t < m.ntile; t += kRawTile) lv[t] = 0ull;
+    if (dense)
+      for (int64_t f = threadIdx.x; f < m.nf1; f += kRawTile) out[f] = 0.0;
     return;
   }
   const double bf = band_f0[b];
@@ -308,6 +314,7 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
     __syncthreads();
     const int64_t f = f0 + threadIdx.x;
     int lo_g[4] = {0, 0, 0, 0};
+    double cand = 0.0;
     if (f < f_end) {
       const double t = (double)f * 1 / 1000;  // basic_temporal_positions (harvest.py:21)
       double v[4];
@@ -360,10 +367,13 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
         const double slope = (y_hi - y_lo) / (x_hi - x_lo);
         v[k] = slope * (t - x_lo) + y_lo;
       }
-      double cand = (((v[0] + v[1]) + v[2]) + v[3]) / 4;
+      cand = (((v[0] + v[1]) + v[2]) + v[3]) / 4;
       if (cand > bf * 1.1 || cand < bf * 0.9 || cand > f0_ceil || cand < f0_floor) cand = 0.0;  // harvest.py:273-276
-      out[f] = cand;
-      lv[f] = cand > 0 ? 1 : 0;
+      if (dense || cand > 0) out[f] = cand;
+    }
+    {
+      const unsigned long long bits = __ballot(cand > 0);  // (lanes behind the utterance's end: 0)
+      if (threadIdx.x == 0) lv[f0 / kRawTile] = bits;
     }
     // the last frame of the tile hands its counts to the next tile as the new cursors
     const int64_t last = f0 + kRawTile - 1 < f_end - 1 ? f0 + kRawTile - 1 : f_end - 1;
@@ -402,7 +412,7 @@ __device__ __forceinline__ double np_sum_strided(const double* __restrict__ a, i
 // count.
 __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict__ meta, int nb,
                                                         const double* __restrict__ raw,
-                                                        const uint8_t* __restrict__ live_map, double* __restrict__ dc,
+                                                        const unsigned long long* __restrict__ live_map, double* __restrict__ dc,
                                                         int32_t* __restrict__ dcount) {
   const HvUtt m = meta[blockIdx.y];
   // the grid is sized by the longest utterance of the batch: blocks wholly behind this utterance's end leave at once
@@ -412,7 +422,10 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
   const bool live_f = f_raw < m.nf1;  // (the tail threads of the last block stay for its output pass)
   const int64_t f = live_f ? f_raw : m.nf1 - 1;
   const double* col = raw + m.f1_off * nb + f;  // element b at col[b * nf1]
-  const uint8_t* lcol = live_map + m.f1_off * nb + f;
+  // the wave's 64 frames are one tile of hv_raw's bit map: ONE word per channel for the whole wave (a uniform address)
+  const int64_t tile_w = ((int64_t)blockIdx.x * 256 + (threadIdx.x & ~63)) / 64;
+  const unsigned long long* lcol = live_map + m.l_off + (tile_w < m.ntile ? tile_w : m.ntile - 1);
+  const int lane_w = threadIdx.x & 63;
 #if !WH_HV_DETECT_STAGE
   double* out = dc + (m.f1_off + f) * kMaxC;
 #endif
@@ -426,9 +439,9 @@ __global__ __launch_bounds__(256) void hv_detect_kernel(const HvUtt* __restrict_
   bool prev = false;   // channel 0 is forced dead
   // the channel walk is a chain of dependent branches; its loads are not: eight channels are fetched together
   for (int b0 = 0; live_f && b0 < nb; b0 += 8) {
-    uint8_t v[8];
+    unsigned v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = lcol[(int64_t)(b0 + q < nb ? b0 + q : nb - 1) * m.nf1];  // clamped, not skipped: a
+    for (int q = 0; q < 8; ++q) v[q] = (unsigned)(lcol[(int64_t)(b0 + q < nb ? b0 + q : nb - 1) * m.ntile] >> lane_w) & 1u;  // clamped, not skipped: a
     // conditional load becomes a branch, and eight of them a chain of load-wait-load (the surplus values are not read)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -1322,6 +1335,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   if (2 * hmax + 1 > WH_MAX_FFT / 2) return wh::fail_msg("wh_harvest", "f0_floor too low for the twiddle tables");
   std::vector<HvUtt> meta(B);
   std::vector<int64_t> e_off((size_t)B * n_bands), e_cap((size_t)B * n_bands);
+  int64_t l_tot = 0;
   int64_t t_tot = 0, y_tot = 0, z_tot = 0, e_tot = 0, f1_tot = 0, max_len = 0, max_ylen = 0, max_nf1 = 0, max_nf = 0;
   for (int u = 0; u < B; ++u) {
     HvUtt& m = meta[u];
@@ -1351,6 +1365,9 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     m.nf1 = (int64_t)(1000.0 * (double)m.n / fs / 1 + 1);
     m.f1_off = f1_tot;
     f1_tot += m.nf1;
+    m.ntile = (m.nf1 + kRawTile - 1) / kRawTile;
+    m.l_off = l_tot;
+    l_tot += m.ntile * n_bands;
     m.f_off = b->h_frame_off[u];
     m.nf = b->h_frame_off[u + 1] - b->h_frame_off[u];
     for (int i = 0; i < n_bands; ++i) {
@@ -1374,7 +1391,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t o_e = off; off += al(sizeof(double) * e_tot);
   const size_t o_cnt = off; off += al(sizeof(int32_t) * (size_t)B * n_bands * 4);
   const size_t o_raw = off; off += al(sizeof(double) * f1_tot * n_bands);
-  const size_t o_live = off; off += al((size_t)f1_tot * n_bands);
+  const size_t o_live = off; off += al(sizeof(unsigned long long) * (size_t)l_tot);
   const size_t o_dc = off; off += al(sizeof(double) * f1_tot * kMaxC);
   const size_t o_dn = off; off += al(sizeof(int32_t) * f1_tot);
   const size_t o_rf0 = off; off += al(sizeof(double) * f1_tot * kRows);
@@ -1412,7 +1429,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   int32_t* d_cnt = reinterpret_cast<int32_t*>(ws + o_cnt);
   wh::BandJob* d_jobs = nullptr;
   double* d_raw = reinterpret_cast<double*>(ws + o_raw);
-  uint8_t* d_live = reinterpret_cast<uint8_t*>(ws + o_live);
+  unsigned long long* d_live = reinterpret_cast<unsigned long long*>(ws + o_live);
   double* d_dc = reinterpret_cast<double*>(ws + o_dc);
   int32_t* d_dn = reinterpret_cast<int32_t*>(ws + o_dn);
   double* d_rf0 = reinterpret_cast<double*>(ws + o_rf0);
@@ -1487,7 +1504,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   // frames of an (utterance, channel) cut into segments with a workgroup each while the grid is a few rounds of the chip
   // (2560 workgroups at ten per CU): 1.80 -> 1.70 ms at 64 utterances; large batches keep one (no second cursor search)
   const int raw_segs = WH_HV_RAW_SEGS > 1 ? WH_HV_RAW_SEGS : ((int64_t)n_bands * B < 16 * 2560 ? 4 : 1);
-  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B, raw_segs), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw, d_live); }
+  { wh::KernelTimer _kt(ctx, st, "hv_raw_kernel"); hipLaunchKernelGGL(hv_raw_kernel, dim3(n_bands, B, raw_segs), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, n_bands, fs_d, f0_floor, f0_ceil, d_raw, d_live, dbg_raw ? 1 : 0); }
   WH_LAUNCH_CHECK("hv_raw_kernel");
   if (dbg_raw) WH_CHECK(hipMemcpyAsync(dbg_raw, d_raw, sizeof(double) * f1_tot * n_bands, hipMemcpyDeviceToDevice, st));
   { wh::KernelTimer _kt(ctx, st, "hv_detect_kernel"); hipLaunchKernelGGL(hv_detect_kernel, dim3((unsigned)((max_nf1 + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw, d_live, d_dc, d_dn); }

@@ -21,6 +21,12 @@ struct BandJob {
   double* seg_edges;    // [nseg][4][seg_cap]
   int32_t* seg_counts;  // [nseg][4]
   int64_t seg_cap;
+  // cursor hints of the overlap-save walker (emit_crossings_block; Harvest): hints[T * hint_stride + train], tile T = 64
+  // frames = hint_spt samples, hint_tiles of them; nullptr: none
+  int32_t* hints;
+  int64_t hint_tiles;
+  double hint_spt, hint_inv_spt;
+  int32_t hint_stride;
 };
 
 constexpr int kBandTile = 1024;   // outputs per tile of the plain path (and the unit of the segment split)
@@ -239,14 +245,15 @@ constexpr int kOlsValid = WH_OLS_VALID;  // outputs kept per block: 256 x 14 pos
                                          // filter (493 taps) leaves 4096 - 495 = 3601
 constexpr int kOlsPer = kOlsValid / 256;
 #ifndef WH_OLS_BANDS
-#define WH_OLS_BANDS 0  // 0: by batch size (below); 1 / 4: forced
+#define WH_OLS_BANDS 1  // 1 (round 6): one channel per workgroup at every batch size; 4: four; 0: by batch size (rounds 4-5)
 #endif
-// Channels per workgroup of band_events_ols_kernel (they share the tile spectrum of each tile): a template parameter,
-// chosen per launch.  Small batches take ONE: 152 x n_utt short workgroups instead of 38 x n_utt long ones — at 64
-// utterances the 2432 long workgroups were 3.2 rounds of the 768 the chip holds, so a quarter of the kernel ran with CUs
-// idle behind the last round (3.69 -> 3.27 ms at config 3) — and the channel's tap spectrum stays in registers for all
-// tiles.  Large batches (1024 utterances: 155 k short workgroups) keep FOUR: rounds no longer matter there and every
-// channel of a one-channel workgroup fetches its own copy of each tile spectrum (54.5 against 52.4 ms).
+// Channels per workgroup of band_events_ols_kernel (they share the tile spectrum of each tile): a template parameter.
+// ONE (round 6, every batch size): the channel's tap spectrum stays in registers for all tiles, and with the XCD-aware
+// workgroup order the tile spectra come out of the L2 the utterance's other channels share.  Four channels per workgroup
+// were 1 ms faster at 1024 utterances (40.7 against 41.7 ms) but re-read their tap spectra per tile — and the 16 GB
+// stream of edge stores kept pushing those (and the tile spectra) out of L2: 36.0 GB of HBM traffic per launch against
+// 20.0 GB (profiles/r06_*; non-temporal edge stores stop the evictions but, scattered 8-byte writes, double the bytes
+// written: 38.6 GB; collected in LDS and written as whole non-temporal runs: 20.0 GB but 44.5 ms).
 constexpr int kOlsBands = 4;  // band_events_ols2_kernel (the pair variant); band_events_ols_kernel is templated on it
 
 // T_b = rfft(taps_b zero-padded to kOlsN): [nb][kOlsN/2+1] complex (the fused front end's product), and
@@ -472,14 +479,23 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
       // output i of the block is s[t0 + i - (H + 1)]: the tile's outputs start at index H + 1 (H + h + 1 with the taps as
       // they lie; the zero-phase rotation of band_taps_fft_kernel advances the output by the half length h)
       const double* sig = sig_all + (H + 1);
-      emit_crossings_block<1, kOlsPer>(sig, t0, M, job.edges, job.cap, base_cnt, scan_scratch, flags);
+      emit_crossings_block<1, kOlsPer>(sig, t0, M, job.edges, job.cap, base_cnt, scan_scratch, flags, job.hints, job.hint_spt,
+                                       job.hint_inv_spt, job.hint_tiles, job.hint_stride);
       __syncthreads();
       if (threadIdx.x < 4) s_cnt[g][threadIdx.x] = base_cnt[threadIdx.x];
     }
   }
   __syncthreads();
-  if (threadIdx.x < kOlsBands * 4 && b0 + (threadIdx.x >> 2) < nb)
-    jobs[(int64_t)u * nb + b0 + (threadIdx.x >> 2)].counts[threadIdx.x & 3] = s_cnt[threadIdx.x >> 2][threadIdx.x & 3];
+  if (threadIdx.x < kOlsBands * 4 && b0 + (threadIdx.x >> 2) < nb) {
+    const BandJob job = jobs[(int64_t)u * nb + b0 + (threadIdx.x >> 2)];
+    const int c = s_cnt[threadIdx.x >> 2][threadIdx.x & 3];
+    job.counts[threadIdx.x & 3] = c;
+    if (job.hints) {  // frame tiles that start behind the last block: everything lies in front of them
+      int64_t T = (int64_t)ceil((double)(tiles * kOlsValid) / job.hint_spt);
+      if ((int64_t)floor((double)T * job.hint_spt) < tiles * kOlsValid) ++T;
+      for (; T < job.hint_tiles; ++T) job.hints[T * job.hint_stride + (threadIdx.x & 3)] = c;
+    }
+  }
 }
 
 // Two channels per inverse transform.  The filtered tiles y_a, y_b of two channels are real, so the complex sequence

@@ -36,6 +36,11 @@ __device__ __forceinline__ double2 ldg2(const double2* p) {
   return make_double2(v.x, v.y);
 }
 __device__ __forceinline__ double ldg(const double* p) { return *(const double __attribute__((address_space(1)))*)p; }
+// The same for stores (a pointer read out of a job record is generic to the compiler: flat_store), plain and non-temporal.
+__device__ __forceinline__ void stg(double* p, double v) { *(double __attribute__((address_space(1)))*)p = v; }
+__device__ __forceinline__ void stg_nt(double* p, double v) {
+  __builtin_nontemporal_store(v, (double __attribute__((address_space(1)))*)p);
+}
 
 // Workgroup-wide synchronisation for NT cooperating threads.  A single-wave group (NT == 64) needs no
 // hardware barrier: its lanes run in lockstep, so a compiler-level wavefront fence is enough to order the

@@ -162,10 +162,19 @@ __device__ __forceinline__ void crossing_edges(const double* s_ptr, int64_t g_fi
 // the first walk only flags the crossings (no divides, nothing kept but four PER-bit masks), the second re-reads the
 // flagged samples and writes the edge positions at the offsets the scan produced.  Used by the overlap-save band
 // walker, whose tiles are 3584 samples (14 positions per thread).
+//
+// Cursor hints (Harvest, round 6; hint == nullptr: none).  The frames are cut into tiles of 64 (hv_rawdet_kernel: one
+// wave per tile walks all channels); tile T starts at sample s_T = floor(T * hint_spt), hint_spt = 64 ms in samples.
+// hint[T * hint_stride + train] receives the number of this train's crossings at positions before s_T — where that
+// tile's search of the edge list starts, give or take the few entries the consumer allows for.  The thread whose
+// positions hold s_T knows it: its first slot plus the crossings it flagged in front of s_T.  A hint is advice: the
+// consumer clamps it into the list and checks every frame's answer against the window it staged (exact either way).
 template <int STRIDE, int PER>
 __device__ __forceinline__ void emit_crossings_block(const double* sig, int64_t t0, int64_t M, double* edges, int64_t cap,
                                                      int* base_cnt, unsigned long long* scratch,
-                                                     int32_t* overflow_flag) {
+                                                     int32_t* overflow_flag, int32_t* hint = nullptr,
+                                                     double hint_spt = 0.0, double hint_inv_spt = 0.0,
+                                                     int64_t hint_tiles = 0, int hint_stride = 0) {
   static_assert(PER <= 16, "masks are 16 bits, counts 16 bits per train");
   const int tid = threadIdx.x;
   const int i0 = tid * PER;
@@ -189,9 +198,30 @@ __device__ __forceinline__ void emit_crossings_block(const double* sig, int64_t 
   int pos[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) pos[t] = base_cnt[t] + (int)((excl >> (16 * t)) & 0xFFFF);
+  if (hint) {
+    // the tile boundary in [g0, g0 + PER), if there is one (tiles are hundreds of samples long): the first tile that
+    // starts at or behind g0, found with a multiply by the reciprocal and corrected by one.  32-bit indices (a signal of
+    // 2^31 decimated samples is days long): the 64-bit conversions are instruction sequences, and this runs per thread
+    // and channel-tile
+    const int g0 = (int)(t0 + i0);
+    int T = (int)((double)g0 * hint_inv_spt);
+    int sT = (int)((double)T * hint_spt);
+    if (sT < g0) {
+      ++T;
+      sT = (int)((double)T * hint_spt);
+    }
+    if (sT >= g0 && sT < g0 + PER && T < hint_tiles) {
+      const unsigned below = (1u << (int)(sT - g0)) - 1u;
+      int32_t* h = hint + (int64_t)T * hint_stride;
+      h[0] = pos[0] + __popc(m01 & below);
+      h[1] = pos[1] + __popc((m01 >> 16) & below);
+      h[2] = pos[2] + __popc(m23 & below);
+      h[3] = pos[3] + __popc((m23 >> 16) & below);
+    }
+  }
   bool over = false;
   crossing_edges<STRIDE>(sig + (int64_t)i0 * STRIDE, t0 + i0, m01, m23, pos, [&](int t, int at, double fe) {
-    if (at < cap) edges[(int64_t)t * cap + at] = fe;
+    if (at < cap) stg(edges + (int64_t)t * cap + at, fe);
     else over = true;
   });
   if (over) atomicOr(overflow_flag, 1);

@@ -387,6 +387,243 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
   }
 }
 
+// ---- raw candidates AND detection in one pass (round 6) ---------------------------------------------------------------
+// hv_raw_kernel walks the frames of ONE channel and leaves a [channel][frame] map for hv_detect_kernel, which walks the
+// channels of one frame: 6 MB of candidate values written and 4.4 MB read back per 10 s utterance, plus the launch.  This
+// kernel is the transpose: one wave per (utterance, tile of 64 frames) walks ALL channels in order, a lane per frame —
+// the interpolation of hv_raw_kernel, value for value (same staging of (location, frequency) intervals in LDS, same
+// doubling search, same window check with the search over the whole list as the way out) — and what DetectCandidates
+// (harvest.py:88-110) needs of a frame's column is kept in the lane as it goes by: the length of the current run of live
+// channels and the sum of its values, added channel after channel.  (np.mean adds them pairwise; hv_detect_kernel
+// reproduces that association, this kernel does not: the values themselves agree with the reference's to ~1e-9 Hz —
+// overlap-save filters against FFT products — so the 1e-16 of a summation order is not what parity rests on, and the
+// eight accumulators + pending group of the pairwise form cost a wave per SIMD: 7.06 against 5.4 ms at 256 utterances.)
+// A run of >= 10 channels that ends becomes a candidate.  Nothing but the 15 candidate slots per frame leaves the kernel.
+//   Where a tile's search of a channel's four edge lists starts is the band walker's advice (emit_crossings_block's
+// hints: crossings in front of the tile's first sample); the edges of the NEXT channel are fetched while the current
+// one is searched.  Workgroup order: an utterance's tiles on one XCD, consecutive (neighbouring tiles read overlapping
+// stretches of every list — from that XCD's L2 the second time).
+struct RdMeta {  // what the edge loads of a channel are addressed by: fetched a channel ahead of them
+  int4 h0, h1, c;  // the tile's hints, the next tile's, the trains' edge counts
+  const double* e;
+  int64_t cap;
+  double bf;
+};
+struct RdStage {
+  int start[4], nloc[4], ni[4];
+  double ea[4][2];  // edge start + lane + 64 r of every train (the interval's other edge is the next lane's)
+  const double* e;
+  int64_t cap;
+  double bf;
+  int need, steps;
+  bool usable;
+};
+
+#ifndef WH_HV_RAWDET_MINW
+#define WH_HV_RAWDET_MINW 3  // (12 KB of LDS per wave: 13 waves per CU whatever the registers)
+#endif
+__global__ __launch_bounds__(kRawTile, WH_HV_RAWDET_MINW) void hv_rawdet_kernel(const HvUtt* __restrict__ meta, const wh::BandJob* __restrict__ jobs,
+                                                             const double* __restrict__ band_f0,
+                                                             const int32_t* __restrict__ hints, int nb, int n_utt, int max_ntile,
+                                                             double fs_d, double f0_floor, double f0_ceil,
+                                                             double* __restrict__ dc, int32_t* __restrict__ dcount,
+                                                             double* __restrict__ raw_dbg) {
+  __shared__ double2 iv[4][kRawChunk];       // (location, frequency) of interval start + i
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int u = (local / max_ntile) * 8 + xcd;
+  if (u >= n_utt) return;
+  const HvUtt m = meta[u];
+  const int64_t T = local % max_ntile;
+  if (T >= m.ntile) return;
+  const int lane = threadIdx.x;
+  const int64_t f = T * kRawTile + lane;
+  const bool live_f = f < m.nf1;
+  const double t = (double)f * 1 / 1000;  // basic_temporal_positions (harvest.py:21)
+  const double half_inv_fs = 0.5 / fs_d;
+  const int32_t* hT = hints + (m.l_off + T * nb) * 4;          // [channel][train] of this tile
+  const int32_t* cU = jobs[(int64_t)u * nb].counts;            // [channel][train] of this utterance (contiguous)
+
+  // Two fetch stages run ahead of the channel being searched: the addressing data of channel b + 2 (hints, counts, list
+  // base: uniform loads), then — from the data fetched one channel earlier — the edges of channel b + 1.  (With both in
+  // one stage every channel waited a memory round trip for its hints before its edge loads could be issued.)
+  auto fetch_meta = [&](int b, RdMeta& q) {
+    b = b < nb ? b : nb - 1;  // (a surplus prefetch behind the last channel: harmless)
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef const v4i __attribute__((address_space(1))) * g4;
+    const v4i a = *(g4)(hT + b * 4), c = *(g4)(cU + b * 4);
+    const v4i n = T + 1 < m.ntile ? *(g4)(hT + (nb + b) * 4) : c;  // (behind the last tile: every edge)
+    q.h0 = make_int4(a.x, a.y, a.z, a.w);
+    q.h1 = make_int4(n.x, n.y, n.z, n.w);
+    q.c = make_int4(c.x, c.y, c.z, c.w);
+    const wh::BandJob* j = jobs + (int64_t)u * nb + b;
+    q.e = j->edges;
+    q.cap = j->cap;
+    q.bf = band_f0[b];
+  };
+  auto fetch = [&](const RdMeta& q, RdStage& s) {
+    s.e = q.e;
+    s.cap = q.cap;
+    s.bf = q.bf;
+    const int cs[4] = {q.c.x, q.c.y, q.c.z, q.c.w}, h0s[4] = {q.h0.x, q.h0.y, q.h0.z, q.h0.w}, h1s[4] = {q.h1.x, q.h1.y, q.h1.z, q.h1.w};
+    bool usable = true;
+    int need = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = __builtin_amdgcn_readfirstlane(cs[k]);  // (uniform: kept in scalar registers)
+      const int ni = c - 1;  // intervals of the whole train
+      usable = usable && (ni >= 3);
+      s.ni[k] = ni;
+      // the hint counts EDGES in front of the tile's first sample; the locations in front of its first frame are that
+      // many, give or take two: start four entries early (hv_raw_kernel starts two in front of the exact count) — and the
+      // NEXT tile's hint says where this tile's edges end: the window is what the tile needs plus that slack, not a
+      // worst-case budget (staged from a budget of twice the band's rate the tiles of an utterance read every list 2.2 times)
+      const int h0 = __builtin_amdgcn_readfirstlane(h0s[k]);
+      const int h1 = __builtin_amdgcn_readfirstlane(h1s[k]);
+      int st = h0 - 4;
+      st = st > ni - 1 ? ni - 1 : st;
+      st = st < 0 ? 0 : st;
+      s.start[k] = st;
+      int n = h1 - st + 3;
+      n = n > kRawChunk - 1 ? kRawChunk - 1 : n;  // (the last slot always holds the +inf sentinel of the search)
+      n = n > ni - st ? ni - st : n;
+      n = n < 1 ? 1 : n;
+      s.nloc[k] = n;
+      need = n > need ? n : need;
+    }
+    int steps = 0;
+    while ((1 << steps) < need + 1) ++steps;
+    s.need = need;
+    s.steps = steps;
+    s.usable = usable;
+    if (!usable) return;  // fewer than 3 intervals in a train: no candidate anywhere in this channel (dio.py:159-162)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double* e = s.e + (int64_t)k * s.cap + s.start[k];
+      {
+        const int ic = lane <= s.nloc[k] ? lane : 0;  // entries 0 .. nloc (start + nloc <= ni: a valid edge); clamped, not skipped: no branch per load
+        s.ea[k][0] = wh::ldg(e + ic);
+      }
+      if (s.need >= kRawTile) {  // (uniform; rare: more than 60 crossings of one kind in 64 ms)
+        const int i = lane + kRawTile;
+        const int ic = i <= s.nloc[k] ? i : 0;
+        s.ea[k][1] = wh::ldg(e + ic);
+      }
+    }
+  };
+
+  // the lane's walk state: DetectCandidates of its frame
+  double run_sum = 0.0;
+  int idx = 0, count = 0;
+  double* out = dc + (m.f1_off + f) * kMaxC;
+
+  auto consume = [&](int b, const RdStage& s) {
+    double cand = 0.0;
+    if (s.usable) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // the interval's upper edge: the next lane's entry (lane 63 of the first round: lane 0 of the second)
+        const double up0 = __shfl_down(s.ea[k][0], 1);
+        if (s.need < kRawTile) {  // (uniform) one round: entries 0 .. 63, intervals 0 .. 62 at most
+          iv[k][lane] = lane < s.nloc[k] ? make_double2((s.ea[k][0] + up0) * half_inv_fs, fs_d / (up0 - s.ea[k][0]))
+                                         : make_double2(INFINITY, 0.0);
+        } else {
+          const double up1 = __shfl_down(s.ea[k][1], 1);
+          const double wrap = __shfl(s.ea[k][1], 0);
+          const double eb[2] = {lane == kRawTile - 1 ? wrap : up0, up1};  // (entry 127 is never an interval: nloc <= 127)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int i = lane + r * kRawTile;
+            iv[k][i] = i < s.nloc[k] ? make_double2((s.ea[k][r] + eb[r]) * half_inv_fs, fs_d / (eb[r] - s.ea[k][r]))
+                                     : make_double2(INFINITY, 0.0);
+          }
+        }
+      }
+      wh::sync<kRawTile>();
+      if (live_f) {
+        double v[4];
+        int lo4[4] = {0, 0, 0, 0};
+        for (int st = 1 << (s.steps - 1); st > 0; st >>= 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int q = lo4[k] + st;
+            lo4[k] = iv[k][q - 1].x < t ? q : lo4[k];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int ni = s.ni[k];
+          const int lo = lo4[k];
+          const double* e = s.e + (int64_t)k * s.cap;
+          // the staged window holds the answer if a location >= t lies inside it (or the list ends in it) AND the count
+          // did not stop at the window's first entry while locations lie in front of the window (the hint was late)
+          const bool inside = (lo < s.nloc[k] || s.start[k] + s.nloc[k] == ni) && (lo > 0 || s.start[k] == 0);
+          int g = s.start[k] + lo;  // count of locations < t over the whole train
+          if (!inside) {            // search over the whole list
+            int l2 = 0, h2 = ni;
+            while (l2 < h2) {
+              const int mid = (l2 + h2) >> 1;
+              const double loc = (e[mid] + e[mid + 1]) * half_inv_fs;
+              if (loc < t) l2 = mid + 1; else h2 = mid;
+            }
+            g = l2;
+          }
+          const int ih = g < 1 ? 1 : (g > ni - 1 ? ni - 1 : g);
+          const int il = ih - 1;
+          double x_lo, x_hi, y_lo, y_hi;
+          if (il >= s.start[k] && ih < s.start[k] + s.nloc[k]) {
+            const double2 a = iv[k][il - s.start[k]], c = iv[k][ih - s.start[k]];
+            x_lo = a.x;
+            y_lo = a.y;
+            x_hi = c.x;
+            y_hi = c.y;
+          } else {
+            const double e0 = e[il], e1 = e[il + 1], e2 = e[ih], e3 = e[ih + 1];
+            x_lo = (e0 + e1) * half_inv_fs;
+            x_hi = (e2 + e3) * half_inv_fs;
+            y_lo = fs_d / (e1 - e0);
+            y_hi = fs_d / (e3 - e2);
+          }
+          const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+          v[k] = slope * (t - x_lo) + y_lo;
+        }
+        cand = (((v[0] + v[1]) + v[2]) + v[3]) / 4;
+        if (cand > s.bf * 1.1 || cand < s.bf * 0.9 || cand > f0_ceil || cand < f0_floor) cand = 0.0;  // harvest.py:273-276
+      }
+      wh::sync<kRawTile>();  // (the next channel's intervals overwrite iv)
+    }
+    if (raw_dbg && live_f) raw_dbg[m.f1_off * nb + (int64_t)b * m.nf1 + f] = cand;
+    // DetectCandidates (harvest.py:88-110): first and last channel count as dead; a run of >= 10 live channels that ends
+    // gives the mean of its values
+    const bool live = live_f && b >= 1 && b < nb - 1 && cand > 0;
+    if (live) {
+      run_sum += cand;
+      ++idx;
+    } else if (idx > 0) {
+      if (idx >= 10 && count < kMaxC) out[count++] = run_sum / (double)idx;
+      idx = 0;
+      run_sum = 0.0;
+    }
+  };
+
+  RdMeta qa, qb;
+  RdStage sa, sb;
+  fetch_meta(0, qa);
+  fetch_meta(1, qb);
+  fetch(qa, sa);
+  for (int b = 0; b < nb; b += 2) {
+    fetch(qb, sb);          // the edges of channel b + 1
+    fetch_meta(b + 2, qa);
+    consume(b, sa);
+    fetch(qa, sa);          // ... of b + 2
+    fetch_meta(b + 3, qb);
+    if (b + 1 < nb) consume(b + 1, sb);
+  }
+  if (live_f) {
+    for (int c = count; c < kMaxC; ++c) out[c] = 0.0;  // (hv_refine reads every slot)
+    dcount[m.f1_off + f] = count;
+  }
+}
+
 // NumPy's pairwise summation for n <= 128 (what np.mean does on the run of channel values)
 __device__ __forceinline__ double np_sum_strided(const double* __restrict__ a, int64_t stride, int n) {
   if (n < 8) {
@@ -1392,6 +1629,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t o_cnt = off; off += al(sizeof(int32_t) * (size_t)B * n_bands * 4);
   const size_t o_raw = off; off += al(sizeof(double) * f1_tot * n_bands);
   const size_t o_live = off; off += al(sizeof(unsigned long long) * (size_t)l_tot);
+  const size_t o_hint = off; off += al(sizeof(int32_t) * 4 * (size_t)l_tot);  // [utterance][tile][channel][train]
   const size_t o_dc = off; off += al(sizeof(double) * f1_tot * kMaxC);
   const size_t o_dn = off; off += al(sizeof(int32_t) * f1_tot);
   const size_t o_rf0 = off; off += al(sizeof(double) * f1_tot * kRows);
@@ -1430,6 +1668,11 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   wh::BandJob* d_jobs = nullptr;
   double* d_raw = reinterpret_cast<double*>(ws + o_raw);
   unsigned long long* d_live = reinterpret_cast<unsigned long long*>(ws + o_live);
+  int32_t* d_hint = reinterpret_cast<int32_t*>(ws + o_hint);
+#ifndef WH_HV_RAWDET
+#define WH_HV_RAWDET 1  // raw candidates + detection in one transposed pass (hv_rawdet_kernel); 0: hv_raw_kernel + hv_detect_kernel
+#endif
+  const bool use_rawdet = WH_HV_RAWDET && use_ols;  // (its cursor hints come from the overlap-save walker)
   double* d_dc = reinterpret_cast<double*>(ws + o_dc);
   int32_t* d_dn = reinterpret_cast<int32_t*>(ws + o_dn);
   double* d_rf0 = reinterpret_cast<double*>(ws + o_rf0);
@@ -1449,6 +1692,13 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
       j.edges = d_e + e_off[(size_t)u * n_bands + i];
       j.cap = e_cap[(size_t)u * n_bands + i];
       j.counts = d_cnt + ((int64_t)u * n_bands + i) * 4;
+      if (use_rawdet) {
+        j.hints = d_hint + (meta[u].l_off + i) * 4;
+        j.hint_tiles = meta[u].ntile;
+        j.hint_spt = kRawTile * fs_d / 1000.0;
+        j.hint_inv_spt = 1.0 / j.hint_spt;
+        j.hint_stride = n_bands * 4;
+      }
     }
   {
     std::vector<double> taps(h_band_taps, h_band_taps + taps_total), bf(h_band_f0, h_band_f0 + n_bands);
@@ -1501,6 +1751,15 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
                                              d_ti + 2 * n_bands, max_lb, true, ctx->d_flags + WH_FLAG_EVENT_OVERFLOW)) {
     return rc;
   }
+  if (use_rawdet) {
+    int64_t max_ntile = 0;
+    for (int u = 0; u < B; ++u) max_ntile = std::max(max_ntile, meta[u].ntile);
+    double* d_rawdbg = nullptr;
+    if (dbg_raw) d_rawdbg = d_raw;
+    { wh::KernelTimer _kt(ctx, st, "hv_rawdet_kernel"); hipLaunchKernelGGL(hv_rawdet_kernel, dim3((unsigned)(wh::xcd_grid(B) * max_ntile)), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, d_hint, n_bands, B, (int)max_ntile, fs_d, f0_floor, f0_ceil, d_dc, d_dn, d_rawdbg); }
+    WH_LAUNCH_CHECK("hv_rawdet_kernel");
+    if (dbg_raw) WH_CHECK(hipMemcpyAsync(dbg_raw, d_raw, sizeof(double) * f1_tot * n_bands, hipMemcpyDeviceToDevice, st));
+  } else {
   // frames of an (utterance, channel) cut into segments with a workgroup each while the grid is a few rounds of the chip
   // (2560 workgroups at ten per CU): 1.80 -> 1.70 ms at 64 utterances; large batches keep one (no second cursor search)
   const int raw_segs = WH_HV_RAW_SEGS > 1 ? WH_HV_RAW_SEGS : ((int64_t)n_bands * B < 16 * 2560 ? 4 : 1);
@@ -1509,6 +1768,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   if (dbg_raw) WH_CHECK(hipMemcpyAsync(dbg_raw, d_raw, sizeof(double) * f1_tot * n_bands, hipMemcpyDeviceToDevice, st));
   { wh::KernelTimer _kt(ctx, st, "hv_detect_kernel"); hipLaunchKernelGGL(hv_detect_kernel, dim3((unsigned)((max_nf1 + 255) / 256), B), dim3(256), 0, st, d_meta, n_bands, d_raw, d_live, d_dc, d_dn); }
   WH_LAUNCH_CHECK("hv_detect_kernel");
+  }
   // ---- refinement + pruning ------------------------------------------------------------------------------
   {
     int tw_n = 1;  // transform length of the longest window (harvest.py:171-172): 2 * 2^ceil(log2(2*hmax+1))

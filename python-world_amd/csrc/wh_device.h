@@ -36,11 +36,105 @@ __device__ __forceinline__ double2 ldg2(const double2* p) {
   return make_double2(v.x, v.y);
 }
 __device__ __forceinline__ double ldg(const double* p) { return *(const double __attribute__((address_space(1)))*)p; }
+#if WH_BOUNDS
+template <class T> struct ckp;
+__device__ __forceinline__ double2 ldg2(const ckp<const double2>& p);
+__device__ __forceinline__ double ldg(const ckp<const double>& p);
+#endif
 // The same for stores (a pointer read out of a job record is generic to the compiler: flat_store), plain and non-temporal.
 __device__ __forceinline__ void stg(double* p, double v) { *(double __attribute__((address_space(1)))*)p = v; }
 __device__ __forceinline__ void stg_nt(double* p, double v) {
   __builtin_nontemporal_store(v, (double __attribute__((address_space(1)))*)p);
 }
+
+// ------------------------------------------------------------------------------------------
+// Checked pointers: the bounds build (-DWH_BOUNDS=1, tools/build_variants.py; never shipped)
+// ------------------------------------------------------------------------------------------
+// This image cannot run device AddressSanitizer (no instrumented ROCm runtime, XNACK off), and round 5's attempt left an
+// abort of the instrumented cheaptrick_kernel that could not be read.  The deterministic replacement: wh::ckp<T> is T*
+// in every normal build — the alias, so the shipped code is the code without it, instruction for instruction — and in
+// the bounds build a pointer that carries the element range it may touch.  Every [] / * through it is compared with that
+// range; the first access outside is recorded (buffer tag, element index, range size) in a device word that
+// wh_take_flags reads: WH_FLAG_OOB with the record behind wh_bounds_last(), and the access itself is redirected to the
+// range's first element, so the kernel runs on instead of faulting.  The kernels that are covered name their buffers with
+// ck_make / ck_sub / ck_as; helpers take ckp<T> parameters; a raw pointer handed to such a helper converts implicitly
+// to an UNCHECKED ckp (kernels not yet converted keep compiling).
+#ifndef WH_BOUNDS
+#define WH_BOUNDS 0
+#endif
+enum {  // buffer tags of the record
+  WH_CK_LDS_MAIN = 1, WH_CK_LDS_AUX = 2, WH_CK_LDS_SCRATCH = 3, WH_CK_TWIDDLE = 4, WH_CK_WAVEFORM = 5, WH_CK_OUT = 6,
+  WH_CK_TABLE = 7, WH_CK_LDS_OTHER = 8, WH_CK_IN = 9
+};
+#if WH_BOUNDS
+#define WH_RESTRICT
+// first out-of-range access by this translation unit's kernels since the last read: count, tag, index, size
+static __device__ unsigned long long g_oob[4];
+__device__ __forceinline__ void oob_report(int tag, long long index, long long size) {
+  if (atomicAdd(&g_oob[0], 1ull) == 0ull) {
+    g_oob[1] = (unsigned long long)tag;
+    g_oob[2] = (unsigned long long)index;
+    g_oob[3] = (unsigned long long)size;
+  }
+}
+template <class T>
+struct ckp {
+  T* p = nullptr;
+  T* base = nullptr;  // element 0 of the range
+  long long n = -1;   // elements in the range; < 0: unchecked
+  int tag = 0;
+  __host__ __device__ ckp() {}
+  __host__ __device__ ckp(T* q) : p(q), base(q), n(-1), tag(0) {}  // a raw pointer: unchecked
+  __host__ __device__ ckp(T* q, T* b, long long nn, int tg) : p(q), base(b), n(nn), tag(tg) {}
+  template <class U, class = decltype(static_cast<T*>(static_cast<U*>(nullptr)))>
+  __host__ __device__ ckp(const ckp<U>& o) : p(o.p), base(o.base), n(o.n), tag(o.tag) {}  // T* -> const T*
+  __device__ __forceinline__ T* at(long long i) const {
+    if (n >= 0) {
+      const long long k = (p - base) + i;
+      if (k < 0 || k >= n) {
+        oob_report(tag, k, n);
+        return base;
+      }
+    }
+    return p + i;
+  }
+  __device__ __forceinline__ T& operator[](long long i) const { return *at(i); }
+  __device__ __forceinline__ T& operator*() const { return *at(0); }
+  __host__ __device__ ckp operator+(long long k) const { return ckp(p + k, base, n, tag); }
+  __host__ __device__ ckp operator-(long long k) const { return ckp(p - k, base, n, tag); }
+  __host__ __device__ explicit operator bool() const { return p != nullptr; }
+};
+template <class T>
+__host__ __device__ __forceinline__ ckp<T> ck_make(T* q, long long n, int tag) { return ckp<T>(q, q, n, tag); }
+// elements [off, off + n) of p's range as a range of its own
+template <class T>
+__host__ __device__ __forceinline__ ckp<T> ck_sub(ckp<T> p, long long off, long long n, int tag) {
+  return ckp<T>(p.p + off, p.p + off, n, tag);
+}
+// the same bytes seen as U (the range is re-expressed in elements of U)
+template <class U, class T>
+__host__ __device__ __forceinline__ ckp<U> ck_as(ckp<T> p) {
+  U* b = reinterpret_cast<U*>(p.base);
+  const long long n = p.n < 0 ? -1 : (long long)((p.n * (long long)sizeof(T)) / (long long)sizeof(U));
+  return ckp<U>(reinterpret_cast<U*>(p.p), b, n, p.tag);
+}
+template <class T>
+__host__ __device__ __forceinline__ T* ck_raw(ckp<T> p) { return p.p; }
+__device__ __forceinline__ double2 ldg2(const ckp<const double2>& p) { return ldg2(static_cast<const double2*>(p.at(0))); }
+__device__ __forceinline__ double ldg(const ckp<const double>& p) { return ldg(static_cast<const double*>(p.at(0))); }
+#else
+#define WH_RESTRICT __restrict__
+template <class T>
+using ckp = T*;
+template <class T>
+__host__ __device__ __forceinline__ T* ck_make(T* q, long long, int) { return q; }
+template <class T>
+__host__ __device__ __forceinline__ T* ck_sub(T* p, long long off, long long, int) { return p + off; }
+template <class U, class T>
+__host__ __device__ __forceinline__ U* ck_as(T* p) { return reinterpret_cast<U*>(p); }
+template <class T>
+__host__ __device__ __forceinline__ T* ck_raw(T* p) { return p; }
+#endif
 
 // Workgroup-wide synchronisation for NT cooperating threads.  A single-wave group (NT == 64) needs no
 // hardware barrier: its lanes run in lockstep, so a compiler-level wavefront fence is enough to order the
@@ -165,7 +259,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Sum over the whole 256-thread block; result broadcast to every thread.
 // `scratch` must hold >= 3*NT/64 doubles of LDS (24 for the largest block used, 512).  Contains two barriers.
 template <int NT = WH_BLOCK>
-__device__ __forceinline__ double block_sum(double v, double* scratch) {
+__device__ __forceinline__ double block_sum(double v, ckp<double> scratch) {
   v = wave_sum(v);
   if constexpr (NT <= WH_WAVE) {
     sync<NT>();
@@ -183,7 +277,7 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 
 // Two sums at once (saves barriers).
 template <int NT = WH_BLOCK>
-__device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch) {
+__device__ __forceinline__ void block_sum2(double& a, double& b, ckp<double> scratch) {
   a = wave_sum(a);
   b = wave_sum(b);
   if constexpr (NT <= WH_WAVE) {
@@ -208,7 +302,7 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch
 }
 
 template <int NT = WH_BLOCK>
-__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* scratch) {
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, ckp<double> scratch) {
   a = wave_sum(a);
   b = wave_sum(b);
   c = wave_sum(c);
@@ -239,7 +333,7 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
 // Five sums at once (the D4C window: two means and the three second moments of its energy, one pair of barriers).
 // `scratch` must hold >= 5*NT/64 doubles.
 template <int NT = WH_BLOCK>
-__device__ __forceinline__ void block_sum5(double& a, double& b, double& c, double& d, double& e, double* scratch) {
+__device__ __forceinline__ void block_sum5(double& a, double& b, double& c, double& d, double& e, ckp<double> scratch) {
   a = wave_sum(a);
   b = wave_sum(b);
   c = wave_sum(c);
@@ -374,7 +468,7 @@ struct FftRadix {
 // Twiddle, butterfly and store of one pass for the butterflies this thread owns: v[p][r] = element
 // j + r*(N/R), j = tid + p*NT.
 template <int N, int NT, int R, int NS, bool INV, bool SWZ_OUT>
-__device__ __forceinline__ void fft_pass_finish(double2* __restrict__ s, double2 (&v)[(N / R + NT - 1) / NT][R],
+__device__ __forceinline__ void fft_pass_finish(ckp<double2> WH_RESTRICT s, double2 (&v)[(N / R + NT - 1) / NT][R],
                                                 const double2 (&w)[(N / R + NT - 1) / NT][R]) {
   constexpr int J = N / R;
   constexpr int PER = (J + NT - 1) / NT;
@@ -405,7 +499,7 @@ __device__ __forceinline__ void fft_pass_finish(double2* __restrict__ s, double2
 // The twiddles of one pass (global table, L1/L2 resident): fetched before the pass's barrier so that their
 // latency is spent waiting for the other waves.
 template <int N, int NT, int R, int NS, bool INV>
-__device__ __forceinline__ void fft_pass_twiddles(const double2* __restrict__ tw, double2 (&w)[(N / R + NT - 1) / NT][R]) {
+__device__ __forceinline__ void fft_pass_twiddles(ckp<const double2> WH_RESTRICT tw, double2 (&w)[(N / R + NT - 1) / NT][R]) {
   constexpr int J = N / R;
   constexpr int PER = (J + NT - 1) / NT;
   const int tid = WH_TID & (NT - 1);
@@ -428,7 +522,7 @@ __device__ __forceinline__ void fft_pass_twiddles(const double2* __restrict__ tw
 }
 
 template <int N, int NT, int R, int NS, bool INV, int SNT, bool SWZ_IN, bool SWZ_OUT>
-__device__ __forceinline__ void fft_pass(double2* __restrict__ s, const double2* __restrict__ tw) {
+__device__ __forceinline__ void fft_pass(ckp<double2> WH_RESTRICT s, ckp<const double2> WH_RESTRICT tw) {
   constexpr int J = N / R;
   constexpr int PER = (J + NT - 1) / NT;
   double2 v[PER][R], w[PER][R];
@@ -454,7 +548,7 @@ __device__ __forceinline__ void fft_pass(double2* __restrict__ s, const double2*
 }
 
 template <int N, int NT, int NS, bool INV, int SNT = NT, int MAXR = 8>
-__device__ __forceinline__ void fft_passes(double2* s, const double2* tw) {
+__device__ __forceinline__ void fft_passes(ckp<double2> s, ckp<const double2> tw) {
   if constexpr (NS < N) {
     constexpr int R = FftRadix<N, NT, NS, MAXR>::value;
     constexpr bool SWZ = WH_FFT_SWZ && N >= 64 && MAXR >= 8;  // radix-4 plans keep the natural layout (one address VGPR per pass)
@@ -467,7 +561,7 @@ __device__ __forceinline__ void fft_passes(double2* s, const double2* tw) {
 // buffer is fully written and visible (barrier) on entry; visible on exit.  The inverse does
 // NOT divide by N.
 template <int N, bool INV, int NT = WH_BLOCK, int SNT = NT, int MAXR = 8>
-__device__ __forceinline__ void fft_lds(double2* s, const double2* tw) {
+__device__ __forceinline__ void fft_lds(ckp<double2> s, ckp<const double2> tw) {
   fft_passes<N, NT, 1, INV, SNT, MAXR>(s, tw);
 }
 
@@ -476,7 +570,7 @@ __device__ __forceinline__ void fft_lds(double2* s, const double2* tw) {
 // of this thread's first-pass butterflies, so the input never makes the trip through LDS.  The buffer must be
 // free (no other thread still reading it): a barrier is taken on entry.
 template <int N, bool INV, int NT = WH_BLOCK, int MAXR = 8>
-__device__ __forceinline__ void fft_lds_from_regs(const double2 (&x)[N / NT], double2* s, const double2* tw) {
+__device__ __forceinline__ void fft_lds_from_regs(const double2 (&x)[N / NT], ckp<double2> s, ckp<const double2> tw) {
   constexpr int R = FftRadix<N, NT, 1, MAXR>::value;
   static_assert(N % (R * NT) == 0 && N >= 64, "register-fed first pass needs N >= R*NT");
   constexpr int PER = N / R / NT;
@@ -502,9 +596,9 @@ __device__ __forceinline__ void fft_lds_from_regs(const double2 (&x)[N / NT], do
 // Forward.  in: z[j] = (x[2j], x[2j+1]), j < N/2 (i.e. the real array itself).  out: z[k] = X[k], k = 0..N/2
 // (N/2 + 1 entries).  Buffer must be visible on entry; visible on exit.
 template <int N, int NT = WH_BLOCK, int SNT = NT, int MAXR = 8>
-__device__ __forceinline__ void rfft_lds(double2* z, const double2* __restrict__ tw_base) {
+__device__ __forceinline__ void rfft_lds(ckp<double2> z, ckp<const double2> WH_RESTRICT tw_base) {
   fft_lds<N / 2, false, NT, SNT, MAXR>(z, tw_base + N / 2);
-  const double2* __restrict__ w = tw_base + N;
+  ckp<const double2> WH_RESTRICT w = tw_base + N;
   for (int k = WH_TID & (NT - 1); k <= N / 4; k += NT) {
     if (k == 0) {
       const double2 a = z[0];
@@ -528,8 +622,8 @@ __device__ __forceinline__ void rfft_lds(double2* z, const double2* __restrict__
 // (imaginary parts of the DC / Nyquist bins are ignored, as taking .real of a full complex IFFT would).
 // out: z[j] = N * (x[2j], x[2j+1]), j < N/2 (unnormalised like fft_lds<.., true>: divide by N).
 template <int N, int NT = WH_BLOCK, int SNT = NT, int MAXR = 8>
-__device__ __forceinline__ void irfft_lds(double2* z, const double2* __restrict__ tw_base) {
-  const double2* __restrict__ w = tw_base + N;
+__device__ __forceinline__ void irfft_lds(ckp<double2> z, ckp<const double2> WH_RESTRICT tw_base) {
+  ckp<const double2> WH_RESTRICT w = tw_base + N;
   for (int k = WH_TID & (NT - 1); k <= N / 4; k += NT) {
     double2 a = z[k], b = z[N / 2 - k];
     if (k == 0) {  // DC and Nyquist bins: only their real parts reach a real output (Re of the inverse DFT)

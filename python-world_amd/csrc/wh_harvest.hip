@@ -1619,6 +1619,19 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     max_nf1 = std::max(max_nf1, m.nf1);
     max_nf = std::max(max_nf, m.nf);
   }
+  int h_max = 0;
+  for (int i = 0; i < n_bands; ++i) h_max = std::max(h_max, (int)h_band_half[i]);
+#ifndef WH_HV_BAND_OLS
+#define WH_HV_BAND_OLS 1
+#endif
+  // the block of kOlsN inputs must cover H + h + 1 + kOlsValid + 2 outputs for every channel
+  const bool use_ols = WH_HV_BAND_OLS && (2 * h_max + 1 + wh::kOlsValid + 2 <= wh::kOlsN) && pad >= h_max + 1;
+#ifndef WH_HV_RAWDET
+#define WH_HV_RAWDET 1  // raw candidates + detection in one transposed pass (hv_rawdet_kernel); 0: hv_raw_kernel + hv_detect_kernel
+#endif
+  const bool use_rawdet = WH_HV_RAWDET && use_ols;  // (its cursor hints come from the overlap-save walker)
+  // the [channel][frame] candidate map (12 GB per 1024 x 10 s) and its bit map exist only where something reads them
+  const bool need_map = !use_rawdet || dbg_raw != nullptr;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
   const size_t o_tmp = off; off += al(sizeof(double) * t_tot);
@@ -1627,9 +1640,9 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t o_mean = off; off += al(sizeof(double) * B * (1 + kMeanParts));  // means, then the partial sums
   const size_t o_e = off; off += al(sizeof(double) * e_tot);
   const size_t o_cnt = off; off += al(sizeof(int32_t) * (size_t)B * n_bands * 4);
-  const size_t o_raw = off; off += al(sizeof(double) * f1_tot * n_bands);
-  const size_t o_live = off; off += al(sizeof(unsigned long long) * (size_t)l_tot);
-  const size_t o_hint = off; off += al(sizeof(int32_t) * 4 * (size_t)l_tot);  // [utterance][tile][channel][train]
+  const size_t o_raw = off; off += need_map ? al(sizeof(double) * f1_tot * n_bands) : 0;
+  const size_t o_live = off; off += need_map ? al(sizeof(unsigned long long) * (size_t)l_tot) : 0;
+  const size_t o_hint = off; off += use_rawdet ? al(sizeof(int32_t) * 4 * (size_t)l_tot) : 0;  // [utterance][tile][channel][train]
   const size_t o_dc = off; off += al(sizeof(double) * f1_tot * kMaxC);
   const size_t o_dn = off; off += al(sizeof(int32_t) * f1_tot);
   const size_t o_rf0 = off; off += al(sizeof(double) * f1_tot * kRows);
@@ -1645,13 +1658,6 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     tile_off[u + 1] = tile_off[u] + t;
     max_tiles = std::max(max_tiles, t);
   }
-  int h_max = 0;
-  for (int i = 0; i < n_bands; ++i) h_max = std::max(h_max, (int)h_band_half[i]);
-#ifndef WH_HV_BAND_OLS
-#define WH_HV_BAND_OLS 1
-#endif
-  // the block of kOlsN inputs must cover H + h + 1 + kOlsValid + 2 outputs for every channel
-  const bool use_ols = WH_HV_BAND_OLS && (2 * h_max + 1 + wh::kOlsValid + 2 <= wh::kOlsN) && pad >= h_max + 1;
   const size_t spec_bins = wh::kOlsN / 2 + 1;
   const size_t o_tspec = off; off += use_ols ? al(sizeof(double2) * spec_bins * n_bands) : 0;
   const size_t o_zspec = off; off += use_ols ? al(sizeof(double2) * spec_bins * (size_t)tile_off[B]) : 0;
@@ -1669,10 +1675,6 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   double* d_raw = reinterpret_cast<double*>(ws + o_raw);
   unsigned long long* d_live = reinterpret_cast<unsigned long long*>(ws + o_live);
   int32_t* d_hint = reinterpret_cast<int32_t*>(ws + o_hint);
-#ifndef WH_HV_RAWDET
-#define WH_HV_RAWDET 1  // raw candidates + detection in one transposed pass (hv_rawdet_kernel); 0: hv_raw_kernel + hv_detect_kernel
-#endif
-  const bool use_rawdet = WH_HV_RAWDET && use_ols;  // (its cursor hints come from the overlap-save walker)
   double* d_dc = reinterpret_cast<double*>(ws + o_dc);
   int32_t* d_dn = reinterpret_cast<int32_t*>(ws + o_dn);
   double* d_rf0 = reinterpret_cast<double*>(ws + o_rf0);

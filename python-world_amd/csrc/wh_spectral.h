@@ -11,7 +11,7 @@ namespace wh {
 __device__ __forceinline__ long long frame_centre(double pos, double fs) { return (long long)(pos * fs + 0.501) + 1; }
 
 // Sample of utterance (x, n) at 1-based index clamped to [1, n]  (cheaptrick.py:89, d4c.py:98).
-__device__ __forceinline__ double sample_clamped(const double* __restrict__ x, long long n, long long idx1) {
+__device__ __forceinline__ double sample_clamped(ckp<const double> WH_RESTRICT x, long long n, long long idx1) {
   idx1 = idx1 < 1 ? 1 : (idx1 > n ? n : idx1);
   return x[idx1 - 1];
 }
@@ -23,7 +23,7 @@ __device__ __forceinline__ double sample_clamped(const double* __restrict__ x, l
 // with SciPy's linear kernel slope*(x-x_lo)+y_lo and end-segment extrapolation; the result is
 // added to bins with f_k < f0.  Two barriers; p must be visible on entry, is visible on exit.
 template <int NT = WH_BLOCK>
-__device__ __forceinline__ void low_band_replica(double* p, double* tmp, int N, double fs, double f0, double reach) {
+__device__ __forceinline__ void low_band_replica(ckp<double> p, ckp<double> tmp, int N, double fs, double f0, double reach) {
   int nlow = (int)(reach / fs * N) + 2;  // count of bins with k/N*fs < reach (monotone in k)
   if (nlow > N) nlow = N;
   while (nlow > 0 && !(((double)(nlow - 1) / N * fs) < reach)) --nlow;
@@ -43,8 +43,11 @@ __device__ __forceinline__ void low_band_replica(double* p, double* tmp, int N, 
         const int lo = hi - 1;
         const double a_lo = f0 - ((double)(nlow - 1 - lo) / N * fs);
         const double a_hi = f0 - ((double)(nlow - 1 - hi) / N * fs);
-        const double y_lo = p[nlow - 1 - lo];
-        const double y_hi = p[nlow - 1 - hi];
+        // (bins above N/2 — reached only by an f0 within fs/N of fs/2 or beyond, which no estimator returns but a
+        // caller-supplied contour can hold — are the mirror images of the stored half: never an index past it)
+        const int i_lo = nlow - 1 - lo, i_hi = nlow - 1 - hi;
+        const double y_lo = p[i_lo <= N / 2 ? i_lo : N - i_lo];
+        const double y_hi = p[i_hi <= N / 2 ? i_hi : N - i_hi];
         const double slope = (y_hi - y_lo) / (a_hi - a_lo);
         tmp[kk] = slope * (fk - a_lo) + y_lo;
       }
@@ -54,7 +57,7 @@ __device__ __forceinline__ void low_band_replica(double* p, double* tmp, int N, 
   if (nlow >= 2) {
     for (int kk = threadIdx.x; kk < nlow; kk += NT) {
       const double fk = (double)kk / N * fs;
-      if (fk < f0) p[kk] = tmp[kk] + p[kk];
+      if (fk < f0 && kk <= N / 2) p[kk] = tmp[kk] + p[kk];
     }
   }
   sync<NT>();
@@ -71,17 +74,17 @@ __device__ __forceinline__ void low_band_replica(double* p, double* tmp, int N, 
 // barrier — not a 2048-element block prefix sum (four barriers and a shuffle scan) plus four interpolated
 // look-ups per bin; and it is free of the cancellation of differencing two large cumulative values.
 template <int NT, int N>
-__device__ __forceinline__ void fill_mirrored(const double* p_half, double* v, double fs) {
+__device__ __forceinline__ void fill_mirrored(ckp<const double> p_half, ckp<double> v, double fs) {
   const double df = fs / N;
   for (int i = threadIdx.x; i < N; i += NT) v[i] = p_half[i <= N / 2 ? i : N - i] * df;
   sync<NT>();
 }
 
 struct BandWindow {
-  const double* v;
+  ckp<const double> v;
   int mask, b_lo, b_hi;
   double f_lo, f_hi;
-  __device__ __forceinline__ void init(const double* vv, int n, double fs, double half) {
+  __device__ __forceinline__ void init(ckp<const double> vv, int n, double fs, double half) {
     v = vv;
     mask = n - 1;
     const double half_bin = fs / n / 2;

@@ -66,7 +66,19 @@ int wh_copy_mapped(wh_ctx* ctx, void* stream, void* dst, const void* src, size_t
 #define WH_FLAG_NOISE_SHORT 2      /* synthesis ran out of host-supplied noise samples */
 #define WH_FLAG_NO_PULSE 3         /* an utterance produced no pulse (reference asserts, synthesis.py:131) */
 #define WH_FLAG_PULSE_OVERFLOW 4   /* more pulses than the pulse capacity, or more overlap-add rows than its row region holds */
+#define WH_FLAG_OOB 5              /* bounds build only (wh_bounds_build() == 1): a kernel indexed outside a named buffer */
 int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16);
+/* The bounds build of the library (tools/build_variants.py ...:-DWH_BOUNDS=1; a test vehicle, never the shipped file):
+ * the covered kernels index their buffers through checked pointers (csrc/wh_device.h, wh::ckp); an access outside a
+ * buffer is redirected to its first element, counted, and the first one recorded.  wh_take_flags then reports
+ * WH_FLAG_OOB, and wh_bounds_last returns that record: out4 = {accesses out of range since the previous take, buffer
+ * tag (WH_CK_* of wh_device.h), element index, elements in the buffer}.  In a normal build wh_bounds_build() is 0, the
+ * flag is never set and the record is all zeros. */
+int wh_bounds_build(void);
+int wh_bounds_last(int64_t* out4);
+/* Positive control (bounds build; fails elsewhere): a kernel that stores one element past a four-element checked
+ * buffer — the next wh_take_flags must report WH_FLAG_OOB with the record {1, WH_CK_TABLE (7), 4, 4}. */
+int wh_bounds_selftest(wh_ctx* ctx, void* stream);
 /* The same flags without a host wait, for callers that keep a pipeline of batches in flight:
  *   wh_flags_post — enqueue (one 16-lane kernel on `stream`) the publication of the flags raised by everything before
  *     it on the stream to a pinned host word per flag, and clear them on the device (discard != 0: clear them

@@ -2,6 +2,7 @@
 #include <math.h>
 #include <string.h>
 
+#include "wh_device.h"
 #include "wh_host.h"
 
 namespace {
@@ -123,9 +124,20 @@ int persistent_scratch(wh_ctx* ctx, const std::string& slot, size_t bytes, void*
 }
 }  // namespace wh
 
+// bounds build: the per-translation-unit readers of the kernels' out-of-range records, and the last record taken
+static std::vector<int (*)(unsigned long long*)>& bounds_readers() {
+  static std::vector<int (*)(unsigned long long*)> v;
+  return v;
+}
+int wh::bounds_register(int (*reader)(unsigned long long*)) {
+  bounds_readers().push_back(reader);
+  return (int)bounds_readers().size();
+}
+static thread_local int64_t g_bounds_last[4] = {0, 0, 0, 0};
+
 extern "C" {
 
-int wh_version(void) { return 104; }
+int wh_version(void) { return 105; }
 const char* wh_last_error(void) { return g_last_error.c_str(); }
 
 int wh_device_count(int* count) {
@@ -223,6 +235,41 @@ static void drain_posted(wh_ctx* ctx, int32_t* h_flags16, bool accumulate) {
   }
 }
 
+
+int wh_bounds_build(void) {
+#if defined(WH_BOUNDS) && WH_BOUNDS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+#if defined(WH_BOUNDS) && WH_BOUNDS
+// positive control of the bounds build: four threads store into a four-element checked buffer, thread 3 one past its end
+static __global__ void bounds_selftest_kernel(double* buf) {
+  const wh::ckp<double> b = wh::ck_make(buf, 4, wh::WH_CK_TABLE);
+  b[threadIdx.x == 3 ? 4 : threadIdx.x] = 1.0;
+}
+#endif
+int wh_bounds_selftest(wh_ctx* ctx, void* stream) {
+  if (!ctx) return wh::fail_msg("wh_bounds_selftest", "null ctx");
+#if defined(WH_BOUNDS) && WH_BOUNDS
+  WH_ENTER(ctx);
+  if (int rc = wh::ws_reserve(ctx, 64)) return rc;
+  hipLaunchKernelGGL(bounds_selftest_kernel, dim3(1), dim3(4), 0, (hipStream_t)stream, reinterpret_cast<double*>(ctx->ws));
+  WH_LAUNCH_CHECK("bounds_selftest_kernel");
+  return 0;
+#else
+  return wh::fail_msg("wh_bounds_selftest", "not a bounds build");
+#endif
+}
+
+int wh_bounds_last(int64_t* out4) {
+  if (!out4) return wh::fail_msg("wh_bounds_last", "null argument");
+  for (int i = 0; i < 4; ++i) out4[i] = g_bounds_last[i];
+  return 0;
+}
+
 int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16) {
   if (!ctx || !h_flags16) return wh::fail_msg("wh_take_flags", "null argument");
   WH_ENTER(ctx);
@@ -231,6 +278,21 @@ int wh_take_flags(wh_ctx* ctx, void* stream, int32_t* h_flags16) {
   WH_CHECK(hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int32_t), st));
   WH_CHECK(hipStreamSynchronize(st));
   drain_posted(ctx, h_flags16, true);  // conditions an earlier wh_flags_post moved out of d_flags
+  // (bounds build: the records of every translation unit's kernels; the device-wide wait orders them behind kernels of
+  // other streams too — this is a test vehicle)
+  for (int i = 0; i < 4; ++i) g_bounds_last[i] = 0;
+  if (!bounds_readers().empty()) {
+    WH_CHECK(hipDeviceSynchronize());
+    for (auto rd : bounds_readers()) {
+      unsigned long long rec[4] = {0, 0, 0, 0};
+      if (rd(rec)) return wh::fail_msg("wh_take_flags", "reading a bounds record failed");
+      if (rec[0]) {
+        if (!g_bounds_last[0]) for (int i = 1; i < 4; ++i) g_bounds_last[i] = (int64_t)rec[i];
+        g_bounds_last[0] += (int64_t)rec[0];
+      }
+    }
+    if (g_bounds_last[0]) h_flags16[WH_FLAG_OOB] = 1;
+  }
   return 0;
 }
 

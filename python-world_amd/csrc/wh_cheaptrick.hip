@@ -33,16 +33,19 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
   constexpr int FT = ft_ct(N);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int K = N / 2 + 1;
-  double2* zb = reinterpret_cast<double2*>(smem);   // N/2+1 complex = the N-sample real buffer (+1 bin)
-  double* zr = reinterpret_cast<double*>(smem);     // same memory viewed as reals; also the mirrored power spectrum
-  double* aux = zr + (N + 2);                       // K+1 reals
-  double* scratch = aux + (K + 1);                  // 32 doubles
+  // (wh::ckp<T> is T* in every shipped build; the bounds build checks each access against the range named here)
+  const wh::ckp<double> lds_all = wh::ck_make(reinterpret_cast<double*>(smem), (N + 2) + (K + 1) + 32, wh::WH_CK_LDS_OTHER);
+  const wh::ckp<double> zr = wh::ck_sub(lds_all, 0, N + 2, wh::WH_CK_LDS_MAIN);  // the N-sample real buffer (+1 bin); also the mirrored power spectrum
+  const wh::ckp<double2> zb = wh::ck_as<double2>(zr);                        // the same memory as N/2+1 complex
+  const wh::ckp<double> aux = wh::ck_sub(lds_all, N + 2, K + 1, wh::WH_CK_LDS_AUX);                // K+1 reals
+  const wh::ckp<double> scratch = wh::ck_sub(lds_all, (N + 2) + (K + 1), 32, wh::WH_CK_LDS_SCRATCH);  // 32 doubles
+  const wh::ckp<const double2> tw = wh::ck_make(tw_base, 2 * WH_MAX_FFT, wh::WH_CK_TWIDDLE);  // the table of size n at offset n
 
   const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
   if (f >= n_frames) return;
   const int u = frame_utt[f];
-  const double* xu = x + x_off[u];
   const long long xn = x_off[u + 1] - x_off[u];
+  const wh::ckp<const double> xu = wh::ck_make(x + x_off[u], xn, wh::WH_CK_WAVEFORM);
   const double pos = tp[f];
   double f0 = f0_io[f];
   // cheaptrick.py:26-27,32-33 — default 500 Hz on unvoiced / too-low frames, written back (Q6)
@@ -117,8 +120,8 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
 
   // ---- power spectrum (cheaptrick.py:64-75): real FFT through an N/2-point complex transform -------
   if (ps_out) {  // the caller wants the complex pitch-synchronous spectrum ('ps spectrogram'): materialise it
-    wh::rfft_lds<N, FT>(zb, tw_base);
-    double2* o = ps_out + f * (int64_t)N;
+    wh::rfft_lds<N, FT>(zb, tw);
+    const wh::ckp<double2> o = wh::ck_make(ps_out + f * (int64_t)N, N, wh::WH_CK_OUT);
     for (int k = threadIdx.x; k < N; k += FT) {
       const double2 z = zb[k <= N / 2 ? k : N - k];
       o[k] = k <= N / 2 ? z : make_double2(z.x, -z.y);
@@ -129,8 +132,8 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
     }
   } else {  // only its power is needed: the post-pass of the real transform goes straight to |X|^2 (no store of X)
     constexpr int M = N / 2;
-    wh::fft_lds<M, false, FT>(zb, tw_base + M);
-    const double2* __restrict__ wtw = tw_base + N;
+    wh::fft_lds<M, false, FT>(zb, tw + M);
+    const wh::ckp<const double2> WH_RESTRICT wtw = tw + N;
     for (int k = threadIdx.x; k <= M / 2; k += FT) {
       const double2 a = zb[k], b = zb[M - k];
       if (k == 0) {
@@ -201,9 +204,9 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
 #if defined(WH_CT_ABLATE_T) && WH_CT_ABLATE_T
     wh::sync<FT>();  // TIMING EXPERIMENT ONLY (wrong results): one of the two lifter transforms costs nothing — the upper bound
 #else                // of halving both (real-even data: DCT-I through quarter-size transforms)
-    wh::fft_lds<M, false, FT>(zb, tw_base + M);  // (its barriers also complete the lifter table for the loop below)
+    wh::fft_lds<M, false, FT>(zb, tw + M);  // (its barriers also complete the lifter table for the loop below)
 #endif
-    const double2* __restrict__ wtw = tw_base + N;
+    const wh::ckp<const double2> WH_RESTRICT wtw = tw + N;
     for (int k = threadIdx.x; k <= M / 2; k += FT) {
       const double2 a = zb[k], b = zb[M - k];
       const double2 wk = wh::ldg2(wtw + k);
@@ -224,9 +227,9 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
       if (k != 0) zb[M - k] = make_double2(er + oi, orr);
     }
     wh::sync<FT>();
-    wh::fft_lds<M, true, FT>(zb, tw_base + M);
+    wh::fft_lds<M, true, FT>(zb, tw + M);
   }
-  double* o = spec_out + f * (int64_t)K;
+  const wh::ckp<double> o = wh::ck_make(spec_out + f * (int64_t)K, K, wh::WH_CK_OUT);
   for (int k = threadIdx.x; k < K; k += FT) o[k] = exp(zr[k] * (1.0 / N));  // N is a power of two: exact
 }
 

@@ -120,6 +120,15 @@ __host__ __device__ __forceinline__ ckp<U> ck_as(ckp<T> p) {
 }
 template <class T>
 __host__ __device__ __forceinline__ T* ck_raw(ckp<T> p) { return p.p; }
+// host side: this translation unit's record, read and cleared (registered with wh_api.hip at load time)
+int bounds_register(int (*reader)(unsigned long long*));
+static int bounds_reader_tu(unsigned long long* out4) {
+  const unsigned long long z[4] = {0ull, 0ull, 0ull, 0ull};
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_oob), sizeof z) != hipSuccess) return 1;
+  if (out4[0] && hipMemcpyToSymbol(HIP_SYMBOL(g_oob), z, sizeof z) != hipSuccess) return 1;
+  return 0;
+}
+static const int bounds_registered_tu = bounds_register(&bounds_reader_tu);
 __device__ __forceinline__ double2 ldg2(const ckp<const double2>& p) { return ldg2(static_cast<const double2*>(p.at(0))); }
 __device__ __forceinline__ double ldg(const ckp<const double>& p) { return ldg(static_cast<const double*>(p.at(0))); }
 #else

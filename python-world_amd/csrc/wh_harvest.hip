@@ -822,10 +822,10 @@ __device__ __forceinline__ bool rotation_path_ok(bool wtab, double a0, double a0
 // window length and harmonic bins (hv_refine_kernel: the seven overlapped copies of a slowly moving pitch track mostly
 // do) — the spectra at the harmonic bins are the same for all of them, only the score looks at the candidate itself.
 template <bool TWL, bool WTAB, int RL, class Members>
-__device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int64_t ybase, int64_t ylen, double fs,
+__device__ __forceinline__ void hv_refine_row(wh::ckp<const double> WH_RESTRICT yl, int64_t ybase, int64_t ylen, double fs,
                                               double t0, double f0c, int pkey, double f0_floor, double f0_ceil,
                                               const double2* __restrict__ tw_base, const char* tw_lds, int tw_n,
-                                              const double2* __restrict__ rot_tab, const double2* __restrict__ win_tab,
+                                              wh::ckp<const double2> WH_RESTRICT rot_tab, wh::ckp<const double2> WH_RESTRICT win_tab,
                                               Members members) {
   static_assert(WTAB || RL == 16, "the rotation path exchanges window values with 16-lane row rotates");
   const int l16 = threadIdx.x & (RL - 1);  // lane within the candidate's group
@@ -843,6 +843,9 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
   const int tw_sh = (TWL ? (__ffs(tw_n) - __ffs(nfft)) : 0) + 4;  // table subsampling, and elements -> bytes
   auto twiddle = [&](int byte_off) -> double2 {
     if constexpr (TWL) {  // the table sits at LDS address 0 (checked by the kernel): the offset IS the address
+#if WH_BOUNDS
+      if ((unsigned)byte_off + 16u > (unsigned)tw_n * 16u || (byte_off & 15)) wh::oob_report(wh::WH_CK_TWIDDLE, byte_off >> 4, tw_n);
+#endif
       typedef double v2d __attribute__((ext_vector_type(2)));
       typedef const v2d __attribute__((address_space(3))) * lds_tw_t;
       const v2d w = *(lds_tw_t)(size_t)(uint32_t)byte_off;
@@ -920,7 +923,7 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
     // Row hwl of the table has a zero entry in front of and behind its 2*hwl + 1 pairs, and a lane past the window's end
     // (m > hwl in the last iteration) reads those: no predicate and no select inside the loop; the staged signal
     // replicates the utterance's edge samples, so the sample index needs no clamp either.
-    const double2* wt = win_tab + hwl * (hwl + 2) + (hwl + 1);  // the centre pair
+    const wh::ckp<const double2> wt = win_tab + (hwl * (hwl + 2) + (hwl + 1));  // the centre pair
     int tix[6], tstep[6];  // byte offsets into the twiddle table (see the rotation path below)
     const int tmask = ((nfft - 1) << tw_sh);
 #pragma unroll
@@ -929,7 +932,7 @@ __device__ __forceinline__ void hv_refine_row(const double* __restrict__ yl, int
       tstep[h] = ((bins[h] * RL) & (nfft - 1)) << tw_sh;
     }
     const int n_it = (hwl + RL - 1) / RL;
-    const double* yc = yl + ((int)((int64_t)a0 - 1 - ybase) + hwl);  // the centre sample in the staged signal
+    const wh::ckp<const double> yc = yl + ((int)((int64_t)a0 - 1 - ybase) + hwl);  // the centre sample in the staged signal
     if (l16 == 0) {  // the centre sample: cos = 1 for every bin
       const double2 wc = wt[0];
       const double smp = yc[0];
@@ -1165,18 +1168,24 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
   // LDS: the twiddle table of the largest transform length first (tw_n points; TWL false: none, the global tables are
   // read) — every sample of every refinement gathers 6 twiddles at scattered indices, LDS serves those, the L1 does
   // not — then the staged signal around the block's frames.
-  double2* twl = reinterpret_cast<double2*>(smem);
+  // (wh::ckp<T>: T* in every shipped build, range-checked in the bounds build — wh_device.h)
+  const wh::ckp<double2> twl = wh::ck_make(reinterpret_cast<double2*>(smem), TWL ? tw_n : 0, wh::WH_CK_TWIDDLE);
   if (TWL && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
-  double* yl = reinterpret_cast<double*>(smem + (TWL ? sizeof(double2) * (size_t)tw_n : 0));
   constexpr int kItems = refine_item_cap(WTAB);                // (>= kRows: a single frame always fits)
-  double* cl_val = yl + ((seglen + 1) & ~1);                 // kItems
-  int* cl_meta = reinterpret_cast<int*>(cl_val + kItems);    // kItems
-  int* order = cl_meta + kItems;                             // kItems
-  int* key_s = order + kItems;                               // kItems: packed geometry of an item (refine_pack)
-  int* bucket = key_s + kItems;                              // kBuckets
+  const int seg_pad = (seglen + 1) & ~1;
+  double* yl_raw = reinterpret_cast<double*>(smem + (TWL ? sizeof(double2) * (size_t)tw_n : 0));
+  const wh::ckp<double> yl = wh::ck_make(yl_raw, seg_pad, wh::WH_CK_LDS_MAIN);
+  const wh::ckp<double> cl_val = wh::ck_make(yl_raw + seg_pad, kItems, wh::WH_CK_LDS_AUX);  // kItems
+  int* ints_raw = reinterpret_cast<int*>(yl_raw + seg_pad + kItems);
+  const wh::ckp<int> cl_meta = wh::ck_make(ints_raw, kItems, wh::WH_CK_LDS_OTHER);               // kItems
+  const wh::ckp<int> order = wh::ck_make(ints_raw + kItems, kItems, wh::WH_CK_LDS_OTHER);        // kItems
+  const wh::ckp<int> key_s = wh::ck_make(ints_raw + 2 * kItems, kItems, wh::WH_CK_LDS_OTHER);    // kItems: packed geometry of an item (refine_pack)
+  const wh::ckp<int> bucket = wh::ck_make(ints_raw + 3 * kItems, kBuckets + 1, wh::WH_CK_LDS_SCRATCH);  // kBuckets (+ the class count)
   int& cl_n = bucket[kBuckets];
-  uint32_t* nzmask = reinterpret_cast<uint32_t*>(bucket + kBuckets + 1);  // [kFramesPerBlock][4]: rows of a frame that hold a candidate
-  int* foff = reinterpret_cast<int*>(nzmask + kFramesPerBlock * 4);       // [kFramesPerBlock + 1]: first list slot of a frame
+  const wh::ckp<uint32_t> nzmask = wh::ck_make(reinterpret_cast<uint32_t*>(ints_raw + 3 * kItems + kBuckets + 1), kFramesPerBlock * 4,
+                                               wh::WH_CK_LDS_SCRATCH);  // [kFramesPerBlock][4]: rows of a frame that hold a candidate
+  const wh::ckp<int> foff = wh::ck_make(ints_raw + 3 * kItems + kBuckets + 1 + kFramesPerBlock * 4, kFramesPerBlock + 1,
+                                        wh::WH_CK_LDS_SCRATCH);  // [kFramesPerBlock + 1]: first list slot of a frame
   for (int i = threadIdx.x; i < kFramesPerBlock * 4; i += 256) nzmask[i] = 0;
   if (TWL)
     for (int i = threadIdx.x; i < tw_n; i += 256) twl[i] = tw_base[tw_n + i];
@@ -1184,7 +1193,14 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
   // (may be negative: the staged signal replicates the utterance's first and last sample beyond its ends, which is what
   // the reference's index clamp reads there, harvest.py:179)
   const int64_t ybase = centre0 - hmax - 3;
-  const double* yu = y + m.y_off;
+  const wh::ckp<const double> yu = wh::ck_make(y + m.y_off, m.ylen, wh::WH_CK_WAVEFORM);
+  // the utterance's share of the global arrays: candidate slots in, result pool and list heads out, the window tables
+  const wh::ckp<const double> dc_u = wh::ck_make(dc + m.f1_off * kMaxC, m.nf1 * kMaxC, wh::WH_CK_IN) - m.f1_off * kMaxC;
+  const wh::ckp<double> rf0_u = wh::ck_make(rf0 + m.f1_off * kRows, m.nf1 * kRows, wh::WH_CK_OUT) - m.f1_off * kRows;
+  const wh::ckp<double> rsc_u = wh::ck_make(rsc + m.f1_off * kRows, m.nf1 * kRows, wh::WH_CK_OUT) - m.f1_off * kRows;
+  const wh::ckp<int64_t> lst_u = wh::ck_make(lst + m.f1_off, m.nf1, wh::WH_CK_OUT) - m.f1_off;
+  const wh::ckp<const double2> win_ck = wh::ck_make(win_tab, win_tab ? (long long)(hmax + 2) * (hmax + 4) : 0, wh::WH_CK_TABLE);
+  const wh::ckp<const double2> rot_ck = wh::ck_make(rot_tab, hmax + 2, wh::WH_CK_TABLE);
   for (int i = threadIdx.x; i < seglen; i += 256) {
     const int64_t g = ybase + i;
     yl[i] = yu[g < 0 ? 0 : (g > m.ylen - 1 ? m.ylen - 1 : g)];
@@ -1208,7 +1224,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
     const int fl = qc / kRows, e = qc % kRows;
     int64_t src = f_first + fl + (e / kMaxC - 3);
     src = src < 0 ? 0 : (src > m.nf1 - 1 ? m.nf1 - 1 : src);
-    cv[it] = dc[(m.f1_off + src) * kMaxC + e % kMaxC];
+    cv[it] = dc_u[(m.f1_off + src) * kMaxC + e % kMaxC];
   }
   // The work list is written in LIST-SLOT order (the rank of a row among its frame's rows: the order the results are
   // stored in), so a frame's items are contiguous and an item's index is its result slot: a first pass marks the rows
@@ -1224,7 +1240,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
     if (f >= m.nf1) continue;
     const int64_t src = f + (e / kMaxC - 3);
     double cand = (src >= 0 && src < m.nf1) ? cv[it] : 0.0;
-    if (e == 0 && f < 3) cand = dc[(m.f1_off + f) * kMaxC + 6];  // stray seeding of row 0 (harvest.py:119)
+    if (e == 0 && f < 3) cand = dc_u[(m.f1_off + f) * kMaxC + 6];  // stray seeding of row 0 (harvest.py:119)
     cv[it] = cand;
     if (cand != 0.0 && ceil(3 * fs / cand / 2) <= (double)hmax) {
       live_q[it] = true;
@@ -1250,7 +1266,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
     }
     if (fl < kFramesPerBlock) {
       foff[fl] = incl - c;
-      if (f_first + fl < m.nf1) lst[m.f1_off + f_first + fl] = ((pool_base + (incl - c)) << 8) | (int64_t)c;
+      if (f_first + fl < m.nf1) lst_u[m.f1_off + f_first + fl] = ((pool_base + (incl - c)) << 8) | (int64_t)c;
     }
     if (fl == 63) foff[kFramesPerBlock] = incl;
   }
@@ -1266,7 +1282,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
     return fb;
   };
   auto slot_of = [&](int fl, int e, int s0) {
-    const uint32_t* mw = nzmask + fl * 4;
+    const wh::ckp<const uint32_t> mw = nzmask + fl * 4;
     int slot = foff[fl] - s0 + __popc(mw[e >> 5] & ((1u << (e & 31)) - 1u));  // rank of row e among the round's rows
     for (int w = 0; w < (e >> 5); ++w) slot += __popc(mw[w]);
     return slot;
@@ -1376,15 +1392,15 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
         const int src = order[it];
         const int64_t f = f_first + (cl_meta[src] & 31);
         hv_refine_row<TWL, WTAB, RL>(
-            yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], key_s[src], f0_floor, f0_ceil, tw_base, smem, tw_n, rot_tab, win_tab,
+            yl, ybase, m.ylen, fs, (double)f * 1 / 1000, cl_val[src], key_s[src], f0_floor, f0_ceil, tw_base, smem, tw_n, rot_ck, win_ck,
             [&](auto eval) {
               int p = src;
               while (true) {
                 double r0, r1;
                 eval(cl_val[p], &r0, &r1);
                 if ((threadIdx.x & (RL - 1)) == 0) {
-                  rf0[pool_base + s0 + p] = r0;  // (an item's index is its slot in the round's part of the block's pool region)
-                  rsc[pool_base + s0 + p] = r1;
+                  rf0_u[pool_base + s0 + p] = r0;  // (an item's index is its slot in the round's part of the block's pool region)
+                  rsc_u[pool_base + s0 + p] = r1;
                 }
                 const int nx = (cl_meta[p] >> 17) & 0x7ff;
                 if (!nx) break;
@@ -1402,7 +1418,7 @@ __global__ __launch_bounds__(256, WTAB ? WH_HV_MINW : 1) void hv_refine_kernel(c
       if (fl < fa || fl >= fb || !((nzmask[fl * 4 + (e >> 5)] >> (e & 31)) & 1u)) continue;
       const int64_t f = f_first + fl;
       const int64_t src = f + (e / kMaxC - 3);
-      const double cand = (e == 0 && f < 3) ? dc[(m.f1_off + f) * kMaxC + 6] : dc[(m.f1_off + src) * kMaxC + e % kMaxC];
+      const double cand = (e == 0 && f < 3) ? dc_u[(m.f1_off + f) * kMaxC + 6] : dc_u[(m.f1_off + src) * kMaxC + e % kMaxC];
       const int slot = slot_of(fl, e, foff[fa]);
       cl_val[slot] = cand;
       cl_meta[slot] = fl;

@@ -67,6 +67,8 @@ struct wh_batch {
 #define WH_MAX_FFT 8192
 
 namespace wh {
+// bounds build: every translation unit registers a reader of its kernels' out-of-range record (wh_device.h)
+int bounds_register(int (*reader)(unsigned long long*));
 void set_error(const std::string& msg);
 int fail(const char* where, hipError_t e);
 int fail_msg(const char* where, const char* msg);

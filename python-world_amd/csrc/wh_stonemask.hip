@@ -197,9 +197,9 @@ __device__ __forceinline__ double group_sum(double v) {  // over the kSmLanes la
 
 // X[b], D[b] for NB bins, this lane's share (j = lane, lane + 4, ...), then summed over the group
 template <int NB>
-__device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long long xn, double t0, double fs, int hwl, int L,
-                                         const double2* __restrict__ wt, const double* __restrict__ qt, int nfft,
-                                         int tw_sh, const int* bins, double2* X, double2* D) {
+__device__ __forceinline__ void tab_bins(wh::ckp<const double> WH_RESTRICT xu, long long xn, double t0, double fs, int hwl, int L,
+                                         wh::ckp<const double2> WH_RESTRICT wt, wh::ckp<const double> WH_RESTRICT qt, int nfft,
+                                         int tw_sh, const int* bins, double2* X, double2* D, int tw_n) {
   const int lg = threadIdx.x & (kSmLanes - 1);
   int tix[NB], tstep[NB];
   const int tmask = (nfft - 1) << tw_sh;
@@ -235,6 +235,9 @@ __device__ __forceinline__ void tab_bins(const double* __restrict__ xu, long lon
 #pragma unroll
     for (int h = 0; h < NB; ++h) {
       typedef double v2d __attribute__((ext_vector_type(2)));
+#if WH_BOUNDS
+      if ((unsigned)tix[h] + 16u > (unsigned)tw_n * 16u || (tix[h] & 15)) wh::oob_report(wh::WH_CK_TWIDDLE, tix[h] >> 4, tw_n);
+#endif
       const v2d w = *(const v2d __attribute__((address_space(3)))*)(size_t)(uint32_t)tix[h];  // table at LDS address 0
       X[h].x = fma(a, w.x, X[h].x);
       X[h].y = fma(a, w.y, X[h].y);
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256, WH_SM_MINW) void stonemask_tab_kernel(
     int tw_n, uint8_t* __restrict__ todo, long long n_frames) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // the twiddle table of tw_n points, at LDS address 0
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
-  double2* twl = reinterpret_cast<double2*>(smem);
+  const wh::ckp<double2> twl = wh::ck_make(reinterpret_cast<double2*>(smem), tw_n, wh::WH_CK_TWIDDLE);  // (T* unless WH_BOUNDS)
   for (int i = threadIdx.x; i < tw_n; i += 256) twl[i] = tw_base[tw_n + i];
   __syncthreads();
   constexpr int kPerBlock = 256 / kSmLanes;
@@ -282,13 +285,13 @@ __global__ __launch_bounds__(256, WH_SM_MINW) void stonemask_tab_kernel(
   if (live && f0i == 0.0 && lg == 0) f0_out[f] = f0i;
   double hwl_d = 1.0, t0 = 0.0;
   long long xn = 1;
-  const double* xu = x;
+  wh::ckp<const double> xu = wh::ck_make(x, 1, wh::WH_CK_WAVEFORM);
   if (work) {
     hwl_d = ceil(3 * fs / f0i / 2);
     t0 = tp[f];
     const int u = frame_utt[f];
-    xu = x + x_off[u];
     xn = x_off[u + 1] - x_off[u];
+    xu = wh::ck_make(x + x_off[u], xn, wh::WH_CK_WAVEFORM);
     // the table holds windows up to kmax; every tap must sit at a positive time (the quantisation moves a tap by less
     // than a sample)
     if (!(hwl_d <= (double)kmax) || !(t0 * fs - hwl_d - 2.0 > 0.0)) {
@@ -305,8 +308,9 @@ __global__ __launch_bounds__(256, WH_SM_MINW) void stonemask_tab_kernel(
     nfft = 1 << (e + 1);
   }
   const int tw_sh = (__ffs(tw_n) - __ffs(nfft)) + 4;  // table subsampling, and elements -> bytes
-  const double2* wt = win_tab + (long long)hwl * hwl;
-  const double* qt = qtime + kmax;
+  // row hwl of the window table: 2 hwl + 1 pairs at offset hwl^2 ((kmax + 1)^2 pairs in all); the tap times: 2 kmax + 1
+  const wh::ckp<const double2> wt = wh::ck_make(win_tab, (long long)(kmax + 1) * (kmax + 1), wh::WH_CK_TABLE) + (long long)hwl * hwl;
+  const wh::ckp<const double> qt = wh::ck_make(qtime, 2 * kmax + 1, wh::WH_CK_TABLE) + kmax;
   int bins[6];
   double2 X[6], D[6];
   auto weighted = [&](int nbins) -> double {  // lane l evaluates bins l and l + 4, the group adds up
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256, WH_SM_MINW) void stonemask_tab_kernel(
 #pragma unroll
   for (int h = 0; h < 6; ++h) bins[h] = 0;
   for (int h = 0; h < 2; ++h) bins[h] = (int)(f0i * nfft / fs * (h + 1) + 0.5);
-  tab_bins<2>(xu, xn, t0, fs, hwl, L, wt, qt, nfft, tw_sh, bins, X, D);
+  tab_bins<2>(xu, xn, t0, fs, hwl, L, wt, qt, nfft, tw_sh, bins, X, D, tw_n);
   const double f_first = weighted(2);
   double refined = 0.0;
   bool second = work && !(f_first < 0);
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256, WH_SM_MINW) void stonemask_tab_kernel(
     }
   }
   // (the group is uniform in `second`: every lane derived it from the same sums)
-  tab_bins<6>(xu, xn, t0, fs, hwl, second ? L : 0, wt, qt, nfft, tw_sh, bins, X, D);
+  tab_bins<6>(xu, xn, t0, fs, hwl, second ? L : 0, wt, qt, nfft, tw_sh, bins, X, D, tw_n);
   if (second) refined = weighted(6);
   else (void)weighted(6);
   if (work) {

@@ -166,8 +166,9 @@ __device__ __forceinline__ int wave_min_int(int v) {
 // All integer quantities (r_j, their prefix sums, V_j < 2^53) are carried as integer-valued doubles: exact, and
 // the whole pass stays on the FP64 pipe.
 // carry_in: the running sum in front of p[0] (0 at the start of a sequence); returns the running sum behind p[n-1].
-__device__ __forceinline__ double exact_cumsum_block(double* __restrict__ p, int64_t n, double* xin, double* xout,
-                                                     double* scr, double carry_in = 0.0) {
+// (wh::ckp<T>: T* in every shipped build, a range-checked pointer in the bounds build — wh_device.h)
+__device__ __forceinline__ double exact_cumsum_block(wh::ckp<double> WH_RESTRICT p, int64_t n, wh::ckp<double> xin, wh::ckp<double> xout,
+                                                     wh::ckp<double> scr, double carry_in = 0.0) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   constexpr double kTop = 0x1p53;  // V reaches this: the sum has left the binade
@@ -236,7 +237,7 @@ __device__ __forceinline__ double exact_cumsum_block(double* __restrict__ p, int
           if (idx >= s && idx < cnt && before + r[j] >= kTop && first_x == kXTile) first_x = idx;
         }
         const int mine = wave_min_int(first_tie < first_x ? first_tie : first_x);
-        int* iscr = reinterpret_cast<int*>(scr + 16);
+        const wh::ckp<int> iscr = wh::ck_as<int>(scr + 16);
         if (lane == 0) iscr[w] = mine;
         __syncthreads();
         jstop = iscr[0];
@@ -274,7 +275,9 @@ __device__ __forceinline__ double exact_cumsum_block(double* __restrict__ p, int
 __global__ __launch_bounds__(kXThreads) void exact_cumsum_pairs_kernel(double* __restrict__ data,
                                                                        const int64_t* __restrict__ pairs) {
   __shared__ double xin[kXLds], xout[kXLds], scr[32];
-  exact_cumsum_block(data + pairs[2 * blockIdx.x], pairs[2 * blockIdx.x + 1] - pairs[2 * blockIdx.x], xin, xout, scr);
+  const int64_t n = pairs[2 * blockIdx.x + 1] - pairs[2 * blockIdx.x];
+  exact_cumsum_block(wh::ck_make(data + pairs[2 * blockIdx.x], n, wh::WH_CK_OUT), n, wh::ck_make(xin, kXLds, wh::WH_CK_LDS_MAIN),
+                     wh::ck_make(xout, kXLds, wh::WH_CK_LDS_AUX), wh::ck_make(scr, 32, wh::WH_CK_LDS_SCRATCH));
 }
 
 // ---- the same scan, tile-parallel -----------------------------------------------------------------------------------
@@ -419,7 +422,8 @@ __global__ __launch_bounds__(kXThreads) void xs_carry_kernel(double* __restrict_
     if (stopped) {
       const int64_t begin = pairs[2 * sq] + (t - t0) * kXTile;
       const int64_t end = begin + kXTile < pairs[2 * sq + 1] ? begin + kXTile : pairs[2 * sq + 1];
-      a = exact_cumsum_block(data + begin, end - begin, xin, xout, scr, a);
+      a = exact_cumsum_block(wh::ck_make(data + begin, end - begin, wh::WH_CK_OUT), end - begin, wh::ck_make(xin, kXLds, wh::WH_CK_LDS_MAIN),
+                             wh::ck_make(xout, kXLds, wh::WH_CK_LDS_AUX), wh::ck_make(scr, 32, wh::WH_CK_LDS_SCRATCH), a);
       if (threadIdx.x == 0) tiles[t].flag = 2;
       ++t;
     }

@@ -45,6 +45,9 @@ SIGNATURES = {
     "wh_profile_collect": (_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_float), _int,
                                   ctypes.POINTER(_int)]),
     "wh_take_flags": (_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
+    "wh_bounds_build": (_int, []),
+    "wh_bounds_last": (_int, [_c_i64p]),
+    "wh_bounds_selftest": (_int, [_vp, _vp]),
     "wh_flags_post": (_int, [_vp, _vp, _int]),
     "wh_flags_poll": (_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
     "wh_dio": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _int,
@@ -88,7 +91,7 @@ class WorldHipError(RuntimeError):
 
 
 # WH_FLAG_* of include/world_hip.h: sticky conditions raised by kernels instead of failing silently
-FLAG_STONEMASK_WINDOW, FLAG_EVENT_OVERFLOW, FLAG_NOISE_SHORT, FLAG_NO_PULSE, FLAG_PULSE_OVERFLOW = range(5)
+FLAG_STONEMASK_WINDOW, FLAG_EVENT_OVERFLOW, FLAG_NOISE_SHORT, FLAG_NO_PULSE, FLAG_PULSE_OVERFLOW, FLAG_OOB = range(6)
 FLAG_MESSAGES = {
     FLAG_STONEMASK_WINDOW: "StoneMask: a frame's f0 needs a longer analysis window than the one sized from min_f0 "
                            "(frame left unrefined)",
@@ -97,7 +100,20 @@ FLAG_MESSAGES = {
     FLAG_NO_PULSE: "an utterance produced no pulse (the reference asserts, world/synthesis.py:131)",
     FLAG_PULSE_OVERFLOW: "more pulses (or overlap-add rows) than pulse_cap provides for: trailing pulses / runs were dropped "
                          "(pass pulse_cap=world.synthesis.safe_pulse_cap(ny))",
+    FLAG_OOB: "bounds build: a kernel indexed outside one of its buffers (world._hip.bounds_last() has the record)",
 }
+
+
+def bounds_build():
+    """True when the loaded library is the bounds build (tools/build_variants.py ...:-DWH_BOUNDS=1)."""
+    return bool(load_library().wh_bounds_build())
+
+
+def bounds_last():
+    """(count, buffer tag, element index, buffer size) of the out-of-range accesses the last take_flags() found."""
+    buf = (ctypes.c_int64 * 4)()
+    check(load_library().wh_bounds_last(buf))
+    return tuple(int(v) for v in buf)
 
 
 def load_library():

@@ -1,0 +1,78 @@
+"""Helper of tests/test_hip_bounds.py: runs in a process whose WH_LIB is the BOUNDS build of the library
+(tools/build_variants.py bounds=...:-DWH_BOUNDS=1; world/_hip.py loads WH_LIB).  Prints one JSON line."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "python-world_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def rel_rms(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2) / np.mean(b ** 2)))
+
+
+def main():
+    from world import _hip
+    from world._synthetic import synth_utterance
+    from world.batch import WorldBatch
+    from world.cheaptrick import cheaptrick
+
+    out = {"bounds_build": _hip.bounds_build()}
+    rt = _hip.Runtime.get()
+    # ---- positive control: the checker sees a store one past a four-element buffer -----------------------------------
+    _hip.check(rt.lib.wh_bounds_selftest(rt.ctx, rt.stream()))
+    flags = rt.take_flags()
+    out["selftest_flag"] = flags[_hip.FLAG_OOB]
+    out["selftest_record"] = list(_hip.bounds_last())
+    out["clean_after"] = rt.take_flags()[_hip.FLAG_OOB], list(_hip.bounds_last())
+    # ---- the CheapTrick fixtures (reference outputs) -----------------------------------------------------------------
+    fix = {}
+    for tag in ("syn16k", "syn48k"):
+        g = dict(np.load(os.path.join(ROOT, "tests", "golden", "golden_%s.npz" % tag)))
+        fs = int(g["fs"])
+        src = {"f0": g["stonemask_f0"].copy(), "vuv": g["dio_vuv"].copy(), "temporal_positions": g["tp"].copy()}
+        res = cheaptrick(g["x"], fs, src)
+        fix[tag] = {"rel_rms": rel_rms(res["spectrogram"], g["ct_spectrogram"]),
+                    "flag": rt.take_flags()[_hip.FLAG_OOB], "record": list(_hip.bounds_last())}
+    out["fixtures"] = fix
+    # ---- f0 sweep: constant contours from far below the floor to beyond fs/2, three rates, transforms 512 ... 4096 ----
+    sweep = []
+    for fs, fft in ((16000, 1024), (16000, 512), (22050, 1024), (48000, 2048), (96000, 4096)):
+        x = synth_utterance(5, fs, 0.6)
+        n = int(1000 * len(x) / fs / 5 + 1)
+        tp = np.arange(n) * 0.005
+        for f0 in (1.0, 20.0, 47.0, 70.0, 71.0, 123.4, 250.0, 499.9, 800.0, 1500.0, 0.45 * fs, 0.4999 * fs, 0.5 * fs,
+                   0.75 * fs, 1.5 * fs):
+            src = {"f0": np.full(n, f0), "vuv": np.ones(n), "temporal_positions": tp.copy()}
+            res = cheaptrick(x, fs, src, fft_size=fft)
+            fl = rt.take_flags()
+            sweep.append({"fs": fs, "fft": fft, "f0": f0, "flag": fl[_hip.FLAG_OOB], "record": list(_hip.bounds_last()),
+                          "finite": bool(np.all(np.isfinite(res["spectrogram"])))})
+    out["sweep_bad"] = [s for s in sweep if s["flag"] or not s["finite"]]
+    out["sweep_cases"] = len(sweep)
+    # ---- config 2 at full size: 64 x 10 s through every stage of the DIO path + decode, Harvest + Requiem on 8 ----------
+    xs = [synth_utterance(u, 16000, 10.0) for u in range(64)]
+    wb = WorldBatch()
+    enc = wb.encode(xs, 16000, f0_method="dio", check=False)
+    y, _ = wb.decode_device(enc, seed=3, check=False)
+    out["config2_flags"] = wb.rt.take_flags()
+    out["config2_record"] = list(_hip.bounds_last())
+    enc = wb.encode(xs[:8], 16000, f0_method="harvest", is_requiem=True, check=False)
+    y, _ = wb.decode_device(enc, check=False)
+    out["harvest_flags"] = wb.rt.take_flags()
+    out["harvest_record"] = list(_hip.bounds_last())
+    x48 = [synth_utterance(75, 48000, 3.0)]
+    enc = wb.encode(x48, 48000, f0_method="harvest", check=False)
+    y, _ = wb.decode_device(enc, seed=1, check=False)
+    out["cfg5_flags"] = wb.rt.take_flags()
+    out["cfg5_record"] = list(_hip.bounds_last())
+    print("BOUNDS_JSON " + json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

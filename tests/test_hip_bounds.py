@@ -1,0 +1,78 @@
+"""GPU: the BOUNDS build.  The image cannot run device AddressSanitizer, and round 5's attempt left
+an abort of the instrumented cheaptrick_kernel<1024> that could not be read.  The deterministic replacement is a build of
+the library in which the covered kernels index every buffer through checked pointers (csrc/wh_device.h, wh::ckp: T* in
+the shipped build, a range-carrying pointer under -DWH_BOUNDS=1): an access outside a named buffer is recorded (buffer,
+index, size), reported as WH_FLAG_OOB by wh_take_flags and redirected, so the run completes and says what happened.
+Covered: cheaptrick_kernel (LDS buffers, waveform gather, twiddle table, output rows), wh_spectral.h (low-band replica,
+mirrored fill, sliding band windows), every transform helper (fft_lds / rfft_lds / irfft_lds and their passes), the block
+reductions, and — the kernels the sanitizer could not load — stonemask_tab_kernel, hv_refine_kernel and the exact phase
+scan.  The test builds that variant (hipcc, ~1 min) if it is not there, runs tests/_bounds_script.py against it and
+expects: the positive control fires with the right record; the CheapTrick fixtures reproduce the reference with zero
+records; an f0 sweep from 1 Hz to 1.5 fs at five (rate, transform) pairs — caller-supplied contours the reference's
+estimators never return (world/cheaptrick.py:64-131 takes any f0) — stays inside every buffer; config 2 at its full
+size, a Harvest + Requiem batch and a 48 kHz utterance run clean."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+BOUNDS_TUS = ("wh_api", "wh_cheaptrick", "wh_stonemask", "wh_harvest", "wh_synthesis", "wh_d4c")
+VARIANT = os.path.join(ROOT, "python-world_amd", "lib", "variants", "libworld_hip_bounds.so")
+
+
+def _build_variant():
+    spec = "bounds=" + ";".join("%s:-DWH_BOUNDS=1" % tu for tu in BOUNDS_TUS)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variants.py"), spec], capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0 and "bounds ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.fixture(scope="module")
+def report():
+    lib = os.path.join(ROOT, "python-world_amd", "lib", "libworld_hip.so")
+    if not os.path.exists(VARIANT) or os.path.getmtime(VARIANT) < os.path.getmtime(lib):
+        _build_variant()
+    env = dict(os.environ, WH_LIB=VARIANT)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_bounds_script.py")], capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("BOUNDS_JSON ")][-1]
+    return json.loads(line[len("BOUNDS_JSON "):])
+
+
+def test_the_checker_fires_on_the_positive_control(report):
+    assert report["bounds_build"] is True
+    assert report["selftest_flag"] == 1
+    assert report["selftest_record"] == [1, 7, 4, 4]  # one access, WH_CK_TABLE, element 4 of 4
+    assert report["clean_after"] == [0, [0, 0, 0, 0]]  # read-and-clear
+
+
+def test_cheaptrick_fixtures_run_inside_their_buffers(report):
+    for tag, r in report["fixtures"].items():
+        assert r["flag"] == 0 and r["record"] == [0, 0, 0, 0], (tag, r)
+        assert r["rel_rms"] < 1e-9, (tag, r)  # and reproduce the reference (tests/test_hip_cheaptrick.py's bar)
+
+
+def test_cheaptrick_f0_sweep_stays_inside_its_buffers(report):
+    assert report["sweep_cases"] == 75
+    assert report["sweep_bad"] == []
+
+
+def test_whole_pipelines_run_clean(report):
+    for key in ("config2", "harvest", "cfg5"):
+        assert report[key + "_flags"] == [0] * 16, (key, report[key + "_flags"], report[key + "_record"])
+
+
+def test_shipped_library_is_not_a_bounds_build():
+    from world import _hip
+
+    assert _hip.bounds_build() is False
+    rt = _hip.Runtime.get()
+    with pytest.raises(_hip.WorldHipError):
+        _hip.check(rt.lib.wh_bounds_selftest(rt.ctx, rt.stream()))

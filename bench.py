@@ -176,6 +176,53 @@ def _cpu_one(job):
     return len(dat["f0"])
 
 
+def _cpu_one_north(job):
+    from oracle import api as oapi
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except Exception:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    x, fs, _ = job
+    with ctx:
+        dat = oapi.encode_np(fs, x, f0_method="harvest", is_requiem=True)
+        oapi.decode_np(dat)
+    return len(dat["f0"])
+
+
+def cpu_baseline_north(xs, fs, repeats=2):
+    """The same-box CPU figure of the NORTH-STAR path: the NumPy oracle's encode(harvest,
+    is_requiem=True) + Requiem decode, 1 core on one utterance and a process pool of one utterance per physical core;
+    1 warm-up + `repeats` repeats each (about half a minute in all)."""
+    import multiprocessing as mp
+
+    cores = os.cpu_count() or 1
+    _cpu_one_north((xs[0], fs, 0))
+    one = []
+    for r in range(repeats):
+        t0 = time.perf_counter()
+        frames = _cpu_one_north((xs[(r + 1) % len(xs)], fs, r))
+        one.append(frames / (time.perf_counter() - t0))
+    pool_n = max(1, cores // 2)
+    jobs = [(xs[u % len(xs)], fs, u) for u in range(pool_n)]
+    allc = []
+    with mp.get_context("fork").Pool(pool_n) as pool:
+        pool.map(_cpu_one_north, jobs)
+        for r in range(repeats):
+            t0 = time.perf_counter()
+            frames = sum(pool.map(_cpu_one_north, jobs, chunksize=1))
+            allc.append(frames / (time.perf_counter() - t0))
+    v1, vn = float(np.median(one)), float(np.median(allc))
+    return {"value": v1, "unit": "frames/s", "cores": 1, "kind": "port", "x_realtime": v1 * 0.005,
+            "sample": "one 10 s utterance per repeat, encode(harvest, is_requiem=True)+decode through oracle/ (NumPy), "
+                      "1 warm-up + median of %d repeats" % repeats,
+            "all_cores": {"value": vn, "unit": "frames/s", "cores": pool_n, "host_cpus": cores, "x_realtime": vn * 0.005,
+                          "sample": "%d utterances per repeat over a %d-process pool, median of %d repeats"
+                                    % (pool_n, pool_n, repeats)},
+            "repeats_1core": [round(v, 1) for v in one], "repeats_all_cores": [round(v, 1) for v in allc]}
+
+
 def cpu_baseline(xs, fs, n_utts, repeats=3):
     """The NumPy oracle (a 'port' of the reference path) on a bounded sample of the same workload:
     (i) 1 core, per-utterance loop — the reference's execution model; (ii) all host cores, a process pool over
@@ -248,7 +295,31 @@ def pmc_traffic(kernel, lanes, config):
     return None, None
 
 
-def measure_pmc_traffic(args, timeout_s=240, config=None, utts=None, seconds=None, steps=2):
+SQ_PASS = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64",
+           "SQ_INSTS_VALU_TRANS_F64", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAVES")
+LAST_SQ = {}  # per kernel: the SQ counters of the latest measure_pmc_traffic call (third child run), averaged per launch
+
+
+def fp64_view(kernel, avg_launch_ms):
+    """The FP64-issue view of one kernel from the SQ pass of the latest measure_pmc_traffic call (the
+    honest roof of this path is FP64 vector issue, not HBM): FLOPs per launch = (2 FMA + ADD + MUL + TRANS) x 64 lanes over
+    the launch duration THIS run measured with HIP events; the VALU's share of a resident wave's lifetime; the share of
+    the VALU instructions that are FP64 arithmetic.  None when the pass did not run."""
+    c = LAST_SQ.get(kernel)
+    if not c or not avg_launch_ms:
+        return None
+    f64 = sum(c.get(k, 0.0) for k in SQ_PASS[1:5])
+    flops = (f64 + c.get("SQ_INSTS_VALU_FMA_F64", 0.0)) * 64.0
+    tf = flops / (avg_launch_ms * 1e-3) / 1e12
+    return {"fp64_TFLOPs": tf, "fp64_peak_TFLOPs": FP64_VECTOR_PEAK_TFLOPS, "fp64_peak_frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+            "valu_busy": c.get("SQ_ACTIVE_INST_VALU", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 0.0)),
+            "fp64_inst_share": f64 / max(1.0, c.get("SQ_INSTS_VALU", 0.0)), "flops_per_launch": flops,
+            "note": "valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: the VALU's share of ONE resident wave's lifetime (a "
+                    "SIMD holds 3-6 such waves); counters from a third rocprofv3 --pmc child run of this workload, "
+                    "duration from this run's HIP events"}
+
+
+def measure_pmc_traffic(args, timeout_s=240, config=None, utts=None, seconds=None, steps=2, sq=True):
     """HBM bytes per launch of every kernel of THIS workload, measured now: two child runs of this script under
     `rocprofv3 --pmc <counter> --kernel-trace` (FETCH_SIZE and WRITE_SIZE cannot share a pass; nothing but the kernel
     trace beside the counters), corrected as MI355X_MICROARCH.md prescribes for gfx950: (2*FETCH_SIZE + WRITE_SIZE) KiB.
@@ -269,9 +340,11 @@ def measure_pmc_traffic(args, timeout_s=240, config=None, utts=None, seconds=Non
              "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-graph", "--no-pmc", "--in-flight", "1"]
     per = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        LAST_SQ.clear()
+        for counter in ("FETCH_SIZE", "WRITE_SIZE") + (("SQ",) if sq else ()):
             d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--"] + child
+            names = list(SQ_PASS) if counter == "SQ" else [counter]
+            cmd = [exe, "--pmc"] + names + ["--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--"] + child
             env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
@@ -281,6 +354,19 @@ def measure_pmc_traffic(args, timeout_s=240, config=None, utts=None, seconds=Non
                 for f in files:
                     if f.endswith("counter_collection.csv"):
                         path = os.path.join(dirpath, f)
+            if counter == "SQ":  # the FP64-issue view: optional, never costs the traffic figures
+                if r.returncode == 0 and path is not None:
+                    tot2 = collections.defaultdict(lambda: collections.defaultdict(float))
+                    n2 = collections.defaultdict(collections.Counter)
+                    for row in csv.DictReader(open(path)):
+                        mt = re.search(r"(\w+_kernel)\b", row["Kernel_Name"])
+                        if not mt or "at::native" in row["Kernel_Name"]:
+                            continue
+                        tot2[mt.group(1)][row["Counter_Name"]] += float(row["Counter_Value"])
+                        n2[mt.group(1)][row["Counter_Name"]] += 1
+                    for k, cs in tot2.items():
+                        LAST_SQ[k] = {c: v / n2[k][c] for c, v in cs.items()}
+                continue
             if r.returncode != 0 or path is None:
                 return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "")[-300:])
             tot, n = collections.defaultdict(float), collections.Counter()
@@ -300,11 +386,12 @@ def measure_pmc_traffic(args, timeout_s=240, config=None, utts=None, seconds=Non
     out = {k: (2.0 * f + per["WRITE_SIZE"].get(k, 0.0)) * 1024.0 for k, f in per["FETCH_SIZE"].items()}
     # a few HIP-event timer names (what kernel_ms is keyed by) cover a kernel whose symbol carries a variant suffix:
     # "band_events_kernel" times band_events_ols_kernel<1|4>
-    for sym in list(out):
-        stem = sym[:-len("_kernel")]
-        for cut in ("_ols", "_tab"):
-            if stem.endswith(cut):
-                out.setdefault(stem[:-len(cut)] + "_kernel", out[sym])
+    for table in (out, LAST_SQ):
+        for sym in list(table):
+            stem = sym[:-len("_kernel")]
+            for cut in ("_ols", "_tab"):
+                if stem.endswith(cut):
+                    table.setdefault(stem[:-len(cut)] + "_kernel", table[sym])
     return out, ("measured in this run: two child runs of this workload under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE in "
                  "separate passes, --kernel-trace only), bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB averaged per launch "
                  "(gfx950 correction of MI355X_MICROARCH.md)")
@@ -341,6 +428,12 @@ def main():
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline and args.config == 2:
         cpu = cpu_baseline(xs_distinct, FS, args.cpu_utts)
+    args.north_star_cpu = None
+    if cpu is not None and not args.no_extras and args.scaling == "weak":
+        try:
+            args.north_star_cpu = cpu_baseline_north(xs_distinct, FS)
+        except Exception as e:  # never costs the headline
+            args.north_star_cpu = {"error": "%s: %s" % (type(e).__name__, e)}
     xs_cfg5 = None
     xs_north = None
     if world == 1 and not args.no_extras and args.config == 2 and args.scaling == "weak":
@@ -517,8 +610,17 @@ def main():
                         "avg_launch_ms": kernel_ms[dominant],
                         "timing": "HIP events around every launch, un-captured pass of the same %d steps" % args.steps,
                         "path_algorithmic_GBps": path_b * frames_per_step * args.steps / elapsed / 1e9}
-            # second view of the same kernel: the path is FP64-compute/latency-bound, not HBM-bound
-            flops, flops_src = pmc_fp64_flops(dominant, len(rts), args.config) if std else (None, None)
+            # second view of the same kernel: the path is FP64-compute/latency-bound, not HBM-bound —
+            # measured in this run when the PMC child runs ran (fp64_TFLOPs, fp64_peak_frac, valu_busy), else from the
+            # committed digest
+            live = fp64_view(dominant, kernel_ms[dominant]) if traffic_all is not None else None
+            if live:
+                roofline.update({k: live[k] for k in ("fp64_TFLOPs", "fp64_peak_frac", "valu_busy", "fp64_inst_share")})
+                roofline["fp64_vector"] = dict(live, achieved=live["fp64_TFLOPs"], peak=FP64_VECTOR_PEAK_TFLOPS, unit="TFLOP/s",
+                                               frac=live["fp64_peak_frac"], flops_source={"source": "measured in this run"})
+                roofline["fp64_per_kernel"] = {k: {kk: round(v[kk], 4) for kk in ("fp64_TFLOPs", "fp64_peak_frac", "valu_busy", "fp64_inst_share")}
+                                               for k, v in ((k, fp64_view(k, kernel_ms.get(k))) for k in list(kernel_ms)[:6]) if v}
+            flops, flops_src = pmc_fp64_flops(dominant, len(rts), args.config) if (std and not live) else (None, None)
             if flops:
                 roofline["fp64_vector"] = {"achieved": flops / avg_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                                            "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
@@ -1255,6 +1357,15 @@ def north_star_block(torch, device_index, xs_distinct, fs, args, steps=6):
                 "algorithmic_bytes_per_launch": per_frame * frames_per_launch, "frames_per_launch": frames_per_launch,
                 "avg_launch_ms": dom_ms, "timing": "HIP events around every launch, one un-captured step",
                 "path_algorithmic_GBps": path_b * frames / dt / 1e9}
+    kms = {k: v[0] / v[1] for k, v in agg.items()}
+    live = fp64_view(dom, dom_ms) if traffic_all is not None else None
+    if live:
+        roofline.update({k: live[k] for k in ("fp64_TFLOPs", "fp64_peak_frac", "valu_busy", "fp64_inst_share")})
+        roofline["fp64_per_kernel"] = {k: {kk: round(v[kk], 4) for kk in ("fp64_TFLOPs", "fp64_peak_frac", "valu_busy", "fp64_inst_share")}
+                                       for k, v in ((k, fp64_view(k, kms[k])) for k in sorted(kms, key=lambda q: -agg[q][0])[:6]) if v}
+    if traffic_all is not None:  # the Harvest front chain on its own (91 GB in round 5)
+        front = [k for k in ("band_events_kernel", "hv_rawdet_kernel", "hv_raw_kernel", "hv_detect_kernel") if k in traffic_all]
+        roofline["harvest_front_chain_GB"] = {"kernels": front, "total": round(sum(traffic_all[k] for k in front) / 1e9, 2)}
     return {"workload": "%d x %.0f s synthetic 16 kHz utterances (%d distinct) on 1 GPU: Harvest+CheapTrick+"
                         "D4C-Requiem encode + Requiem decode, HBM-resident" % (n, len(xs[0]) / fs, min(n, len(xs_distinct))),
             "distinct_utterances": min(n, len(xs_distinct)), "host_enqueue_ms_per_step": enq * 1e3,
@@ -1262,7 +1373,7 @@ def north_star_block(torch, device_index, xs_distinct, fs, args, steps=6):
             "ms_per_step_one_in_flight": dt_one * 1e3,
             "ms_per_step": dt * 1e3, "value": frames / dt, "unit": "frames/s", "x_realtime": n * len(xs[0]) / fs / dt,
             "target_x_realtime": 500, "steps": steps, "frames_per_step": frames,
-            "roofline": roofline,
+            "roofline": roofline, "cpu_baseline": getattr(args, "north_star_cpu", None),
             "kernel_ms": {k: round(v[0] / v[1], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]}}
 
 

@@ -15,9 +15,24 @@
 // offsets and index-to-double conversions as common subexpressions of all of them, computes them once and parks them
 // in registers for the whole kernel (193 VGPRs wanted where four workgroups per CU allow 128).  Re-deriving them per
 // use costs a few integer instructions.
+// Round-6 experiment (tools/build_variants.py): WH_D4C_PAIR frames per workgroup, one after the other;
+// WH_D4C_HOIST=1 lifts the three fences (plain thread index, fresh_table, stage_fence) so that the compiler may keep the
+// per-thread addresses, twiddles and index conversions it wants in registers and share them across the frames of a
+// workgroup and all their transforms; WH_D4C_PAIR_MINW sets the register budget (2: 256 VGPRs).  Shipped: 1 / 0.
+#ifndef WH_D4C_PAIR
+#define WH_D4C_PAIR 1
+#endif
+#ifndef WH_D4C_HOIST
+#define WH_D4C_HOIST 0
+#endif
+#ifndef WH_D4C_PAIR_MINW
+#define WH_D4C_PAIR_MINW 2
+#endif
 __device__ __forceinline__ int wh_opaque_tid() {
   int t = threadIdx.x;
+#if !WH_D4C_HOIST
   asm volatile("" : "+v"(t));
+#endif
   return t;
 }
 #define WH_TID wh_opaque_tid()
@@ -78,7 +93,9 @@ namespace {
 // (203 VGPRs); passing the table pointer through an empty asm before each transform makes every instance re-derive
 // what it needs from L1/L2-resident data.
 __device__ __forceinline__ const double2* fresh_table(const double2* p) {
+#if !WH_D4C_HOIST
   asm volatile("" : "+s"(p));
+#endif
   return p;
 }
 // Stage fence for a per-frame scalar: everything a stage derives from the returned value (window phase, sample
@@ -86,7 +103,9 @@ __device__ __forceinline__ const double2* fresh_table(const double2* p) {
 // stage's loads and transcendental set-up underneath the current stage's transform (which it does otherwise, and
 // pays for with ~60 VGPRs of values parked across the FFT).
 __device__ __forceinline__ double stage_fence(double v) {
+#if !WH_D4C_HOIST
   asm volatile("" : "+v"(v));
+#endif
   return v;
 }
 
@@ -868,13 +887,13 @@ __device__ __forceinline__ void add_centroid(const double* xu, const double* wta
 // Blackman frame and the Hann frame of the smoothed power spectrum are two real sequences → ONE complex FFT,
 // separated by Hermitian symmetry; the separate love_train_kernel launch and one transform disappear.
 template <int N, bool FUSED>
-__global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
+__device__ __forceinline__ void d4c_frame(
     const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
     const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv,
     const int32_t* __restrict__ gate, double threshold, double fs, int nap, int interval,
     const double* __restrict__ window, int wlen, const double2* __restrict__ tw_base,
     int k_spec,                       // >0: dense amplitude output [F][k_spec]; 0: Requiem band output [F][nap+2]
-    double* __restrict__ out, double* __restrict__ coarse_dbg, long long n_frames, D4cLaunchConst lc) {
+    double* __restrict__ out, double* __restrict__ coarse_dbg, long long n_frames, const D4cLaunchConst& lc, int64_t f) {
   constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2* buf = reinterpret_cast<double2*>(smem);   // N complex (centroid FFT) / N/2+1 complex (real FFTs)
@@ -886,7 +905,6 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   double* td = zr + 2 * N - KPAD;                    // band stage: the shaped group delay, above the real-FFT buffer
 
   STAGE_TIMER_BEGIN
-  const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
   if (f >= n_frames) return;
   const int u = frame_utt[f];
   const double* xu = x + x_off[u];
@@ -1168,6 +1186,34 @@ __global__ __launch_bounds__(ft_of(N), minblk_of(N)) void d4c_kernel(
   STAGE_MARK(6)
 }
 
+template <int N, bool FUSED>
+__global__ __launch_bounds__(ft_of(N), WH_D4C_PAIR > 1 ? WH_D4C_PAIR_MINW : minblk_of(N)) void d4c_kernel(
+    const double* __restrict__ x, const int64_t* __restrict__ x_off, const int32_t* __restrict__ frame_utt,
+    const double* __restrict__ tp, double* __restrict__ f0_io, const double* __restrict__ vuv,
+    const int32_t* __restrict__ gate, double threshold, double fs, int nap, int interval,
+    const double* __restrict__ window, int wlen, const double2* __restrict__ tw_base, int k_spec,
+    double* __restrict__ out, double* __restrict__ coarse_dbg, long long n_frames, D4cLaunchConst lc) {
+#if WH_D4C_PAIR > 1
+  // (experiment) WH_D4C_PAIR neighbouring frames per workgroup, one after the other
+  const long long n_units = (n_frames + WH_D4C_PAIR - 1) / WH_D4C_PAIR;
+  const long long unit = wh::xcd_unit(blockIdx.x, n_units);
+  if (unit >= n_units) return;
+#if defined(WH_D4C_PAIR_ROLLED) && WH_D4C_PAIR_ROLLED
+#pragma unroll 1  // one copy of the frame's code (two copies are 130 KB: twice the instruction cache two CUs share)
+#else
+#pragma unroll
+#endif
+  for (int rep = 0; rep < WH_D4C_PAIR; ++rep) {
+    d4c_frame<N, FUSED>(x, x_off, frame_utt, tp, f0_io, vuv, gate, threshold, fs, nap, interval, window, wlen, tw_base, k_spec,
+                        out, coarse_dbg, n_frames, lc, unit * WH_D4C_PAIR + rep);
+    __syncthreads();
+  }
+#else
+  d4c_frame<N, FUSED>(x, x_off, frame_utt, tp, f0_io, vuv, gate, threshold, fs, nap, interval, window, wlen, tw_base, k_spec, out,
+                      coarse_dbg, n_frames, lc, wh::xcd_unit(blockIdx.x, n_frames));
+#endif
+}
+
 int pow2_at_least(double v) { return (int)llround(pow(2.0, ceil(log2(v)))); }
 
 // Nuttall window of (possibly float-valued) length n, world/d4c.py:237-245.
@@ -1197,7 +1243,7 @@ int launch_main(wh_ctx* ctx, hipStream_t st, const wh_batch* b, const double* x,
                 int wlen, int k_spec, double* out, double* coarse) {
   const size_t lds = sizeof(double) * (2 * N + 40 + 8 + 4 * kWinTab);
   if (int rc = wh::allow_lds(&d4c_kernel<N, FUSED>, lds)) return rc;
-  { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL((d4c_kernel<N, FUSED>), dim3((unsigned)wh::xcd_grid(b->total_frames)), dim3(ft_of(N)), lds, st, x, b->d_x_off,
+  { wh::KernelTimer _kt(ctx, st, "d4c_kernel"); hipLaunchKernelGGL((d4c_kernel<N, FUSED>), dim3((unsigned)wh::xcd_grid((b->total_frames + WH_D4C_PAIR - 1) / WH_D4C_PAIR)), dim3(ft_of(N)), lds, st, x, b->d_x_off,
                      b->d_frame_utt, tp, f0, vuv, gate, thr, fs, nap, interval, win, wlen, ctx->d_twiddle, k_spec, out,
                      coarse, (long long)b->total_frames, d4c_launch_const(fs, N, wlen, interval, nap)); }
   WH_LAUNCH_CHECK("d4c_kernel");

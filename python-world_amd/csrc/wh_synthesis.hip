@@ -1021,7 +1021,7 @@ struct RespArgs {
   const double* dc_base;
   const double2* tw_base;
   double* rows;             // overlap-add rows of the runs (response_gather_kernel sums them into y)
-  int64_t row_stride;       // doubles per utterance in `rows`
+  const int64_t* row_base;  // [B + 1]: where every utterance's region of `rows` begins (sized from ITS sample count)
   const int64_t* run_base;  // [n_utt + 1] first run of every utterance (pulse_run_base_kernel)
   const int64_t* row_off;   // [n_utt][runs_cap] where run r's row begins in the utterance's region (pulse_rows_kernel)
   int64_t runs_cap;
@@ -1035,7 +1035,7 @@ struct RespArgs {
 // whether an utterance is decoded alone, in a batch or on another rank (runs are numbered per utterance).  The
 // reference adds pulse after pulse into y (synthesis.py:67-81); summing runs of pulses first is another association
 // of the same sum (1e-17 relative).
-// Row layout (per utterance a region of row_stride doubles): the rows lie one behind the other, row r at row_off[r]
+// Row layout (per utterance a region of row_base[u + 1] - row_base[u] doubles): the rows lie one behind the other, row r at row_off[r]
 // (pulse_rows_kernel: an exclusive scan of the row lengths, which follow from the pulse positions); slot 0 = what the
 // run adds to the LAST sample (Q8, below), slot 1 + (t - start_r) = its sum at the 1-based sample t < ny, start_r =
 // max(1, first tap of the run's first pulse).  A region holds 12 doubles per output sample (a mean f0 up to ~fs / 16 at
@@ -1370,7 +1370,7 @@ __global__ void pulse_run_base_kernel(const int32_t* __restrict__ p_count, int n
 template <int N>
 __global__ __launch_bounds__(256) void pulse_rows_kernel(const SynUtt* __restrict__ meta, const int64_t* __restrict__ p_idx,
                                                          const int32_t* __restrict__ p_count, int64_t runs_cap,
-                                                         int64_t row_stride, int64_t* __restrict__ row_off,
+                                                         const int64_t* __restrict__ row_base, int64_t* __restrict__ row_off,
                                                          int32_t* __restrict__ flags) {
   constexpr int RUN = resp_run(N);
   __shared__ int wsum[4];
@@ -1381,6 +1381,7 @@ __global__ __launch_bounds__(256) void pulse_rows_kernel(const SynUtt* __restric
   int64_t* out = row_off + (int64_t)blockIdx.x * runs_cap;
   int64_t carry = 0;
   bool over = false;
+  const int64_t room = row_base[blockIdx.x + 1] - row_base[blockIdx.x];
   for (int base = 0; base < n_runs; base += 256) {
     const int r = base + threadIdx.x;
     int len = 0;
@@ -1396,7 +1397,7 @@ __global__ __launch_bounds__(256) void pulse_rows_kernel(const SynUtt* __restric
     const int excl = block_excl_scan_256(len, wsum, &total);
     if (r < n_runs) {
       const int64_t at = carry + excl;
-      const bool fits = at + len <= row_stride;
+      const bool fits = at + len <= room;
       out[r] = fits ? at : -1;
       over = over || !fits;
     }
@@ -1435,7 +1436,7 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
   const int64_t gp1 = gp0 + RUN < A.p_base[u + 1] ? gp0 + RUN : A.p_base[u + 1];
   const int64_t my_off = A.row_off[(int64_t)u * A.runs_cap + r_in_utt];
   if (my_off < 0) return;  // the utterance's row region is full (flagged by pulse_rows_kernel)
-  double* row = A.rows + (int64_t)u * A.row_stride + my_off;  // slot i of the row at row[i]
+  double* row = A.rows + A.row_base[u] + my_off;  // slot i of the row at row[i]
   // A pulse's record travels as ONE dword per lane (lane i & 15 holds dword i) and is turned into scalars by
   // v_readlane at the top of the pulse that uses it — a pulse after its load was issued.  Fetched as a struct the
   // compiler made scalars of it (readfirstlane) right behind the load: the "prefetch" was waited for at once.
@@ -1502,7 +1503,7 @@ template <int N>
 __global__ __launch_bounds__(256) void response_gather_kernel(const SynUtt* __restrict__ meta,
                                                               const int64_t* __restrict__ p_idx,
                                                               const int32_t* __restrict__ p_count,
-                                                              const double* __restrict__ rows, int64_t row_stride,
+                                                              const double* __restrict__ rows, const int64_t* __restrict__ row_base,
                                                               const int64_t* __restrict__ row_off, int64_t runs_cap,
                                                               double* __restrict__ y) {
   constexpr int RUN = resp_run(N);
@@ -1512,7 +1513,7 @@ __global__ __launch_bounds__(256) void response_gather_kernel(const SynUtt* __re
   if (n0 >= m.ny) return;
   const int count = p_count[blockIdx.y];
   const int64_t* pi = p_idx + m.p_off;
-  const double* ru = rows + (int64_t)blockIdx.y * row_stride;
+  const double* ru = rows + row_base[blockIdx.y];
   const int64_t* ro = row_off + (int64_t)blockIdx.y * runs_cap;
   // pulses whose window [pidx - N/2 + 1, pidx + N/2] reaches the tile's samples n0 + 1 .. n0 + kGatherTile
   const int k0 = first_pulse_at(pi, count, n0 + 1 - N / 2);
@@ -1558,7 +1559,7 @@ __global__ __launch_bounds__(256) void response_gather_kernel(const SynUtt* __re
 
 
 template <int N>
-int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, int64_t max_ny, const SynUtt* d_meta, const double* tp,
+int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, int64_t max_ny, const std::vector<int64_t>& h_ny, const SynUtt* d_meta, const double* tp,
                 const double* spec, const double* ap, double fs, const PulseRec* p_rec, const int64_t* p_base,
                 const int64_t* p_idx, const int32_t* p_count, const double* noise, uint64_t seed, double* y) {
   std::vector<double> dc(N);
@@ -1580,23 +1581,28 @@ int launch_resp(wh_ctx* ctx, hipStream_t st, int B, int64_t pcap_max, int64_t ma
   // the safe capacity of the retry (ny / 2: f0 up to fs / 4 at N = 1024)
   int64_t per_sample = (96 * pcap_max + max_ny - 1) / (max_ny > 0 ? max_ny : 1);
   per_sample = per_sample < 12 ? 12 : (per_sample > 48 ? 48 : per_sample);
-  const int64_t row_stride = per_sample * max_ny + 4 * (N + 1);
+  // every utterance's region from ITS OWN sample count (sized from the longest utterance a ragged batch held
+  // max_ny per utterance, ~1 GB per 64 x 10 s whatever the other lengths were)
+  std::vector<int64_t> row_base((size_t)B + 1, 0);
+  for (int u = 0; u < B; ++u) row_base[u + 1] = row_base[u] + per_sample * h_ny[u] + 4 * (N + 1);
+  int64_t* d_row_base = nullptr;
+  if (int rc = wh::persistent_upload(ctx, st, "syn.row_base", row_base, &d_row_base)) return rc;
   void* d_rows = nullptr;
   void* d_rb = nullptr;
   void* d_ro = nullptr;
-  if (int rc = wh::persistent_scratch(ctx, "syn.ola_rows", sizeof(double) * (size_t)row_stride * B, &d_rows)) return rc;
+  if (int rc = wh::persistent_scratch(ctx, "syn.ola_rows", sizeof(double) * (size_t)row_base[B], &d_rows)) return rc;
   if (int rc = wh::persistent_scratch(ctx, "syn.run_base", sizeof(int64_t) * ((size_t)B + 1), &d_rb)) return rc;
   if (int rc = wh::persistent_scratch(ctx, "syn.row_off", sizeof(int64_t) * (size_t)runs_cap * B, &d_ro)) return rc;
   { wh::KernelTimer _kt(ctx, st, "pulse_run_base_kernel"); hipLaunchKernelGGL(pulse_run_base_kernel, dim3(1), dim3(64), 0, st, p_count, B, resp_run(N), reinterpret_cast<int64_t*>(d_rb)); }
   WH_LAUNCH_CHECK("pulse_run_base_kernel");
-  { wh::KernelTimer _kt(ctx, st, "pulse_rows_kernel"); hipLaunchKernelGGL(pulse_rows_kernel<N>, dim3(B), dim3(256), 0, st, d_meta, p_idx, p_count, runs_cap, row_stride, reinterpret_cast<int64_t*>(d_ro), ctx->d_flags); }
+  { wh::KernelTimer _kt(ctx, st, "pulse_rows_kernel"); hipLaunchKernelGGL(pulse_rows_kernel<N>, dim3(B), dim3(256), 0, st, d_meta, p_idx, p_count, runs_cap, d_row_base, reinterpret_cast<int64_t*>(d_ro), ctx->d_flags); }
   WH_LAUNCH_CHECK("pulse_rows_kernel");
   // one workgroup per run of resp_run(N) pulse slots; runs past the real pulse count exit at once
   const int64_t grid = wh::xcd_grid(runs_cap * B);
-  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_rec, p_base, B, noise, seed, d_dc, ctx->d_twiddle, reinterpret_cast<double*>(d_rows), row_stride, reinterpret_cast<const int64_t*>(d_rb), reinterpret_cast<const int64_t*>(d_ro), runs_cap};
+  { wh::KernelTimer _kt(ctx, st, "response_kernel"); RespArgs ra{d_meta, tp, spec, ap, fs, p_rec, p_base, B, noise, seed, d_dc, ctx->d_twiddle, reinterpret_cast<double*>(d_rows), d_row_base, reinterpret_cast<const int64_t*>(d_rb), reinterpret_cast<const int64_t*>(d_ro), runs_cap};
   hipLaunchKernelGGL(response_kernel<N>, dim3((unsigned)grid), dim3(ft_syn(N)), lds, st, ra); }
   WH_LAUNCH_CHECK("response_kernel");
-  { wh::KernelTimer _kt(ctx, st, "response_gather_kernel"); hipLaunchKernelGGL(response_gather_kernel<N>, dim3((unsigned)((max_ny + kGatherTile - 1) / kGatherTile), B), dim3(256), 0, st, d_meta, p_idx, p_count, reinterpret_cast<const double*>(d_rows), row_stride, reinterpret_cast<const int64_t*>(d_ro), runs_cap, y); }
+  { wh::KernelTimer _kt(ctx, st, "response_gather_kernel"); hipLaunchKernelGGL(response_gather_kernel<N>, dim3((unsigned)((max_ny + kGatherTile - 1) / kGatherTile), B), dim3(256), 0, st, d_meta, p_idx, p_count, reinterpret_cast<const double*>(d_rows), d_row_base, reinterpret_cast<const int64_t*>(d_ro), runs_cap, y); }
   WH_LAUNCH_CHECK("response_gather_kernel");
   return 0;
 }
@@ -2021,12 +2027,14 @@ extern "C" int wh_synthesis_render(wh_ctx* ctx, void* stream, const wh_batch* b,
     hipLaunchKernelGGL(noise_cover_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, d_meta, d_rec, d_pb, B, ctx->d_flags);
   }
   WH_LAUNCH_CHECK("noise_cover_kernel");
+  std::vector<int64_t> h_ny((size_t)B);
+  for (int u = 0; u < B; ++u) h_ny[u] = meta[u].ny;
   int rc;
   switch (fft_size) {
-    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, max_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
-    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, max_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
-    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, max_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
-    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, max_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
+    case 512: rc = launch_resp<512>(ctx, st, B, pulse_cap, max_ny, h_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
+    case 1024: rc = launch_resp<1024>(ctx, st, B, pulse_cap, max_ny, h_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
+    case 2048: rc = launch_resp<2048>(ctx, st, B, pulse_cap, max_ny, h_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
+    case 4096: rc = launch_resp<4096>(ctx, st, B, pulse_cap, max_ny, h_ny, d_meta, tp, spectrogram, aperiodicity, fs, d_rec, d_pb, d_pi, d_pc, noise, seed, y); break;
     default: return wh::fail_msg("wh_synthesis_render", "fft_size must be a power of two in [512, 4096]");
   }
   if (rc) return rc;

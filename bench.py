@@ -204,12 +204,14 @@ def cpu_baseline_north(xs, fs, repeats=2):
         t0 = time.perf_counter()
         frames = _cpu_one_north((xs[(r + 1) % len(xs)], fs, r))
         one.append(frames / (time.perf_counter() - t0))
-    pool_n = max(1, cores // 2)
+    # a pool of 32 processes, one repeat: the Harvest oracle scales to ~5 x one core on this class of host whatever the pool
+    # (3.0 k frames/s with 128 processes, memory-bound), and 128 utterances per repeat took 84 s
+    pool_n = max(1, min(cores // 2, 32))
     jobs = [(xs[u % len(xs)], fs, u) for u in range(pool_n)]
     allc = []
     with mp.get_context("fork").Pool(pool_n) as pool:
-        pool.map(_cpu_one_north, jobs)
-        for r in range(repeats):
+        pool.map(_cpu_one_north, [(xs[0][:fs], fs, 0)] * pool_n)  # warm-up on a 1 s excerpt (imports; pocketfft keeps no plans)
+        for r in range(1):
             t0 = time.perf_counter()
             frames = sum(pool.map(_cpu_one_north, jobs, chunksize=1))
             allc.append(frames / (time.perf_counter() - t0))
@@ -218,8 +220,8 @@ def cpu_baseline_north(xs, fs, repeats=2):
             "sample": "one 10 s utterance per repeat, encode(harvest, is_requiem=True)+decode through oracle/ (NumPy), "
                       "1 warm-up + median of %d repeats" % repeats,
             "all_cores": {"value": vn, "unit": "frames/s", "cores": pool_n, "host_cpus": cores, "x_realtime": vn * 0.005,
-                          "sample": "%d utterances per repeat over a %d-process pool, median of %d repeats"
-                                    % (pool_n, pool_n, repeats)},
+                          "sample": "%d utterances over a %d-process pool, one repeat (128 processes: 3.0 k frames/s, "
+                                    "profiles/r06_bench_default_v1.json)" % (pool_n, pool_n)},
             "repeats_1core": [round(v, 1) for v in one], "repeats_all_cores": [round(v, 1) for v in allc]}
 
 
@@ -244,8 +246,10 @@ def cpu_baseline(xs, fs, n_utts, repeats=3):
     allc = []
     t_pool = time.perf_counter()
     with mp.get_context("fork").Pool(pool_n) as pool:
-        pool.map(_cpu_one, jobs[:pool_n])  # warm-up inside the workers
-        for r in range(repeats):
+        # warm-up inside the workers on 1 s excerpts (imports; pocketfft keeps no plans), then two repeats: this leg was
+        # 100 of the 126 s the CPU baseline took of a default run
+        pool.map(_cpu_one, [(xs[0][:fs], fs, 0)] * pool_n)
+        for r in range(min(repeats, 2)):
             t0 = time.perf_counter()
             frames = sum(pool.map(_cpu_one, jobs, chunksize=1))
             allc.append(frames / (time.perf_counter() - t0))
@@ -266,7 +270,7 @@ def cpu_baseline(xs, fs, n_utts, repeats=3):
             "x_realtime": v1 * 0.005,
             "all_cores": {"value": vn, "unit": "frames/s", "cores": pool_n, "host_cpus": cores, "x_realtime": vn * 0.005,
                           "sample": "%d utterances per repeat over a %d-process pool, median of %d repeats"
-                                    % (pool_n, pool_n, repeats)},
+                                    % (pool_n, pool_n, min(repeats, 2))},
             # the reference ITSELF (not this port), measured once in the authoring container (8 vCPU
             # Xeon 2.1 GHz, numba absent): sum of its five stages on one 10 s / 16 kHz utterance = 5.14 s
             "reference_measured": {"value": 389.0, "unit": "frames/s", "cores": 1, "x_realtime": 1.95,
@@ -404,6 +408,10 @@ def pmc_fp64_flops(kernel, lanes, config):
     return None, None
 
 
+SECTION_S = {}
+T_START = time.perf_counter()
+
+
 def main():
     global FS
     args = parse()
@@ -426,14 +434,19 @@ def main():
     xs_distinct = make_inputs(first, distinct, FS, args.seconds)
     xs = [xs_distinct[i % distinct] for i in range(count)]
     cpu = None
+    SECTION_S["inputs"] = round(time.perf_counter() - T_START, 1)
     if world == 1 and rank == 0 and not args.no_cpu_baseline and args.config == 2:
+        t_blk = time.perf_counter()
         cpu = cpu_baseline(xs_distinct, FS, args.cpu_utts)
+        SECTION_S["cpu_baseline"] = round(time.perf_counter() - t_blk, 1)
     args.north_star_cpu = None
     if cpu is not None and not args.no_extras and args.scaling == "weak":
+        t_blk = time.perf_counter()
         try:
             args.north_star_cpu = cpu_baseline_north(xs_distinct, FS)
         except Exception as e:  # never costs the headline
             args.north_star_cpu = {"error": "%s: %s" % (type(e).__name__, e)}
+        SECTION_S["cpu_baseline_north_star"] = round(time.perf_counter() - t_blk, 1)
     xs_cfg5 = None
     xs_north = None
     if world == 1 and not args.no_extras and args.config == 2 and args.scaling == "weak":
@@ -447,6 +460,7 @@ def main():
                                                      cache=False)
         except Exception:
             xs_north = None
+        SECTION_S["inputs_all"] = round(time.perf_counter() - T_START, 1)
 
     import torch
     import torch.distributed as dist
@@ -670,6 +684,7 @@ def main():
                                            "of the multi-rank path, not a scaling measurement" % world
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        SECTION_S["headline_done_at"] = round(time.perf_counter() - T_START, 1)
         if world == 1 and not args.no_extras and args.config == 2 and args.scaling == "weak":
             graph = graphs = None  # (the graphs' private pools go back to the allocator)
             if depth > 1:
@@ -694,10 +709,14 @@ def main():
             blocks.append(("swipe", lambda: swipe_block(torch, wl, FS)))
             blocks.append(("other_configs", lambda: other_configs_block(torch, local_rank, xs_distinct, xs_cfg5, max(1, args.in_flight))))
             for key, fn in blocks + [("north_star", lambda: north_star_block(torch, local_rank, xs_north or xs_distinct, FS, args))]:
+                t_blk = time.perf_counter()
                 try:
                     out[key] = fn()
                 except Exception as e:  # an extra block must never cost the headline line
                     out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                SECTION_S[key] = round(time.perf_counter() - t_blk, 1)
+            SECTION_S["total"] = round(time.perf_counter() - T_START, 1)
+            out["section_seconds"] = dict(SECTION_S)  # where the wall time of this run went (host clock)
             piped = out.get("with_transfers_pipelined", {})
             if "value" in piped:  # SURVEY §8(d) states the metric with the API's H2D / D2H inside
                 out["value_with_transfers"] = piped["value"]
@@ -927,12 +946,12 @@ def facade_batch_block(torch, xs, fs, reps=3):
 
     W = main.World()
 
-    def resynthesis():
+    def resynthesis(copy_out=True):
         dats = W.encode_batch(fs, xs, f0_method="dio")
         for d in dats:
             W.scale_pitch(d, 1.5)
             W.scale_duration(d, 2.0)
-        return W.decode_batch(dats)
+        return W.decode_batch(dats, copy_out=copy_out)
 
     def materialised():
         t0 = time.perf_counter()
@@ -943,8 +962,8 @@ def facade_batch_block(torch, xs, fs, reps=3):
         torch.cuda.synchronize()
         return dats, t1 - t0, time.perf_counter() - t1
 
-    def roundtrip():  # no modification: directly comparable with the resident step and with round 4's 46 + 40 ms
-        return W.decode_batch(W.encode_batch(fs, xs, f0_method="dio"))
+    def roundtrip(copy_out=True):  # no modification: directly comparable with the resident step and with round 4's 46 + 40 ms
+        return W.decode_batch(W.encode_batch(fs, xs, f0_method="dio"), copy_out=copy_out)
 
     resynthesis()
     materialised()
@@ -979,8 +998,25 @@ def facade_batch_block(torch, xs, fs, reps=3):
             single_s.append(time.perf_counter() - t0)
     finally:
         main.FACADE_SPLIT_BYTES = split_bytes
+    # the same two flows with copy_out=False: every 'out' a view into the batch's page-locked block (what round 5 timed;
+    # since round 6 the default hands out arrays of their own in pageable memory, like decode() — ADVICE r5)
+    view_flow, view_rt = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        resynthesis(copy_out=False)
+        torch.cuda.synchronize()
+        view_flow.append(time.perf_counter() - t0)
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        roundtrip(copy_out=False)
+        torch.cuda.synchronize()
+        view_rt.append(time.perf_counter() - t0)
     f, e, d = float(np.median(flow_s)), float(np.median(enc_s)), float(np.median(dec_s))
     return {"resynthesis_flow_ms": f * 1e3, "roundtrip_unmodified_ms": float(np.median(rt_s)) * 1e3,
+            "resynthesis_flow_views_ms": float(np.median(view_flow)) * 1e3,
+            "roundtrip_unmodified_views_ms": float(np.median(view_rt)) * 1e3,
+            "out_arrays": "default: one pageable array per utterance (copied out of the pinned block by the staging threads); "
+                          "*_views_ms: copy_out=False, views into the pinned block (round 5's figures)",
             "resynthesis_flow_single_batch_ms": float(np.median(single_s)) * 1e3,
             "parts": 2 if 8 * sum(len(x) for x in xs) >= split_bytes and len(xs) >= 2 else 1,
             "value": frames / f, "unit": "frames/s",

@@ -160,13 +160,13 @@ _pool = None
 
 
 class _copy_pool:
-    """The process-wide 8-thread pool for host-side staging copies (created on first use, kept)."""
+    """The process-wide 16-thread pool for host-side staging copies (created on first use, kept)."""
 
     def __enter__(self):
         global _pool
         if _pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            _pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="wh-stage")
+            _pool = ThreadPoolExecutor(max_workers=16, thread_name_prefix="wh-stage")
         return _pool
 
     def __exit__(self, *exc):

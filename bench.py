@@ -633,7 +633,8 @@ def main():
                 roofline["fp64_vector"] = dict(live, achieved=live["fp64_TFLOPs"], peak=FP64_VECTOR_PEAK_TFLOPS, unit="TFLOP/s",
                                                frac=live["fp64_peak_frac"], flops_source={"source": "measured in this run"})
                 roofline["fp64_per_kernel"] = {k: {kk: round(v[kk], 4) for kk in ("fp64_TFLOPs", "fp64_peak_frac", "valu_busy", "fp64_inst_share")}
-                                               for k, v in ((k, fp64_view(k, kernel_ms.get(k))) for k in list(kernel_ms)[:6]) if v}
+                                               for k, v in ((k, fp64_view(k, kernel_ms.get(k)))
+                                                            for k in sorted(kernel_ms, key=lambda q: -kernel_ms[q])[:6]) if v}
             flops, flops_src = pmc_fp64_flops(dominant, len(rts), args.config) if (std and not live) else (None, None)
             if flops:
                 roofline["fp64_vector"] = {"achieved": flops / avg_s / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,

@@ -1645,7 +1645,19 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
 #ifndef WH_HV_RAWDET
 #define WH_HV_RAWDET 1  // raw candidates + detection in one transposed pass (hv_rawdet_kernel); 0: hv_raw_kernel + hv_detect_kernel
 #endif
-  const bool use_rawdet = WH_HV_RAWDET && use_ols;  // (its cursor hints come from the overlap-save walker)
+#ifndef WH_HV_RAWDET_MIN_TILES
+#define WH_HV_RAWDET_MIN_TILES 8192  // (~52 utterances of 10 s; measured: 1 / 8 / 32 / 64 utterances 0.46 / 0.46 / 0.96 / 1.54 ms fused against 0.15 / 0.29 / 0.82 / 1.52 ms for the pair)
+#endif
+  // The transposed kernel runs one wave per (utterance, 64-frame tile), each walking all channels: a handful of utterances
+  // is a few hundred waves with a 152-step chain each (one 4.6 s utterance: 74), where hv_raw_kernel spreads the same work
+  // over channels x utterances x segments workgroups — the reference's own benchmark, ONE encode of its test recording,
+  // went from 2.5 to 3.0 ms.  Below WH_HV_RAWDET_MIN_TILES tiles in the batch the pair of kernels runs instead
+  // (WH_HV_RAWDET_MIN_TILES in the environment overrides it: tests run both forms on the same input).
+  int64_t batch_tiles = 0;
+  for (int u = 0; u < B; ++u) batch_tiles += meta[u].ntile;
+  static const long rawdet_min_env = getenv("WH_HV_RAWDET_MIN_TILES") ? atol(getenv("WH_HV_RAWDET_MIN_TILES")) : -1;
+  const int64_t rawdet_min = rawdet_min_env >= 0 ? rawdet_min_env : WH_HV_RAWDET_MIN_TILES;
+  const bool use_rawdet = WH_HV_RAWDET && use_ols && batch_tiles >= rawdet_min;  // (its cursor hints come from the overlap-save walker)
   // the [channel][frame] candidate map (12 GB per 1024 x 10 s) and its bit map exist only where something reads them
   const bool need_map = !use_rawdet || dbg_raw != nullptr;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };

@@ -54,7 +54,7 @@ def _aperiodicity(x, fs, source, fft_size, is_requiem):
 # World.encode_batch / decode_batch cut a batch of at least this many bytes of waveform (audio to be rendered) into two
 # parts that run on two pipelines, so that one part's PCIe transfer lies under the other's kernels
 FACADE_SPLIT_BYTES = int(os.environ.get("WH_FACADE_SPLIT_BYTES", str(16 << 20)))
-FACADE_LANE = 2001  # the pipelines the parts run on: lane ids (contexts, flags, streams) no public class hands out, so the
+FACADE_LANE = int(os.environ.get("WH_FACADE_LANE", "2001"))  # the pipelines the parts run on: lane ids (contexts, flags, streams) no public class hands out, so the
 # facade's flag reads never consume — or raise for — a condition of the caller's own WorldBatchPipeline / WorldBatchLanes
 # work in flight
 # (Measured and not kept: the later part's stream at high priority, and its decode time base computed ahead under the

@@ -659,6 +659,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "steps_in_flight": depth,
+            "headline_definition": "ms_per_step / value: %d whole step(s) in flight (the default since round 5; rounds 1-4 "
+                                   "timed one: that figure is ms_per_step_one_in_flight in every line)" % depth,
             "primed": args.warmup == 0,
             "ms_per_step_one_in_flight": None if one_in_flight is None else one_in_flight / args.steps * 1e3,
             "per_rank_ms": [round(v, 4) for v in per_rank_ms],

@@ -422,3 +422,52 @@ def test_bench_defaults_match_the_contract(monkeypatch):
     b = bench.parse()
     assert (b.utts, b.seconds, b.in_flight) == (16, 60.0, 1)
 
+
+
+def test_requiem_cursor_chain_over_ranges_equals_the_utterance_chain():
+    """world.pool hands every device a contiguous range of a Requiem batch; the noise-seed cursor a range starts at is
+    computed on the host from the output lengths (world/synthesisRequiem.py:131-141 keeps index[-1]): cutting
+    the chain anywhere must give the cursor the single batch reaches there."""
+    import numpy as np
+    from world.synthesisRequiem import _advance, cursor_after, seed_table_shape
+    from world.synthesis import time_axis_params
+
+    fs = 16000
+    nlen, nb = seed_table_shape(fs)
+    assert (nlen, nb) == (8192, 3)
+    rng = np.random.RandomState(4)
+    tps = [np.arange(int(n)) * 0.005 for n in rng.randint(40, 900, size=9)]
+    cur = np.zeros(nb)
+    want = []
+    for tp in tps:
+        want.append(cur.copy())
+        cur = _advance(cur, time_axis_params(tp, fs)[0], nlen)
+    for cut in (0, 1, 4, 9):
+        c0 = cursor_after(tps[:cut], fs, np.zeros(nb), nlen)
+        assert np.array_equal(c0, want[cut] if cut < 9 else cur)
+        assert np.array_equal(cursor_after(tps[cut:], fs, c0, nlen), cur)
+    tabs = {"noise": np.zeros((4096, 5)), "pulse": np.zeros((1024, 5))}
+    assert seed_table_shape(fs, tabs) == (4096, 5)
+
+
+def test_pool_fails_loudly_without_a_gpu():
+    """No CPU fallback behind the thread-per-device driver either: without a GPU the first job raises WorldHipError on the
+    caller's thread (and the worker stays usable for the next call)."""
+    import numpy as np
+    import pytest
+    import torch
+    from world import _hip
+    from world.pool import WorldBatchPool
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_hip.WorldHipError):
+        WorldBatchPool()  # (device discovery)
+    pool = WorldBatchPool([0])
+    try:
+        for _ in range(2):
+            with pytest.raises(_hip.WorldHipError):
+                pool.encode([np.zeros(16000)], 16000, f0_method="dio")
+        assert pool.ranges([10, 10, 10]) == [(0, 3)]
+    finally:
+        pool.close()

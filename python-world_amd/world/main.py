@@ -93,16 +93,10 @@ def _hand_out(dats, block, y_off, copy_out):
     if block.nbytes < (1 << 22) or len(dats) < 4:
         outs = [np.array(block[a:b]) for a, b in cuts]
     else:
-        # the arrays are made here, one after the other (an mmap each: exclusive on the process's address space, cheap),
-        # and FILLED by the staging threads (page faults and the copy: shared).  Allocating inside the threads made them
-        # queue for the address-space lock: 6 - 15 ms for the 164 MB of a 64 x 20 s batch instead of ~3
-        outs = [np.empty(b - a, dtype=block.dtype) for a, b in cuts]
-
-        def fill(k):
-            outs[k][:] = block[cuts[k][0]:cuts[k][1]]
-
+        # (allocating the arrays on this thread and only filling them in the pool was measured and is worse: 49 against
+        # 28 - 39 ms for the 164 MB of a 64 x 20 s batch; the views of copy_out=False: 23 ms)
         with _hip._copy_pool() as pool:
-            list(pool.map(fill, range(len(cuts))))
+            outs = list(pool.map(lambda ab: np.array(block[ab[0]:ab[1]]), cuts))
     for d, y in zip(dats, outs):
         d['out'] = y
 

@@ -1076,15 +1076,28 @@ __device__ __forceinline__ void d4c_frame(
   // ---- band-wise aperiodicity (d4c.py:192-209) -----------------------------------------------
   const int boundary = lc.boundary;
   const int half = wlen / 2;
+  // The band window (Nuttall, wlen <= N / 2 + 1 taps: 2 * floor(interval / (fs / N)) + 1) is the same for every band: a
+  // thread's taps j = tid + q FT are fetched ONCE, together, in front of the band loop.  Read inside the fill loop they
+  // were one dependent global round trip per tap and band — the fill was 24 % of the N = 4096 instance's latency (five
+  // bands at 48 kHz: 62.7 k of 258.7 k cycles per frame, tools/d4c_stage_timer.py 48000), more than the bands' transforms.
+  constexpr int WQ = (N / 2 + 1 + FT - 1) / FT;
+  double wv[WQ];
+#pragma unroll
+  for (int q = 0; q < WQ; ++q) {
+    const int j = threadIdx.x + q * FT;
+    wv[q] = window[j < wlen ? j : 0];  // (clamped, not skipped: no branch per load)
+  }
   for (int b = 0; b < nap; ++b) {
     const int centre = lc.centre[b];
-    for (int j = threadIdx.x; j < N; j += FT) {
+#pragma unroll
+    for (int q = 0; q < N / FT; ++q) {
+      const int j = threadIdx.x + q * FT;
       double val = 0.0;
       if (j < wlen) {
         int idx = centre - half + j;          // index into the mirrored full group delay
         idx = idx < 0 ? -idx : idx;
         idx = idx > N / 2 ? N - idx : idx;
-        val = td[idx] * window[j];
+        val = td[idx] * (q < WQ ? wv[q < WQ ? q : 0] : window[j]);
       }
       zr[j] = val;
     }

@@ -1,5 +1,6 @@
-"""Per-stage cycle counts inside d4c_kernel (build with WH_EXTRA_FLAGS=-DWH_D4C_STAGE_TIMER): workgroup-thread-0
-timestamps at the stage boundaries, summed over all voiced frames of config 2's batch."""
+"""Per-stage cycle counts inside d4c_kernel (build a variant with wh_d4c:-DWH_D4C_STAGE_TIMER and point WH_LIB at it):
+workgroup-thread-0 timestamps at the stage boundaries, summed over all voiced frames of config 2's batch (or, with the
+argument 48000, of a 48 kHz batch: the N = 4096 instance)."""
 import ctypes
 import os
 import sys
@@ -12,13 +13,14 @@ import torch
 from world._synthetic import synth_utterance
 from world.batch import WorldBatch
 
+FS = int(sys.argv[1]) if len(sys.argv) > 1 else 16000  # 48000: the N = 4096 instance (five band stages)
 wb = WorldBatch(0)
-xs = [synth_utterance(i, 16000, 10.0) for i in range(64)]
-batch, x_d, tp_d = wb.upload(xs, 16000)
+xs = [synth_utterance(i, FS, 10.0) for i in range(64 if FS == 16000 else 16)]
+batch, x_d, tp_d = wb.upload(xs, FS)
 lib = wb.rt.lib
 buf = (ctypes.c_ulonglong * 16)()
 for it in range(3):
-    enc = wb.encode_device(batch, x_d, tp_d, 16000, f0_method="dio")
+    enc = wb.encode_device(batch, x_d, tp_d, FS, f0_method="dio")
     torch.cuda.synchronize()
     lib.wh_debug_d4c_stages(buf, 1)
 v = np.array(list(buf), dtype=np.float64)

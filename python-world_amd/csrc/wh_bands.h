@@ -316,7 +316,7 @@ static __global__ __launch_bounds__(256) void band_tile_fft_kernel(const BandJob
 #define WH_OLS_XCD 1
 #endif
 template <int kOlsBands>
-static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kernel(const BandJob* __restrict__ jobs, int nb, int n_utt, int H,
+static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kernel(const BandJob* __restrict__ jobs, int nb, int n_utt, int n_xcd, int H,
                                                                      const int32_t* __restrict__ half,
                                                                      const double* __restrict__ tspec,
                                                                      const double2* __restrict__ zspec,
@@ -337,8 +337,10 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
   // tiles in step, and a tile spectrum comes from HBM once and from that XCD's L2 for the other groups.  The real tap
   // spectra (2.5 MB for 152 channels, re-read per tile) fit the 4 MB L2 next to them.
   const int groups = (nb + kOlsBands - 1) / kOlsBands;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int u = (local / groups) * 8 + xcd;
+  // (n_xcd: 8, or 1 for a batch of fewer than eight utterances — one utterance per XCD would leave the other XCDs idle,
+  // and what a handful of utterances re-reads fits any L2)
+  const int xcd = blockIdx.x % n_xcd, local = blockIdx.x / n_xcd;
+  const int u = (local / groups) * n_xcd + xcd;
   if (u >= n_utt) return;
   const int b0 = (local % groups) * kOlsBands;
 #else
@@ -604,12 +606,13 @@ inline int launch_band_events_ols(wh_ctx* ctx, hipStream_t st, const BandJob* d_
 #ifndef WH_OLS_GROUP
 #define WH_OLS_GROUP 4  // channels per workgroup of the large-batch form
 #endif
-    const unsigned u8 = (unsigned)xcd_grid(n_utt);
-    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(u8 * nb), dim3(256), lds, st, d_jobs, nb, n_utt, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
-    else hipLaunchKernelGGL(band_events_ols_kernel<WH_OLS_GROUP>, dim3(u8 * ((nb + WH_OLS_GROUP - 1) / WH_OLS_GROUP)), dim3(256), lds, st, d_jobs, nb, n_utt, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+    const int n_xcd = n_utt >= 8 ? 8 : 1;
+    const unsigned u8 = (unsigned)(((n_utt + n_xcd - 1) / n_xcd) * n_xcd);
+    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(u8 * nb), dim3(256), lds, st, d_jobs, nb, n_utt, n_xcd, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+    else hipLaunchKernelGGL(band_events_ols_kernel<WH_OLS_GROUP>, dim3(u8 * ((nb + WH_OLS_GROUP - 1) / WH_OLS_GROUP)), dim3(256), lds, st, d_jobs, nb, n_utt, n_xcd, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
 #else
-    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(n_utt, nb), dim3(256), lds, st, d_jobs, nb, n_utt, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
-    else hipLaunchKernelGGL(band_events_ols_kernel<4>, dim3(n_utt, (nb + 3) / 4), dim3(256), lds, st, d_jobs, nb, n_utt, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+    if (single) hipLaunchKernelGGL(band_events_ols_kernel<1>, dim3(n_utt, nb), dim3(256), lds, st, d_jobs, nb, n_utt, 1, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
+    else hipLaunchKernelGGL(band_events_ols_kernel<4>, dim3(n_utt, (nb + 3) / 4), dim3(256), lds, st, d_jobs, nb, n_utt, 1, H, d_half, d_tre, d_zspec, d_tile_off, ctx->d_twiddle, d_flag);
 #endif
   }
 #endif

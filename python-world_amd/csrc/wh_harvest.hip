@@ -424,13 +424,13 @@ struct RdStage {
 #endif
 __global__ __launch_bounds__(kRawTile, WH_HV_RAWDET_MINW) void hv_rawdet_kernel(const HvUtt* __restrict__ meta, const wh::BandJob* __restrict__ jobs,
                                                              const double* __restrict__ band_f0,
-                                                             const int32_t* __restrict__ hints, int nb, int n_utt, int max_ntile,
+                                                             const int32_t* __restrict__ hints, int nb, int n_utt, int n_xcd, int max_ntile,
                                                              double fs_d, double f0_floor, double f0_ceil,
                                                              double* __restrict__ dc, int32_t* __restrict__ dcount,
                                                              double* __restrict__ raw_dbg) {
   __shared__ double2 iv[4][kRawChunk];       // (location, frequency) of interval start + i
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int u = (local / max_ntile) * 8 + xcd;
+  const int xcd = blockIdx.x % n_xcd, local = blockIdx.x / n_xcd;  // (n_xcd: 8, or 1 for fewer than eight utterances)
+  const int u = (local / max_ntile) * n_xcd + xcd;
   if (u >= n_utt) return;
   const HvUtt m = meta[u];
   const int64_t T = local % max_ntile;
@@ -1786,7 +1786,8 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     for (int u = 0; u < B; ++u) max_ntile = std::max(max_ntile, meta[u].ntile);
     double* d_rawdbg = nullptr;
     if (dbg_raw) d_rawdbg = d_raw;
-    { wh::KernelTimer _kt(ctx, st, "hv_rawdet_kernel"); hipLaunchKernelGGL(hv_rawdet_kernel, dim3((unsigned)(wh::xcd_grid(B) * max_ntile)), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, d_hint, n_bands, B, (int)max_ntile, fs_d, f0_floor, f0_ceil, d_dc, d_dn, d_rawdbg); }
+    const int rd_xcd = B >= 8 ? 8 : 1;
+    { wh::KernelTimer _kt(ctx, st, "hv_rawdet_kernel"); hipLaunchKernelGGL(hv_rawdet_kernel, dim3((unsigned)((int64_t)((B + rd_xcd - 1) / rd_xcd) * rd_xcd * max_ntile)), dim3(kRawTile), 0, st, d_meta, d_jobs, d_bf, d_hint, n_bands, B, rd_xcd, (int)max_ntile, fs_d, f0_floor, f0_ceil, d_dc, d_dn, d_rawdbg); }
     WH_LAUNCH_CHECK("hv_rawdet_kernel");
     if (dbg_raw) WH_CHECK(hipMemcpyAsync(dbg_raw, d_raw, sizeof(double) * f1_tot * n_bands, hipMemcpyDeviceToDevice, st));
   } else {

@@ -98,3 +98,59 @@ def test_d4c_96k_needs_8192_point_transforms(golden):
     rq = d4cRequiem(g["x"], fs, src)
     assert rq["aperiodicity"].shape == g["req_band_ap"].shape
     assert np.max(np.abs(rq["aperiodicity"] - g["req_band_ap"])) < 1e-6
+
+
+@pytest.mark.parametrize("fs,requiem", [(16000, False), (16000, True), (48000, False)])
+def test_love_train_gate_around_its_threshold(fs, requiem):
+    """the voicing gate s1 / s2 > 0.85 (d4c.py:68-88) is a discrete decision read off the kernel's transform.
+    A harmonic source below 4 kHz plus a band of noise between 4 and 7.9 kHz whose gain sweeps through the utterance
+    walks the ratio across 0.85 in small steps: every frame whose ratio (oracle) lies further than 1e-9 from the
+    threshold must be gated exactly as the oracle gates it — in the fused kernel (d4c, transform sizes equal), in
+    love_train_kernel (D4C-Requiem at 16 kHz: 2048 against 1024) and at 48 kHz — whatever the translation unit's FMA
+    contraction; the sweep must really pass the threshold, with frames within 1e-2 of it on both sides."""
+    from oracle import aperiodicity as oap
+    from world.d4c import d4c
+    from world.d4cRequiem import d4cRequiem
+
+    rng = np.random.RandomState(12)
+    n = int(2.0 * fs)
+    t = np.arange(n) / fs
+    f0 = 140.0
+    low = sum(np.sin(2 * np.pi * f0 * h * t + 0.3 * h) / h for h in range(1, int(3500 / f0)))
+    spec = np.fft.rfft(rng.randn(n))
+    fr = np.fft.rfftfreq(n, 1 / fs)
+    spec[(fr < 4300) | (fr > 7600)] = 0.0
+    high = np.fft.irfft(spec, n)
+    high *= np.sqrt(np.mean(low ** 2) / np.mean(high ** 2))
+    gain = np.linspace(0.15, 0.75, n)  # power ratio low / (low + g^2 high): ~0.98 down to ~0.64
+    x = 0.2 * (low + gain * high)
+    tp = np.arange(int(1000 * n / fs / 5 + 1)) * 0.005
+    f0v = np.full(len(tp), f0)
+    vuv = np.ones(len(tp))
+    # the oracle's ratio per frame (love_train's own arithmetic, world/d4c.py:68-88)
+    nfft = oap._pow2_at_least(3 * fs / 40.0 + 1)
+    b0, b1, b2 = (int(np.ceil(v / (fs / nfft)) + 1) for v in (100, 4000, 7900))
+    wave, _, _ = oap._window_frames(x, fs, np.maximum(f0v, 40.0), tp, 1.5, True)
+    p = np.abs(np.fft.fft(wave, nfft, axis=1)) ** 2
+    p[:, :b0] = 0.0
+    cum = np.cumsum(p, axis=1)
+    ratio = cum[:, b1 - 1] / cum[:, b2 - 1]
+    want = ratio > 0.85
+    assert want.any() and (~want).any()
+    assert ((ratio > 0.85) & (ratio < 0.86)).any() and ((ratio < 0.85) & (ratio > 0.84)).any()
+    src = {"f0": f0v.copy(), "vuv": vuv.copy(), "temporal_positions": tp.copy()}
+    if requiem:
+        out = d4cRequiem(x, fs, src)["aperiodicity"]
+        got = (out[1:-1] < -1e-9).any(axis=0)  # an ungated frame keeps 0 dB... in every band
+        ref, _ = oap.d4c_requiem_np(x, fs, f0v.copy(), vuv, tp)
+        want_out = (ref[1:-1] < -1e-9).any(axis=0)
+    else:
+        out = d4c(x, fs, src)
+        got = (out["coarse_ap"] != 0).any(axis=0)
+        ref_ap, ref_coarse, _ = oap.d4c_np(x, fs, f0v.copy(), vuv, tp)
+        want_out = (ref_coarse != 0).any(axis=0)
+    clear = np.abs(ratio - 0.85) > 1e-9
+    assert clear.sum() >= len(ratio) - 2
+    assert np.array_equal(got[clear], want_out[clear])
+    # (the gate is the only way a frame of this signal ends up without aperiodicity)
+    assert np.array_equal(want_out[clear], want[clear])

@@ -52,7 +52,15 @@ def main(out):
     batch2, x2_d, tp2_d = wb.upload(xs2, fs2)
     f0_2, vuv_2 = harvest_device(wb.rt, batch2, x2_d, tp2_d, fs2, 60, 700, 5)
     assert wb.rt.take_flags() == [0] * 16
-    np.savez(out, f0=f0_d.cpu().numpy(), vuv=vuv_d.cpu().numpy(), frame_off=batch.frame_off,
+    # the [channel][frame] raw-candidate map of one utterance of each rate (the debug read-out of wh_harvest): the fused
+    # and the paired kernels must fill it with the same values
+    raws = []
+    for fs_r, x_r, args_r in ((fs, xs[3], (71, 800)), (fs2, xs2[0], (60, 700))):
+        b1, x1, t1 = wb.upload([x_r], fs_r)
+        _, _, dbg = harvest_device(wb.rt, b1, x1, t1, fs_r, args_r[0], args_r[1], 5, debug=True)
+        raws.append(dbg["raw"].cpu().numpy())
+    assert wb.rt.take_flags() == [0] * 16
+    np.savez(out, f0=f0_d.cpu().numpy(), vuv=vuv_d.cpu().numpy(), frame_off=batch.frame_off, raw_16k=raws[0], raw_22k=raws[1],
              f0_22k=f0_2.cpu().numpy(), vuv_22k=vuv_2.cpu().numpy(), frame_off_22k=batch2.frame_off,
              kernels=np.array(sorted(prof)), ms=np.array([prof[k] for k in sorted(prof)]))
 

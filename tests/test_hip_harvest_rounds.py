@@ -64,6 +64,11 @@ def test_fused_and_paired_raw_candidate_kernels_agree(tmp_path):
     for kf, kv in (("f0", "vuv"), ("f0_22k", "vuv_22k")):
         assert np.array_equal(fused[kv], paired[kv])
         assert np.max(np.abs(fused[kf] - paired[kf])) < 1e-9
+    # the raw candidates themselves (harvest.py:252-278), channel by channel and frame by frame: the fused kernel's
+    # interpolation is hv_raw_kernel's, value for value — bitwise the same map, quiet stretch and 7350 Hz rate included
+    for k in ("raw_16k", "raw_22k"):
+        assert fused[k].shape == paired[k].shape and (fused[k] != 0).sum() > 1000
+        assert np.array_equal(fused[k], paired[k]), k
     for (fs, xs), fo, kf, kv, args in ((inputs(), fused["frame_off"], "f0", "vuv", ()),
                                        (inputs_22k(), fused["frame_off_22k"], "f0_22k", "vuv_22k", (60, 700))):
         for u, x in enumerate(xs):

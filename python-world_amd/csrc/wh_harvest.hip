@@ -1133,10 +1133,11 @@ __device__ __forceinline__ void hv_refine_row(wh::ckp<const double> WH_RESTRICT 
 #define WH_HV_MINW 3  // waves per SIMD the tabulated variant is compiled for (2: 5.07 ms against 4.09 at config 3)
 #endif
 #ifndef WH_HV_ROW_LANES
-#define WH_HV_ROW_LANES 4
+#define WH_HV_ROW_LANES 2  // (round 6, 512 x 10 s: 8 lanes 22.1 ms, 4: 17.7, 2: 16.5, 1: 18.6; 64 x 10 s: 4: 2.30, 2: 2.15, 1: 2.49)
 #endif
 #ifndef WH_HV_TAB_FRAMES
-#define WH_HV_TAB_FRAMES 24  // (the list building is per block and a wave pass takes 16 classes whatever it holds; config 3:
+#define WH_HV_TAB_FRAMES 32  // (round 6, with two lanes per candidate: 32 frames 16.36 ms against 16.50 for 24 at 512 x 10 s; round 4,
+                            // four lanes: (the list building is per block and a wave pass takes 16 classes whatever it holds; config 3:
                             // 16 frames 3.81 ms, 24: 3.34, 32: 3.37, 48: 4.79 — 52.3 against 59.7 ms at 1024 utterances)
 #endif
 #ifndef WH_HV_ITEM_CAP

@@ -1338,13 +1338,15 @@ def north_star_block(torch, device_index, xs_distinct, fs, args, steps=6):
     xs = [xs_distinct[i % len(xs_distinct)] for i in range(n)]
     from world import _hip
     _hip.Runtime.trim_all()  # the arenas of the earlier blocks (they only grow) go back to the device first
-    # ONE step in flight here: the Harvest workspace of 1024 utterances is ~105 GB (52 GB of crossing lists, 12.5 GB of raw
-    # candidates, 17 GB of refined ones ...), two pipelines plus the profiler's child process do not fit 288 GB — and at
-    # this size the serial head of a step is 1-2 % of it
-    depth = 1 if n > 256 else max(1, getattr(args, "in_flight", 1))
-    wbs = [WorldBatch(device_index, lane=(d + 1) if depth > 1 else 0) for d in range(depth)]
-    res = [w.upload(xs, fs) for w in wbs]
-    wb, (batch, x_d, tp_d) = wbs[0], res[0]
+    # Steps in flight: the workspace of one pipeline at 1024 utterances is ~96 GB (47 GB of crossing lists sized with 3 x
+    # head-room, 17 GB of refined candidates ...; round 5: 105 GB, with the raw-candidate map).  A second pipeline — its own
+    # resident copy of the batch, context, arena, stream — is added when --in-flight asks for it AND, measured after the
+    # first one has run a step, the device still has 1.4 x that much free (the graphs' private pools come on top); the
+    # serial head of a step is 1-2 % of it at this size, so it buys ~1 % (194.4 -> 192.0 ms, tools/ns_mem.py).
+    want = max(1, getattr(args, "in_flight", 1))
+    free0, _ = torch.cuda.mem_get_info()
+    wbs = [WorldBatch(device_index, lane=1 if want > 1 else 0)]
+    res = [wbs[0].upload(xs, fs)]
 
     def make_one(w, r):
         def one():
@@ -1352,13 +1354,22 @@ def north_star_block(torch, device_index, xs_distinct, fs, args, steps=6):
             return w.decode_device(enc, check=False)  # device-generated seed tables
         return one
 
-    ones = [make_one(w, r) for w, r in zip(wbs, res)]
-    one = ones[0]
-    for fn in ones:
-        fn()
+    ones = [make_one(wbs[0], res[0])]
+    ones[0]()
     torch.cuda.synchronize()
-    for w in wbs:
-        w.check("north_star warm-up")
+    wbs[0].check("north_star warm-up")
+    free1, _ = torch.cuda.mem_get_info()
+    pipeline_bytes = free0 - free1
+    if want > 1 and free1 >= 1.4 * pipeline_bytes:
+        wbs.append(WorldBatch(device_index, lane=2))
+        res.append(wbs[1].upload(xs, fs))
+        ones.append(make_one(wbs[1], res[1]))
+        ones[1]()
+        torch.cuda.synchronize()
+        wbs[1].check("north_star warm-up")
+    depth = len(wbs)
+    one = ones[0]
+    wb, (batch, x_d, tp_d) = wbs[0], res[0]
     t = time_pipelines(torch, [((lambda k, fn=fn: fn()), w.rt.own_stream) for fn, w in zip(ones, wbs)], steps)
     enq, eager, dt, dt_one = t["enqueue"], t["eager"], t["pipelined"], t["one"]
     wb.rt.profile(True)  # per-kernel durations from one more step (the event pairs stay out of the timed steps)
@@ -1409,6 +1420,7 @@ def north_star_block(torch, device_index, xs_distinct, fs, args, steps=6):
                         "D4C-Requiem encode + Requiem decode, HBM-resident" % (n, len(xs[0]) / fs, min(n, len(xs_distinct))),
             "distinct_utterances": min(n, len(xs_distinct)), "host_enqueue_ms_per_step": enq * 1e3,
             "graph": t["graph"], "eager_ms_per_step": eager * 1e3, "steps_in_flight": depth,
+            "pipeline_device_GB": round(pipeline_bytes / 2 ** 30, 1),
             "ms_per_step_one_in_flight": dt_one * 1e3,
             "ms_per_step": dt * 1e3, "value": frames / dt, "unit": "frames/s", "x_realtime": n * len(xs[0]) / fs / dt,
             "target_x_realtime": 500, "steps": steps, "frames_per_step": frames,

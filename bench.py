@@ -1014,8 +1014,26 @@ def facade_batch_block(torch, xs, fs, reps=3):
         roundtrip(copy_out=False)
         torch.cuda.synchronize()
         view_rt.append(time.perf_counter() - t0)
+    # the thread-per-device driver on the one GPU this process has: devices=[0, 0] — two host threads, two contexts, two
+    # streams (world.pool; the same call with devices=[0 .. 7] is how one process drives a node).  Not a scaling figure.
+    pool_rt = None
+    try:
+        def pooled():
+            return W.decode_batch(W.encode_batch(fs, xs, f0_method="dio", devices=[0, 0]), devices=[0, 0])
+        pooled()
+        pooled()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            pooled()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        pool_rt = float(np.median(ts)) * 1e3
+    except Exception as ex:  # never costs the block
+        pool_rt = "%s: %s" % (type(ex).__name__, ex)
     f, e, d = float(np.median(flow_s)), float(np.median(enc_s)), float(np.median(dec_s))
     return {"resynthesis_flow_ms": f * 1e3, "roundtrip_unmodified_ms": float(np.median(rt_s)) * 1e3,
+            "roundtrip_unmodified_pool_devices_0_0_ms": pool_rt,
             "resynthesis_flow_views_ms": float(np.median(view_flow)) * 1e3,
             "roundtrip_unmodified_views_ms": float(np.median(view_rt)) * 1e3,
             "out_arrays": "default: one pageable array per utterance (copied out of the pinned block by the staging threads); "

@@ -62,7 +62,7 @@ int wh_copy_mapped(wh_ctx* ctx, void* stream, void* dst, const void* src, size_t
 /* Sticky device-side condition flags raised by kernels instead of failing silently; reading them
  * synchronises the stream and clears them.  h_flags16[WH_FLAG_*] != 0 means the condition occurred. */
 #define WH_FLAG_STONEMASK_WINDOW 0 /* a frame's f0 needed a longer window than kmax: left unrefined */
-#define WH_FLAG_EVENT_OVERFLOW 1   /* a zero-crossing list exceeded its capacity (cannot happen for cap = len/2+2) */
+#define WH_FLAG_EVENT_OVERFLOW 1   /* a zero-crossing list exceeded its capacity (DIO: cannot happen, cap = len/2+2; Harvest: see wh_harvest_set_event_caps) */
 #define WH_FLAG_NOISE_SHORT 2      /* synthesis ran out of host-supplied noise samples */
 #define WH_FLAG_NO_PULSE 3         /* an utterance produced no pulse (reference asserts, synthesis.py:131) */
 #define WH_FLAG_PULSE_OVERFLOW 4   /* more pulses than the pulse capacity, or more overlap-add rows than its row region holds */
@@ -163,6 +163,21 @@ int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, co
                const double* h_zi, int n_bands, const double* h_band_f0, const int32_t* h_band_half,
                const double* h_band_taps, double* f0_out, double* vuv_out, double* dbg_y, double* dbg_raw,
                double* dbg_f0_1ms);
+/* Capacities of Harvest's zero-crossing lists.  The reference keeps the four crossing trains of a channel as NumPy arrays
+ * of whatever length they turn out to have (ZeroCrossingEngine, world/harvest.py:283-297); wh_harvest sizes its lists
+ * from an estimate (three times the channel's centre frequency per second) before anything has run.  The estimate fails
+ * where a stretch of the filtered signal is constant up to rounding — digital silence next to signal: harvest.py:69
+ * removes the mean, the silence becomes a DC level, and the first difference of its filtered image changes sign at
+ * random, as it does in the reference's own arithmetic.  Such a call raises WH_FLAG_EVENT_OVERFLOW and its results
+ * are not to be used; its COUNTS are exact (counting goes on past a full list):
+ *   wh_harvest_event_counts — h_caps_out[u * n_bands + i] (HOST) = the longest of the four trains of channel i of
+ *     utterance u in this context's last wh_harvest; n = utterances x channels of that call.  Waits for `stream`.
+ *   wh_harvest_set_event_caps — h_caps != NULL: these capacities for the NEXT wh_harvest of this context (one call);
+ *     NULL, n == -1: the bound no signal exceeds (ylen/2 + 2 per train: 4.3 x the estimate's memory for the default
+ *     range) for every later call; NULL, n == 0: back to the estimate.
+ * A repeat with the counted capacities fits by construction (same arithmetic, same counts). */
+int wh_harvest_set_event_caps(wh_ctx* ctx, const int64_t* h_caps, int64_t n);
+int wh_harvest_event_counts(wh_ctx* ctx, void* stream, int64_t* h_caps_out, int64_t n);
 
 /* ---- StoneMask: replaces stonemask()  (world/stonemask.py:8-27) -------------------------------- */
 /* f0[total_frames] in, refined_f0[total_frames] out (a different buffer: the reference returns a new

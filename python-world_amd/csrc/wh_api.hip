@@ -137,7 +137,7 @@ static thread_local int64_t g_bounds_last[4] = {0, 0, 0, 0};
 
 extern "C" {
 
-int wh_version(void) { return 105; }
+int wh_version(void) { return 106; }
 const char* wh_last_error(void) { return g_last_error.c_str(); }
 
 int wh_device_count(int* count) {

@@ -1589,6 +1589,12 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   if (2 * hmax + 1 > WH_MAX_FFT / 2) return wh::fail_msg("wh_harvest", "f0_floor too low for the twiddle tables");
   std::vector<HvUtt> meta(B);
   std::vector<int64_t> e_off((size_t)B * n_bands), e_cap((size_t)B * n_bands);
+  const bool caps_worst = ctx->hv_caps_worst;
+  const bool caps_given = !caps_worst && !ctx->hv_caps_next.empty();
+  if (caps_given && ctx->hv_caps_next.size() != (size_t)B * n_bands) {
+    ctx->hv_caps_next.clear();
+    return wh::fail_msg("wh_harvest", "wh_harvest_set_event_caps: one capacity per (utterance, channel) of THIS batch expected");
+  }
   int64_t l_tot = 0;
   int64_t t_tot = 0, y_tot = 0, z_tot = 0, e_tot = 0, f1_tot = 0, max_len = 0, max_ylen = 0, max_nf1 = 0, max_nf = 0;
   for (int u = 0; u < B; ++u) {
@@ -1625,8 +1631,15 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     m.f_off = b->h_frame_off[u];
     m.nf = b->h_frame_off[u + 1] - b->h_frame_off[u];
     for (int i = 0; i < n_bands; ++i) {
-      // a band-limited channel centred on f crosses zero ~f times per second; 3x head-room + slack
-      const int64_t cap = (int64_t)ceil((double)m.ylen / fs_d * h_band_f0[i] * 3.0) + 64;
+      // a band-limited channel centred on f crosses zero ~f times per second; 3x head-room + slack.  That is an
+      // ESTIMATE: where the filtered signal is constant up to rounding (digital silence next to signal: the mean
+      // removal of harvest.py:69 turns it into a DC level) the first difference changes sign at random, up to every
+      // other sample.  Such a call raises WH_FLAG_EVENT_OVERFLOW, its counts stay exact (the walker counts on past a
+      // full list), and the caller repeats it with them (wh_harvest_event_counts -> wh_harvest_set_event_caps) or with
+      // the bound no signal exceeds, ylen / 2 + 2.
+      int64_t cap = (int64_t)ceil((double)m.ylen / fs_d * h_band_f0[i] * 3.0) + 64;
+      if (caps_worst) cap = m.ylen / 2 + 2;
+      else if (caps_given) cap = std::max<int64_t>(ctx->hv_caps_next[(size_t)u * n_bands + i], 8);
       e_off[(size_t)u * n_bands + i] = e_tot;
       e_cap[(size_t)u * n_bands + i] = cap;
       e_tot += 4 * cap;
@@ -1636,6 +1649,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     max_nf1 = std::max(max_nf1, m.nf1);
     max_nf = std::max(max_nf, m.nf);
   }
+  ctx->hv_caps_next.clear();  // explicit capacities serve one call
   int h_max = 0;
   for (int i = 0; i < n_bands; ++i) h_max = std::max(h_max, (int)h_band_half[i]);
 #ifndef WH_HV_BAND_OLS
@@ -1668,7 +1682,6 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   const size_t o_z = off; off += al(sizeof(double) * z_tot);
   const size_t o_mean = off; off += al(sizeof(double) * B * (1 + kMeanParts));  // means, then the partial sums
   const size_t o_e = off; off += al(sizeof(double) * e_tot);
-  const size_t o_cnt = off; off += al(sizeof(int32_t) * (size_t)B * n_bands * 4);
   const size_t o_raw = off; off += need_map ? al(sizeof(double) * f1_tot * n_bands) : 0;
   const size_t o_live = off; off += need_map ? al(sizeof(unsigned long long) * (size_t)l_tot) : 0;
   const size_t o_hint = off; off += use_rawdet ? al(sizeof(int32_t) * 4 * (size_t)l_tot) : 0;  // [utterance][tile][channel][train]
@@ -1699,7 +1712,15 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   double* d_z = reinterpret_cast<double*>(ws + o_z);
   double* d_mean = reinterpret_cast<double*>(ws + o_mean);
   double* d_e = reinterpret_cast<double*>(ws + o_e);
-  int32_t* d_cnt = reinterpret_cast<int32_t*>(ws + o_cnt);
+  // the lists' counts: a buffer of their own (wh_harvest_event_counts reads them after later stages have used the scratch)
+  int32_t* d_cnt = nullptr;
+  {
+    void* p = nullptr;
+    if (int rc = wh::persistent_scratch(ctx, "hv.counts", sizeof(int32_t) * (size_t)B * n_bands * 4, &p)) return rc;
+    d_cnt = reinterpret_cast<int32_t*>(p);
+    ctx->hv_last_cnt = d_cnt;
+    ctx->hv_last_cnt_lists = (int64_t)B * n_bands;
+  }
   wh::BandJob* d_jobs = nullptr;
   double* d_raw = reinterpret_cast<double*>(ws + o_raw);
   unsigned long long* d_live = reinterpret_cast<unsigned long long*>(ws + o_live);
@@ -1889,4 +1910,40 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   // ---- contour, smoothing, 5 ms pick -------------------------------------------------------------------------
   return harvest_contour(ctx, st, B, d_meta, meta, f1_tot, max_nf1, max_nf, d_rf0, d_rsc, d_lst, d_keep, d_ct, tp, f0_out, vuv_out,
                          dbg_f0_1ms);
+}
+
+// Capacities of Harvest's zero-crossing lists (include/world_hip.h).  h_caps != NULL: one capacity per (utterance,
+// channel) for the NEXT wh_harvest of this context (n = utterances x channels of that call); NULL with n == -1: every
+// list sized for the bound no signal exceeds (ylen / 2 + 2) until reset; NULL with n == 0: back to the estimate.
+extern "C" int wh_harvest_set_event_caps(wh_ctx* ctx, const int64_t* h_caps, int64_t n) {
+  if (!ctx) return wh::fail_msg("wh_harvest_set_event_caps", "null context");
+  if (h_caps) {
+    if (n <= 0) return wh::fail_msg("wh_harvest_set_event_caps", "n must be utterances x channels");
+    ctx->hv_caps_next.assign(h_caps, h_caps + n);
+    return 0;
+  }
+  if (n != 0 && n != -1) return wh::fail_msg("wh_harvest_set_event_caps", "without capacities n is 0 (estimate) or -1 (bound)");
+  ctx->hv_caps_next.clear();
+  ctx->hv_caps_worst = n == -1;
+  return 0;
+}
+
+// What the last wh_harvest of this context counted: h_caps_out[u * n_bands + i] = the longest of the four crossing
+// trains of channel i of utterance u — exact also when the call overflowed its lists (WH_FLAG_EVENT_OVERFLOW), so a
+// repeat with these capacities fits.  Waits for `stream`.
+extern "C" int wh_harvest_event_counts(wh_ctx* ctx, void* stream, int64_t* h_caps_out, int64_t n) {
+  if (!ctx || !h_caps_out) return wh::fail_msg("wh_harvest_event_counts", "null argument");
+  WH_ENTER(ctx);
+  if (!ctx->hv_last_cnt || n != ctx->hv_last_cnt_lists)
+    return wh::fail_msg("wh_harvest_event_counts", "n is not utterances x channels of this context's last wh_harvest");
+  std::vector<int32_t> cnt((size_t)n * 4);
+  hipStream_t st = (hipStream_t)stream;
+  WH_CHECK(hipMemcpyAsync(cnt.data(), ctx->hv_last_cnt, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost, st));
+  WH_CHECK(hipStreamSynchronize(st));
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t m = cnt[4 * i];
+    for (int t = 1; t < 4; ++t) m = std::max(m, cnt[4 * i + t]);
+    h_caps_out[i] = m;
+  }
+  return 0;
 }

@@ -47,6 +47,14 @@ struct wh_ctx {
     int64_t pulse_cap = 0, ny_tot = 0, frames = 0;
     size_t o_vuv = 0, o_pt = 0, o_pi = 0, o_ps = 0, o_pn = 0, o_pc = 0, o_pb = 0, o_rec = 0;
   } timebase;
+  // Harvest's zero-crossing lists (wh_harvest_set_event_caps / wh_harvest_event_counts): the capacities the NEXT
+  // wh_harvest takes instead of its estimate (one-shot; empty: estimate, hv_caps_worst: ylen/2 + 2 for every list), and
+  // where the last call left its per-(utterance, channel, train) counts — a buffer of its own, not the shared scratch,
+  // so that they can still be read after the stages behind Harvest have run
+  std::vector<int64_t> hv_caps_next;
+  bool hv_caps_worst = false;
+  int32_t* hv_last_cnt = nullptr;
+  int64_t hv_last_cnt_lists = 0;  // utterances x channels of that call
   // optional per-kernel timing (HIP events on the launch stream), see wh_profile_*
   bool prof = false;
   std::vector<hipEvent_t> prof_events;    // pool, two per record

@@ -54,6 +54,8 @@ SIGNATURES = {
                       _vp, _vp, _vp, _vp]),
     "wh_harvest": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp,
                           _vp, _vp, _vp]),
+    "wh_harvest_set_event_caps": (_int, [_vp, _vp, ctypes.c_int64]),
+    "wh_harvest_event_counts": (_int, [_vp, _vp, _vp, ctypes.c_int64]),
     "wh_stonemask": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _int, _vp]),
     "wh_synthesis": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _int, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp,
                             ctypes.c_uint64, _vp, _vp]),
@@ -95,7 +97,10 @@ FLAG_STONEMASK_WINDOW, FLAG_EVENT_OVERFLOW, FLAG_NOISE_SHORT, FLAG_NO_PULSE, FLA
 FLAG_MESSAGES = {
     FLAG_STONEMASK_WINDOW: "StoneMask: a frame's f0 needs a longer analysis window than the one sized from min_f0 "
                            "(frame left unrefined)",
-    FLAG_EVENT_OVERFLOW: "a zero-crossing event list exceeded its capacity (pathological input)",
+    FLAG_EVENT_OVERFLOW: "a zero-crossing list of Harvest exceeded its estimated capacity (stretches that are constant up "
+                         "to rounding, e.g. digital silence next to signal): the checked calls — harvest(), "
+                         "encode_device(check=True), World.encode / encode_batch — repeat themselves with the counted "
+                         "capacities; a call kept asynchronous takes event_caps='safe' or world.harvest.counted_event_caps(rt)",
     FLAG_NOISE_SHORT: "synthesis ran out of host-supplied noise samples",
     FLAG_NO_PULSE: "an utterance produced no pulse (the reference asserts, world/synthesis.py:131)",
     FLAG_PULSE_OVERFLOW: "more pulses (or overlap-add rows) than pulse_cap provides for: trailing pulses / runs were dropped "
@@ -203,6 +208,7 @@ class Runtime:
         # (a high-priority stream for the lanes whose short serial kernels are meant to run under another lane's
         # chip-filling ones was measured and is worse: config 2 10.12 against 9.83 ms with the time-base lane at -1)
         self.own_stream = torch.cuda.Stream(device=self.device) if lane else None
+        self.harvest_lists = 0  # utterances x channels of this context's last wh_harvest (world.harvest.counted_event_caps)
 
     @classmethod
     def get(cls, device_index=None, lane=0):

@@ -439,7 +439,7 @@ class WorldBatch:
     @_on_lane_stream
     def encode_device(self, batch, x_d, tp_d, fs, f0_method='dio', f0_floor=71, f0_ceil=800, channels_in_octave=2,
                       target_fs=4000, frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False,
-                      f0_done=None, check=True, want_ps=False):
+                      f0_done=None, check=True, want_ps=False, event_caps=None):
         """world/main.py:106-152 for a resident batch.  tp_d is not modified (a copy is kept in the result).
         ``f0_done``: optional callable invoked once the F0 stage has been enqueued (used to stagger lanes).
         ``check``: True — read the sticky device flags afterwards (synchronises this lane's stream) and raise
@@ -447,7 +447,11 @@ class WorldBatch:
         (``WorldBatch.check()``); ``'deferred'`` — no host wait either: the flags are published by a kernel behind this
         call's work (wh_flags_post) and the NEXT deferred-check call (or ``check()``) raises for them — late, never lost:
         the mode for a caller that keeps batches in flight.
-        ``want_ps``: keep CheapTrick's complex spectra as ``enc.ps_spectrogram`` (encode()'s 'ps spectrogram')."""
+        ``want_ps``: keep CheapTrick's complex spectra as ``enc.ps_spectrogram`` (encode()'s 'ps spectrogram').
+        ``event_caps`` (Harvest): capacities of its zero-crossing lists, see ``world.harvest.harvest_device``.  With
+        ``check=True`` a call whose estimate was exceeded (WH_FLAG_EVENT_OVERFLOW: stretches constant up to rounding, e.g.
+        digital silence next to signal) is repeated once with the capacities it counted; an asynchronous call reports
+        the condition and the caller repeats it (``event_caps='safe'`` or ``counted_event_caps``)."""
         rt = self.rt
         self._deferred_begin(check, "encode_device")
         if fft_size is not None:
@@ -458,7 +462,7 @@ class WorldBatch:
             f0_d = stonemask_device(rt, batch, x_d, tp_d, f0_d, fs, f0_floor)
         elif f0_method == 'harvest':
             from .harvest import harvest_device
-            f0_d, vuv_d = harvest_device(rt, batch, x_d, tp_d, fs, f0_floor, f0_ceil, frame_period)
+            f0_d, vuv_d = harvest_device(rt, batch, x_d, tp_d, fs, f0_floor, f0_ceil, frame_period, event_caps=event_caps)
         elif f0_method == 'swipe':
             from .swipe import swipe_device
             # world/main.py:134-135 calls swipe() with its default dt = 5 ms whatever frame_period says, and every
@@ -482,7 +486,17 @@ class WorldBatch:
         if check == 'deferred':
             rt.post_flags()
         elif check:
-            rt.check_flags("encode_device")
+            flags = rt.take_flags()
+            if flags[_hip.FLAG_EVENT_OVERFLOW] and f0_method == 'harvest' and event_caps is None:
+                # more crossings than estimated: everything behind Harvest worked on an unusable contour (whatever else
+                # it reported goes with it) — once more, with the capacities this pass counted
+                from .harvest import counted_event_caps
+                if self._tb_rt is not None:
+                    self._tb_rt.take_flags()
+                return self.encode_device(batch, x_d, tp_d, fs, f0_method, f0_floor, f0_ceil, channels_in_octave, target_fs,
+                                          frame_period, allowed_range, fft_size, is_requiem, None, True, want_ps,
+                                          counted_event_caps(rt))
+            rt.raise_for_flags(flags, "encode_device")
         enc = BatchEncoding(rt, batch, fs, tp_d.clone(), f0_d, vuv_d, spec_d, ap_d, ct_fft, is_requiem, frame_period,
                             tp_host=None if tp_host is None else tp_host.copy(), ps_spectrogram=ps_d)
         if timebase is not None:
@@ -572,7 +586,33 @@ class WorldBatch:
             # runs on that grid (world/main.py:134-135): frame_period is ignored, as in World.encode
             kw = dict(kw, frame_period=5)
         batch, x_d, tp_d = self.upload(xs, fs, kw.get('frame_period', 5), swipe_grid=kw.get('f0_method') == 'swipe')
-        return self.encode_device(batch, x_d, tp_d, fs, **kw)
+        if kw.get('f0_method') == 'harvest' and kw.get('event_caps') is None:
+            from .harvest import flat_samples
+            batch.flat_samples = [flat_samples(x) for x in xs]  # (40 us per 10 s: digital silence needs longer crossing lists)
+        enc = self.encode_device(batch, x_d, tp_d, fs, **kw)
+        if kw.get('f0_method') == 'harvest' and kw.get('check', True) is not True and kw.get('event_caps') is None:
+            # an asynchronous Harvest encode: whoever reads its flags can repeat it (settle_encode)
+            enc._repeat = (batch, x_d, tp_d, fs, {k: v for k, v in kw.items() if k not in ('check', 'f0_done')})
+        return enc
+
+    def settle_encode(self, enc, where="WorldBatch"):
+        """``check()`` for a lane whose last work was the asynchronous ``encode`` that returned ``enc`` (the lane's stream has
+        been waited for): raises like ``check()`` — except for Harvest's WH_FLAG_EVENT_OVERFLOW (more zero crossings than
+        estimated: stretches constant up to rounding, e.g. digital silence next to signal), where the encode is repeated
+        with the capacities the first pass counted.  Returns the encoding to use."""
+        with self.rt.on_stream():
+            flags = self.rt.take_flags()
+            tb_flags = self._tb_rt.take_flags() if self._tb_rt is not None else [0] * len(flags)
+            rep = getattr(enc, "_repeat", None)
+            if rep is not None:
+                enc._repeat = None
+            if not (flags[_hip.FLAG_EVENT_OVERFLOW] and rep is not None):
+                self.rt.raise_for_flags([a | b for a, b in zip(flags, tb_flags)], where)
+                return enc
+            from .harvest import counted_event_caps
+            batch, x_d, tp_d, fs, kw = rep
+            caps = counted_event_caps(self.rt)
+        return self.encode_device(batch, x_d, tp_d, fs, check=True, event_caps=caps, **kw)
 
     @_on_lane_stream
     def upload_pcm16(self, pcm_list, fs, frame_period=5):

@@ -185,8 +185,17 @@ class World(object):
             # utterance, so the dicts are the ones the single batch gives, bit for bit.
             pipe = WorldBatchPipeline(sb.backend.rt.index, depth=2, prefetch_timebase=False, first_lane=FACADE_LANE)
             parts = [(a, b) for a, b in shard_ranges([len(x) for x in mine], 2) if b > a]
-            encs = [pipe.next().encode(mine[a:b], fs, check=False, **kw) for a, b in parts]
-            pipe.synchronize(check=True)
+            wbs = [pipe.next() for _ in parts]
+            encs = [wb.encode(mine[a:b], fs, check=False, **kw) for wb, (a, b) in zip(wbs, parts)]
+            pipe.synchronize(check=False)
+            err = None
+            for i, wb in enumerate(wbs):  # every part's flags are read (and a Harvest part that needs it repeated), then the first error raised
+                try:
+                    encs[i] = wb.settle_encode(encs[i], "World.encode_batch")
+                except _hip.WorldHipError as e:
+                    err = err or e
+            if err is not None:
+                raise err
             dats = [d for e in encs for d in e.to_dicts(want_ps=want_ps, lazy=True)]
         else:
             enc = sb.encode(xs, fs, **kw)

@@ -182,8 +182,7 @@ class WorldBatchPool:
             def run(wb):
                 enc = wb.encode(list(xs[a:b]), fs, check=False, **kw)
                 wb.rt.own_stream.synchronize()
-                wb.check("WorldBatchPool.encode")
-                return enc
+                return wb.settle_encode(enc, "WorldBatchPool.encode")
             return run
 
         res = self._run({s: job(a, b) for s, (a, b) in enumerate(ranges) if b > a})

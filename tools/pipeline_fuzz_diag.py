@@ -1,7 +1,7 @@
 """Diagnostic (GPU): the off-regime signals of tests/_harvest_script.py through both whole pipelines against the oracle."""
 import os, sys, traceback
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "python-world_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 from _harvest_script import fuzz_inputs

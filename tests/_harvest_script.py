@@ -69,15 +69,17 @@ if __name__ == "__main__" and len(sys.argv) == 2:
     main(sys.argv[1])
 
 
-def fuzz_inputs():
+def fuzz_inputs(fs=16000):
     """Signals that leave the speech-like regime (tests/test_hip_harvest_fuzz.py): gaps without a single crossing, noise,
-    a chirp through the whole search range, clicks, a DC offset, a very short and a very quiet utterance, two tones."""
-    fs = 16000
+    a chirp through the whole search range, clicks, a DC offset, a very short and a very quiet utterance, two tones.
+    At another rate than 16 kHz the tones are detuned by 0.3 % (no whole number of decimated samples per half period
+    at 7350 or 8000 Hz, see the click train below)."""
+    k = 1.0 if fs == 16000 else 1.00317
     rng = np.random.RandomState(77)
     t = np.arange(int(1.2 * fs)) / fs
     out = []
     x = np.zeros_like(t)  # tone bursts between stretches of digital silence
-    for a, b, f in ((0.10, 0.35, 120.0), (0.55, 0.70, 310.0), (0.95, 1.15, 75.0)):
+    for a, b, f in ((0.10, 0.35, 120.0 * k), (0.55, 0.70, 310.0 * k), (0.95, 1.15, 75.0 * k)):
         m = (t >= a) & (t < b)
         x[m] = 0.3 * np.sin(2 * np.pi * f * t[m])
     out.append(x)
@@ -98,9 +100,9 @@ def fuzz_inputs():
     x[at + 2] = -0.2 * x[at]  #  alone in the short windows of the channels above 500 Hz)
     out.append(x)
     out.append(0.5 + 1e-3 * rng.randn(len(t)))  # DC offset + a little noise
-    out.append(0.3 * np.sin(2 * np.pi * 203.7 * t[: int(0.2 * fs)] + 0.3))  # 0.2 s
-    out.append(1e-8 * (np.sin(2 * np.pi * 150.0 * t) + 0.01 * rng.randn(len(t))))  # very quiet
-    out.append(0.3 * np.sin(2 * np.pi * 110.0 * t) + 0.25 * np.sin(2 * np.pi * 173.0 * t + 1.0))  # two tones
+    out.append(0.3 * np.sin(2 * np.pi * 203.7 * k * t[: int(0.2 * fs)] + 0.3))  # 0.2 s
+    out.append(1e-8 * (np.sin(2 * np.pi * 150.0 * k * t) + 0.01 * rng.randn(len(t))))  # very quiet
+    out.append(0.3 * np.sin(2 * np.pi * 110.0 * k * t) + 0.25 * np.sin(2 * np.pi * 173.0 * k * t + 1.0))  # two tones
     out.append(np.zeros(int(0.5 * fs)))  # digital silence (the reference raises; this build returns unvoiced)
     return fs, out
 

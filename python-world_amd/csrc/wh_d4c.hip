@@ -98,6 +98,14 @@ __device__ __forceinline__ const double2* fresh_table(const double2* p) {
 #endif
   return p;
 }
+#if WH_BOUNDS
+__device__ __forceinline__ wh::ckp<const double2> fresh_table(wh::ckp<const double2> p) {
+#if !WH_D4C_HOIST
+  asm volatile("" : "+s"(p.p));
+#endif
+  return p;
+}
+#endif
 // Stage fence for a per-frame scalar: everything a stage derives from the returned value (window phase, sample
 // addresses, rotation constants ...) can only be computed after this point, i.e. the compiler cannot start the next
 // stage's loads and transcendental set-up underneath the current stage's transform (which it does otherwise, and
@@ -165,7 +173,7 @@ struct WinSetup {
   long long centre;
   double rot_s, rot_c, base_s, base_c, delta, inv_span, phase, cf;
 };
-__device__ __forceinline__ void win_setup(double* tab, long long xn, double fs, double cf, double pos, double half_length,
+__device__ __forceinline__ void win_setup(wh::ckp<double> tab, long long xn, double fs, double cf, double pos, double half_length,
                                           int ft) {
   const int hwl = (int)(half_length * fs / cf + 0.5);
   const long long centre = wh::frame_centre(pos, fs);
@@ -194,7 +202,7 @@ __device__ __forceinline__ void win_setup(double* tab, long long xn, double fs, 
   tab[11] = phase;
   tab[12] = cf;
 }
-__device__ __forceinline__ WinSetup win_load(const double* tab) {
+__device__ __forceinline__ WinSetup win_load(wh::ckp<const double> tab) {
   WinSetup w;
   w.hwl = (int)tab[0];
   w.L = (int)tab[1];
@@ -221,8 +229,8 @@ __device__ __forceinline__ double2 win_thread_phase(double delta) {
 // slot / STRIDE: sample j is parked at slot[j * STRIDE] (LDS) between the gather and the second walk — the place emit()
 // overwrites with the final value, so the park costs no extra memory.
 template <bool BLACKMAN, int N, bool ENERGY, int STRIDE, int FT_ = 0, class Emit>
-__device__ __forceinline__ void d4c_window(const double* __restrict__ xu, const double* tab, double2 e_tid,
-                                           double* scratch, double* slot, Emit emit) {
+__device__ __forceinline__ void d4c_window(wh::ckp<const double> WH_RESTRICT xu, wh::ckp<const double> tab, double2 e_tid,
+                                           wh::ckp<double> scratch, wh::ckp<double> slot, Emit emit) {
   constexpr int FT = FT_ ? FT_ : ft_of(N);
   constexpr int Q = N / FT;
   const WinSetup ws = win_load(tab);
@@ -232,7 +240,7 @@ __device__ __forceinline__ void d4c_window(const double* __restrict__ xu, const 
     return BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);  // cos(2a) = 2cos^2(a)-1
   };
   auto win = [&](int j) -> double { return shape(cospi(((double)(j - hwl) * inv_span + phase) * cf)); };
-  const double* xb = xu + (ws.centre - 1);  // (re-derived from laundered bits before the second walk)
+  const wh::ckp<const double> xb = xu + (ws.centre - 1);  // (re-derived from laundered bits before the second walk)
   auto sample = [&](int j) -> double {
     int rel = j - hwl;
     rel = rel < rlo ? rlo : rel;
@@ -320,8 +328,8 @@ __device__ __forceinline__ void d4c_window(const double* __restrict__ xu, const 
 // CU, MI355X_MICROARCH.md) — and the walks stop at the window's end: rows q >= ceil(L / FT) are zeros (a window spans
 // 4 pitch periods, ~640 of the 2048 samples at 100 Hz), uniformly for the workgroup.
 template <bool BLACKMAN, int N, bool ENERGY>
-__device__ __forceinline__ void d4c_window_regs(const double* __restrict__ xu, const double* tab, double2 e_tid,
-                                                double* scratch, double (&out)[N / ft_of(N)]) {
+__device__ __forceinline__ void d4c_window_regs(wh::ckp<const double> WH_RESTRICT xu, wh::ckp<const double> tab, double2 e_tid,
+                                                wh::ckp<double> scratch, double (&out)[N / ft_of(N)]) {
   constexpr int FT = ft_of(N);
   constexpr int Q = N / FT;
   const WinSetup ws = win_load(tab);
@@ -331,7 +339,7 @@ __device__ __forceinline__ void d4c_window_regs(const double* __restrict__ xu, c
     return BLACKMAN ? (0.08 * (2 * c1 * c1 - 1) + 0.5 * c1 + 0.42) : (0.5 * c1 + 0.5);  // cos(2a) = 2cos^2(a)-1
   };
   auto win = [&](int j) -> double { return shape(cospi(((double)(j - hwl) * inv_span + phase) * cf)); };
-  const double* xb = xu + (ws.centre - 1);
+  const wh::ckp<const double> xb = xu + (ws.centre - 1);
   auto sample = [&](int j) -> double {
     int rel = j - hwl;
     rel = rel < rlo ? rlo : rel;
@@ -474,10 +482,13 @@ __global__ __launch_bounds__(ft_love(NLT)) void love_train_kernel(
     double threshold, const double2* __restrict__ tw_base, int32_t* __restrict__ gate, long long n_frames) {
   constexpr int FT = ft_love(NLT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double2* zb = reinterpret_cast<double2*>(smem);  // NLT/2+1 complex after the real FFT
-  double* zr = reinterpret_cast<double*>(smem);    // the NLT real samples, then the half spectrum (NLT + 2 doubles)
-  double* scratch = zr + NLT + 2;
-  double* wtab = scratch + 48;  // window set-up table (kWinTab doubles)
+  // (wh::ckp<T> is T* in every shipped build; the bounds build checks each access against the range named here)
+  const wh::ckp<double> lds_all = wh::ck_make(reinterpret_cast<double*>(smem), NLT + 2 + 48 + kWinTab, wh::WH_CK_LDS_OTHER);
+  const wh::ckp<double> zr = wh::ck_sub(lds_all, 0, NLT + 2, wh::WH_CK_LDS_MAIN);  // the NLT real samples, then the half spectrum (NLT + 2 doubles)
+  const wh::ckp<double2> zb = wh::ck_as<double2>(zr);                               // NLT/2+1 complex after the real FFT
+  const wh::ckp<double> scratch = wh::ck_sub(lds_all, NLT + 2, 48, wh::WH_CK_LDS_SCRATCH);
+  const wh::ckp<double> wtab = wh::ck_sub(lds_all, NLT + 2 + 48, kWinTab, wh::WH_CK_LDS_AUX);  // window set-up table (kWinTab doubles)
+  const wh::ckp<const double2> tw = wh::ck_make(tw_base, 2 * WH_MAX_FFT, wh::WH_CK_TWIDDLE);
   const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
   if (f >= n_frames) return;
   double f0 = f0_io[f];
@@ -488,14 +499,14 @@ __global__ __launch_bounds__(ft_love(NLT)) void love_train_kernel(
     return;
   }
   const int u = frame_utt[f];
-  const double* xu = x + x_off[u];
   const long long xn = x_off[u + 1] - x_off[u];
+  const wh::ckp<const double> xu = wh::ck_make(x + x_off[u], xn, wh::WH_CK_WAVEFORM);
   const double cf = fmax(f0, 40.0);
   if (threadIdx.x == 0) win_setup(wtab, xn, fs, cf, tp[f], 1.5, FT);
   wh::sync<FT>();
   d4c_window<true, NLT, false, 1, FT>(xu, wtab, win_thread_phase(wtab[9]), scratch, zr, [&](int j, double val) { zr[j] = val; });
   wh::sync<FT>();
-  wh::rfft_lds<NLT, FT, FT, WH_LOVE_MAXR>(zb, tw_base);  // (66 VGPRs here: the radix-8 plan fits, unlike in d4c_kernel)
+  wh::rfft_lds<NLT, FT, FT, WH_LOVE_MAXR>(zb, tw);  // (66 VGPRs here: the radix-8 plan fits, unlike in d4c_kernel)
   const int b0 = (int)(ceil(100.0 / (fs / NLT)) + 1);
   const int b1 = (int)(ceil(4000.0 / (fs / NLT)) + 1);
   const int b2 = (int)(ceil(7900.0 / (fs / NLT)) + 1);
@@ -577,7 +588,7 @@ __device__ __forceinline__ void wave_digit_counts(Digit digit, int (&mine)[WIN])
 }
 
 template <int K, int FT, int PER>
-__device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned valid, int m, void* work, double* scratch,
+__device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned valid, int m, wh::ckp<double> work, wh::ckp<double> scratch,
                                              double* s_small, double* s_total) {
   constexpr int NW = FT / 64;
   // exponents per round.  On speech the K - m (~22) largest bins lie within 4 octaves of the maximum on average, 7 at
@@ -593,8 +604,8 @@ __device__ __forceinline__ void sum_smallest(const double (&x)[PER], unsigned va
 #endif
   constexpr int DB = K > 1100 ? WH_D4C_SEL_DB_LONG : WH_D4C_SEL_DB;   // mantissa bits per refinement level
   constexpr int WIN = 1 << DB;           // exponents per round = values of a mantissa digit
-  int* cnts = reinterpret_cast<int*>(work);                     // [NW][WIN + 1]: counts per exponent, then the wave's top
-  double* list = reinterpret_cast<double*>(cnts + NW * (WIN + 1) + (NW * (WIN + 1) & 1));
+  const wh::ckp<int> cnts = wh::ck_as<int>(work);               // [NW][WIN + 1]: counts per exponent, then the wave's top
+  const wh::ckp<double> list = work + (NW * (WIN + 1) + (NW * (WIN + 1) & 1)) / 2;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int key[PER];
   int kmax = 0;
@@ -775,14 +786,14 @@ struct Runs {
 // thread-strided loop (a handful of bins; kept out of the unrolled per-run code, whose five copies of the divides and
 // searches cost ~30 VGPRs of spills) and the owners add it to their registers.
 template <int N>
-__device__ __forceinline__ void low_band_replica_runs(double (&p)[Runs<N>::KR], double* tmp, double fs, double f0,
+__device__ __forceinline__ void low_band_replica_runs(double (&p)[Runs<N>::KR], wh::ckp<double> tmp, double fs, double f0,
                                                       double reach) {
   constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
   const int k0 = threadIdx.x * KR;
   int nlow = (int)(reach / fs * N) + 2;  // count of bins with k/N*fs < reach (monotone in k)
   if (nlow > K) nlow = K;                // (the reference indexes the half spectrum: bins beyond it do not exist)
   while (nlow > 0 && !(((double)(nlow - 1) / N * fs) < reach)) --nlow;
-  double* add = tmp + ((nlow + 1) & ~1);
+  const wh::ckp<double> add = tmp + ((nlow + 1) & ~1);
   // The bins below `reach` (1.2 f0 <= 960 Hz: a few dozen) all belong to the first lanes of wave 0.  When they fit one
   // wave — always, at the supported rates — that wave does the whole correction with wave-level ordering and the other
   // waves only meet it at the closing barrier: one barrier instead of three, and three waves skip the code.
@@ -828,7 +839,7 @@ __device__ __forceinline__ void low_band_replica_runs(double (&p)[Runs<N>::KR], 
 
 // v[0..N) = Hermitian mirror of the run-resident half spectrum times fs/N (wh::fill_mirrored for runs).
 template <int N>
-__device__ __forceinline__ void fill_mirrored_runs(const double (&p)[Runs<N>::KR], double* v, double fs) {
+__device__ __forceinline__ void fill_mirrored_runs(const double (&p)[Runs<N>::KR], wh::ckp<double> v, double fs) {
   constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
   const int k0 = threadIdx.x * KR;
   const double df = fs / N;
@@ -847,9 +858,9 @@ __device__ __forceinline__ void fill_mirrored_runs(const double (&p)[Runs<N>::KR
 // Group-delay centroid of one Blackman frame, added into the run-resident cent (d4c.py:146-153).
 // x and n*x (two real sequences) share ONE complex FFT: z = x + i*n*x, separated afterwards by symmetry.
 template <int N>
-__device__ __forceinline__ void add_centroid(const double* xu, const double* wtab, double2 e_tid,
-                                             double2* buf, double (&cent)[Runs<N>::KR], bool first,
-                                             const double2* tw_base, double* scratch) {
+__device__ __forceinline__ void add_centroid(wh::ckp<const double> xu, wh::ckp<const double> wtab, double2 e_tid,
+                                             wh::ckp<double2> buf, double (&cent)[Runs<N>::KR], bool first,
+                                             wh::ckp<const double2> tw_base, wh::ckp<double> scratch) {
   constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
   // z[j] = x[j] + i*(j+1)*x[j] (n is 1-based), normalised frame
   if constexpr (d4c_regfed<N>()) {
@@ -861,7 +872,7 @@ __device__ __forceinline__ void add_centroid(const double* xu, const double* wta
     wh::fft_lds_from_regs<N, false, FT, 8>(zin, buf, fresh_table(tw_base) + N);
   } else {
     // written straight into the transform buffer
-    d4c_window<true, N, true, 2>(xu, wtab, e_tid, scratch, reinterpret_cast<double*>(buf),
+    d4c_window<true, N, true, 2>(xu, wtab, e_tid, scratch, wh::ck_as<double>(buf),
                                  [&](int j, double val) { buf[j] = make_double2(val, val * (double)(j + 1)); });
     wh::sync<FT>();
     wh::fft_lds<N, false, FT, FT, d4c_maxr(N)>(buf, fresh_table(tw_base) + N);
@@ -896,19 +907,23 @@ __device__ __forceinline__ void d4c_frame(
     double* __restrict__ out, double* __restrict__ coarse_dbg, long long n_frames, const D4cLaunchConst& lc, int64_t f) {
   constexpr int FT = Runs<N>::FT, K = Runs<N>::K, KR = Runs<N>::KR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double2* buf = reinterpret_cast<double2*>(smem);   // N complex (centroid FFT) / N/2+1 complex (real FFTs)
-  double* zr = reinterpret_cast<double*>(smem);      // the same 2N doubles: real buffers, mirrored spectra, scratch
-  double* scratch = zr + 2 * N;                      // 40 (block_sum5 at 8 waves)
-  double* band = scratch + 40;                       // nap (<= 8)
-  double* wtab = band + 8;                           // 4 windows x kWinTab: gate, power, centroid +, centroid -
+  // (wh::ckp<T> is T* in every shipped build; the bounds build checks each access against the range named here)
+  const wh::ckp<double> lds_all = wh::ck_make(reinterpret_cast<double*>(smem), 2 * N + 40 + 8 + 4 * kWinTab, wh::WH_CK_LDS_OTHER);
+  const wh::ckp<double> zr = wh::ck_sub(lds_all, 0, 2 * N, wh::WH_CK_LDS_MAIN);  // 2N doubles: real buffers, mirrored spectra, scratch
+  const wh::ckp<double2> buf = wh::ck_as<double2>(zr);   // the same as N complex (centroid FFT) / N/2+1 complex (real FFTs)
+  const wh::ckp<double> scratch = wh::ck_sub(lds_all, 2 * N, 40, wh::WH_CK_LDS_SCRATCH);  // 40 (block_sum5 at 8 waves)
+  const wh::ckp<double> band = wh::ck_sub(lds_all, 2 * N + 40, 8, wh::WH_CK_LDS_AUX);     // nap (<= 8)
+  const wh::ckp<double> wtab = wh::ck_sub(lds_all, 2 * N + 48, 4 * kWinTab, wh::WH_CK_LDS_AUX);  // 4 windows x kWinTab: gate, power, centroid +, centroid -
   constexpr int KPAD = (K + 1) & ~1;
-  double* td = zr + 2 * N - KPAD;                    // band stage: the shaped group delay, above the real-FFT buffer
+  const wh::ckp<double> td = zr + (2 * N - KPAD);        // band stage: the shaped group delay, above the real-FFT buffer
+  const wh::ckp<const double2> tw = wh::ck_make(tw_base, 2 * WH_MAX_FFT, wh::WH_CK_TWIDDLE);  // the table of size n at offset n
+  const wh::ckp<const double> win_tab = wh::ck_make(window, wlen, wh::WH_CK_TABLE);
 
   STAGE_TIMER_BEGIN
   if (f >= n_frames) return;
   const int u = frame_utt[f];
-  const double* xu = x + x_off[u];
   const long long xn = x_off[u + 1] - x_off[u];
+  const wh::ckp<const double> xu = wh::ck_make(x + x_off[u], xn, wh::WH_CK_WAVEFORM);
   const double pos = tp[f];
   double f0v = f0_io[f];
   bool voiced;
@@ -945,13 +960,13 @@ __device__ __forceinline__ void d4c_frame(
       double2 zin[N / FT];
 #pragma unroll
       for (int q = 0; q < N / FT; ++q) zin[q] = make_double2(va[q], vb[q]);
-      wh::fft_lds_from_regs<N, false, FT, 8>(zin, buf, fresh_table(tw_base) + N);
+      wh::fft_lds_from_regs<N, false, FT, 8>(zin, buf, fresh_table(tw) + N);
     } else {
       d4c_window<true, N, false, 2>(xu, wtab, win_thread_phase(wtab[9]), scratch, zr, [&](int j, double val) { zr[2 * j] = val; });
       d4c_window<false, N, false, 2>(xu, wtab + kWinTab, e_frame, scratch, zr + 1, [&](int j, double val) { zr[2 * j + 1] = val; });
       STAGE_MARK(7)
       wh::sync<FT>();
-      wh::fft_lds<N, false, FT, FT, d4c_maxr(N)>(buf, fresh_table(tw_base) + N);
+      wh::fft_lds<N, false, FT, FT, d4c_maxr(N)>(buf, fresh_table(tw) + N);
     }
     STAGE_MARK(8)
     const int b0 = lc.b0, b1 = lc.b1, b2 = lc.b2;
@@ -985,11 +1000,11 @@ __device__ __forceinline__ void d4c_frame(
   }
   if (!voiced) {
     if (k_spec > 0) {
-      double* o = out + f * (int64_t)k_spec;
+      const wh::ckp<double> o = wh::ck_make(out + f * (int64_t)k_spec, k_spec, wh::WH_CK_OUT);
       for (int k = threadIdx.x; k < k_spec; k += FT) o[k] = 1 - 0.000000000001;
       if (coarse_dbg) for (int b = threadIdx.x; b < nap; b += FT) coarse_dbg[f * nap + b] = 0.0;
     } else {
-      double* o = out + f * (int64_t)(nap + 2);
+      const wh::ckp<double> o = wh::ck_make(out + f * (int64_t)(nap + 2), nap + 2, wh::WH_CK_OUT);
       for (int b = threadIdx.x; b < nap + 2; b += FT) o[b] = -0.000000000001;
     }
     return;
@@ -1006,13 +1021,13 @@ __device__ __forceinline__ void d4c_frame(
   // shrinks by a fifth (66 KB -> 52 KB), below the 64 KB instruction cache that two CUs share
 #pragma unroll 1
   for (int c = 0; c < 2; ++c) {
-    add_centroid<N>(xu, wtab + (2 + c) * kWinTab, e_frame, buf, cent, false, tw_base, scratch);
+    add_centroid<N>(xu, wtab + (2 + c) * kWinTab, e_frame, buf, cent, false, tw, scratch);
     STAGE_MARK(1 + c)
   }
 #else
-  add_centroid<N>(xu, wtab + 2 * kWinTab, e_frame, buf, cent, true, tw_base, scratch);
+  add_centroid<N>(xu, wtab + 2 * kWinTab, e_frame, buf, cent, true, tw, scratch);
   STAGE_MARK(1)
-  add_centroid<N>(xu, wtab + 3 * kWinTab, e_frame, buf, cent, false, tw_base, scratch);
+  add_centroid<N>(xu, wtab + 3 * kWinTab, e_frame, buf, cent, false, tw, scratch);
   STAGE_MARK(2)
 #endif
   low_band_replica_runs<N>(cent, zr, fs, cf, 1.2 * cf);
@@ -1026,7 +1041,7 @@ __device__ __forceinline__ void d4c_frame(
   if (!FUSED) {
     d4c_window<false, N, false, 1>(xu, wtab + kWinTab, e_frame, scratch, zr, [&](int j, double val) { zr[j] = val; });
     wh::sync<FT>();
-    wh::rfft_lds<N, FT, FT, d4c_rmaxr(N)>(buf, fresh_table(tw_base));
+    wh::rfft_lds<N, FT, FT, d4c_rmaxr(N)>(buf, fresh_table(tw));
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
       if (k0 + r < K) {
@@ -1036,7 +1051,7 @@ __device__ __forceinline__ void d4c_frame(
     }
     wh::sync<FT>();
   }
-  double* cum = zr;  // the FFT buffer is idle during the smoothing steps (low-band scratch, then the mirrored spectra)
+  const wh::ckp<double> cum = zr;  // the FFT buffer is idle during the smoothing steps (low-band scratch, then the mirrored spectra)
   const double inv_cf = 1.0 / cf;
   low_band_replica_runs<N>(pw, cum, fs, cf, 1.2 * cf);
   // the three rectangular smoothings as sliding windowed sums (wh_spectral.h: BandWindow) over the owned runs
@@ -1085,7 +1100,7 @@ __device__ __forceinline__ void d4c_frame(
 #pragma unroll
   for (int q = 0; q < WQ; ++q) {
     const int j = threadIdx.x + q * FT;
-    wv[q] = window[j < wlen ? j : 0];  // (clamped, not skipped: no branch per load)
+    wv[q] = win_tab[j < wlen ? j : 0];  // (clamped, not skipped: no branch per load)
   }
   for (int b = 0; b < nap; ++b) {
     const int centre = lc.centre[b];
@@ -1097,7 +1112,7 @@ __device__ __forceinline__ void d4c_frame(
         int idx = centre - half + j;          // index into the mirrored full group delay
         idx = idx < 0 ? -idx : idx;
         idx = idx > N / 2 ? N - idx : idx;
-        val = td[idx] * (q < WQ ? wv[q < WQ ? q : 0] : window[j]);
+        val = td[idx] * (q < WQ ? wv[q < WQ ? q : 0] : win_tab[j]);
       }
       zr[j] = val;
     }
@@ -1111,9 +1126,9 @@ __device__ __forceinline__ void d4c_frame(
     double px[2 * PJ];
     unsigned pvalid = 0;
     {
-      const double2* twb = fresh_table(tw_base);
+      const wh::ckp<const double2> twb = fresh_table(tw);
       wh::fft_lds<MB, false, FT, FT, d4c_rmaxr(N)>(buf, twb + MB);
-      const double2* __restrict__ wpost = twb + N;
+      const wh::ckp<const double2> WH_RESTRICT wpost = twb + N;
 #pragma unroll
       for (int i = 0; i < PJ; ++i) {
         const int k = threadIdx.x + i * FT;
@@ -1164,7 +1179,7 @@ __device__ __forceinline__ void d4c_frame(
   const double tilt = (cf - 100) * 2 / 100;
   if (k_spec > 0) {
     if (coarse_dbg) for (int b = threadIdx.x; b < nap; b += FT) coarse_dbg[f * nap + b] = -fmax(0.0, band[b] - tilt);
-    double* o = out + f * (int64_t)k_spec;
+    const wh::ckp<double> o = wh::ck_make(out + f * (int64_t)k_spec, k_spec, wh::WH_CK_OUT);
     const int nn = nap + 2;  // nodes: 0, interval, ..., interval*nap, fs/2
     // k * fs / (2 (K-1)): the divisor is a power of two for every FFT size, so k * (fs / divisor) is the same double
     // (both roundings are of the exact quotient) without a divide per bin
@@ -1192,7 +1207,7 @@ __device__ __forceinline__ void d4c_frame(
       o[k] = exp(db * (M_LN10 / 20));  // 10^(db/20)
     }
   } else {
-    double* o = out + f * (int64_t)(nap + 2);
+    const wh::ckp<double> o = wh::ck_make(out + f * (int64_t)(nap + 2), nap + 2, wh::WH_CK_OUT);
     for (int b = threadIdx.x; b < nap + 2; b += FT)
       o[b] = b == 0 ? -60.0 : (b == nap + 1 ? -0.000000000001 : -fmax(0.0, band[b - 1] - tilt));
   }

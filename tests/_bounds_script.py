@@ -55,6 +55,38 @@ def main():
                           "finite": bool(np.all(np.isfinite(res["spectrogram"])))})
     out["sweep_bad"] = [s for s in sweep if s["flag"] or not s["finite"]]
     out["sweep_cases"] = len(sweep)
+    # ---- D4C / D4C-Requiem / love-train (round 6, second half: their LDS blocks, waveform gathers, twiddle and window tables and
+    # output rows are checked pointers too): the same constant contours, voiced everywhere, at every transform length
+    # 512 ... 8192 the two entry points reach, fused and stand-alone gate
+    from world.d4c import d4c
+    from world.d4cRequiem import d4cRequiem
+    dsweep = []
+    for fs, req, fft in ((16000, False, None), (22050, False, None), (48000, False, None), (96000, False, None), (8000, False, None),
+                         (16000, True, None), (16000, True, 512), (48000, True, None), (96000, True, 4096)):
+        x = synth_utterance(6, fs, 0.4)
+        n = int(1000 * len(x) / fs / 5 + 1)
+        tp = np.arange(n) * 0.005
+        for f0 in (1.0, 20.0, 47.0, 70.0, 71.0, 123.4, 250.0, 499.9, 800.0, 1500.0, 0.45 * fs, 0.4999 * fs, 0.5 * fs,
+                   0.75 * fs, 1.5 * fs):
+            src = {"f0": np.full(n, f0), "vuv": np.ones(n), "temporal_positions": tp.copy()}
+            res = d4cRequiem(x, fs, src, fft_size=fft) if req else d4c(x, fs, src)
+            fl = rt.take_flags()
+            dsweep.append({"fs": fs, "requiem": req, "fft": fft, "f0": f0, "flag": fl[_hip.FLAG_OOB],
+                           "record": list(_hip.bounds_last()), "nan": bool(np.any(np.isnan(res["aperiodicity"])))})
+    out["d4c_sweep_bad"] = [s for s in dsweep if s["flag"]]
+    out["d4c_sweep_cases"] = len(dsweep)
+    # ---- the off-regime signals of the fuzz tests through both pipelines (tone bursts between digital silence, noise, a
+    # chirp, clicks, DC, a 0.2 s and a 1e-8 utterance, two tones, silence) -----------------------------------------------
+    from _harvest_script import fuzz_inputs
+    wbf = WorldBatch()
+    for fs_f in (16000, 48000):
+        _, xf = fuzz_inputs(fs_f)
+        enc = wbf.encode(xf, fs_f, f0_method="dio")
+        wbf.decode_device(enc, seed=2)
+        enc = wbf.encode(xf, fs_f, f0_method="harvest", is_requiem=True)
+        wbf.decode_device(enc)
+    out["fuzz_flags"] = wbf.rt.take_flags()
+    out["fuzz_record"] = list(_hip.bounds_last())
     # ---- config 2 at full size: 64 x 10 s through every stage of the DIO path + decode, Harvest + Requiem on 8 ----------
     xs = [synth_utterance(u, 16000, 10.0) for u in range(64)]
     wb = WorldBatch()

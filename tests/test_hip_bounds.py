@@ -64,6 +64,15 @@ def test_cheaptrick_f0_sweep_stays_inside_its_buffers(report):
     assert report["sweep_bad"] == []
 
 
+def test_d4c_f0_sweep_stays_inside_its_buffers(report):
+    assert report["d4c_sweep_cases"] == 135
+    assert report["d4c_sweep_bad"] == []
+
+
+def test_off_regime_signals_run_clean(report):
+    assert report["fuzz_flags"] == [0] * 16, (report["fuzz_flags"], report["fuzz_record"])
+
+
 def test_whole_pipelines_run_clean(report):
     for key in ("config2", "harvest", "cfg5"):
         assert report[key + "_flags"] == [0] * 16, (key, report[key + "_flags"], report[key + "_record"])

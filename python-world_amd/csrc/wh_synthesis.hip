@@ -888,16 +888,16 @@ struct SpectrumIdentity {
   __device__ __forceinline__ double2 operator()(int, double2 e) const { return e; }
 };
 template <int N, int GT, class Mul = SpectrumIdentity>
-__device__ __forceinline__ void min_phase_response(double2* zb, const double2* tw_base, double delay_pi, Mul mul = Mul()) {
+__device__ __forceinline__ void min_phase_response(wh::ckp<double2> zb, wh::ckp<const double2> tw_base, double delay_pi, Mul mul = Mul()) {
 #if WH_SYN_CONTRACT
 #pragma clang fp contract(fast)
 #endif
   constexpr int FT = ft_syn(N);
   constexpr int M = N / 2;
   constexpr int PP = (M / 2 + 1 + GT - 1) / GT;  // bin pairs (k, M-k), k <= M/2, per thread
-  double* zr = reinterpret_cast<double*>(zb);
+  const wh::ckp<double> zr = wh::ck_as<double>(zb);
   const int gt = WH_TID & (GT - 1);
-  const double2* __restrict__ w = tw_base + N;
+  const wh::ckp<const double2> WH_RESTRICT w = tw_base + N;
 #if defined(WH_RESP_ABLATE_T1) && WH_RESP_ABLATE_T1
   wh::sync<FT>();  // TIMING EXPERIMENT ONLY (wrong results): the chain's first transform costs nothing — twice the upper
 #else              // bound of packing the two chains' real-even first transforms into one (DCT-I)
@@ -1053,7 +1053,7 @@ struct RunState {
 
 // Samples [a, b) (1-based, within the ring's current window) are final for this run: to the row, clear the ring.
 template <int N>
-__device__ __forceinline__ void ring_flush(double* ring, int64_t a, int64_t b, double* __restrict__ row, int64_t row_start,
+__device__ __forceinline__ void ring_flush(wh::ckp<double> ring, int64_t a, int64_t b, wh::ckp<double> WH_RESTRICT row, int64_t row_start,
                                            int64_t ny) {
   constexpr int FT = ft_syn(N);
   a = a < 1 ? 1 : a;
@@ -1067,8 +1067,8 @@ __device__ __forceinline__ void ring_flush(double* ring, int64_t a, int64_t b, d
 
 // One pulse of a run.
 template <int N>
-__device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec& rec, char* smem, double* ring, RunState& rs,
-                                               double* __restrict__ row,
+__device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec& rec, char* smem, wh::ckp<double> ring, RunState& rs,
+                                               wh::ckp<double> WH_RESTRICT row,
                                                const double (&dcw)[N / ft_syn(N) <= 4 ? N / ft_syn(N) : 1]) {
 #if WH_SYN_CONTRACT
 #pragma clang fp contract(fast)
@@ -1080,8 +1080,9 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   const double* __restrict__ noise = A.noise;
   const uint64_t seed = A.seed;
   const double* __restrict__ dc_base = A.dc_base;
-  const double2* __restrict__ tw_base = A.tw_base;
-  asm volatile("" : "+s"(tw_base));  // per pulse: no twiddle address / value of one pulse survives into the next
+  const double2* __restrict__ tw_raw = A.tw_base;
+  asm volatile("" : "+s"(tw_raw));  // per pulse: no twiddle address / value of one pulse survives into the next
+  const wh::ckp<const double2> tw_base = wh::ck_make(tw_raw, 2 * WH_MAX_FFT, wh::WH_CK_TWIDDLE);
   constexpr int FT = ft_syn(N);
   constexpr int K = N / 2 + 1;
   constexpr int NZ = 256;
@@ -1089,13 +1090,15 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   static_assert(R % 2 == 0 && NZ % (2 * R) == 0, "pairwise reads; whole blocks of 2R noise samples");
   constexpr int GT = FT >= 256 ? FT / 2 : FT;  // threads per chain: the periodic and aperiodic chains run side by side
   constexpr int NG = FT / GT;
-  double2* zbA = reinterpret_cast<double2*>(smem);                 // N/2+1 complex: aperiodic chain
-  double* zrA = reinterpret_cast<double*>(smem);
-  double2* zbP = zbA + (N / 2 + 1);                                 // N/2+1 complex: periodic chain
-  double* zrP = reinterpret_cast<double*>(zbP);
-  double* rap = zrP + (N + 2);                                      // N + N/16 + 2: padded aperiodic response
-  double* nz = rap + (N + N / 16 + 2);                              // NZ
-  double* scratch = nz + NZ;                                        // 16
+  // (wh::ckp<T> is T* in every shipped build; the bounds build checks each access against the range named here)
+  const wh::ckp<double> lds_all = wh::ck_make(reinterpret_cast<double*>(smem), 2 * (N + 2) + (N + N / 16 + 2) + NZ + 32, wh::WH_CK_LDS_OTHER);
+  const wh::ckp<double> zrA = wh::ck_sub(lds_all, 0, N + 2, wh::WH_CK_LDS_MAIN);       // N/2+1 complex: aperiodic chain
+  const wh::ckp<double2> zbA = wh::ck_as<double2>(zrA);
+  const wh::ckp<double> zrP = wh::ck_sub(lds_all, N + 2, N + 2, wh::WH_CK_LDS_AUX);    // N/2+1 complex: periodic chain
+  const wh::ckp<double2> zbP = wh::ck_as<double2>(zrP);
+  const wh::ckp<double> rap = wh::ck_sub(lds_all, 2 * (N + 2), N + N / 16 + 2, wh::WH_CK_LDS_OTHER);  // padded aperiodic response
+  const wh::ckp<double> nz = wh::ck_sub(lds_all, 2 * (N + 2) + (N + N / 16 + 2), NZ, wh::WH_CK_LDS_OTHER);
+  const wh::ckp<double> scratch = wh::ck_sub(lds_all, 2 * (N + 2) + (N + N / 16 + 2) + NZ, 32, wh::WH_CK_LDS_SCRATCH);
 
   RSTAGE_BEGIN
   wh::sync<FT>();
@@ -1253,7 +1256,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   #pragma unroll
         for (int t = 0; t < R; t += 2) {
           double2 v = make_double2(0.0, 0.0);
-          if (base >= 0) v = *reinterpret_cast<const double2*>(rap + rap_index(base + t));
+          if (base >= 0) v = wh::ck_as<const double2>(rap + rap_index(base + t))[0];
           g[t] = v.x;
           g[t + 1] = v.y;
         }
@@ -1262,7 +1265,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
         double n[R];
   #pragma unroll
         for (int t = 0; t < R; t += 2) {
-          const double2 v = *reinterpret_cast<const double2*>(nz + j + t);
+          const double2 v = wh::ck_as<const double2>(nz + (j + t))[0];
           n[t] = v.x;
           n[t + 1] = v.y;
         }
@@ -1292,10 +1295,10 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
       }
       const int steps = (cnt + 1) & ~1;
       for (int j = 0; j < steps; j += 2) {
-        const double2 nn = *reinterpret_cast<const double2*>(nz + j);
+        const double2 nn = wh::ck_as<const double2>(nz + j)[0];
         const int inew = m0 - (int)j0 - j - 2;  // even: (ra[inew], ra[inew+1]) is an aligned pair
         double2 fresh = make_double2(0.0, 0.0);
-        if (inew >= 0) fresh = *reinterpret_cast<const double2*>(rap + rap_index(inew));
+        if (inew >= 0) fresh = wh::ck_as<const double2>(rap + rap_index(inew))[0];
   #pragma unroll
         for (int q = 0; q < R; ++q) acc[q] = fma(nn.x, r[q], acc[q]);
   #pragma unroll
@@ -1429,14 +1432,15 @@ __global__ __launch_bounds__(ft_syn(N), 4) void response_kernel(RespArgs A) {
     u = lo;
   }
   const int64_t r_in_utt = run - A.run_base[u];
-  double* ring = reinterpret_cast<double*>(smem) + (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32);
+  const wh::ckp<double> ring = wh::ck_make(reinterpret_cast<double*>(smem) + (2 * (N + 2) + (N + N / 16 + 2) + 256 + 32), N, wh::WH_CK_LDS_OTHER);
   for (int i = threadIdx.x; i < N; i += FT) ring[i] = 0.0;
   RunState rs{false, 0, 1, 0.0};
   const int64_t gp0 = A.p_base[u] + r_in_utt * RUN;
   const int64_t gp1 = gp0 + RUN < A.p_base[u + 1] ? gp0 + RUN : A.p_base[u + 1];
   const int64_t my_off = A.row_off[(int64_t)u * A.runs_cap + r_in_utt];
   if (my_off < 0) return;  // the utterance's row region is full (flagged by pulse_rows_kernel)
-  double* row = A.rows + A.row_base[u] + my_off;  // slot i of the row at row[i]
+  // slot i of the row at row[i]; what is left of the utterance's region behind the row's start is the range it may touch
+  const wh::ckp<double> row = wh::ck_make(A.rows + A.row_base[u] + my_off, A.row_base[u + 1] - A.row_base[u] - my_off, wh::WH_CK_OUT);
   // A pulse's record travels as ONE dword per lane (lane i & 15 holds dword i) and is turned into scalars by
   // v_readlane at the top of the pulse that uses it — a pulse after its load was issued.  Fetched as a struct the
   // compiler made scalars of it (readfirstlane) right behind the load: the "prefetch" was waited for at once.
@@ -1772,13 +1776,16 @@ __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int FT = ft_syn(N);
   constexpr int K = N / 2 + 1;
-  const double2* tw_base = tw_base_arg;
-  double2* zb = reinterpret_cast<double2*>(smem);        // minimum-phase half spectrum (N/2+1 complex)
-  double2* sb = zb + (N / 2 + 1);                         // windowed excitation frame / its half spectrum
-  double* sr = reinterpret_cast<double*>(sb);
-  double* acc = reinterpret_cast<double*>(sb + (N / 2 + 1));  // RUNF > 1: the run's sums, (RUNF - 1) hop + N doubles
+  const double2* tw_raw = tw_base_arg;
   const SynUtt m = meta[blockIdx.y];
   const ReqUtt q = rq[blockIdx.y];
+  // (wh::ckp<T> is T* in every shipped build; the bounds build checks each access against the range named here)
+  const wh::ckp<double> zr = wh::ck_make(reinterpret_cast<double*>(smem), N + 2, wh::WH_CK_LDS_MAIN);  // minimum-phase half spectrum (N/2+1 complex)
+  const wh::ckp<double2> zb = wh::ck_as<double2>(zr);
+  const wh::ckp<double> sr = wh::ck_make(reinterpret_cast<double*>(smem) + (N + 2), N + 2, wh::WH_CK_LDS_AUX);  // windowed excitation frame / its half spectrum
+  const wh::ckp<double2> sb = wh::ck_as<double2>(sr);
+  // RUNF > 1: the run's sums, (RUNF - 1) hop + N doubles
+  const wh::ckp<double> acc = wh::ck_make(reinterpret_cast<double*>(smem) + 2 * (N + 2), RUNF > 1 ? (RUNF - 1) * q.hop + N : 0, wh::WH_CK_LDS_OTHER);
   if ((int64_t)blockIdx.x >= q.n_runs) return;
   const int64_t hop = q.hop;
   int64_t wlen = 2 * hop - 1;
@@ -1786,20 +1793,20 @@ __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1
   const int64_t i1 = i0 + RUNF - 1 < m.nf - 2 ? i0 + RUNF - 1 : m.nf - 2;
   const int64_t a_r = (i0 - 2) * hop + 1;  // 1-based sample of the run's first tap (= the first frame's origin)
   const int64_t W = (RUNF - 1) * hop + N + 1;
-  double* row = rows + q.row_off + (int64_t)blockIdx.x * W;
+  const wh::ckp<double> row = wh::ck_make(rows + q.row_off + (int64_t)blockIdx.x * W, W, wh::WH_CK_OUT);
   const int span = (int)(W - 1);
   if (RUNF > 1) {
     for (int j = threadIdx.x; j < span; j += FT) acc[j] = 0.0;  // (ordered before the first add by the chain's barriers)
   }
   double last = 0.0;  // (thread FT-1: tap N-1 of every frame whose response reaches the utterance's last sample)
-  const double* eu = exc + m.y_off;
-  double* zr = reinterpret_cast<double*>(zb);
+  const wh::ckp<const double> eu = wh::ck_make(exc + m.y_off, m.ny, wh::WH_CK_WAVEFORM);
 #pragma unroll 1
   for (int64_t i = i0; i <= i1; ++i) {
     const int64_t origin = (i - 1) * hop - (hop - 1);  // 1-based
     // per frame: neither the twiddles nor the window values of one frame are parked in registers for the next (both are
     // the same for every frame, and hoisted out of this loop they cost a wave per SIMD)
-    asm volatile("" : "+s"(tw_base));
+    asm volatile("" : "+s"(tw_raw));
+    const wh::ckp<const double2> tw_base = wh::ck_make(tw_raw, 2 * WH_MAX_FFT, wh::WH_CK_TWIDDLE);
     {
       int hop_s = __builtin_amdgcn_readfirstlane((int)hop);  // (uniform by construction; said so for the constraint)
       asm volatile("" : "+s"(hop_s));
@@ -1816,7 +1823,7 @@ __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1
       }
       sr[j] = v;
     }
-    const double* sp = spectrogram + (m.f_off + (i - 1)) * K;
+    const wh::ckp<const double> sp = wh::ck_make(spectrogram + (m.f_off + (i - 1)) * K, K, wh::WH_CK_IN);
     for (int k = WH_TID; k < K; k += FT) {  // log|S| / 2, Hermitian-mirrored: the input of the chain's first transform
       const double lw = log_call(fabs(sp[k])) / 2;
       zr[k] = lw;

@@ -87,6 +87,29 @@ def main():
         wbf.decode_device(enc)
     out["fuzz_flags"] = wbf.rt.take_flags()
     out["fuzz_record"] = list(_hip.bounds_last())
+    # ---- decode sweep (round 6, second half: response_kernel's two chain buffers, padded response, noise block, ring and row,
+    # req_filter_kernel's buffers, run accumulator and row, and the shared minimum-phase chain are checked pointers): frame
+    # periods 1 / 5 / 10 ms (Requiem hops of 16 ... 480 samples), pulse rates from a quarter to eight times the contour's
+    # (windows further apart than a transform; more pulses than the default capacity: the overflow retry), durations
+    # halved and tripled, transforms 1024 ... 4096
+    wbd = WorldBatch()
+    dec_flags = [0] * 16
+    dec_cases = 0
+    for fs_d, period in ((16000, 1), (16000, 5), (16000, 10), (48000, 5), (48000, 10), (96000, 5)):
+        xd = [synth_utterance(9, fs_d, 0.5), synth_utterance(10, fs_d, 0.3)]
+        for req in (False, True):
+            for pitch, dur in ((1.0, 1.0), (0.25, 1.0), (8.0, 1.0), (1.0, 0.5), (1.5, 3.0)):
+                enc = wbd.encode(xd, fs_d, f0_method="dio", frame_period=period, is_requiem=req)
+                if pitch != 1.0:
+                    enc.scale_pitch(pitch)
+                if dur != 1.0:
+                    enc.scale_duration(dur)
+                wbd.decode_device(enc, seed=4)  # (check=True: a pulse overflow is retried with the safe capacity)
+                dec_flags = [a | b for a, b in zip(dec_flags, wbd.rt.take_flags())]
+                dec_cases += 1
+    out["decode_sweep_flags"] = dec_flags
+    out["decode_sweep_record"] = list(_hip.bounds_last())
+    out["decode_sweep_cases"] = dec_cases
     # ---- config 2 at full size: 64 x 10 s through every stage of the DIO path + decode, Harvest + Requiem on 8 ----------
     xs = [synth_utterance(u, 16000, 10.0) for u in range(64)]
     wb = WorldBatch()

@@ -69,6 +69,11 @@ def test_d4c_f0_sweep_stays_inside_its_buffers(report):
     assert report["d4c_sweep_bad"] == []
 
 
+def test_decode_sweep_stays_inside_its_buffers(report):
+    assert report["decode_sweep_cases"] == 60
+    assert report["decode_sweep_flags"] == [0] * 16, (report["decode_sweep_flags"], report["decode_sweep_record"])
+
+
 def test_off_regime_signals_run_clean(report):
     assert report["fuzz_flags"] == [0] * 16, (report["fuzz_flags"], report["fuzz_record"])
 

@@ -471,3 +471,35 @@ def test_pool_fails_loudly_without_a_gpu():
         assert pool.ranges([10, 10, 10]) == [(0, 3)]
     finally:
         pool.close()
+
+
+def test_harvest_event_capacity_hints():
+    """world.harvest.hinted_event_caps: nothing to add -> None (the library sizes its crossing lists itself: the benchmark
+    path); with flat stretches in the host waveforms -> the library's estimate plus one entry per two flat DECIMATED samples
+    per list, utterance by utterance; and the setter of the C-ABI refuses nonsense without touching a device."""
+    import ctypes
+    from types import SimpleNamespace
+
+    from world import _hip, _tables
+    from world.harvest import flat_samples, hinted_event_caps
+
+    fs = 16000
+    tb = _tables.harvest_tables(fs, 71, 800)
+    nb = len(tb["band_f0"])
+    assert nb == 152 and int(tb["r"]) == 2
+    x = np.random.RandomState(0).randn(16000)
+    padded = np.concatenate([np.zeros(4800), x, np.full(1600, 0.25)])
+    assert flat_samples(x) == 0 and flat_samples(padded) == 4799 + 1599
+    mk = lambda lens, flat: SimpleNamespace(n_utt=len(lens), x_off=np.concatenate([[0], np.cumsum(lens)]), flat_samples=flat)  # noqa: E731
+    assert hinted_event_caps(SimpleNamespace(n_utt=1, x_off=np.array([0, 16000])), fs, tb) is None  # (no host arrays seen)
+    assert hinted_event_caps(mk([16000], [0]), fs, tb) is None
+    assert hinted_event_caps(mk([16000], [100]), fs, tb) is None  # (100 / 4 = 25 entries: inside the estimate's slack)
+    caps = hinted_event_caps(mk([16000, len(padded)], [0, flat_samples(padded)]), fs, tb).reshape(2, nb)
+    est = lambda n: np.ceil((n // 2 + 2) / 8000.0 * tb["band_f0"] * 3.0).astype(np.int64) + 64  # noqa: E731
+    assert np.array_equal(caps[0], est(16000) + 16)
+    assert np.array_equal(caps[1], est(len(padded)) + 6398 // 4 + 16)
+    assert caps[1].min() > 6398 // 4  # every list can take the flat stretches' sign changes
+    lib = _hip.load_library()
+    assert lib.wh_harvest_set_event_caps(None, None, 0) != 0            # null context
+    assert lib.wh_harvest_event_counts(None, None, None, 0) != 0
+    assert b"null" in lib.wh_last_error()

@@ -150,8 +150,10 @@ int wh_dio(wh_ctx* ctx, void* stream, const wh_batch* b, const double* x, const 
 /* ---- Harvest: replaces harvest()  (world/harvest.py:17-54) ---------------------------------------- */
 /* tp[total_frames]: output frame times (s).  Host-supplied filter DATA (the reference obtains them from
  * SciPy / NumPy at run time, so the host language evaluates the same expressions):
- *   decimation_ratio r = int(fs/8000 + 0.5); if r > 1: h_ba[8] = (b0..b3, a0..a3) of
- *   scipy.signal.cheby1(3, 0.05, 0.8/r) and h_zi[3] = scipy.signal.lfilter_zi(b, a)   (harvest.py:599-603);
+ *   decimation_ratio r = int(fs/8000 + 0.5) (1 for fs <= 8000); if fs > 8000 — ALSO where r rounds to 1, 8 kHz < fs <
+ *   12 kHz: harvest.py:60 branches on the rate and still low-pass filters — h_ba[8] = (b0..b3, a0..a3) of
+ *   scipy.signal.cheby1(3, 0.05, 0.8/r) and h_zi[3] = scipy.signal.lfilter_zi(b, a)   (harvest.py:599-603); else
+ *   h_ba = NULL or all zeros (a0 == 0: no filter);
  *   h_band_f0[n_bands]: channel centre frequencies (harvest.py:22-29, 152 for the default range);
  *   h_band_half[n_bands]: h = round-half-up(2*fs_d/f) (harvest.py:253);
  *   h_band_taps: concatenated band-pass FIRs nuttall(2h+1)*cos(2*pi*f*k/fs_d), k=-h..h (harvest.py:254-256).

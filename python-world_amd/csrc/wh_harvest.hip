@@ -1573,6 +1573,10 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   hipStream_t st = (hipStream_t)stream;
   const int B = b->n_utt;
   const int r = decimation_ratio < 1 ? 1 : decimation_ratio;
+  // The anti-aliasing filter runs whenever fs > 8000 Hz — ALSO when the ratio rounds to 1 (8 kHz < fs < 12 kHz, e.g.
+  // 11.025 kHz): the reference branches on `fs <= target_fs` (harvest.py:60) and then low-pass filters at 0.8 / r of
+  // Nyquist with r = 1, keeping every sample.  The host says so by handing over the coefficients (a0 != 0).
+  const bool filtered = r > 1 || (h_ba && h_zi && h_ba[4] != 0.0);
   const double fs_d = fs / r;
   int max_lb = 0, taps_total = 0;
   std::vector<int32_t> ti(n_bands * 3);
@@ -1602,7 +1606,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
     m.x_off = b->h_x_off[u];
     m.n = b->h_x_off[u + 1] - b->h_x_off[u];
     if (m.n < 32) return wh::fail_msg("wh_harvest", "utterance shorter than 32 samples");
-    if (r > 1) {
+    if (filtered) {
       m.offset = (int64_t)ceil(140.0 / r) * r;
       m.nd = m.n + 2 * m.offset;
       const double n_out = ceil((double)m.nd / r);
@@ -1762,7 +1766,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   }
 
   // ---- decimation -----------------------------------------------------------------------------------
-  if (r > 1) {
+  if (filtered) {
     Tdf2 c;
     c.b0 = h_ba[0]; c.b1 = h_ba[1]; c.b2 = h_ba[2]; c.b3 = h_ba[3];
     c.a1 = h_ba[5] / h_ba[4]; c.a2 = h_ba[6] / h_ba[4]; c.a3 = h_ba[7] / h_ba[4];

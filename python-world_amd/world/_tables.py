@@ -86,7 +86,9 @@ def harvest_tables(fs, f0_floor, f0_ceil):
     if fs <= target_fs:
         r = 1
     fs_d = fs / r if r > 1 else fs
-    if r > 1:
+    # the filter runs whenever fs > target_fs — also at a ratio of 1 (8 kHz < fs < 12 kHz: harvest.py:60 branches on the
+    # rate, and decimate_matlab(x, 1) still low-pass filters at 0.8 of Nyquist); zeros: no filter (wh_harvest reads a0)
+    if fs > target_fs:
         b, a = signal.cheby1(3, 0.05, 0.8 / r)
         ba = np.concatenate([b, a]).astype(np.float64)
         zi = np.asarray(signal.lfilter_zi(b, a), dtype=np.float64)

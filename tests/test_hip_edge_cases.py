@@ -63,7 +63,7 @@ def test_silence_and_short_utterances():
     wb.rt.take_flags()
 
 
-@pytest.mark.parametrize("fs", [8000, 11025, 22050, 32000, 44100, 88200])
+@pytest.mark.parametrize("fs", [8000, 9600, 11025, 22050, 32000, 44100, 88200])
 def test_other_sampling_rates_match_oracle(fs):
     from oracle import api as oapi
     from world._synthetic import synth_utterance

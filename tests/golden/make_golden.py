@@ -414,6 +414,61 @@ def differential_fixture():
     print("differential written; worst", {k: "%.2e" % v for k, v in worst.items()})
 
 
+def sweep_fixture():
+    """Reference vs oracle over World.encode arguments and inputs the other fixtures leave at their defaults
+    (tests/_sweep_cases.py), in the format of the differential fixture: per case the reference's f0 / vuv / frame times,
+    compact sums of its dense tensors and of the seeded decode, and the oracle's worst error measured here."""
+    from oracle import api
+
+    spec = importlib.util.spec_from_file_location("_sweep_cases", os.path.join(ROOT, "tests", "_sweep_cases.py"))
+    sc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sc)
+    W = R.main.World()
+    out = {"seed": SEED}
+    worst = {}
+    for i, case in enumerate(sc.sweep_cases()):
+        u, fs, sec, amp, kw = case
+        x = sc.sweep_input(_syn.synth_utterance, case)
+        ref = W.encode(fs, x.copy(), **kw)
+        mine = api.encode_np(fs, x.copy(), **kw)
+        random.seed(SEED + 200 + i)
+        np.random.seed(SEED + 200 + i)
+        R.synthesisRequiem.generate_noise.current_index = None
+        ref_y = W.decode({k: (v.copy() if hasattr(v, "copy") else v) for k, v in ref.items()})["out"]
+        random.seed(SEED + 200 + i)
+        np.random.seed(SEED + 200 + i)
+        my_y = api.decode_np({k: (v.copy() if hasattr(v, "copy") else v) for k, v in mine.items()})["out"]
+        errs = {"vuv_mismatch": float(np.sum(ref["vuv"] != mine["vuv"])),
+                "frames_mismatch": float(len(ref["f0"]) != len(mine["f0"])),
+                "out_len_mismatch": float(len(ref_y) != len(my_y)),
+                "f0_maxrel": float(np.max(np.abs(mine["f0"] - ref["f0"]) / np.maximum(ref["f0"], 1.0))),
+                "tp_maxabs": _worst(mine["temporal_positions"], ref["temporal_positions"])[1],
+                "spectrogram_relrms": _worst(mine["spectrogram"], ref["spectrogram"])[0],
+                "aperiodicity_maxabs": _worst(mine["aperiodicity"], ref["aperiodicity"])[1],
+                "out_relrms": _worst(my_y, ref_y)[0] if len(ref_y) == len(my_y) else 1.0}
+        for k, v in errs.items():
+            out.setdefault("err_" + k, []).append(v)
+            worst[k] = max(worst.get(k, 0.0), v)
+        out["f0_%d" % i] = ref["f0"].copy()
+        out["vuv_%d" % i] = ref["vuv"].copy()
+        out["tp_%d" % i] = ref["temporal_positions"].copy()
+        out["spec_shape_%d" % i] = np.array(ref["spectrogram"].shape)
+        out["spec_colsum_%d" % i] = ref["spectrogram"].sum(axis=0)
+        out["spec_rowsum_%d" % i] = ref["spectrogram"].sum(axis=1)
+        out["ap_colsum_%d" % i] = ref["aperiodicity"].sum(axis=0)
+        out["ap_rowsum_%d" % i] = ref["aperiodicity"].sum(axis=1)
+        out["out_len_%d" % i] = len(ref_y)
+        out["out_blocksum_%d" % i] = np.add.reduceat(ref_y, np.arange(0, len(ref_y), 256))
+        print(i, (u, fs, sec, amp, kw), {k: "%.2e" % v for k, v in errs.items()}, flush=True)
+    for k in list(out):
+        if k.startswith("err_"):
+            out[k] = np.array(out[k])
+    for k, v in worst.items():
+        out["worst_" + k] = v
+    np.savez_compressed(os.path.join(HERE, "golden_sweep.npz"), **out)
+    print("sweep written; worst", {k: "%.2e" % v for k, v in worst.items()})
+
+
 def hires_fixture():
     """96 kHz: the rates beyond 48 kHz need 8192-point transforms in D4C (d4c.py:20: 2^ceil(log2(4 fs / 47 + 1))) and the
     love-train gate (d4c.py:75).  DIO is all-unvoiced up there, so the dense stages are driven with
@@ -456,4 +511,5 @@ if __name__ == "__main__":
     modifiers_fixture()
     longform_fixture()
     differential_fixture()
+    sweep_fixture()
     hires_fixture()

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(WS >= 512 ? 256 : WS / 2) void swipe_stft_kernel(co
                                                                                const double2* __restrict__ tw_base,
                                                                                double* __restrict__ mag) {
   constexpr int NT = WS >= 512 ? 256 : WS / 2;
-  __shared__ __attribute__((aligned(16))) double buf[WS + 2];
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // WS + 2 doubles (dynamic: 64 KB + 16 B at WS = 8192)
+  double* buf = reinterpret_cast<double*>(smem);
   const int64_t g = blockIdx.x;  // flat STFT frame
   int u = 0;
   {
@@ -169,10 +170,13 @@ __global__ __launch_bounds__(64) void swipe_pick_kernel(const double* __restrict
 }
 
 template <int WS>
-void launch_stft(hipStream_t st, int64_t total_seg, const double* x, const SwUtt* d_meta, int B, const double* d_win, int hop,
-                 const double2* tw, double* mag) {
+int launch_stft(hipStream_t st, int64_t total_seg, const double* x, const SwUtt* d_meta, int B, const double* d_win, int hop,
+                const double2* tw, double* mag) {
   constexpr int NT = WS >= 512 ? 256 : WS / 2;
-  hipLaunchKernelGGL(swipe_stft_kernel<WS>, dim3((unsigned)total_seg), dim3(NT), 0, st, x, d_meta, B, d_win, hop, tw, mag);
+  const size_t lds = sizeof(double) * (WS + 2);
+  if (int rc = wh::allow_lds(&swipe_stft_kernel<WS>, lds)) return rc;
+  hipLaunchKernelGGL(swipe_stft_kernel<WS>, dim3((unsigned)total_seg), dim3(NT), lds, st, x, d_meta, B, d_win, hop, tw, mag);
+  return 0;
 }
 
 }  // namespace
@@ -194,7 +198,7 @@ extern "C" int wh_swipe(wh_ctx* ctx, void* stream, const wh_batch* b, const doub
   size_t max_mag = 0, max_l = 0, max_si = 0;
   for (int i = 0; i < n_win; ++i) {
     const wh_swipe_window& w = h_win[i];
-    if (w.ws < 64 || w.ws > 4096 || (w.ws & (w.ws - 1)) || w.hop < 1) return wh::fail_msg("wh_swipe", "window size outside [64, 4096]");
+    if (w.ws < 64 || w.ws > 8192 || (w.ws & (w.ws - 1)) || w.hop < 1) return wh::fail_msg("wh_swipe", "window size outside [64, 8192]");
     if (w.j0 < 0 || w.n_c < 1 || w.j0 + w.n_c > n_cand) return wh::fail_msg("wh_swipe", "candidate range outside the set");
     int64_t seg = 0;
     for (int u = 0; u < B; ++u) {
@@ -240,15 +244,19 @@ extern "C" int wh_swipe(wh_ctx* ctx, void* stream, const wh_batch* b, const doub
     const int64_t total_seg = metas[i][B - 1].seg_off + metas[i][B - 1].nseg;
     {
       wh::KernelTimer _kt(ctx, st, "swipe_stft_kernel");
+      int rc_stft = 0;
       switch (w.ws) {
-        case 64: launch_stft<64>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
-        case 128: launch_stft<128>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
-        case 256: launch_stft<256>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
-        case 512: launch_stft<512>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
-        case 1024: launch_stft<1024>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
-        case 2048: launch_stft<2048>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
-        default: launch_stft<4096>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
+        case 64: rc_stft = launch_stft<64>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
+        case 128: rc_stft = launch_stft<128>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
+        case 256: rc_stft = launch_stft<256>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
+        case 512: rc_stft = launch_stft<512>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
+        case 1024: rc_stft = launch_stft<1024>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
+        case 2048: rc_stft = launch_stft<2048>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
+        case 4096: rc_stft = launch_stft<4096>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
+        // (8 fs / f0_floor rounds to 2^13 from 88.2 kHz up at the default floor, and for floors below ~60 Hz at 44.1 / 48 kHz)
+        default: rc_stft = launch_stft<8192>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
       }
+      if (rc_stft) return rc_stft;
     }
     WH_LAUNCH_CHECK("swipe_stft_kernel");
     const int nbins = w.ws / 2 + 1;

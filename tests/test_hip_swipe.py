@@ -96,3 +96,19 @@ def test_swipe_batch_equals_single():
         got = f0[int(fo[u]):int(fo[u + 1])]
         assert np.array_equal(got > 0, one["f0"] > 0)
         assert np.array_equal(got[got > 0], one["f0"][one["f0"] > 0])
+
+
+@pytest.mark.parametrize("fs,floor", [(96000, 71), (88200, 71), (44100, 40.9), (48000, 45)])
+def test_swipe_with_8192_sample_windows(fs, floor):
+    """The longest window is 2^round(log2(8 fs / f0_floor)) samples (world/swipe.py:33-35): 8192 from 88.2 kHz up at the
+    default floor and for floors below ~60 Hz at 44.1 / 48 kHz (round 6: refused before — found by the differential campaign)."""
+    from oracle import pitch_swipe
+    from world._synthetic import synth_utterance
+    from world.swipe import swipe
+
+    x = synth_utterance(7, fs, 0.5)
+    o = pitch_swipe.swipe_np(fs, x, [floor, 800], sTHR=0.3)
+    d = swipe(fs, x, [floor, 800], 0.005, 0.3)
+    assert np.array_equal(d["vuv"], o["vuv"]) and o["vuv"].sum() > 50
+    v = o["vuv"] > 0
+    assert np.max(np.abs(d["f0"][v] - o["f0"][v]) / o["f0"][v]) < 1e-12

@@ -7,7 +7,8 @@ profiles/.
 
 Draws: fs in {8, 11.025, 16, 22.05, 24, 32, 44.1, 48} kHz; DIO + StoneMask or Harvest; D4C or D4C-Requiem (where the rate has
 a band); frame periods 1 / 2 / 2.5 / 5 / 10 ms; F0 floor 40-120 Hz, ceiling 400-1200 Hz; 0.2-2.5 s; amplitude 1e-4 / 1 / 32767;
-a speech-like utterance optionally between digital silence, in white noise, on a DC offset, hard-clipped.
+a speech-like utterance optionally between digital silence, in white noise, on a DC offset, hard-clipped; SWIPE' on 12 % of
+the draws; scale_pitch / scale_duration (0.5 - 2.5) between encode and decode on 30 % each.
 The oracle (NumPy restatement, tests/: equal to the unmodified reference on every fixture) runs in a process pool on
 the host cores; the HIP path runs in this process.  Compared per case: frame times and VUV (exact), f0, spectrogram,
 aperiodicity, and the decode of the HIP encoding by both sides with the same host noise / seed tables."""
@@ -33,6 +34,9 @@ def draw_case(i, seed):
     method = "harvest" if rng.rand() < 0.5 else "dio"
     req = bool(rng.rand() < 0.5) and fs / 2 - 3000 >= 3000
     kw = dict(f0_method=method, is_requiem=req, frame_period=float(rng.choice([1, 2, 2.5, 5, 5, 5, 10])))
+    if rng.rand() < 0.12:  # SWIPE' (world/main.py:134-135: its own 5 ms grid whatever frame_period says)
+        method = kw["f0_method"] = "swipe"
+        kw["frame_period"] = 5
     if rng.rand() < 0.5:
         kw["f0_floor"] = float(np.round(40 + 80 * rng.rand(), 1))
     if rng.rand() < 0.5:
@@ -51,6 +55,9 @@ def draw_case(i, seed):
         shape["dc"] = float(np.round(rng.randn() * 0.2, 3))
     if rng.rand() < 0.15:
         shape["clip"] = float(np.round(0.2 + 0.6 * rng.rand(), 2))
+    # modifiers between encode and decode (world/main.py:166-189): the decode then runs on scaled contours and frame times
+    shape["scale_pitch"] = float(np.round(0.5 + 2.0 * rng.rand(), 2)) if rng.rand() < 0.3 else None
+    shape["scale_duration"] = float(np.round(0.5 + 2.0 * rng.rand(), 2)) if rng.rand() < 0.3 else None
     return dict(i=i, fs=fs, kw=kw, shape=shape, noise_seed=int(rng.randint(1 << 30)))
 
 
@@ -136,6 +143,12 @@ def main():
                 enc = wb.encode([x], c["fs"], **c["kw"])  # (check=True: a Harvest whose crossing lists overflow repeats itself)
                 d = enc.to_dicts()[0]
                 rec = dict(ok=True, d=d)
+                if c["shape"]["scale_pitch"] or c["shape"]["scale_duration"]:
+                    if c["shape"]["scale_pitch"]:
+                        enc.scale_pitch(c["shape"]["scale_pitch"])
+                    if c["shape"]["scale_duration"]:
+                        enc.scale_duration(c["shape"]["scale_duration"])
+                    d = enc.to_dicts()[0]  # (what both sides decode; rec["d"] stays the analysis)
                 if c["kw"]["is_requiem"]:
                     if c["fs"] not in seeds_by_fs:
                         random.seed(7)
@@ -144,7 +157,8 @@ def main():
                     y, _ = wb.decode_device(enc, seeds=seeds_by_fs[c["fs"]])
                     dec_jobs[c["i"]] = (d, None, seeds_by_fs[c["fs"]])
                 else:
-                    noise = np.random.RandomState(c["noise_seed"] + 1).randn(2 * len(x) + 8192)
+                    stretch = max(1.0, c["shape"]["scale_duration"] or 1.0)
+                    noise = np.random.RandomState(c["noise_seed"] + 1).randn(int(2 * len(x) * stretch) + 16384)
                     y, _ = wb.decode_device(enc, noise=[noise])
                     dec_jobs[c["i"]] = (d, noise, None)
                 dec_mine[c["i"]] = y.cpu().numpy()
@@ -184,8 +198,9 @@ def main():
         sh = c["shape"]
         t = np.asarray(o["tp"])
         # (and the contour of the utterance's first and last voiced stretch is tracked INTO the padding over such candidates, then
-        # smoothed as one segment, harvest.py SmoothF0: what the padding holds decays by e every 7.5 ms into the utterance (2.6e-6 relative at 60 ms, measured).)
-        edge = 0.1
+        # smoothed as one segment, harvest.py SmoothF0: what the padding holds decays by e every 7.5 ms into the utterance (2.6e-6 relative at 60 ms, measured); with a DC offset the padding's edge is a
+        # step whose response keeps DIO's lowest band without crossings for ~0.15 s: 0.25 s are left out.)
+        edge = 0.25
         inside = ((t >= sh["pad_head"] + edge) & (t <= sh["pad_head"] + sh["seconds"] - edge)) if (sh["pad_head"] or sh["pad_tail"]) else np.ones(len(t), bool)
         vm = d["vuv"] != o["vuv"]
         row["vuv_mismatch"] = int(np.sum(vm & inside))

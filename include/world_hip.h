@@ -291,7 +291,7 @@ int wh_context_frames(wh_ctx* ctx, void* stream, const double* x, int64_t n_rows
 /* One entry of the window-size table (HOST): candidates [j0, j0+n_c) of the candidate set use window size ws with
  * hop `hop` (= ws - noverlap of the reference's specgram call, swipe.py:35-38). */
 typedef struct wh_swipe_window {
-  int32_t ws, hop;          /* window length (power of two in [64, 8192]), hop in samples */
+  int32_t ws, hop;          /* window length (power of two in [64, 16384]), hop in samples */
   int32_t j0, n_c;
   const double* h_window;   /* [ws]               np.hanning(ws + 2)[1:-1] */
   const double* h_interp;   /* [ws/2+1][n_erb]    magnitude bins -> ERB grid: interp1d(kind='cubic') as a matrix, k-major */

@@ -150,10 +150,10 @@ int wh_ctx_create(int device, wh_ctx** out) {
   WH_CHECK(hipSetDevice(device));
   wh_ctx* c = new wh_ctx();
   c->device = device;
-  // twiddle tables: for N = 2,4,..,WH_MAX_FFT the table exp(-2*pi*i*k/N), k<N, lives at [N, 2N)
-  std::vector<double2> tw(2 * WH_MAX_FFT);
+  // twiddle tables: for N = 2,4,..,WH_MAX_TWIDDLE the table exp(-2*pi*i*k/N), k<N, lives at [N, 2N)
+  std::vector<double2> tw(2 * WH_MAX_TWIDDLE);
   tw[0] = tw[1] = make_double2(1.0, 0.0);
-  for (int n = 2; n <= WH_MAX_FFT; n <<= 1) {
+  for (int n = 2; n <= WH_MAX_TWIDDLE; n <<= 1) {
     for (int k = 0; k < n; ++k) {
       long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
       tw[n + k] = make_double2((double)cosl(a), (double)sinl(a));

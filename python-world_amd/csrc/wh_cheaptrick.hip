@@ -39,7 +39,7 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
   const wh::ckp<double2> zb = wh::ck_as<double2>(zr);                        // the same memory as N/2+1 complex
   const wh::ckp<double> aux = wh::ck_sub(lds_all, N + 2, K + 1, wh::WH_CK_LDS_AUX);                // K+1 reals
   const wh::ckp<double> scratch = wh::ck_sub(lds_all, (N + 2) + (K + 1), 32, wh::WH_CK_LDS_SCRATCH);  // 32 doubles
-  const wh::ckp<const double2> tw = wh::ck_make(tw_base, 2 * WH_MAX_FFT, wh::WH_CK_TWIDDLE);  // the table of size n at offset n
+  const wh::ckp<const double2> tw = wh::ck_make(tw_base, 2 * WH_MAX_TWIDDLE, wh::WH_CK_TWIDDLE);  // the table of size n at offset n
 
   const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
   if (f >= n_frames) return;

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(ft_love(NLT)) void love_train_kernel(
   const wh::ckp<double2> zb = wh::ck_as<double2>(zr);                               // NLT/2+1 complex after the real FFT
   const wh::ckp<double> scratch = wh::ck_sub(lds_all, NLT + 2, 48, wh::WH_CK_LDS_SCRATCH);
   const wh::ckp<double> wtab = wh::ck_sub(lds_all, NLT + 2 + 48, kWinTab, wh::WH_CK_LDS_AUX);  // window set-up table (kWinTab doubles)
-  const wh::ckp<const double2> tw = wh::ck_make(tw_base, 2 * WH_MAX_FFT, wh::WH_CK_TWIDDLE);
+  const wh::ckp<const double2> tw = wh::ck_make(tw_base, 2 * WH_MAX_TWIDDLE, wh::WH_CK_TWIDDLE);
   const int64_t f = wh::xcd_unit(blockIdx.x, n_frames);
   if (f >= n_frames) return;
   double f0 = f0_io[f];
@@ -916,7 +916,7 @@ __device__ __forceinline__ void d4c_frame(
   const wh::ckp<double> wtab = wh::ck_sub(lds_all, 2 * N + 48, 4 * kWinTab, wh::WH_CK_LDS_AUX);  // 4 windows x kWinTab: gate, power, centroid +, centroid -
   constexpr int KPAD = (K + 1) & ~1;
   const wh::ckp<double> td = zr + (2 * N - KPAD);        // band stage: the shaped group delay, above the real-FFT buffer
-  const wh::ckp<const double2> tw = wh::ck_make(tw_base, 2 * WH_MAX_FFT, wh::WH_CK_TWIDDLE);  // the table of size n at offset n
+  const wh::ckp<const double2> tw = wh::ck_make(tw_base, 2 * WH_MAX_TWIDDLE, wh::WH_CK_TWIDDLE);  // the table of size n at offset n
   const wh::ckp<const double> win_tab = wh::ck_make(window, wlen, wh::WH_CK_TABLE);
 
   STAGE_TIMER_BEGIN

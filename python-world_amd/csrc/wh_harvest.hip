@@ -1590,7 +1590,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   }
   const int pad = max_lb + 2;
   const int hmax = (int)ceil(3 * fs_d / f0_floor / 2) + 1;
-  if (2 * hmax + 1 > WH_MAX_FFT / 2) return wh::fail_msg("wh_harvest", "f0_floor too low for the twiddle tables");
+  if (2 * hmax + 1 > WH_MAX_TWIDDLE / 2) return wh::fail_msg("wh_harvest", "f0_floor too low for the twiddle tables");
   std::vector<HvUtt> meta(B);
   std::vector<int64_t> e_off((size_t)B * n_bands), e_cap((size_t)B * n_bands);
   const bool caps_worst = ctx->hv_caps_worst;

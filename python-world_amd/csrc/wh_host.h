@@ -14,7 +14,7 @@
 
 struct wh_ctx {
   int device = 0;
-  double2* d_twiddle = nullptr;  // tables for N = 2 .. WH_MAX_FFT, table of size N at offset N
+  double2* d_twiddle = nullptr;  // tables for N = 2 .. WH_MAX_TWIDDLE, table of size N at offset N
   void* ws = nullptr;            // growable scratch
   size_t ws_bytes = 0;
   std::map<std::string, double*> tables;  // small constant tables resident on the device (windows, taps)
@@ -72,7 +72,12 @@ struct wh_batch {
   int32_t* d_frame_utt = nullptr;  // [total_frames]
 };
 
-#define WH_MAX_FFT 8192
+#define WH_MAX_FFT 8192  // longest in-LDS transform (CheapTrick / synthesis stop at 4096, D4C / love-train / SWIPE' at 8192)
+// The twiddle tables go further: StoneMask and the Harvest refinement evaluate a handful of bins of a transform of
+// 2^(2 + floor(log2(window))) points directly (stonemask.py:33-35) — no transform is run, only exp(-2 pi i k / n) is
+// looked up — and a 3-period window at a low floor and a high rate asks for 16384 or 32768 (96 kHz below 70 Hz, 48 kHz
+// below 35 Hz: the fft_size override).  1 MB per context.
+#define WH_MAX_TWIDDLE 32768
 
 namespace wh {
 // bounds build: every translation unit registers a reader of its kernels' out-of-range record (wh_device.h)

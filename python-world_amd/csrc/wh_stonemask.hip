@@ -375,7 +375,7 @@ extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   if (kmax < 1) return wh::fail_msg("wh_stonemask", "kmax must be >= 1");
   const size_t lds = sizeof(double) * 2 * (2 * (size_t)kmax + 1);
   if (lds > 160 * 1024) return wh::fail_msg("wh_stonemask", "window too long for LDS (f0 floor too low for this fs)");
-  if (2 * kmax + 1 > WH_MAX_FFT / 2) return wh::fail_msg("wh_stonemask", "window longer than the largest twiddle table");
+  if (2 * kmax + 1 > WH_MAX_TWIDDLE / 2) return wh::fail_msg("wh_stonemask", "window longer than the largest twiddle table");
   hipStream_t st = (hipStream_t)stream;
   // quantised time table (host-built, Python string-formatting semantics — SURVEY Q2)
   std::vector<double> qt(h_qtime, h_qtime + 2 * kmax + 1);

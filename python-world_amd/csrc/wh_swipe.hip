@@ -35,7 +35,7 @@ __global__ __launch_bounds__(WS >= 512 ? 256 : WS / 2) void swipe_stft_kernel(co
                                                                                const double2* __restrict__ tw_base,
                                                                                double* __restrict__ mag) {
   constexpr int NT = WS >= 512 ? 256 : WS / 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // WS + 2 doubles (dynamic: 64 KB + 16 B at WS = 8192)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // WS + 2 doubles (dynamic: 64 KB + 16 B at WS = 8192, 128 KB at 16384)
   double* buf = reinterpret_cast<double*>(smem);
   const int64_t g = blockIdx.x;  // flat STFT frame
   int u = 0;
@@ -198,7 +198,7 @@ extern "C" int wh_swipe(wh_ctx* ctx, void* stream, const wh_batch* b, const doub
   size_t max_mag = 0, max_l = 0, max_si = 0;
   for (int i = 0; i < n_win; ++i) {
     const wh_swipe_window& w = h_win[i];
-    if (w.ws < 64 || w.ws > 8192 || (w.ws & (w.ws - 1)) || w.hop < 1) return wh::fail_msg("wh_swipe", "window size outside [64, 8192]");
+    if (w.ws < 64 || w.ws > 16384 || (w.ws & (w.ws - 1)) || w.hop < 1) return wh::fail_msg("wh_swipe", "window size outside [64, 16384]");
     if (w.j0 < 0 || w.n_c < 1 || w.j0 + w.n_c > n_cand) return wh::fail_msg("wh_swipe", "candidate range outside the set");
     int64_t seg = 0;
     for (int u = 0; u < B; ++u) {
@@ -254,7 +254,9 @@ extern "C" int wh_swipe(wh_ctx* ctx, void* stream, const wh_batch* b, const doub
         case 2048: rc_stft = launch_stft<2048>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
         case 4096: rc_stft = launch_stft<4096>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
         // (8 fs / f0_floor rounds to 2^13 from 88.2 kHz up at the default floor, and for floors below ~60 Hz at 44.1 / 48 kHz)
-        default: rc_stft = launch_stft<8192>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
+        case 8192: rc_stft = launch_stft<8192>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
+        // (and to 2^14 below ~66 Hz at 88.2 / 96 kHz: a real transform of 16384 samples is the 8192-point complex one D4C runs at 96 kHz)
+        default: rc_stft = launch_stft<16384>(st, total_seg, x, d_meta, B, d_win, w.hop, ctx->d_twiddle, d_mag); break;
       }
       if (rc_stft) return rc_stft;
     }

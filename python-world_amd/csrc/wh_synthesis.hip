@@ -1082,7 +1082,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   const double* __restrict__ dc_base = A.dc_base;
   const double2* __restrict__ tw_raw = A.tw_base;
   asm volatile("" : "+s"(tw_raw));  // per pulse: no twiddle address / value of one pulse survives into the next
-  const wh::ckp<const double2> tw_base = wh::ck_make(tw_raw, 2 * WH_MAX_FFT, wh::WH_CK_TWIDDLE);
+  const wh::ckp<const double2> tw_base = wh::ck_make(tw_raw, 2 * WH_MAX_TWIDDLE, wh::WH_CK_TWIDDLE);
   constexpr int FT = ft_syn(N);
   constexpr int K = N / 2 + 1;
   constexpr int NZ = 256;
@@ -1806,7 +1806,7 @@ __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1
     // per frame: neither the twiddles nor the window values of one frame are parked in registers for the next (both are
     // the same for every frame, and hoisted out of this loop they cost a wave per SIMD)
     asm volatile("" : "+s"(tw_raw));
-    const wh::ckp<const double2> tw_base = wh::ck_make(tw_raw, 2 * WH_MAX_FFT, wh::WH_CK_TWIDDLE);
+    const wh::ckp<const double2> tw_base = wh::ck_make(tw_raw, 2 * WH_MAX_TWIDDLE, wh::WH_CK_TWIDDLE);
     {
       int hop_s = __builtin_amdgcn_readfirstlane((int)hop);  // (uniform by construction; said so for the constraint)
       asm volatile("" : "+s"(hop_s));

@@ -98,10 +98,11 @@ def test_swipe_batch_equals_single():
         assert np.array_equal(got[got > 0], one["f0"][one["f0"] > 0])
 
 
-@pytest.mark.parametrize("fs,floor", [(96000, 71), (88200, 71), (44100, 40.9), (48000, 45)])
-def test_swipe_with_8192_sample_windows(fs, floor):
+@pytest.mark.parametrize("fs,floor", [(96000, 71), (88200, 71), (44100, 40.9), (48000, 45), (96000, 57.1), (88200, 50)])
+def test_swipe_with_8192_and_16384_sample_windows(fs, floor):
     """The longest window is 2^round(log2(8 fs / f0_floor)) samples (world/swipe.py:33-35): 8192 from 88.2 kHz up at the
-    default floor and for floors below ~60 Hz at 44.1 / 48 kHz (round 6: refused before — found by the differential campaign)."""
+    default floor and for floors below ~60 Hz at 44.1 / 48 kHz, 16384 below ~66 Hz at 88.2 / 96 kHz (round 6: refused before —
+    found by the differential campaign)."""
     from oracle import pitch_swipe
     from world._synthetic import synth_utterance
     from world.swipe import swipe

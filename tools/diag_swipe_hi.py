@@ -5,7 +5,7 @@ for p in (ROOT, os.path.join(ROOT,"python-world_amd")): sys.path.insert(0,p)
 from oracle import pitch_swipe
 from world._synthetic import synth_utterance
 from world.swipe import swipe
-for fs, floor in ((96000, 71), (88200, 71), (44100, 40.9), (48000, 45)):
+for fs, floor in ((96000, 71), (88200, 71), (44100, 40.9), (48000, 45), (96000, 57.1), (88200, 50)):
     x = synth_utterance(7, fs, 0.5)
     o = pitch_swipe.swipe_np(fs, x, [floor, 800], sTHR=0.3)
     d = swipe(fs, x, [floor, 800], 0.005, 0.3)

@@ -5,7 +5,7 @@ profiles/.
 
     python tools/differential_campaign.py --cases 240 --seed 1 --procs 48 --out gpurun_out/campaign.json
 
-Draws: fs in {8, 11.025, 16, 22.05, 24, 32, 44.1, 48} kHz; DIO + StoneMask or Harvest; D4C or D4C-Requiem (where the rate has
+Draws: fs in {8, 9.6, 11.025, 12, 16, 22.05, 24, 32, 44.1, 48, 88.2, 96} kHz; the fft_size override (twice the default) on 10 %; DIO + StoneMask or Harvest; D4C or D4C-Requiem (where the rate has
 a band); frame periods 1 / 2 / 2.5 / 5 / 10 ms; F0 floor 40-120 Hz, ceiling 400-1200 Hz; 0.2-2.5 s; amplitude 1e-4 / 1 / 32767;
 a speech-like utterance optionally between digital silence, in white noise, on a DC offset, hard-clipped; SWIPE' on 12 % of
 the draws; scale_pitch / scale_duration (0.5 - 2.5) between encode and decode on 30 % each.
@@ -25,7 +25,7 @@ for p in (ROOT, os.path.join(ROOT, "python-world_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-RATES = (8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000)
+RATES = (8000, 9600, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000)
 
 
 def draw_case(i, seed):
@@ -44,6 +44,10 @@ def draw_case(i, seed):
     if method == "dio" and rng.rand() < 0.3:
         kw["channels_in_octave"] = int(rng.choice([1, 2, 3, 4]))
         kw["allowed_range"] = float(rng.choice([0.05, 0.1, 0.2]))
+    if method != "swipe" and fs <= 48000 and rng.rand() < 0.1:
+        # the fft_size override: twice the default transform, which also moves the F0 floor to 3 fs / fft_size (main.py:121-122)
+        kw["fft_size"] = int(2 ** np.ceil(np.log2(3.0 * fs / 71.0 + 1))) * 2
+        kw.pop("f0_floor", None)
     shape = dict(seconds=float(np.round(0.2 + 2.3 * rng.rand() ** 2, 3)), utt=int(rng.randint(1000, 9000)),
                  amp=float(rng.choice([1e-4, 1.0, 1.0, 1.0, 32767.0])), pad_head=0.0, pad_tail=0.0, snr_db=None, dc=0.0, clip=None)
     if rng.rand() < 0.3:

@@ -106,7 +106,7 @@ def test_rates_beyond_the_transform_ceiling_fail_loudly():
         d4c(x, fs, src())
 
 
-@pytest.mark.parametrize("fs,kw", [(96000, dict(f0_method="dio", f0_floor=50.0)), (48000, dict(f0_method="dio", fft_size=4096)),
+@pytest.mark.parametrize("fs,kw", [(96000, dict(f0_method="harvest", f0_floor=50.0)), (48000, dict(f0_method="dio", fft_size=4096)),
                                    (88200, dict(f0_method="harvest", f0_floor=52.0, is_requiem=True)),
                                    (32000, dict(f0_method="dio", fft_size=4096))])
 def test_low_floors_at_high_rates_match_oracle(fs, kw):

@@ -112,6 +112,56 @@ def oracle_decode(job):
         return "%s: %s" % (type(e).__name__, e)
 
 
+def compare_case(c, d, o, ym, yo):
+    """One case: the HIP analysis dict ``d`` against the oracle's ``o`` (keys tp / vuv / f0 / spectrogram / aperiodicity) and the
+    two decodes of the HIP encoding, ``ym`` and ``yo`` (the oracle's waveform, or the text of the exception it raised).
+    Returns the row, with 'fail'."""
+    row = dict(i=c["i"], fs=c["fs"], kw=c["kw"], shape=c["shape"])
+    row["frames"] = int(len(o["f0"]))
+    row["tp_equal"] = bool(np.array_equal(d["temporal_positions"], o["tp"]))
+    if not row["tp_equal"]:
+        row["fail"] = True
+        return row
+    # Frames inside the utterance proper, and frames of the zero padding around it.  In digital silence the reference's
+    # Harvest works on the rounding noise of its FFT products (DESIGN.md section 2): it can report a VOICED stretch there
+    # — 70 Hz out of nothing — and another correct implementation reports another; those frames are counted, not judged.
+    sh = c["shape"]
+    t = np.asarray(o["tp"])
+    # (and the contour of the utterance's first and last voiced stretch is tracked INTO the padding over such candidates, then
+    # smoothed as one segment, harvest.py SmoothF0: what the padding holds decays by e every 7.5 ms into the utterance (2.6e-6 relative at 60 ms, measured); with a DC offset the padding's edge is a
+    # step whose response keeps DIO's lowest band without crossings for ~0.15 s: 0.25 s are left out.)
+    edge = 0.25
+    inside = ((t >= sh["pad_head"] + edge) & (t <= sh["pad_head"] + sh["seconds"] - edge)) if (sh["pad_head"] or sh["pad_tail"]) else np.ones(len(t), bool)
+    vm = d["vuv"] != o["vuv"]
+    row["vuv_mismatch"] = int(np.sum(vm & inside))
+    row["vuv_mismatch_in_padding"] = int(np.sum(vm & ~inside))
+    both = (o["f0"] > 0) & (d["f0"] > 0)
+    rel = np.zeros(len(t))
+    rel[both] = np.abs(d["f0"][both] - o["f0"][both]) / o["f0"][both]
+    row["f0_rel"] = float(rel[inside].max()) if inside.any() else 0.0
+    row["f0_rel_in_padding"] = float(rel[~inside].max()) if (~inside).any() else 0.0
+    # the dense tensors of a frame follow from its f0 / vuv: compared where those agree
+    cols = inside & ~vm & (rel <= 1e-6)
+    row["frames_compared"] = int(cols.sum())
+    row["spectrogram_relrms"] = rel_rms(d["spectrogram"][:, cols], o["spectrogram"][:, cols]) if cols.any() else 0.0
+    fin = np.isfinite(o["aperiodicity"]).all(axis=0)
+    row["oracle_nan_frames"] = int((~fin).sum())
+    row["hip_finite"] = bool(np.isfinite(d["aperiodicity"]).all() and np.isfinite(d["spectrogram"]).all())
+    row["aperiodicity_maxabs"] = float(np.max(np.abs(d["aperiodicity"][:, fin & cols] - o["aperiodicity"][:, fin & cols]))) if (fin & cols).any() else 0.0
+    if isinstance(yo, str):
+        row["oracle_decode_error"] = yo
+        row["decode_relrms"] = 0.0
+    else:
+        row["decode_len_equal"] = bool(len(ym) == len(yo))
+        row["decode_relrms"] = rel_rms(ym, yo) if len(ym) == len(yo) else 1.0
+    # tolerances: the suite's (tests/test_hip_pipeline_fuzz.py); the aperiodicity where the oracle's prefix sums are sound
+    fail = (row["vuv_mismatch"] != 0 or row["f0_rel"] > 1e-6 or row["spectrogram_relrms"] > 1e-6
+            or not row["hip_finite"] or row["decode_relrms"] > 1e-8
+            or (row["oracle_nan_frames"] == 0 and row["aperiodicity_maxabs"] > 1e-5))
+    row["fail"] = bool(fail)
+    return row
+
+
 def rel_rms(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.sqrt(np.mean((a - b) ** 2) / max(np.mean(b ** 2), 1e-300)))
@@ -188,55 +238,11 @@ def main():
             if o["ok"] and not m["ok"]:
                 bad.append(row)
             continue
-        d = m["d"]
-        row["frames"] = int(len(o["f0"]))
-        row["tp_equal"] = bool(np.array_equal(d["temporal_positions"], o["tp"]))
-        if not row["tp_equal"]:
-            row["fail"] = True
-            rows.append(row)
-            bad.append(row)
-            continue
-        # Frames inside the utterance proper, and frames of the zero padding around it.  In digital silence the reference's
-        # Harvest works on the rounding noise of its FFT products: it can report a VOICED stretch there
-        # — 70 Hz out of nothing — and another correct implementation reports another; those frames are counted, not judged.
-        sh = c["shape"]
-        t = np.asarray(o["tp"])
-        # (and the contour of the utterance's first and last voiced stretch is tracked INTO the padding over such candidates, then
-        # smoothed as one segment, harvest.py SmoothF0: what the padding holds decays by e every 7.5 ms into the utterance (2.6e-6 relative at 60 ms, measured); with a DC offset the padding's edge is a
-        # step whose response keeps DIO's lowest band without crossings for ~0.15 s: 0.25 s are left out.)
-        edge = 0.25
-        inside = ((t >= sh["pad_head"] + edge) & (t <= sh["pad_head"] + sh["seconds"] - edge)) if (sh["pad_head"] or sh["pad_tail"]) else np.ones(len(t), bool)
-        vm = d["vuv"] != o["vuv"]
-        row["vuv_mismatch"] = int(np.sum(vm & inside))
-        row["vuv_mismatch_in_padding"] = int(np.sum(vm & ~inside))
-        both = (o["f0"] > 0) & (d["f0"] > 0)
-        rel = np.zeros(len(t))
-        rel[both] = np.abs(d["f0"][both] - o["f0"][both]) / o["f0"][both]
-        row["f0_rel"] = float(rel[inside].max()) if inside.any() else 0.0
-        row["f0_rel_in_padding"] = float(rel[~inside].max()) if (~inside).any() else 0.0
-        # the dense tensors of a frame follow from its f0 / vuv: compared where those agree
-        cols = inside & ~vm & (rel <= 1e-6)
-        row["frames_compared"] = int(cols.sum())
-        row["spectrogram_relrms"] = rel_rms(d["spectrogram"][:, cols], o["spectrogram"][:, cols]) if cols.any() else 0.0
-        fin = np.isfinite(o["aperiodicity"]).all(axis=0)
-        row["oracle_nan_frames"] = int((~fin).sum())
-        row["hip_finite"] = bool(np.isfinite(d["aperiodicity"]).all() and np.isfinite(d["spectrogram"]).all())
-        row["aperiodicity_maxabs"] = float(np.max(np.abs(d["aperiodicity"][:, fin & cols] - o["aperiodicity"][:, fin & cols]))) if (fin & cols).any() else 0.0
-        yo = dec_ora.get(i)
-        if isinstance(yo, str):
-            row["oracle_decode_error"] = yo
-            row["decode_relrms"] = 0.0
-        else:
-            ym = dec_mine[i]
-            row["decode_len_equal"] = bool(len(ym) == len(yo))
-            row["decode_relrms"] = rel_rms(ym, yo) if len(ym) == len(yo) else 1.0
-        for k in worst:
-            worst[k] = max(worst[k], row[k])
-        # tolerances: the suite's (tests/test_hip_pipeline_fuzz.py); the aperiodicity where the oracle's prefix sums are sound
-        fail = (row["vuv_mismatch"] != 0 or row["f0_rel"] > 1e-6 or row["spectrogram_relrms"] > 1e-6
-                or not row["hip_finite"] or row["decode_relrms"] > 1e-8
-                or (row["oracle_nan_frames"] == 0 and row["aperiodicity_maxabs"] > 1e-5))
-        row["fail"] = bool(fail)
+        row = compare_case(c, m["d"], o, dec_mine.get(i), dec_ora.get(i))
+        if "spectrogram_relrms" in row:
+            for k in worst:
+                worst[k] = max(worst[k], row[k])
+        fail = row["fail"]
         rows.append(row)
         if fail:
             bad.append(row)

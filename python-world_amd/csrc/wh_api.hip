@@ -68,7 +68,17 @@ int const_table(wh_ctx* ctx, const std::string& key, const std::vector<double>& 
   WH_CHECK(hipMalloc((void**)&d, (host.size() ? host.size() : 1) * sizeof(double)));
   WH_CHECK(hipMemcpy(d, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
   ctx->tables[key] = d;
+  ctx->table_bytes += (host.size() ? host.size() : 1) * sizeof(double);
   *out = d;
+  return 0;
+}
+int tables_make_room(wh_ctx* ctx) {
+  if (ctx->table_bytes <= kTableCacheBytes) return 0;
+  WH_CHECK(hipDeviceSynchronize());  // kernels of earlier calls may still read them
+  for (auto& kv : ctx->tables)
+    if (kv.second) WH_CHECK(hipFree(kv.second));
+  ctx->tables.clear();
+  ctx->table_bytes = 0;
   return 0;
 }
 int persistent_upload(wh_ctx* ctx, hipStream_t st, const std::string& slot, const void* host, size_t bytes, void** dptr) {

@@ -1570,6 +1570,7 @@ extern "C" int wh_harvest(wh_ctx* ctx, void* stream, const wh_batch* b, const do
   WH_ENTER(ctx);
   if (decimation_ratio > 1 && (!h_ba || !h_zi)) return wh::fail_msg("wh_harvest", "decimation filter missing");
   if (n_bands < 3 || n_bands > 1024) return wh::fail_msg("wh_harvest", "n_bands out of range");
+  if (int rc = wh::tables_make_room(ctx)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int B = b->n_utt;
   const int r = decimation_ratio < 1 ? 1 : decimation_ratio;

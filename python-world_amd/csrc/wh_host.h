@@ -18,6 +18,7 @@ struct wh_ctx {
   void* ws = nullptr;            // growable scratch
   size_t ws_bytes = 0;
   std::map<std::string, double*> tables;  // small constant tables resident on the device (windows, taps)
+  size_t table_bytes = 0;                 // their total; tables_make_room() empties the cache beyond kTableCacheBytes
   int32_t* d_flags = nullptr;             // [16] sticky device-side condition flags (see wh_take_flags)
   // deferred reading of the flags (wh_flags_post / wh_flags_poll): d_flag_cum[i] counts the posts that found flag i set;
   // h_flag_cum is its mirror in pinned, device-mapped host memory (the post kernel is its only writer, the host only
@@ -89,6 +90,12 @@ int ws_reserve(wh_ctx* ctx, size_t bytes);  // grows ctx->ws (hipFree + hipMallo
 inline const double2* twiddle(const wh_ctx* ctx, int n) { return ctx->d_twiddle + n; }
 // Upload-once constant table keyed by name (synchronous on first use, cached afterwards).
 int const_table(wh_ctx* ctx, const std::string& key, const std::vector<double>& host, const double** out);
+// The cache is keyed by what the tables depend on — rate, window bound, F0 floor — and a long-running caller that varies
+// those (StoneMask on contours with ever new minima: a window table of up to 2 MB per distinct bound) would grow it without
+// limit.  Called at the top of the entry points that cache large tables, BEFORE any table pointer is taken: beyond
+// kTableCacheBytes everything is freed (one device synchronisation) and rebuilt on demand.
+constexpr size_t kTableCacheBytes = (size_t)256 << 20;
+int tables_make_room(wh_ctx* ctx);
 // Upload `bytes` from host memory into the persistent device buffer named `slot` unless it already holds
 // exactly these bytes.  Changed content goes through a ring of pinned staging buffers and hipMemcpyAsync on `st`
 // (no device synchronisation; a context is driven from one stream at a time, so stream order protects readers of

@@ -373,6 +373,7 @@ extern "C" int wh_stonemask(wh_ctx* ctx, void* stream, const wh_batch* b, const 
   WH_ENTER(ctx);
   if (b->total_frames == 0) return 0;
   if (kmax < 1) return wh::fail_msg("wh_stonemask", "kmax must be >= 1");
+  if (int rc = wh::tables_make_room(ctx)) return rc;
   const size_t lds = sizeof(double) * 2 * (2 * (size_t)kmax + 1);
   if (lds > 160 * 1024) return wh::fail_msg("wh_stonemask", "window too long for LDS (f0 floor too low for this fs)");
   if (2 * kmax + 1 > WH_MAX_TWIDDLE / 2) return wh::fail_msg("wh_stonemask", "window longer than the largest twiddle table");

@@ -56,6 +56,8 @@ def quantised_times(fs, kmax):
     t = _QT_CACHE.get(key)
     if t is None:
         t = np.array([float("{0:.4f}".format(e)) for e in (np.arange(-kmax, kmax + 1) / fs)], dtype=np.float64)
+        if len(_QT_CACHE) >= 64:  # (bounded: a long-running caller with ever new rates / bounds starts over)
+            _QT_CACHE.clear()
         _QT_CACHE[key] = t
     return t
 
@@ -107,6 +109,8 @@ def harvest_tables(fs, f0_floor, f0_ceil):
     t = {"r": r, "fs_d": fs_d, "ba": np.ascontiguousarray(ba), "zi": np.ascontiguousarray(zi),
          "band_f0": np.ascontiguousarray(bands, dtype=np.float64), "band_half": np.asarray(halves, dtype=np.int32),
          "band_taps": np.ascontiguousarray(np.concatenate(taps), dtype=np.float64)}
+    if len(_HV_CACHE) >= 32:  # (bounded, ~1 MB an entry: a caller that varies the search range without end starts over)
+        _HV_CACHE.clear()
     _HV_CACHE[key] = t
     return t
 

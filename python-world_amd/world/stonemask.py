@@ -12,6 +12,10 @@ def stonemask_device(rt, batch, x_d, tp_d, f0_d, fs, min_f0):
     """Device-resident core: returns a NEW refined-f0 device tensor.  ``min_f0`` bounds the longest
     analysis window (lowest non-zero f0 that can occur, e.g. DIO's f0_floor)."""
     kmax = int(math.ceil(3 * fs / min_f0 / 2))
+    # the bound is rounded up to a multiple of 32: the library caches a window table per (rate, bound) — up to 2 MB each —
+    # and World.encode / stonemask() derive the bound from the contour's own minimum, another one for every utterance
+    # (a frame's window depends on its f0 alone: a longer bound changes no result)
+    kmax = -(-kmax // 32) * 32
     qt = _tables.quantised_times(fs, kmax)
     out = rt.empty((batch.total_frames,))
     _hip.check(rt.lib.wh_stonemask(rt.ctx, rt.stream(), batch.handle, rt.ptr(x_d), rt.ptr(tp_d), rt.ptr(f0_d),

@@ -31,13 +31,14 @@ def main():
         xs = [pool[fs][int(rng.randint(12))][: int(fs * (0.2 + 2.8 * rng.rand()))] for _ in range(n)]
         method = "harvest" if rng.rand() < 0.5 else "dio"
         req = bool(rng.rand() < 0.5)
-        dats = w.encode_batch(fs, xs, f0_method=method, is_requiem=req)
+        devs = [0, 0] if (it % 4 == 1 and n >= 2) else None  # the thread-per-device pool (two contexts on the one GPU) now and then
+        dats = w.encode_batch(fs, xs, f0_method=method, is_requiem=req, devices=devs)
         if rng.rand() < 0.5:
             for d in dats:
                 w.scale_pitch(d, 0.7 + rng.rand())
         if rng.rand() < 0.3:
             _ = dats[0]["spectrogram"]  # (materialise one dense tensor now and then)
-        outs = w.decode_batch(dats)
+        outs = w.decode_batch(dats, devices=devs)
         assert all(np.isfinite(d["out"]).all() for d in outs)
         if it % 3 == 0:  # the single-utterance facade as well
             d1 = w.encode(fs, xs[0], f0_method=method, is_requiem=req)

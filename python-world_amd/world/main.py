@@ -33,6 +33,8 @@ def _pick(d, keys):
 def _estimate_source(fs, x, method, floor, ceil, channels, target_fs, period, allowed_range):
     """F0 stage shared by get_f0 / get_spectrum / encode (world/main.py:36-46, 62-72, 121-135).  allowed_range is None
     for the two getters, which call dio() positionally without it."""
+    if np.ndim(x) != 1:
+        raise ValueError("the waveform must be 1-D (one channel), got shape %s" % (np.shape(x),))
     if method == 'dio':
         extra = {} if allowed_range is None else {'allowed_range': allowed_range}
         source = _dio.dio(x, fs, floor, ceil, channels, target_fs, period, **extra)
@@ -99,6 +101,38 @@ def _hand_out(dats, block, y_off, copy_out):
             outs = list(pool.map(lambda ab: np.array(block[ab[0]:ab[1]]), cuts))
     for d, y in zip(dats, outs):
         d['out'] = y
+
+
+def _check_decodable(dats):
+    """What decode() / decode_batch() are handed: the per-frame arrays of a dict must agree in length and the dense tensors
+    be (bins, frames) over those frames; the dicts of one batch must share rate, synthesis path and bin count.  The
+    reference fails somewhere inside NumPy on such input (an interp1d shape error, a broadcast error); here the kernels
+    index by the batch's frame count, so a short array would be read past its end — refused up front instead.  Dense values
+    still resident in HBM (lazy dicts) are what encode made: not looked at, not materialised."""
+    fs0 = req0 = k0 = None
+    for n, d in enumerate(dats):
+        tp, f0, vuv = (np.asarray(d[k]) for k in ('temporal_positions', 'f0', 'vuv'))
+        if not (tp.ndim == f0.ndim == vuv.ndim == 1 and len(tp) == len(f0) == len(vuv)):
+            raise ValueError("dict %d: temporal_positions / f0 / vuv must be 1-D and of one length (%s, %s, %s)"
+                             % (n, tp.shape, f0.shape, vuv.shape))
+        if len(tp) < 2:
+            raise ValueError("dict %d: fewer than 2 frames" % n)
+        for key in ('spectrogram', 'aperiodicity'):
+            v = dict.get(d, key)
+            if isinstance(v, np.ndarray) and (v.ndim != 2 or v.shape[1] != len(tp)):
+                raise ValueError("dict %d: '%s' must be (bins, %d frames), got %s" % (n, key, len(tp), v.shape))
+        sp = dict.get(d, 'spectrogram')
+        k = sp.shape[0] if isinstance(sp, np.ndarray) else None
+        if fs0 is None:
+            fs0, req0 = d['fs'], bool(d['is_requiem'])
+        elif d['fs'] != fs0 or bool(d['is_requiem']) != req0:
+            raise ValueError("dict %d: the dicts of one decode_batch must share fs and is_requiem (%s / %s against %s / %s)"
+                             % (n, d['fs'], bool(d['is_requiem']), fs0, req0))
+        if k is not None:
+            if k0 is None:
+                k0 = k
+            elif k != k0:
+                raise ValueError("dict %d: spectrogram of %d bins in a batch of %d" % (n, k, k0))
 
 
 class World(object):
@@ -222,6 +256,7 @@ class World(object):
 
         if not dats:
             return dats
+        _check_decodable(dats)
         if devices is not None:
             from .pool import WorldBatchPool
             for d, y in zip(dats, WorldBatchPool.shared(devices).decode_dicts(dats, **kw)):
@@ -361,6 +396,7 @@ class World(object):
     # ---- synthesis ----------------------------------------------------------------------------------------------
     def decode(self, dat):
         """world/main.py:198-214: pulse-wise or Requiem synthesis, then peak normalisation above 1."""
+        _check_decodable([dat])
         if dat['is_requiem']:
             y = _synr.synthesisRequiem(dat, dat, _seeds.get_seeds_signals(dat['fs']))
         else:

@@ -503,3 +503,23 @@ def test_harvest_event_capacity_hints():
     assert lib.wh_harvest_set_event_caps(None, None, 0) != 0            # null context
     assert lib.wh_harvest_event_counts(None, None, None, 0) != 0
     assert b"null" in lib.wh_last_error()
+
+
+def test_decode_refuses_dicts_whose_arrays_disagree():
+    """World.decode / decode_batch index the per-frame arrays by the frame count: arrays of other lengths, dense tensors of
+    another layout and batches of mixed rate / path / bin count are refused before anything reaches the device."""
+    from world.main import _check_decodable
+
+    F, K = 50, 513
+    good = {"temporal_positions": np.arange(F) * 0.005, "f0": np.full(F, 120.0), "vuv": np.ones(F), "fs": 16000,
+            "is_requiem": False, "spectrogram": np.ones((K, F)), "aperiodicity": np.ones((K, F))}
+    _check_decodable([good, dict(good)])
+    for bad in (dict(good, f0=good["f0"][:-3]), dict(good, vuv=np.ones((F, 1))), dict(good, spectrogram=np.ones((F, K))),
+                dict(good, aperiodicity=np.ones((K, F - 1))), dict(good, temporal_positions=good["temporal_positions"][:1], f0=good["f0"][:1], vuv=good["vuv"][:1])):
+        with pytest.raises(ValueError):
+            _check_decodable([bad])
+    for other in (dict(good, fs=22050), dict(good, is_requiem=True), dict(good, spectrogram=np.ones((257, F)))):
+        with pytest.raises(ValueError):
+            _check_decodable([good, other])
+    with pytest.raises(KeyError):
+        _check_decodable([{k: v for k, v in good.items() if k != "f0"}])

@@ -92,6 +92,21 @@ class WorldHipError(RuntimeError):
     pass
 
 
+def same_frames(where, dense=(), **per_frame):
+    """The per-frame arrays a stage function is handed must be 1-D and of one length, the dense ones (bins, frames) over it:
+    the kernels index all of them by the batch's frame count, so a short one would be read past its end (the reference fails
+    inside NumPy on such input).  Returns the frame count."""
+    shapes = {k: np.shape(v) for k, v in per_frame.items()}
+    lens = {s[0] if len(s) == 1 else None for s in shapes.values()}
+    if len(lens) != 1 or None in lens:
+        raise ValueError("%s: per-frame arrays must be 1-D and of one length, got %s" % (where, shapes))
+    n = lens.pop()
+    for name, v in dense:
+        if np.ndim(v) != 2 or np.shape(v)[1] != n:
+            raise ValueError("%s: '%s' must be (bins, %d frames), got %s" % (where, name, n, np.shape(v)))
+    return n
+
+
 # WH_FLAG_* of include/world_hip.h: sticky conditions raised by kernels instead of failing silently
 FLAG_STONEMASK_WINDOW, FLAG_EVENT_OVERFLOW, FLAG_NOISE_SHORT, FLAG_NO_PULSE, FLAG_PULSE_OVERFLOW, FLAG_OOB = range(6)
 FLAG_MESSAGES = {

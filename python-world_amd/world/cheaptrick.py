@@ -33,11 +33,11 @@ def cheaptrick(x, fs, source_object, q1=-0.15, fft_size=None):
     if fft_size is None:
         fft_size = default_fft_size(fs)
     fft_size = int(fft_size)
-    rt = _hip.Runtime.get()
     x = np.asarray(x, dtype=np.float64)
     tp = source_object['temporal_positions']
     f0 = source_object['f0']
-    nf = len(f0)
+    nf = _hip.same_frames("cheaptrick", temporal_positions=tp, f0=f0, vuv=source_object['vuv'])
+    rt = _hip.Runtime.get()
     batch = rt.make_batch([0, len(x)], [0, nf])
     x_d = rt.to_device(x)
     tp_d = rt.to_device(tp)

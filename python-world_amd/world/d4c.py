@@ -28,6 +28,7 @@ def d4c(x, fs, f0_object, threshold=0.85, fft_size_for_spectrum=None):
     rt = _hip.Runtime.get()
     x = np.asarray(x, dtype=np.float64)
     f0 = f0_object['f0']
+    _hip.same_frames("d4c", temporal_positions=f0_object['temporal_positions'], f0=f0, vuv=f0_object['vuv'])
     batch = rt.make_batch([0, len(x)], [0, len(f0)])
     f0_d = rt.to_device(f0)
     ap, coarse = d4c_device(rt, batch, rt.to_device(x), rt.to_device(f0_object['temporal_positions']), f0_d,

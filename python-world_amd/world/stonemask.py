@@ -25,9 +25,10 @@ def stonemask_device(rt, batch, x_d, tp_d, f0_d, fs, min_f0):
 
 def stonemask(x, fs, temporal_positions, f0):
     """Same contract as the reference: returns a new refined f0 array; the input is not modified."""
-    rt = _hip.Runtime.get()
     x = np.asarray(x, dtype=np.float64)
     f0 = np.asarray(f0, dtype=np.float64)
+    _hip.same_frames("stonemask", temporal_positions=temporal_positions, f0=f0)
+    rt = _hip.Runtime.get()
     pos = f0[f0 > 0]
     if len(pos) == 0:
         return np.copy(f0)

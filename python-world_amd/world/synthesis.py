@@ -127,7 +127,8 @@ def synthesis(source_object, filter_object):
     spectrogram = np.asarray(filter_object['spectrogram'], dtype=np.float64)
     aperiodicity = np.asarray(source_object['aperiodicity'], dtype=np.float64)
     tp = np.asarray(source_object['temporal_positions'], dtype=np.float64)
-    nf = len(tp)
+    nf = _hip.same_frames("synthesis", dense=(("spectrogram", spectrogram), ("aperiodicity", aperiodicity)),
+                          temporal_positions=tp, f0=f0, vuv=vuv)
     fft_size = (spectrogram.shape[0] - 1) * 2
     ny, t0, dt = time_axis_params(tp, fs)
     batch = rt.make_batch([0, 0], [0, nf])

@@ -139,6 +139,8 @@ def synthesisRequiem(source_object, filter_object, seeds_signals):
     vuv = np.asarray(source_object['vuv'], dtype=np.float64)
     spectrogram = np.asarray(filter_object['spectrogram'], dtype=np.float64)
     band = np.asarray(source_object['aperiodicity'], dtype=np.float64)
+    _hip.same_frames("synthesisRequiem", dense=(("spectrogram", spectrogram), ("aperiodicity", band)),
+                     temporal_positions=tp, f0=f0, vuv=vuv)
     fft_size = (spectrogram.shape[0] - 1) * 2
     nb = seeds_signals['pulse'].shape[1]
     nlen = seeds_signals['noise'].shape[0]

@@ -523,3 +523,25 @@ def test_decode_refuses_dicts_whose_arrays_disagree():
             _check_decodable([good, other])
     with pytest.raises(KeyError):
         _check_decodable([{k: v for k, v in good.items() if k != "f0"}])
+
+
+def test_stage_functions_refuse_arrays_of_different_lengths():
+    """_hip.same_frames, the guard in front of every per-stage drop-in (cheaptrick, d4c, d4cRequiem, stonemask, synthesis,
+    synthesisRequiem): nothing reaches a kernel that would index a short array by the batch's frame count."""
+    from world import _hip
+    from world.cheaptrick import cheaptrick
+    from world.stonemask import stonemask
+
+    assert _hip.same_frames("t", temporal_positions=np.zeros(7), f0=np.zeros(7), vuv=[0] * 7) == 7
+    assert _hip.same_frames("t", dense=(("spectrogram", np.zeros((5, 7))),), f0=np.zeros(7)) == 7
+    with pytest.raises(ValueError):
+        _hip.same_frames("t", temporal_positions=np.zeros(7), f0=np.zeros(6))
+    with pytest.raises(ValueError):
+        _hip.same_frames("t", f0=np.zeros((7, 1)))
+    with pytest.raises(ValueError):
+        _hip.same_frames("t", dense=(("spectrogram", np.zeros((7, 5))),), f0=np.zeros(7))
+    x = np.zeros(1600)
+    with pytest.raises(ValueError):  # (before any device call: holds without a GPU)
+        cheaptrick(x, 16000, {"f0": np.full(20, 100.0), "vuv": np.ones(21), "temporal_positions": np.arange(21) * 0.005})
+    with pytest.raises(ValueError):
+        stonemask(x, 16000, np.arange(21) * 0.005, np.full(20, 100.0))

@@ -50,6 +50,9 @@ namespace {
 #ifndef WH_RESP_ABLATE
 #define WH_RESP_ABLATE 0
 #endif
+#ifndef WH_RESP_CONV8
+#define WH_RESP_CONV8 1  // the noise convolution with eight outputs per thread from N = 2048 up (see response_pulse); 0: four everywhere
+#endif
 #ifndef WH_FT_SYNTH
 #define WH_FT_SYNTH 256
 #endif
@@ -57,6 +60,11 @@ namespace {
 // of LDS per pulse leave two workgroups per CU and the thread count is the occupancy (measured 58.6 -> 50.5 ms on
 // config 5).
 constexpr int ft_syn(int n) { return n >= 2048 ? 2 * WH_FT_SYNTH : WH_FT_SYNTH; }
+// Where it pays: the long noise runs of 44.1 / 48 kHz (config 5: response_kernel 41.8 -> 39.6 ms).  At 16 kHz a pulse's run
+// is ~64 samples — two 16-sample rounds per half — and the prologue and the merge cost more than the reads they save
+// (config 2: 3.43 -> 3.58 ms), so N = 1024 keeps four outputs per thread.
+template <int N>
+constexpr bool resp_conv8() { return WH_RESP_CONV8 && N / ft_syn(N) == 4 && N >= 2048; }
 
 struct SynUtt {
   int64_t f_off, nf;      // frames
@@ -1233,6 +1241,9 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   double acc[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) acc[q] = 0.0;
+  double acc8[resp_conv8<N>() ? 8 : 1];
+#pragma unroll
+  for (int q = 0; q < (resp_conv8<N>() ? 8 : 1); ++q) acc8[q] = 0.0;
   const int m0 = WH_TID * R;
 #if WH_RESP_ABLATE == 1
   for (int64_t j0 = 0; j0 < 0; j0 += NZ) {
@@ -1247,7 +1258,58 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
       nz[j] = v;  // zero padded to an even count
     }
     wh::sync<FT>();
-    if constexpr (R <= 4) {
+    if constexpr (resp_conv8<N>()) {
+      // EIGHT outputs per thread, the noise range of the chunk split over the two halves of the workgroup (round 6).
+      // With four outputs per thread a block of 4 noise samples is 16 FMAs against four 16-byte LDS reads (two for the
+      // noise, two for the new response group): 32 LDS cycles per 64 FMA cycles of a wave, and the CU's four SIMDs share ONE
+      // LDS pipe (MI355X_MICROARCH.md) — twice what it can feed.  At 48 kHz, where a pulse's noise run is ~100-200 samples
+      // against a 2048-sample response, the convolution was a third of the kernel (tools/resp_stage_timer.py 48000 16 60
+      // 1.5 2.0) and LDS-bound.  Eight outputs per thread: the same four reads feed 32 FMAs.  Half h of the workgroup
+      // takes the outputs m = 8 t .. 8 t + 7 (t = tid mod FT/2) over ITS half of the noise samples; the two partial sums
+      // meet in LDS behind the loop.  Response samples travel as aligned groups of four through a ring of four register
+      // groups (three in use by a block, the fourth being fetched for the next): nothing is shifted.
+      constexpr int HT = FT / 2;
+      const int half_id = WH_TID / HT, t8 = WH_TID - half_id * HT;
+      const int c_all = ((cnt + 15) / 16) * 16;              // (nz is zero-padded to NZ, a multiple of 16)
+      const int c_mid = ((c_all / 16 + 1) / 2) * 16;          // half 0: [0, c_mid), half 1: [c_mid, c_all)
+      const int jb = half_id == 0 ? 0 : c_mid, je = half_id == 0 ? c_mid : c_all;
+      auto load4 = [&](int base, double (&g)[4]) {  // base is a multiple of 4: all four valid or all in front of the response
+        double2 v0 = make_double2(0.0, 0.0), v1 = make_double2(0.0, 0.0);
+        if (base >= 0) {
+          v0 = wh::ck_as<const double2>(rap + rap_index(base))[0];
+          v1 = wh::ck_as<const double2>(rap + rap_index(base + 2))[0];
+        }
+        g[0] = v0.x; g[1] = v0.y; g[2] = v1.x; g[3] = v1.y;
+      };
+      // outputs q = 0..7 at noise step s = 0..3 read ra[mb + q - s]: hi = ra[mb+4 .. mb+7], mid = ra[mb .. mb+3], lo = ra[mb-4 .. mb-1]
+      auto block4 = [&](int j, const double (&hi)[4], const double (&mid)[4], const double (&lo)[4]) {
+        const double2 n01 = wh::ck_as<const double2>(nz + j)[0], n23 = wh::ck_as<const double2>(nz + (j + 2))[0];
+        const double n[4] = {n01.x, n01.y, n23.x, n23.y};
+#pragma unroll
+        for (int sft = 0; sft < 4; ++sft)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int idx = q - sft;  // -3 .. 7
+            acc8[q] = fma(n[sft], idx >= 4 ? hi[idx - 4] : (idx >= 0 ? mid[idx] : lo[idx + 4]), acc8[q]);
+          }
+      };
+      const int mb0 = t8 * 8 - (int)j0 - jb;  // response index of output 0 at the half's first noise sample
+      double g0[4], g1[4], g2[4], g3[4];
+      load4(mb0 + 4, g0);
+      load4(mb0, g1);
+      load4(mb0 - 4, g2);
+      for (int j = jb; j < je; j += 16) {
+        const int mb = t8 * 8 - (int)j0 - j;
+        load4(mb - 8, g3);
+        block4(j, g0, g1, g2);
+        load4(mb - 12, g0);
+        block4(j + 4, g1, g2, g3);
+        load4(mb - 16, g1);
+        block4(j + 8, g2, g3, g0);
+        load4(mb - 20, g2);
+        block4(j + 12, g3, g0, g1);
+      }
+    } else if constexpr (R <= 4) {
       // Aligned groups of R response samples around the thread's outputs: hi = ra[mb .. mb+R-1], lo = ra[mb-R .. mb-1],
       // mb = m0 - j0 - j.  A block of R noise samples needs exactly these two groups (output q at step s reads
       // ra[mb + q - s]); for the next block lo becomes hi and ONE new group is fetched — into the registers of the group
@@ -1313,6 +1375,23 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
     }
   }
 
+  if constexpr (resp_conv8<N>()) {
+    // the two halves' partial sums meet: half 0 parks its eight outputs in the aperiodic chain's buffer, half 1 in the
+    // padded response's (both free now), and every thread collects the four outputs the overlap-add expects of it
+    constexpr int HT = FT / 2;
+    const int half_id = WH_TID / HT, t8 = WH_TID - half_id * HT;
+    wh::sync<FT>();  // every thread is done reading rap
+    const wh::ckp<double> park = half_id == 0 ? zrA : rap;
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) wh::ck_as<double2>(park + (t8 * 8 + q))[0] = make_double2(acc8[q], acc8[q + 1]);
+    wh::sync<FT>();
+#pragma unroll
+    for (int q = 0; q < R; q += 2) {
+      const double2 a = wh::ck_as<const double2>(zrA + (m0 + q))[0], b2 = wh::ck_as<const double2>(rap + (m0 + q))[0];
+      acc[q] = a.x + b2.x;
+      acc[q + 1] = a.y + b2.y;
+    }
+  }
   RSTAGE_MARK(3)
   // ---- DC removal of the periodic response (synthesis.py:72-73) ------------------------------------
   double dc_total = 0.0;

@@ -11,10 +11,18 @@ import torch
 from world._synthetic import synth_utterance
 from world.batch import WorldBatch
 
+# tools/resp_stage_timer.py [fs] [utterances] [seconds] [pitch scale] [duration scale]   (config 5: 48000 16 60 1.5 2.0)
+fs = int(sys.argv[1]) if len(sys.argv) > 1 else 16000
+n_utt = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+secs = float(sys.argv[3]) if len(sys.argv) > 3 else 10.0
 wb = WorldBatch(0)
-xs = [synth_utterance(i, 16000, 10.0) for i in range(64)]
-batch, x_d, tp_d = wb.upload(xs, 16000)
-enc = wb.encode_device(batch, x_d, tp_d, 16000, f0_method="dio")
+xs = [synth_utterance(i, fs, secs) for i in range(n_utt)]
+batch, x_d, tp_d = wb.upload(xs, fs)
+enc = wb.encode_device(batch, x_d, tp_d, fs, f0_method="dio" if fs <= 16000 else "harvest")
+if len(sys.argv) > 4:
+    enc.scale_pitch(float(sys.argv[4]))
+if len(sys.argv) > 5:
+    enc.scale_duration(float(sys.argv[5]))
 lib = wb.rt.lib
 buf = (ctypes.c_ulonglong * 8)()
 for it in range(3):

@@ -1094,6 +1094,7 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   constexpr int FT = ft_syn(N);
   constexpr int K = N / 2 + 1;
   constexpr int NZ = 256;
+  constexpr int NZC = resp_conv8<N>() ? 252 : NZ;  // noise samples per chunk (the eight-output form walks them twelve at a time)
   constexpr int R = N / FT;  // consecutive output samples per thread
   static_assert(R % 2 == 0 && NZ % (2 * R) == 0, "pairwise reads; whole blocks of 2R noise samples");
   constexpr int GT = FT >= 256 ? FT / 2 : FT;  // threads per chain: the periodic and aperiodic chains run side by side
@@ -1246,11 +1247,11 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
   for (int q = 0; q < (resp_conv8<N>() ? 8 : 1); ++q) acc8[q] = 0.0;
   const int m0 = WH_TID * R;
 #if WH_RESP_ABLATE == 1
-  for (int64_t j0 = 0; j0 < 0; j0 += NZ) {
+  for (int64_t j0 = 0; j0 < 0; j0 += NZC) {
 #else
-  for (int64_t j0 = 0; j0 < nd; j0 += NZ) {
+  for (int64_t j0 = 0; j0 < nd; j0 += NZC) {
 #endif
-    const int cnt = (int)(nd - j0 < NZ ? nd - j0 : NZ);
+    const int cnt = (int)(nd - j0 < NZC ? nd - j0 : NZC);
     wh::sync<FT>();
     for (int j = WH_TID; j < NZ; j += FT) {
       double v = 0.0;
@@ -1266,12 +1267,12 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
       // against a 2048-sample response, the convolution was a third of the kernel (tools/resp_stage_timer.py 48000 16 60
       // 1.5 2.0) and LDS-bound.  Eight outputs per thread: the same four reads feed 32 FMAs.  Half h of the workgroup
       // takes the outputs m = 8 t .. 8 t + 7 (t = tid mod FT/2) over ITS half of the noise samples; the two partial sums
-      // meet in LDS behind the loop.  Response samples travel as aligned groups of four through a ring of four register
-      // groups (three in use by a block, the fourth being fetched for the next): nothing is shifted.
+      // meet in LDS behind the loop.  Response samples travel as aligned groups of four through a ring of three register
+      // groups: nothing is shifted.
       constexpr int HT = FT / 2;
       const int half_id = WH_TID / HT, t8 = WH_TID - half_id * HT;
-      const int c_all = ((cnt + 15) / 16) * 16;              // (nz is zero-padded to NZ, a multiple of 16)
-      const int c_mid = ((c_all / 16 + 1) / 2) * 16;          // half 0: [0, c_mid), half 1: [c_mid, c_all)
+      const int c_all = ((cnt + 11) / 12) * 12;              // (<= NZC = 252; nz is zero-padded to NZ)
+      const int c_mid = ((c_all / 12 + 1) / 2) * 12;          // half 0: [0, c_mid), half 1: [c_mid, c_all)
       const int jb = half_id == 0 ? 0 : c_mid, je = half_id == 0 ? c_mid : c_all;
       auto load4 = [&](int base, double (&g)[4]) {  // base is a multiple of 4: all four valid or all in front of the response
         double2 v0 = make_double2(0.0, 0.0), v1 = make_double2(0.0, 0.0);
@@ -1283,31 +1284,33 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
       };
       // outputs q = 0..7 at noise step s = 0..3 read ra[mb + q - s]: hi = ra[mb+4 .. mb+7], mid = ra[mb .. mb+3], lo = ra[mb-4 .. mb-1]
       auto block4 = [&](int j, const double (&hi)[4], const double (&mid)[4], const double (&lo)[4]) {
-        const double2 n01 = wh::ck_as<const double2>(nz + j)[0], n23 = wh::ck_as<const double2>(nz + (j + 2))[0];
-        const double n[4] = {n01.x, n01.y, n23.x, n23.y};
 #pragma unroll
-        for (int sft = 0; sft < 4; ++sft)
+        for (int sp = 0; sp < 4; sp += 2) {  // two noise samples at a time: one 16-byte read
+          const double2 nn = wh::ck_as<const double2>(nz + (j + sp))[0];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int idx = q - sft;  // -3 .. 7
-            acc8[q] = fma(n[sft], idx >= 4 ? hi[idx - 4] : (idx >= 0 ? mid[idx] : lo[idx + 4]), acc8[q]);
-          }
+          for (int sft = sp; sft < sp + 2; ++sft)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int idx = q - sft;  // -3 .. 7
+              acc8[q] = fma(sft == sp ? nn.x : nn.y, idx >= 4 ? hi[idx - 4] : (idx >= 0 ? mid[idx] : lo[idx + 4]), acc8[q]);
+            }
+        }
       };
+      // Three register groups in a ring (a fourth, fetched a block ahead, cost 28 spilled registers and 26 GB of scratch
+      // traffic per config-5 step): the group a block has finished with receives the next block's lowest samples.
       const int mb0 = t8 * 8 - (int)j0 - jb;  // response index of output 0 at the half's first noise sample
-      double g0[4], g1[4], g2[4], g3[4];
+      double g0[4], g1[4], g2[4];
       load4(mb0 + 4, g0);
       load4(mb0, g1);
       load4(mb0 - 4, g2);
-      for (int j = jb; j < je; j += 16) {
+      for (int j = jb; j < je; j += 12) {
         const int mb = t8 * 8 - (int)j0 - j;
-        load4(mb - 8, g3);
         block4(j, g0, g1, g2);
-        load4(mb - 12, g0);
-        block4(j + 4, g1, g2, g3);
-        load4(mb - 16, g1);
-        block4(j + 8, g2, g3, g0);
-        load4(mb - 20, g2);
-        block4(j + 12, g3, g0, g1);
+        load4(mb - 8, g0);
+        block4(j + 4, g1, g2, g0);
+        load4(mb - 12, g1);
+        block4(j + 8, g2, g0, g1);
+        load4(mb - 16, g2);
       }
     } else if constexpr (R <= 4) {
       // Aligned groups of R response samples around the thread's outputs: hi = ra[mb .. mb+R-1], lo = ra[mb-R .. mb-1],
@@ -1420,7 +1423,8 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
     const int mm = m0 + q;
     const int64_t tgt = s1 + mm;
     double v = acc[q];
-    if (voiced) v += (zrP[(mm + N / 2) & (N - 1)] / N + (R <= 4 ? dcw[R <= 4 ? q : 0] : dc_base[mm]) * -dc_total) * gain;
+    // (the eight-output form reads the weight where it uses it: four values held across the convolution were registers it lacked)
+    if (voiced) v += (zrP[(mm + N / 2) & (N - 1)] / N + (R <= 4 && !resp_conv8<N>() ? dcw[R <= 4 ? q : 0] : dc_base[mm]) * -dc_total) * gain;
     if (tgt < 1) continue;                    // clipped to 1 and overwritten by the in-range tap
     if (tgt < m.ny) ring[(int)(tgt & (N - 1))] += v;    // this thread is the only writer of its R slots
     else if (mm == N - 1) rs.last += v;                 // last duplicate wins on the high side: the last sample's share

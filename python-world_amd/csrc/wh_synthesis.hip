@@ -1831,7 +1831,9 @@ __global__ __launch_bounds__(256) void req_excite_kernel(const SynUtt* __restric
 
 // frames per run of req_filter_kernel: 4 up to N = 1024 — measured at config 4 (filter + gather) with the run's sums in
 // LDS: 1 frame 1.40 + 0.22 ms, 4 frames 1.57 + 0.08, 8 frames 1.70 + 0.06, 16 frames 1.96 + 0.05; one frame per row
-// beyond (no benchmark config decodes Requiem there)
+// beyond (no benchmark config decodes Requiem there).  At the north-star size (1024 x 10 s, round 6): 1 frame 23.4 + 3.2 ms
+// (nine workgroups per CU instead of six: -7 % for +50 % of the waves — the kernel is not waiting for occupancy), 2 frames
+// 25.3 + 2.0, 4 frames 25.1 + 1.2, 8 frames 27.0 + 0.9
 #ifndef WH_REQ_RUNF
 #define WH_REQ_RUNF 4
 #endif

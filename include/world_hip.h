@@ -79,6 +79,9 @@ int wh_bounds_last(int64_t* out4);
 /* Positive control (bounds build; fails elsewhere): a kernel that stores one element past a four-element checked
  * buffer — the next wh_take_flags must report WH_FLAG_OOB with the record {1, WH_CK_TABLE (7), 4, 4}. */
 int wh_bounds_selftest(wh_ctx* ctx, void* stream);
+/* Test hook: the spectral kernels' own log / exp / sincospi (csrc/wh_math.h: a few ulp, a third of the device library's
+ * instructions) applied to a DEVICE array: which = 0 log -> out[n], 1 exp -> out[n], 2 (sin, cos)(pi x) -> out[2n]. */
+int wh_math_probe(wh_ctx* ctx, void* stream, int which, const double* in, double* out, int64_t n);
 /* The same flags without a host wait, for callers that keep a pipeline of batches in flight:
  *   wh_flags_post — enqueue (one 16-lane kernel on `stream`) the publication of the flags raised by everything before
  *     it on the stream to a pinned host word per flag, and clear them on the device (discard != 0: clear them

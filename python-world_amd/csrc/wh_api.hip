@@ -4,6 +4,7 @@
 
 #include "wh_device.h"
 #include "wh_host.h"
+#include "wh_math.h"
 
 namespace {
 thread_local std::string g_last_error;
@@ -272,6 +273,28 @@ int wh_bounds_selftest(wh_ctx* ctx, void* stream) {
 #else
   return wh::fail_msg("wh_bounds_selftest", "not a bounds build");
 #endif
+}
+
+// the spectral kernels' own log / exp / sincospi (wh_math.h) on a device array: which = 0 log, 1 exp, 2 sincospi (out[2i], out[2i+1])
+static __global__ void math_probe_kernel(int which, const double* __restrict__ in, double* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = in[i];
+  if (which == 0) out[i] = wh::flog(x);
+  else if (which == 1) out[i] = wh::fexp(x);
+  else {
+    const double2 sc = wh::fsincospi(x);
+    out[2 * i] = sc.x;
+    out[2 * i + 1] = sc.y;
+  }
+}
+int wh_math_probe(wh_ctx* ctx, void* stream, int which, const double* in, double* out, int64_t n) {
+  if (!ctx || !in || !out || n < 0 || which < 0 || which > 2) return wh::fail_msg("wh_math_probe", "bad argument");
+  WH_ENTER(ctx);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, in, out, (long long)n);
+  WH_LAUNCH_CHECK("math_probe_kernel");
+  return 0;
 }
 
 int wh_bounds_last(int64_t* out4) {

@@ -4,6 +4,17 @@
 // All three transforms run as N/2-point complex FFTs on sample pairs (wh_device.h: rfft_lds / irfft_lds).
 // Replaces cheaptrick()/estimate_one_slice() of the reference (world/cheaptrick.py:9-157).
 #include "wh_host.h"
+#include "wh_math.h"
+#ifndef WH_FAST_MATH64
+#define WH_FAST_MATH64 1  // wh_math.h's log / exp for the 2 x 513 transcendentals of a frame (0: the device library's)
+#endif
+#if WH_FAST_MATH64
+#define WH_CT_LOG wh::flog
+#define WH_CT_EXP exp
+#else
+#define WH_CT_LOG log
+#define WH_CT_EXP exp
+#endif
 #include "wh_spectral.h"
 
 namespace {
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
     // that guarantee (digital silence) deterministically
 #pragma unroll
     for (int r = 0; r < KR; ++r)
-      if (k0 + r < K) aux[k0 + r] = log(bandv[r] * scale_f0 + 0.5 * 2.220446049250313e-16);
+      if (k0 + r < K) aux[k0 + r] = WH_CT_LOG(bandv[r] * scale_f0 + 0.5 * 2.220446049250313e-16);
   }
   wh::sync<FT>();
 
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
     wh::fft_lds<M, true, FT>(zb, tw + M);
   }
   const wh::ckp<double> o = wh::ck_make(spec_out + f * (int64_t)K, K, wh::WH_CK_OUT);
-  for (int k = threadIdx.x; k < K; k += FT) o[k] = exp(zr[k] * (1.0 / N));  // N is a power of two: exact
+  for (int k = threadIdx.x; k < K; k += FT) o[k] = WH_CT_EXP(zr[k] * (1.0 / N));  // N is a power of two: exact
 }
 
 template <int N>

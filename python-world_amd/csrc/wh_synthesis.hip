@@ -14,6 +14,7 @@
 //                     (direct convolution == the reference's truncated fftfilt), and scatter-add into
 //                     y with the reference's clipped-index semantics.
 #include "wh_host.h"
+#include "wh_math.h"
 // response_kernel walks a run of pulses in a loop.  With the plain thread index every per-thread LDS / twiddle address
 // of the ~15 transform passes in the loop body is a loop invariant: LLVM hoists them all in front of the loop and keeps
 // them alive across it (248 VGPRs, 2 waves per SIMD).  Reading the index through an empty volatile asm makes each use
@@ -871,6 +872,20 @@ __global__ __launch_bounds__(64) void noise_cover_kernel(const SynUtt* __restric
 
 // Transcendentals of the per-pulse loop as real calls: inlined, their polynomial coefficients (64-bit literals live in
 // VGPR pairs) are loop invariants of response_kernel's pulse loop and get parked in registers across the whole body.
+#ifndef WH_FAST_MATH64
+#define WH_FAST_MATH64 1  // wh_math.h's log / exp / sincospi in the minimum-phase chains (0: the device library's)
+#endif
+#if WH_FAST_MATH64
+__device__ __attribute__((noinline)) double log_call(double x) { return wh::flog(x); }
+// (wh::fexp / wh::fsincospi are no shorter than the library's once the compiler has materialised their coefficients — 66 / 75
+// instructions against 56 / 82 — and read as a scalar table they stall on its latency: measured, not used)
+__device__ __attribute__((noinline)) double exp_call(double x) { return exp(x); }
+__device__ __attribute__((noinline)) double2 sincospi_call(double x) {
+  double s, c;
+  sincospi(x, &s, &c);
+  return make_double2(s, c);
+}
+#else
 __device__ __attribute__((noinline)) double log_call(double x) { return log(x); }
 __device__ __attribute__((noinline)) double exp_call(double x) { return exp(x); }
 __device__ __attribute__((noinline)) double2 sincospi_call(double x) {
@@ -878,6 +893,7 @@ __device__ __attribute__((noinline)) double2 sincospi_call(double x) {
   sincospi(x, &s, &c);
   return make_double2(s, c);
 }
+#endif
 
 // Minimum-phase response (synthesis.py:100-116; synthesisRequiem.py:112-118) from the mirrored log-amplitude to the time
 // domain, with the O(N) passes between the three transforms fused:

@@ -48,6 +48,7 @@ SIGNATURES = {
     "wh_bounds_build": (_int, []),
     "wh_bounds_last": (_int, [_c_i64p]),
     "wh_bounds_selftest": (_int, [_vp, _vp]),
+    "wh_math_probe": (_int, [_vp, _vp, _int, _vp, _vp, ctypes.c_int64]),
     "wh_flags_post": (_int, [_vp, _vp, _int]),
     "wh_flags_poll": (_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
     "wh_dio": (_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _int,

@@ -36,6 +36,7 @@ __device__ __forceinline__ unsigned wh_opaque_tid() {
 #include "wh_bands.h"
 #include "wh_device.h"
 #include "wh_host.h"
+#include "wh_math.h"
 
 namespace {
 
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
         const int i = threadIdx.x + r * kRawTile;
         // (slots past the staged intervals hold +inf locations: the search below needs no bounds; written as a select —
         // as a branch that skips the second round's divide for the bands below ~400 Hz: 1.36 against 1.30 ms)
-        iv[k][i] = i < nloc[k] ? make_double2((ea[k][r] + eb[k][r]) * half_inv_fs, fs_d / (eb[k][r] - ea[k][r]))
+        iv[k][i] = i < nloc[k] ? make_double2((ea[k][r] + eb[k][r]) * half_inv_fs, wh::fdiv(fs_d, eb[k][r] - ea[k][r]))
                                : make_double2(INFINITY, 0.0);
       }
     __syncthreads();
@@ -361,10 +362,10 @@ __global__ __launch_bounds__(kRawTile) void hv_raw_kernel(const HvUtt* __restric
           const double e0 = e[il], e1 = e[il + 1], e2 = e[ih], e3 = e[ih + 1];
           x_lo = (e0 + e1) * half_inv_fs;
           x_hi = (e2 + e3) * half_inv_fs;
-          y_lo = fs_d / (e1 - e0);
-          y_hi = fs_d / (e3 - e2);
+          y_lo = wh::fdiv(fs_d, e1 - e0);
+          y_hi = wh::fdiv(fs_d, e3 - e2);
         }
-        const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+        const double slope = wh::fdiv(y_hi - y_lo, x_hi - x_lo);
         v[k] = slope * (t - x_lo) + y_lo;
       }
       cand = (((v[0] + v[1]) + v[2]) + v[3]) / 4;
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(kRawTile, WH_HV_RAWDET_MINW) void hv_rawdet_kernel(
         // the interval's upper edge: the next lane's entry (lane 63 of the first round: lane 0 of the second)
         const double up0 = __shfl_down(s.ea[k][0], 1);
         if (s.need < kRawTile) {  // (uniform) one round: entries 0 .. 63, intervals 0 .. 62 at most
-          iv[k][lane] = lane < s.nloc[k] ? make_double2((s.ea[k][0] + up0) * half_inv_fs, fs_d / (up0 - s.ea[k][0]))
+          iv[k][lane] = lane < s.nloc[k] ? make_double2((s.ea[k][0] + up0) * half_inv_fs, wh::fdiv(fs_d, up0 - s.ea[k][0]))
                                          : make_double2(INFINITY, 0.0);
         } else {
           const double up1 = __shfl_down(s.ea[k][1], 1);
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(kRawTile, WH_HV_RAWDET_MINW) void hv_rawdet_kernel(
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
             const int i = lane + r * kRawTile;
-            iv[k][i] = i < s.nloc[k] ? make_double2((s.ea[k][r] + eb[r]) * half_inv_fs, fs_d / (eb[r] - s.ea[k][r]))
+            iv[k][i] = i < s.nloc[k] ? make_double2((s.ea[k][r] + eb[r]) * half_inv_fs, wh::fdiv(fs_d, eb[r] - s.ea[k][r]))
                                      : make_double2(INFINITY, 0.0);
           }
         }
@@ -580,10 +581,10 @@ __global__ __launch_bounds__(kRawTile, WH_HV_RAWDET_MINW) void hv_rawdet_kernel(
             const double e0 = e[il], e1 = e[il + 1], e2 = e[ih], e3 = e[ih + 1];
             x_lo = (e0 + e1) * half_inv_fs;
             x_hi = (e2 + e3) * half_inv_fs;
-            y_lo = fs_d / (e1 - e0);
-            y_hi = fs_d / (e3 - e2);
+            y_lo = wh::fdiv(fs_d, e1 - e0);
+            y_hi = wh::fdiv(fs_d, e3 - e2);
           }
-          const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+          const double slope = wh::fdiv(y_hi - y_lo, x_hi - x_lo);
           v[k] = slope * (t - x_lo) + y_lo;
         }
         cand = (((v[0] + v[1]) + v[2]) + v[3]) / 4;

@@ -93,6 +93,26 @@ class WorldHipError(RuntimeError):
     pass
 
 
+# The drop-in functions (world.harvest.harvest, world.cheaptrick.cheaptrick, ..., World.encode_batch / decode_batch) run
+# on the process's default context: one arena, one stream, one set of flags.  The reference is plain NumPy and may be called
+# from several threads at once; two threads inside the same library context would lay its scratch out over each other
+# (ctypes releases the GIL during the calls).  So the drop-ins take this lock: concurrent callers are served one after the
+# other and get the results they would get alone.  (Parallelism within a process: world.pool / devices=[...] — contexts of
+# their own — or one WorldBatch lane per thread.)
+FACADE_LOCK = threading.RLock()
+
+
+def serialised(fn):
+    """Decorator of a drop-in entry point: holds FACADE_LOCK for the duration of the call (re-entrant)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        with FACADE_LOCK:
+            return fn(*a, **kw)
+    return wrapped
+
+
 def same_frames(where, dense=(), **per_frame):
     """The per-frame arrays a stage function is handed must be 1-D and of one length, the dense ones (bins, frames) over it:
     the kernels index all of them by the batch's frame count, so a short one would be read past its end (the reference fails

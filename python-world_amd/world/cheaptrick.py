@@ -26,6 +26,7 @@ def cheaptrick_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, fft_size, q1=-0.15,
     return spec, ps
 
 
+@_hip.serialised
 def cheaptrick(x, fs, source_object, q1=-0.15, fft_size=None):
     """Same contract as the reference: returns {'temporal_positions','spectrogram' (K,F),'fs',
     'ps spectrogram' (fft,F) complex} and overwrites source_object['f0'] in place with the 500 Hz

@@ -20,6 +20,7 @@ def d4c_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, threshold, fft_size_for_sp
     return ap, coarse
 
 
+@_hip.serialised
 def d4c(x, fs, f0_object, threshold=0.85, fft_size_for_spectrum=None):
     """Same contract as the reference: zeroes f0_object['f0'] where vuv==0, adds 'aperiodicity' (K,F)
     and 'coarse_ap' (nap,F) to the SAME dict and returns it (world/d4c.py:28-32,61-64)."""

@@ -15,6 +15,7 @@ def d4c_requiem_device(rt, batch, x_d, tp_d, f0_d, vuv_d, fs, threshold=0.85, ff
     return band
 
 
+@_hip.serialised
 def d4cRequiem(x, fs, f0_object, threshold=0.85, fft_size=None):
     """Same contract as the reference: zeroes f0 where vuv==0, stores 'aperiodicity' (nap+2,F) in dB in
     the SAME dict and returns it (world/d4cRequiem.py:17-18,42-44)."""

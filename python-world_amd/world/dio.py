@@ -30,6 +30,7 @@ def dio_device(rt, batch, x_d, tp_d, fs, f0_floor=71, f0_ceil=800, channels_in_o
     return f0, vuv, cand, raw
 
 
+@_hip.serialised
 def dio(x, fs, f0_floor=71, f0_ceil=800, channels_in_octave=2, target_fs=4000, frame_period=5, allowed_range=0.1,
         _index_bias=None):
     """Same contract as the reference: dict with 'f0', 'f0_candidates' (nb,F), 'raw_f0_candidates' (nb,F),

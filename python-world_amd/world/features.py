@@ -133,6 +133,7 @@ def context_device(rt, x_d, w=5):
     return out
 
 
+@_hip.serialised
 def _on_device(fn, x, *a, **kw):
     rt = _hip.Runtime.get()
     x_d = rt.to_device(np.ascontiguousarray(x, dtype=np.float64))

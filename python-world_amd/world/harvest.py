@@ -93,6 +93,7 @@ def _harvest_launch(rt, batch, x_d, tp_d, fs, f0_floor, f0_ceil, frame_period, d
     return f0, vuv
 
 
+@_hip.serialised
 def harvest(x, fs, f0_floor=71, f0_ceil=800, frame_period=5):
     """Same contract as the reference: {'temporal_positions', 'f0', 'vuv'} on the frame_period grid."""
     rt = _hip.Runtime.get()

@@ -183,6 +183,7 @@ class World(object):
         return out
 
     # ---- batched convenience (not in the reference; SURVEY.md §8(b): "World.encode_batch/decode_batch") ----------
+    @_hip.serialised
     def encode_batch(self, fs, xs, f0_method='harvest', f0_floor=71, f0_ceil=800, channels_in_octave=2, target_fs=4000,
                      frame_period=5, allowed_range=0.1, fft_size=None, is_requiem=False, want_ps=False, devices=None):
         """encode() — same arguments, same defaults (Harvest) — for a list of utterances in one pass per kernel.
@@ -238,6 +239,7 @@ class World(object):
             d['_batch_range'] = sb.range
         return dats
 
+    @_hip.serialised
     def decode_batch(self, dats, devices=None, copy_out=True, **kw):
         """decode() for a list of encode()/encode_batch() dicts that share fs / is_requiem / fft size: one batched
         synthesis; adds 'out' to every dict (peak-normalised like decode()) and returns the list.

@@ -23,6 +23,7 @@ def stonemask_device(rt, batch, x_d, tp_d, f0_d, fs, min_f0):
     return out
 
 
+@_hip.serialised
 def stonemask(x, fs, temporal_positions, f0):
     """Same contract as the reference: returns a new refined f0 array; the input is not modified."""
     x = np.asarray(x, dtype=np.float64)

@@ -148,6 +148,7 @@ def swipe_device(rt, batch, x_d, fs, plim=(71, 800), dt=0.005, sTHR=float("-inf"
     return f0, vuv
 
 
+@_hip.serialised
 def swipe(fs, x, plim=[71, 800], dt=0.005, sTHR=float('-inf')):
     """Same contract as the reference: {'temporal_positions', 'f0', 'vuv'} on the dt grid."""
     rt = _hip.Runtime.get()

@@ -113,6 +113,7 @@ def synthesis_plan(rt, batch, tp_d, f0_d, vuv_d, fs, ny_list, t0_list, dt_list, 
     return counts, draws
 
 
+@_hip.serialised
 def synthesis(source_object, filter_object):
     """Same contract as the reference.  Randomness: exactly as many np.random.randn samples are drawn
     from NumPy's global stream as the reference draws (one randn(max(3, noise_size)) per pulse), so a

@@ -129,6 +129,7 @@ def synthesis_requiem_device(rt, enc, ny, geo, seeds=None, cursor=None, pulse_ca
     return y, y_off
 
 
+@_hip.serialised
 def synthesisRequiem(source_object, filter_object, seeds_signals):
     """Same contract as the reference, including the cursor that persists across calls in
     ``generate_noise.current_index``."""

@@ -245,6 +245,9 @@ class Runtime:
         # chip-filling ones was measured and is worse: config 2 10.12 against 9.83 ms with the time-base lane at -1)
         self.own_stream = torch.cuda.Stream(device=self.device) if lane else None
         self.harvest_lists = 0  # utterances x channels of this context's last wh_harvest (world.harvest.counted_event_caps)
+        # a context is driven by one host thread at a time: WorldBatch methods hold this for the duration of a call, so two
+        # threads that share a lane (two WorldBatch() on the default one) enqueue whole calls one after the other
+        self.lock = threading.RLock()
 
     @classmethod
     def get(cls, device_index=None, lane=0):

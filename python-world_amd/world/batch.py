@@ -362,7 +362,7 @@ def _on_lane_stream(fn):
 
     @functools.wraps(fn)
     def wrapped(self, *a, **kw):
-        with self.rt.on_stream():
+        with self.rt.lock, self.rt.on_stream():
             return fn(self, *a, **kw)
     return wrapped
 

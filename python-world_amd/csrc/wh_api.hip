@@ -36,6 +36,11 @@ namespace wh {
 void set_error(const std::string& msg) { g_last_error = msg; }
 int fail(const char* where, hipError_t e) {
   g_last_error = std::string(where) + ": " + hipGetErrorString(e);
+  // The runtime keeps the error of a failed call (an allocation that did not fit, say) as its "last error" until somebody
+  // reads it — and every launch check of this library reads it (hipGetLastError behind a launch): left standing, the NEXT,
+  // perfectly ordinary call reported it as its own ("wh_batch_create: out of memory" after a workspace that could not be
+  // allocated; tools/oom_probe.py).  Reported once, here, and cleared.
+  (void)hipGetLastError();
   return (int)e == 0 ? -1 : (int)e;
 }
 int fail_msg(const char* where, const char* msg) {

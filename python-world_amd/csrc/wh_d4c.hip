@@ -62,6 +62,9 @@ __device__ __forceinline__ int wh_opaque_tid() {
 #endif
 constexpr int d4c_maxr(int n) { return WH_D4C_MAXR ? WH_D4C_MAXR : ((n <= 1024 || WH_D4C_REGFED) ? 8 : 4); }
 constexpr int d4c_rmaxr(int n) { return WH_D4C_RMAXR ? WH_D4C_RMAXR : ((n <= 1024 || WH_D4C_REGFED) ? 8 : 4); }
+#ifndef WH_LOVE_REGWIN
+#define WH_LOVE_REGWIN 1
+#endif
 #ifndef WH_LOVE_MAXR
 #define WH_LOVE_MAXR 8
 #endif
@@ -327,10 +330,10 @@ __device__ __forceinline__ void d4c_window(wh::ckp<const double> WH_RESTRICT xu,
 // 2048 complex values and the first pass's read of them — stores are what an FFT pass costs on this LDS (~80 B/clk per
 // CU, MI355X_MICROARCH.md) — and the walks stop at the window's end: rows q >= ceil(L / FT) are zeros (a window spans
 // 4 pitch periods, ~640 of the 2048 samples at 100 Hz), uniformly for the workgroup.
-template <bool BLACKMAN, int N, bool ENERGY>
+template <bool BLACKMAN, int N, bool ENERGY, int FT_ = 0>
 __device__ __forceinline__ void d4c_window_regs(wh::ckp<const double> WH_RESTRICT xu, wh::ckp<const double> tab, double2 e_tid,
-                                                wh::ckp<double> scratch, double (&out)[N / ft_of(N)]) {
-  constexpr int FT = ft_of(N);
+                                                wh::ckp<double> scratch, double (&out)[N / (FT_ ? FT_ : ft_of(N))]) {
+  constexpr int FT = FT_ ? FT_ : ft_of(N);
   constexpr int Q = N / FT;
   const WinSetup ws = win_load(tab);
   const int hwl = ws.hwl, L = ws.L, rlo = ws.rlo, rhi = ws.rhi;
@@ -504,7 +507,18 @@ __global__ __launch_bounds__(ft_love(NLT)) void love_train_kernel(
   const double cf = fmax(f0, 40.0);
   if (threadIdx.x == 0) win_setup(wtab, xn, fs, cf, tp[f], 1.5, FT);
   wh::sync<FT>();
+#if WH_LOVE_REGWIN
+  {
+    // the frame's samples stay in registers from the gather through both walks (round 6): parked in LDS between them, the
+    // window cost a store and two reads per sample on an LDS pipe this kernel keeps busy all the time
+    double v[NLT / FT];
+    d4c_window_regs<true, NLT, false, FT>(xu, wtab, win_thread_phase(wtab[9]), scratch, v);
+#pragma unroll
+    for (int q = 0; q < NLT / FT; ++q) zr[WH_TID + q * FT] = v[q];
+  }
+#else
   d4c_window<true, NLT, false, 1, FT>(xu, wtab, win_thread_phase(wtab[9]), scratch, zr, [&](int j, double val) { zr[j] = val; });
+#endif
   wh::sync<FT>();
   wh::rfft_lds<NLT, FT, FT, WH_LOVE_MAXR>(zb, tw);  // (66 VGPRs here: the radix-8 plan fits, unlike in d4c_kernel)
   const int b0 = (int)(ceil(100.0 / (fs / NLT)) + 1);

@@ -1091,7 +1091,8 @@ __device__ __forceinline__ void hv_refine_row(wh::ckp<const double> WH_RESTRICT 
     const double p = sa[q] * sa[q] + sb[q] * sb[q];
     const double nm = sa[q] * sd[q] - sb[q] * sc_[q];
     // bin / nfft is exact (power of two), and so is the halving
-    inst_q[q] = ((double)my_bin[q] * (1.0 / (double)nfft) + nm / p * 0.5 / M_PI) * fs;
+    // (the quotients of this epilogue — seventeen per lane — go through wh::fdiv: they were two thirds of its instructions)
+    inst_q[q] = ((double)my_bin[q] * (1.0 / (double)nfft) + wh::fdiv(wh::fdiv(nm, p) * 0.5, M_PI)) * fs;
     amp_q[q] = sqrt(p);
   }
   // numerator and denominator run over the harmonics below nh — the same for every member (nh is part of the class key)
@@ -1099,25 +1100,25 @@ __device__ __forceinline__ void hv_refine_row(wh::ckp<const double> WH_RESTRICT 
 #pragma unroll
   for (int q = 0; q < P; ++q) {
     const int h = l16 + q * RL;
-    a_q[q] = inst_q[q] / (double)(h + 1);
+    a_q[q] = wh::fdiv(inst_q[q], (double)(h + 1));
     if (h < nh) {
       t_num += amp_q[q] * inst_q[q];
       t_den += amp_q[q] * (double)(h + 1);
     }
   }
   const double num = row_sum<RL>(t_num), den = row_sum<RL>(t_den);
-  const double rf_all = num / den;
+  const double rf_all = wh::fdiv(num, den);
   // (scoring four members at a time, one per lane, was measured and is no faster: 3.51 against 3.53 ms)
   members([&](double f0m, double* out_f0, double* out_sc) {
     double t_var = 0.0;
 #pragma unroll
     for (int q = 0; q < P; ++q) {
       const int h = l16 + q * RL;
-      if (h < nh) t_var += fabs((a_q[q] - f0m) / f0m);
+      if (h < nh) t_var += fabs(wh::fdiv(a_q[q] - f0m, f0m));
     }
     const double var = row_sum<RL>(t_var);
     double rf = rf_all;
-    double sc = 1 / (0.000000000001 + var / (double)nh);
+    double sc = wh::fdiv(1.0, 0.000000000001 + wh::fdiv(var, (double)nh));
     if (rf < f0_floor || rf > f0_ceil || sc < 2.5) {
       rf = 0.0;
       sc = 0.0;

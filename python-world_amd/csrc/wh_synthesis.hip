@@ -1845,6 +1845,14 @@ __global__ __launch_bounds__(256) void req_excite_kernel(const SynUtt* __restric
   exc[m.y_off + i] = periodic + aperiodic;  // synthesisRequiem.py:62
 }
 
+// The Hanning window of the Requiem frames, hanning(2 hop + 1)[1:-1] (synthesisRequiem.py:84-86): the same for every frame of
+// every utterance with that hop.  Evaluated on the device with req_filter_kernel's own expression (bitwise what the kernel
+// computes in place), cached per context and window length.
+__global__ void req_hann_kernel(double* __restrict__ w, int wlen) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < wlen) w[j] = 0.5 - 0.5 * cospi(2.0 * (double)(j + 1) / (double)(wlen + 1));
+}
+
 // frames per run of req_filter_kernel: 4 up to N = 1024 — measured at config 4 (filter + gather) with the run's sums in
 // LDS: 1 frame 1.40 + 0.22 ms, 4 frames 1.57 + 0.08, 8 frames 1.70 + 0.06, 16 frames 1.96 + 0.05; one frame per row
 // beyond (no benchmark config decodes Requiem there).  At the north-star size (1024 x 10 s, round 6): 1 frame 23.4 + 3.2 ms
@@ -1873,7 +1881,8 @@ template <int N, int RUNF>
 __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1)) void req_filter_kernel(const SynUtt* __restrict__ meta, const ReqUtt* __restrict__ rq,
                                                         const double* __restrict__ spectrogram,
                                                         const double* __restrict__ exc,
-                                                        const double2* __restrict__ tw_base_arg, double* rows) {
+                                                        const double2* __restrict__ tw_base_arg, double* rows,
+                                                        const double* __restrict__ hann) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int FT = ft_syn(N);
   constexpr int K = N / 2 + 1;
@@ -1919,7 +1928,10 @@ __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1
         int64_t g = origin + j;
         g = g > m.ny ? m.ny : g;
         g = g < 1 ? 1 : g;
-        const double wv = 0.5 - 0.5 * cospi(2.0 * (double)(j + 1) / (double)(wlen + 1));  // hanning(wlen+2)[1:-1]
+        // hanning(wlen+2)[1:-1] — from the launch's table when every utterance has this hop (req_hann_kernel: the same
+        // expression, evaluated once instead of per frame: a cospi and a divide per sample were ~5 % of the kernel's
+        // instructions), else in place
+        const double wv = hann ? hann[j] : 0.5 - 0.5 * cospi(2.0 * (double)(j + 1) / (double)(wlen + 1));
         v = eu[g - 1] * wv;
       }
       sr[j] = v;
@@ -1988,18 +2000,38 @@ __global__ __launch_bounds__(256) void req_gather_kernel(const SynUtt* __restric
 template <int N>
 int launch_req_filter(wh_ctx* ctx, hipStream_t st, int B, int64_t max_nf, int64_t max_ny, int64_t max_hop, bool runs,
                       const SynUtt* d_meta, const ReqUtt* d_rq, const double* spec, const double* exc, double* rows,
-                      double* y) {
+                      double* y, int64_t uniform_hop) {
   constexpr int RUNF = req_runf(N);
+  const double* d_hann = nullptr;
+#ifndef WH_REQ_HANN_TAB
+#define WH_REQ_HANN_TAB 1
+#endif
+  if (WH_REQ_HANN_TAB && uniform_hop > 0 && 2 * uniform_hop - 1 <= N) {
+    const int wlen = (int)(2 * uniform_hop - 1);
+    const std::string key = "req.hann:" + std::to_string(wlen);
+    auto it = ctx->tables.find(key);
+    if (it == ctx->tables.end()) {
+      double* d = nullptr;
+      WH_CHECK(hipMalloc((void**)&d, sizeof(double) * (size_t)wlen));
+      hipLaunchKernelGGL(req_hann_kernel, dim3((unsigned)((wlen + 255) / 256)), dim3(256), 0, st, d, wlen);
+      WH_LAUNCH_CHECK("req_hann_kernel");
+      ctx->tables[key] = d;
+      ctx->table_bytes += sizeof(double) * (size_t)wlen;
+      d_hann = d;
+    } else {
+      d_hann = it->second;
+    }
+  }
   const size_t lds = sizeof(double2) * 2 * (N / 2 + 1) + 64;  // the chain's buffer and the excitation frame's
   if (max_nf >= 4) {
     wh::KernelTimer _kt(ctx, st, "req_filter_kernel");
     if (runs && RUNF > 1) {
       const size_t lds_run = lds + sizeof(double) * (size_t)((RUNF - 1) * max_hop + N);  // + the run's sums
       if (int rc = wh::allow_lds(&req_filter_kernel<N, RUNF>, lds_run)) return rc;
-      hipLaunchKernelGGL((req_filter_kernel<N, RUNF>), dim3((unsigned)((max_nf - 3 + RUNF - 1) / RUNF), B), dim3(ft_syn(N)), lds_run, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, rows);
+      hipLaunchKernelGGL((req_filter_kernel<N, RUNF>), dim3((unsigned)((max_nf - 3 + RUNF - 1) / RUNF), B), dim3(ft_syn(N)), lds_run, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, rows, d_hann);
     } else {
       if (int rc = wh::allow_lds(&req_filter_kernel<N, 1>, lds)) return rc;
-      hipLaunchKernelGGL((req_filter_kernel<N, 1>), dim3((unsigned)(max_nf - 3), B), dim3(ft_syn(N)), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, rows);
+      hipLaunchKernelGGL((req_filter_kernel<N, 1>), dim3((unsigned)(max_nf - 3), B), dim3(ft_syn(N)), lds, st, d_meta, d_rq, spec, exc, ctx->d_twiddle, rows, d_hann);
     }
   }
   WH_LAUNCH_CHECK("req_filter_kernel");
@@ -2342,7 +2374,7 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   const int B = b->n_utt;
   std::vector<SynUtt> meta(B);
   std::vector<ReqUtt> rq(B);
-  int64_t max_ny = 0, max_nf = 0, max_hop = 0;
+  int64_t max_ny = 0, max_nf = 0, max_hop = 0, uniform_hop = 0;  // (uniform_hop: the hop every utterance has, or 0)
   for (int u = 0; u < B; ++u) {
     SynUtt& m = meta[u];
     m.f_off = b->h_frame_off[u];
@@ -2359,6 +2391,8 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
     rq[u].hop = h_hop[u];
     if (rq[u].hop < 1) return wh::fail_msg("wh_synthesis_requiem", "frame hop below one sample");
     max_hop = std::max(max_hop, rq[u].hop);
+    if (u == 0) uniform_hop = rq[u].hop;
+    else if (rq[u].hop != uniform_hop) uniform_hop = 0;
     for (int k = 0; k < 8; ++k) rq[u].cursor[k] = k < n_bands ? ((h_cursor[(int64_t)u * n_bands + k] % noise_len) + noise_len) % noise_len : 0;
     max_ny = std::max(max_ny, m.ny);
     max_nf = std::max(max_nf, m.nf);
@@ -2426,10 +2460,10 @@ extern "C" int wh_synthesis_requiem(wh_ctx* ctx, void* stream, const wh_batch* b
   { wh::KernelTimer _kt(ctx, st, "req_excite_kernel"); hipLaunchKernelGGL(req_excite_kernel, dim3((unsigned)((max_ny + 255) / 256), B), dim3(256), 0, st, d_meta, d_rq, tp, d_lin, n_bands, noise_seed, noise_len, pulse_seed, pulse_fft, d_pi, d_pc, d_pt, d_pw, d_exc); }
   WH_LAUNCH_CHECK("req_excite_kernel");
   switch (fft_size) {
-    case 512: return launch_req_filter<512>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
-    case 1024: return launch_req_filter<1024>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
-    case 2048: return launch_req_filter<2048>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
-    case 4096: return launch_req_filter<4096>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y);
+    case 512: return launch_req_filter<512>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y, uniform_hop);
+    case 1024: return launch_req_filter<1024>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y, uniform_hop);
+    case 2048: return launch_req_filter<2048>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y, uniform_hop);
+    case 4096: return launch_req_filter<4096>(ctx, st, B, max_nf, max_ny, max_hop, runs, d_meta, d_rq, spectrogram, d_exc, d_rows, y, uniform_hop);
     default: return wh::fail_msg("wh_synthesis_requiem", "fft_size must be a power of two in [512, 4096]");
   }
 }

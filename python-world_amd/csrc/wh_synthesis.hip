@@ -875,7 +875,19 @@ __global__ __launch_bounds__(64) void noise_cover_kernel(const SynUtt* __restric
 #ifndef WH_FAST_MATH64
 #define WH_FAST_MATH64 1  // wh_math.h's log / exp / sincospi in the minimum-phase chains (0: the device library's)
 #endif
+#ifndef WH_TRANS_PAIRS
+#define WH_TRANS_PAIRS 1
+#endif
+// (exp(a0) cos(pi b0), exp(a0) sin(pi b0), exp(a1) cos(pi b1), exp(a1) sin(pi b1)): two bins of a minimum-phase spectrum
+__device__ __attribute__((noinline)) double4 cis_pair_call(double a0, double b0, double a1, double b1) {
+  const double e0 = exp(a0), e1 = exp(a1);
+  double s0, c0, s1, c1;
+  sincospi(b0, &s0, &c0);
+  sincospi(b1, &s1, &c1);
+  return make_double4(e0 * c0, e0 * s0, e1 * c1, e1 * s1);
+}
 #if WH_FAST_MATH64
+__device__ __attribute__((noinline)) double2 log_pair_call(double x, double y) { return make_double2(wh::flog(x), wh::flog(y)); }
 __device__ __attribute__((noinline)) double log_call(double x) { return wh::flog(x); }
 // (wh::fexp / wh::fsincospi are no shorter than the library's once the compiler has materialised their coefficients — 66 / 75
 // instructions against 56 / 82 — and read as a scalar table they stall on its latency: measured, not used)
@@ -886,6 +898,7 @@ __device__ __attribute__((noinline)) double2 sincospi_call(double x) {
   return make_double2(s, c);
 }
 #else
+__device__ __attribute__((noinline)) double2 log_pair_call(double x, double y) { return make_double2(log(x), log(y)); }
 __device__ __attribute__((noinline)) double log_call(double x) { return log(x); }
 __device__ __attribute__((noinline)) double exp_call(double x) { return exp(x); }
 __device__ __attribute__((noinline)) double2 sincospi_call(double x) {
@@ -982,9 +995,18 @@ __device__ __forceinline__ void min_phase_response(wh::ckp<double2> zb, wh::ckp<
       x1 = make_double2(er - tr, ti - ei);
     }
     // minimum-phase spectrum exp(conj(R) / N) with the fractional delay in the angle (both in units of pi)
+#if WH_TRANS_PAIRS
+    // the pair of bins through ONE call: the library's exp / sincospi spend a third of their instructions putting polynomial
+    // coefficients into registers, and two evaluations inside one function share them
+    const double4 cis = cis_pair_call(x0.x / N, -x0.y / N * M_1_PI - delay_pi * (double)k, x1.x / N,
+                                      -x1.y / N * M_1_PI - delay_pi * (double)(M - k));
+    const double e0 = 1.0, e1 = 1.0;
+    const double2 s0 = make_double2(cis.y, cis.x), s1 = make_double2(cis.w, cis.z);  // (sin, cos), already scaled by the exponential
+#else
     const double e0 = exp_call(x0.x / N), e1 = exp_call(x1.x / N);
     const double2 s0 = sincospi_call(-x0.y / N * M_1_PI - delay_pi * (double)k);
     const double2 s1 = sincospi_call(-x1.y / N * M_1_PI - delay_pi * (double)(M - k));
+#endif
     double2 A = mul(k, make_double2(e0 * s0.y, e0 * s0.x)), B = mul(M - k, make_double2(e1 * s1.y, e1 * s1.x));
     if (k == 0) {  // DC and Nyquist bins: only their real parts reach a real output
       A.y = 0.0;
@@ -1183,11 +1205,23 @@ __device__ __forceinline__ void response_pulse(const RespArgs& A, const PulseRec
     if (w == 0.0) w = 2.220446049250313e-16;
     // log|.| / 2 of the Hermitian-mirrored spectrum (synthesis.py:103-105), written where the chain's first
     // transform reads it: no amplitude arrays, no separate log and mirror passes
+#if WH_TRANS_PAIRS
+    // (a voiced pulse's two logarithms through one call, like the pair of complex exponentials in min_phase_response)
+    double2 lg;
+    if (voiced) lg = log_pair_call(fabs(w), fabs(v));
+    else lg = make_double2(log_call(fabs(w)), 0.0);
+    const double lw = lg.x / 2;
+#else
     const double lw = log_call(fabs(w)) / 2;
+#endif
     zrA[k] = lw;
     if (k > 0 && k < N / 2) zrA[N - k] = lw;
     if (voiced) {
+#if WH_TRANS_PAIRS
+      const double lv = lg.y / 2;
+#else
       const double lv = log_call(fabs(v)) / 2;
+#endif
       zrP[k] = lv;
       if (k > 0 && k < N / 2) zrP[N - k] = lv;
     }

@@ -1972,7 +1972,7 @@ __global__ __launch_bounds__(ft_syn(N), (RUNF > 1 && N <= 1024 ? WH_REQ_MINW : 1
     }
     const wh::ckp<const double> sp = wh::ck_make(spectrogram + (m.f_off + (i - 1)) * K, K, wh::WH_CK_IN);
     for (int k = WH_TID; k < K; k += FT) {  // log|S| / 2, Hermitian-mirrored: the input of the chain's first transform
-      const double lw = log_call(fabs(sp[k])) / 2;
+      const double lw = log_call(fabs(sp[k])) / 2;  // (two bins per call: measured, no gain here — 24.0 ms either way)
       zr[k] = lw;
       if (k > 0 && k < N / 2) zr[N - k] = lw;
     }

@@ -6,6 +6,7 @@
 // scan, and appended to per-(band, train) edge lists; frames later binary-search those lists.
 #pragma once
 #include "wh_device.h"
+#include "wh_math.h"
 
 
 namespace wh {
@@ -43,7 +44,7 @@ __device__ __forceinline__ void emit_crossings(const double* sig, int64_t t0, in
     const int64_t g = t0 + i;
     const double a = sig[i * STRIDE], b = sig[(i + 1) * STRIDE], c = sig[(i + 2) * STRIDE];
     if (g + 1 < M && a * b < 0) {  // crossing of s between g and g+1
-      const double fe = (double)(g + 1) - a / (b - a);
+      const double fe = (double)(g + 1) - wh::fdiv(a, b - a);
       if (b < a) {
         mask[0] |= 1u << q;
         fine[0][q] = fe;
@@ -55,7 +56,7 @@ __device__ __forceinline__ void emit_crossings(const double* sig, int64_t t0, in
     if (g + 2 < M) {
       const double d0 = b - a, d1 = c - b;
       if (d0 * d1 < 0) {
-        const double fe = (double)(g + 1) - d0 / (d1 - d0);
+        const double fe = (double)(g + 1) - wh::fdiv(d0, d1 - d0);
         if (d1 < d0) {
           mask[2] |= 1u << q;
           fine[2][q] = fe;
@@ -141,7 +142,7 @@ __device__ __forceinline__ void crossing_edges(const double* s_ptr, int64_t g_fi
     any &= any - 1;
     const double a = s_ptr[q * STRIDE], b = s_ptr[(q + 1) * STRIDE];
     const int t = (m01 >> q) & 1u ? 0 : 1;
-    const double fe = (double)(g_first + q + 1) - a / (b - a);
+    const double fe = (double)(g_first + q + 1) - wh::fdiv(a, b - a);
     put(t, pos[t], fe);
     ++pos[t];
   }
@@ -152,7 +153,7 @@ __device__ __forceinline__ void crossing_edges(const double* s_ptr, int64_t g_fi
     const double a = s_ptr[q * STRIDE], b = s_ptr[(q + 1) * STRIDE], c = s_ptr[(q + 2) * STRIDE];
     const int t = (m23 >> q) & 1u ? 2 : 3;
     const double d0 = b - a, d1 = c - b;
-    const double fe = (double)(g_first + q + 1) - d0 / (d1 - d0);
+    const double fe = (double)(g_first + q + 1) - wh::fdiv(d0, d1 - d0);
     put(t, pos[t], fe);
     ++pos[t];
   }

@@ -70,7 +70,8 @@ __device__ __forceinline__ constexpr MathTab math_tab() { return MathTab(); }
 // <= 1 ulp where the IEEE division the compiler emits is ~15 (two v_div_scale, the reciprocal, five fused steps, v_div_fmas,
 // v_div_fixup).  For divides whose operands are ordinary normal numbers and whose result feeds values compared at
 // tolerances (the interval frequencies and interpolation slopes of Harvest's raw candidates, eight per frame and channel:
-// hv_rawdet_kernel 5.65 -> 5.50 ms at 256 x 10 s; both forms of the raw-candidate stage use it, so they still agree bit for bit).  b = 0, Inf or NaN give Inf / NaN like the hardware reciprocal does.
+// hv_rawdet_kernel 5.65 -> 5.50 ms at 256 x 10 s; both forms of the raw-candidate stage use it, so they still agree bit for bit;
+// the quotients of the refinement's epilogue and the crossing positions of the band walkers).  b = 0, Inf or NaN give Inf / NaN like the hardware reciprocal does.
 #ifndef WH_FAST_DIV64
 #define WH_FAST_DIV64 1
 #endif

@@ -188,17 +188,27 @@ __global__ __launch_bounds__(ft_ct(N), ct_minw(N)) void cheaptrick_kernel(
   // The log-spectrum and both lifters are even about N/2, so the transcendental functions run on the K
   // distinct bins only and both transforms are real (forward of a real sequence, inverse to a real one).
   for (int n = threadIdx.x; n < N; n += FT) zr[n] = aux[n <= N / 2 ? n : N - n];
-  wh::sync<FT>();
   const double inv_fs = 1.0 / fs;
+  // the rotation by FT bins is the same for every thread: one wave evaluates it and the others read it behind the barrier
+  // (a sincospi is 82 instructions whatever the number of active lanes)
+  if (threadIdx.x < 64) {
+    double rs0, rc0;
+    sincospi(f0 * ((double)FT * inv_fs), &rs0, &rc0);
+    if (threadIdx.x == 0) {
+      scratch[0] = rs0;
+      scratch[1] = rc0;
+    }
+  }
+  wh::sync<FT>();
   {
     // sin(pi*f0*q_m) for m = tid, tid + FT, ...: start value + rotation by FT bins, as for the window
-    double sn, cs, rs, rc;
+    double sn, cs;
     sincospi(f0 * ((double)threadIdx.x * inv_fs), &sn, &cs);
-    sincospi(f0 * ((double)FT * inv_fs), &rs, &rc);
+    const double rs = scratch[0], rc = scratch[1];
     for (int m = threadIdx.x; m < K; m += FT) {
       const double q = (double)m * inv_fs;
       double sl = 1.0;
-      if (m > 0) sl = sn / (M_PI * f0 * q);
+      if (m > 0) sl = wh::fdiv(sn, M_PI * f0 * q);
       const double cl = (1 - 2 * q1) + 2 * q1 * (1 - 2 * sn * sn);  // cos(2*pi*q*f0) = 1 - 2 sin^2(pi*q*f0)
       aux[m] = sl * cl;
       const double cn = cs * rc - sn * rs;

@@ -462,7 +462,9 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
         }
       }
       sync_lds<256>();
+#if WH_OLS_ABLATE != 1
       fft_lds<NH, true, 256>(ybuf, tw_base + NH);
+#endif
 #else
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
@@ -481,8 +483,13 @@ static __global__ __launch_bounds__(256, WH_OLS_MINW) void band_events_ols_kerne
       // output i of the block is s[t0 + i - (H + 1)]: the tile's outputs start at index H + 1 (H + h + 1 with the taps as
       // they lie; the zero-phase rotation of band_taps_fft_kernel advances the output by the half length h)
       const double* sig = sig_all + (H + 1);
+#if WH_OLS_ABLATE == 1 || WH_OLS_ABLATE == 2
+      __syncthreads();
+      if (sig[threadIdx.x * kOlsPer] == 1.2345e300) stg(job.edges, sig[threadIdx.x]);  // (keeps what was computed alive)
+#else
       emit_crossings_block<1, kOlsPer>(sig, t0, M, job.edges, job.cap, base_cnt, scan_scratch, flags, job.hints, job.hint_spt,
                                        job.hint_inv_spt, job.hint_tiles, job.hint_stride);
+#endif
       __syncthreads();
       if (threadIdx.x < 4) s_cnt[g][threadIdx.x] = base_cnt[threadIdx.x];
     }

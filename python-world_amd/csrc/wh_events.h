@@ -8,6 +8,11 @@
 #include "wh_device.h"
 #include "wh_math.h"
 
+#ifndef WH_OLS_ABLATE
+#define WH_OLS_ABLATE 0  // timing experiments on the overlap-save band walker (never shipped; results differ): 1: neither the inverse
+                         // transform nor the crossing pass, 2: no crossing pass, 3: the crossing pass without its second walk
+#endif
+
 
 namespace wh {
 
@@ -221,10 +226,14 @@ __device__ __forceinline__ void emit_crossings_block(const double* sig, int64_t 
     }
   }
   bool over = false;
+#if WH_OLS_ABLATE == 3
+  over = m01 == 0xDEADBEEFu && m23 == m01;  // (timing experiment: the pass without its second walk)
+#else
   crossing_edges<STRIDE>(sig + (int64_t)i0 * STRIDE, t0 + i0, m01, m23, pos, [&](int t, int at, double fe) {
     if (at < cap) stg(edges + (int64_t)t * cap + at, fe);
     else over = true;
   });
+#endif
   if (over) atomicOr(overflow_flag, 1);
 #pragma unroll
   for (int t = 0; t < 4; ++t) base_cnt[t] += (int)((total >> (16 * t)) & 0xFFFF);
